@@ -1,0 +1,198 @@
+/*
+ * mneslam_hip.h -- C ABI of the MI355X (gfx950) mapping hot path of MNE-SLAM.
+ *
+ * Drop-in boundary: the reference has no FFI on this path -- its
+ * JointEncoding / Mapper Python classes call ATen + tinycudann.  This library is what a
+ * Python (ctypes) binding of those classes binds instead; every entry point lists the reference
+ * code it replaces.  Plain pointers and sizes only: all device buffers are owned by the caller
+ * (PyTorch tensors in the shipped host layer) and are borrowed for the duration of the call.
+ * Nothing is cached between calls (planes may be re-bound wholesale, mp_slam/mapper.py:718-719).
+ * Every kernel is launched on the caller's stream (`stream` = hipStream_t, may be NULL).
+ *
+ * Return value: 0 on success, negative on error; mne_last_error() gives the message
+ * (thread-local).  No entry point aborts or throws.
+ *
+ * Physical layouts
+ *   plane      : [H][W][C] fp32 (torch channels_last storage of the reference's [1,C,H,W] plane)
+ *   rays, rgb  : [R][3] fp32        target_d, depth : [R] fp32        z_vals : [R][S] fp32
+ *   raw        : [R][S][4] fp32 = (r, g, b raw logits, sdf)   (model/decoder.py:141,175)
+ *   decoder    : nn.Linear layout [out][in] fp32, bias-free (model/decoder.py:51,104)
+ */
+#ifndef MNESLAM_HIP_H
+#define MNESLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNE_ABI_VERSION 1
+
+/* orientation index of a plane triple, as in JointEncoding.all_planes (scene_rep.py:117) */
+enum { MNE_XY = 0, MNE_XZ = 1, MNE_YZ = 2 };
+/* loss slots: order of the scalars JointEncoding.forward returns (scene_rep.py:597-609) */
+enum { MNE_L_RGB = 0, MNE_L_DEPTH = 1, MNE_L_CO_SDF = 2, MNE_L_CO_FS = 3, MNE_L_E_FS = 4,
+       MNE_L_E_CENTER = 5, MNE_L_E_TAIL = 6, MNE_L_PSNR = 7, MNE_N_LOSS = 8 };
+/* mask-count slots produced by mne_sample_z */
+enum { MNE_C_VALID = 0, MNE_C_E_FRONT = 1, MNE_C_E_CENTER = 2, MNE_C_E_TAIL = 3, MNE_C_CO_FS = 4,
+       MNE_C_CO_SDF = 5, MNE_N_COUNT = 8 };
+
+typedef struct mne_plane {
+    const float* data;   /* [h][w][c_dim] */
+    float* grad;         /* same layout; accumulated into (atomics); NULL when not needed */
+    int32_t h, w;
+} mne_plane_t;
+
+/* One JointEncoding's tensors (model/scene_rep.py:15-26, :85-181). */
+typedef struct mne_scene {
+    int32_t n_sets;        /* 1 = geometry planes only (grid.oneGrid), 2 = + colour planes */
+    int32_t c_dim;         /* model.c_dim; this build supports 32 */
+    int32_t hidden;        /* decoder.hidden_dim       (32 or 64), num_layers == 2 */
+    int32_t hidden_color;  /* decoder.hidden_dim_color (32 or 64), num_layers_color == 2 */
+    int32_t geo_feat_dim;  /* decoder.geo_feat_dim; this build supports 15 */
+    int32_t n_bins;        /* pos.n_bins; this build supports 16 */
+    int32_t bb_is_f64;     /* OneBlob input normalised in fp64 (bounding_box is float64, A4) */
+    int32_t reserved;
+    mne_plane_t plane[2][3][2];          /* [set][xy,xz,yz][coarse,fine] */
+    float bound_lo[3], bound_hi[3];      /* EXTENDED bound (scene_rep.py:80-83), planes lookup */
+    double bb_lo[3], bb_hi[3];           /* RAW bounding_box (scene_rep.py:292), OneBlob input */
+    const float* w_sdf0;   /* [hidden][2*c_dim + 3*n_bins]          sdf_net.model.0.weight  */
+    const float* w_sdf1;   /* [1+geo][hidden]                       sdf_net.model.2.weight  */
+    const float* w_col0;   /* [hidden_color][3*n_bins (+2*c_dim) + geo]  color_net.model.0  */
+    const float* w_col1;   /* [3][hidden_color]                     color_net.model.2       */
+} mne_scene_t;
+
+/* Sampling / compositing / loss constants (configs/Replica/replica.yaml:103-142,161). */
+typedef struct mne_render_cfg {
+    /* python floats of the YAML, kept in double so that derived constants such as
+     * 0.4*truncation or sc_factor*trunc round to fp32 exactly as in the reference */
+    double near_z, far_z;      /* cam.near, cam.far */
+    double range_d;            /* training.range_d     */
+    double perturb;            /* training.perturb     */
+    double trunc;              /* training.trunc       (render weights, Co-SLAM losses) */
+    double sc_factor;          /* data.sc_factor       */
+    double truncation;         /* model.truncation     (ESLAM losses) */
+    double depth_trunc;        /* cam.depth_trunc      */
+    int32_t n_samples;         /* training.n_samples   (target_d == NULL path) */
+    int32_t n_samples_d;       /* training.n_samples_d */
+    int32_t n_range_d;         /* training.n_range_d   */
+    int32_t reserved;
+} mne_render_cfg_t;
+
+/* Per-tensor view for the fused Adam step. */
+typedef struct mne_adam_seg {
+    float* p; float* g; float* m; float* v;
+    int64_t n;
+    double lr, beta1, beta2, eps, weight_decay;   /* python floats of the param group */
+    int32_t step;          /* 1-based step number of this tensor's group */
+    int32_t reserved;
+} mne_adam_seg_t;
+
+/* ---- library ------------------------------------------------------------------------- */
+int mne_abi_version(void);
+const char* mne_last_error(void);
+size_t mne_sizeof_scene(void);
+size_t mne_sizeof_render_cfg(void);
+size_t mne_sizeof_adam_seg(void);
+
+/* Number of samples per ray: n_range_d + n_samples_d with depth guidance, n_samples without
+ * (model/scene_rep.py:362-374). */
+int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d);
+
+/* ---- R3: z sampling -------------------------------------------------------------------- */
+/* Replaces render_rays' sampling block, model/scene_rep.py:362-381: near-surface linspace around
+ * target_d (rays with d<=0 get linspace(near,far)), merged with the uniform samples, sorted, then
+ * stratified jitter lower+(upper-lower)*U.  `u` [R][S] supplies U (the reference draws it with the
+ * CPU generator, :381); NULL = counter-based Philox4x32-10 (seed, offset) on the device.
+ * `target_d` NULL = linspace(near,far,n_samples).  `lin_tables` (device) holds the linspace
+ * values themselves, computed by the host exactly as the reference computes them (torch.linspace
+ * on the CPU, :363-373): with depth  [linspace(near,far,n_samples_d) | linspace(-range_d,range_d,
+ * n_range_d) | linspace(near,far,n_range_d)], without  [linspace(near,far,n_samples)].  Also counts the loss masks that depend only on
+ * z and target_d (scene_rep.py:489-499, :570; model/utils.py:131-145) into counts[MNE_N_COUNT]
+ * (int32; zeroed by the call).  `target_d` is [R]. */
+int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d, const float* u,
+                 const float* lin_tables, uint64_t seed, uint64_t offset, float* z_vals,
+                 int32_t* counts, void* stream);
+
+/* ---- R8 helper: decoder weights in the kernels' packed form ------------------------------ */
+size_t mne_packed_decoder_floats(const mne_scene_t* scene);
+int mne_pack_decoder(const mne_scene_t* scene, float* packed, void* stream);
+
+/* ---- R4-R9 (+R10 partial sums): forward -------------------------------------------------- */
+/* Replaces JointEncoding.render_rays' body after sampling, model/scene_rep.py:384-386 ->
+ * run_network (:303-317) -> query_color_sdf (:273-301: tri-plane bilinear lookup :28-53,
+ * OneBlob model/encodings.py:61-71, decoder model/decoder.py:143-175) -> raw2outputs/sdf2weights
+ * (:183-230).  Outputs (any may be NULL except raw): rgb [R][3], depth/disp/acc/depth_var [R],
+ * raw [R][S][4].  When target_rgb/target_d are given, ray_sums [R][MNE_N_LOSS] receives each ray's
+ * partial sums of the seven losses of JointEncoding.forward (:570-590). */
+int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                       const float* rays_o, const float* rays_d, const float* target_rgb,
+                       const float* target_d, const float* z_vals, const float* packed_decoder,
+                       float* rgb, float* depth, float* disp, float* acc, float* depth_var,
+                       float* raw, float* ray_sums, void* stream);
+
+/* ---- R10: loss scalars ------------------------------------------------------------------- */
+/* losses[MNE_N_LOSS] = rgb, depth, co_sdf, co_fs, e_fs, e_center, e_tail, psnr with the reference's
+ * normalisations (means over selections; empty selection -> NaN; Co-SLAM count weights). */
+int mne_loss_finalize(int n_rays, int n_samples, const float* ray_sums, const int32_t* counts,
+                      float* losses, void* stream);
+
+/* d(total)/d(sample) coefficients from d(total)/d(loss_k) (`grad_losses`, device, 7 floats in
+ * MNE_L_* order: the weights of MNESLAM.get_loss_from_ret, mneslam_mp.py:350-372, or whatever
+ * autograd hands back) and the mask counts. coef is 8 floats on the device. */
+int mne_loss_coef(const mne_render_cfg_t* cfg, int n_rays, int n_samples, const int32_t* counts,
+                  const float* grad_losses, float* coef, void* stream);
+
+/* ---- backward of R4-R10 (+R13) ----------------------------------------------------------- */
+/* Rows of the decoder-gradient tape (per contributing sample). */
+size_t mne_tape_row_floats(const mne_scene_t* scene);
+/* Replaces loss.backward() through the graph built by JointEncoding.forward
+ * (mp_slam/mapper.py:159): accumulates plane gradients into scene->plane[..].grad (atomic adds,
+ * buffers must be zeroed by the caller / the fused Adam), writes one tape row per contributing
+ * sample for mne_decoder_wgrad, and optionally d/d rays_o, d/d rays_d [R][3] (R13: pose
+ * optimisation in loop closure, mp_slam/mapper.py:388-408).  `coef` from mne_loss_coef (NULL = no
+ * loss terms); g_rgb [R][3] / g_depth [R] are optional extra upstream gradients of the rendered
+ * maps (callers that build their own loss on render_rays outputs).  `raw` is the forward's output
+ * for the same inputs.  tape_rows (int32 device counter) must be zero on entry. */
+int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                        const float* rays_o, const float* rays_d, const float* target_rgb,
+                        const float* target_d, const float* z_vals, const float* packed_decoder,
+                        const float* raw, const float* coef, const float* g_rgb, const float* g_depth,
+                        float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                        float* d_rays_o, float* d_rays_d, void* stream);
+
+/* Decoder weight gradients from the tape: dW = sum_rows outer(d_out, in) for the four matrices,
+ * written as [w_col0 | w_col1 | w_sdf0 | w_sdf1] (the order of decoder.parameters(),
+ * model/decoder.py:150-159) into grad_out.  `partials` is scratch of
+ * mne_wgrad_partial_floats() floats.  impl: 0 = MFMA (v_mfma_f32_32x32x2_f32), 1 = scalar check. */
+size_t mne_decoder_param_floats(const mne_scene_t* scene);
+size_t mne_wgrad_partial_floats(const mne_scene_t* scene);
+int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* tape_rows,
+                      float* partials, float* grad_out, int impl, void* stream);
+
+/* ---- R12: fused dense Adam --------------------------------------------------------------- */
+/* Replaces torch.optim.Adam.step() + zero_grad() over the groups of MNESLAM.create_optimizer
+ * (mneslam_mp.py:459-469): one pass, m = lerp(m,g,1-b1); v = b2 v + (1-b2) g^2;
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); weight_decay is L2 into g; g is zeroed
+ * when zero_grad != 0.  segs is a HOST array of n_seg (<= 32) entries. */
+int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* stream);
+
+/* ---- point queries (forward only) -------------------------------------------------------- */
+/* Replaces JointEncoding.query_color_sdf / query_sdf / run_network_flat (scene_rep.py:232-331):
+ * raw [N][4] for arbitrary points [N][3]; geo (optional) [N][geo_feat_dim]. */
+#define MNE_QUERY_PTS_NORMALISED 1   /* pts are already in [-1,1] plane coordinates (feat only) */
+int mne_query_points(const mne_scene_t* scene, int64_t n_pts, const float* pts,
+                     const float* packed_decoder, float* raw, float* geo, float* feat, int flags,
+                     void* stream);
+
+/* ---- R7: OneBlob encoding as a stand-alone op -------------------------------------------- */
+/* Replaces tcnn.Encoding(otype="OneBlob", n_bins=16) (model/encodings.py:61-71):
+ * x [N][dims] in [0,1] -> out [N][dims*16], layout [dim0 bins | dim1 bins | ...]. */
+int mne_encode_oneblob(int64_t n_pts, int dims, const float* x, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNESLAM_HIP_H */

@@ -1,0 +1,129 @@
+"""ctypes binding of libmneslam_hip.so (C ABI: include/mneslam_hip.h).
+
+The library is the only compute backend of this package.  If it is missing the import of any hot
+path raises -- there is deliberately no CPU/PyTorch fallback.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmneslam_hip.so")
+
+N_LOSS = 8
+N_COUNT = 8
+L_RGB, L_DEPTH, L_CO_SDF, L_CO_FS, L_E_FS, L_E_CENTER, L_E_TAIL, L_PSNR = range(8)
+
+
+class Plane(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("grad", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("n_sets", C.c_int32), ("c_dim", C.c_int32), ("hidden", C.c_int32), ("hidden_color", C.c_int32),
+                ("geo_feat_dim", C.c_int32), ("n_bins", C.c_int32), ("bb_is_f64", C.c_int32), ("reserved", C.c_int32),
+                ("plane", Plane * 2 * 3 * 2),          # [set][orient][level]
+                ("bound_lo", C.c_float * 3), ("bound_hi", C.c_float * 3),
+                ("bb_lo", C.c_double * 3), ("bb_hi", C.c_double * 3),
+                ("w_sdf0", C.c_void_p), ("w_sdf1", C.c_void_p), ("w_col0", C.c_void_p), ("w_col1", C.c_void_p)]
+
+
+class RenderCfg(C.Structure):
+    _fields_ = [("near_z", C.c_double), ("far_z", C.c_double), ("range_d", C.c_double), ("perturb", C.c_double),
+                ("trunc", C.c_double), ("sc_factor", C.c_double), ("truncation", C.c_double),
+                ("depth_trunc", C.c_double), ("n_samples", C.c_int32), ("n_samples_d", C.c_int32),
+                ("n_range_d", C.c_int32), ("reserved", C.c_int32)]
+
+
+class AdamSeg(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
+
+
+# Plane * 2 * 3 * 2 builds [2][3][2] read right-to-left: ((Plane*2)*3)*2 == plane[2][3][2]  (set, orient, level)
+
+_PROTOS = {
+    "mne_abi_version": (C.c_int, []),
+    "mne_last_error": (C.c_char_p, []),
+    "mne_sizeof_scene": (C.c_size_t, []),
+    "mne_sizeof_render_cfg": (C.c_size_t, []),
+    "mne_sizeof_adam_seg": (C.c_size_t, []),
+    "mne_num_samples": (C.c_int, [C.POINTER(RenderCfg), C.c_int]),
+    "mne_sample_z": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_packed_decoder_floats": (C.c_size_t, [C.POINTER(Scene)]),
+    "mne_pack_decoder": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p]),
+    "mne_render_forward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 14),
+    "mne_loss_finalize": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_loss_coef": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_tape_row_floats": (C.c_size_t, [C.POINTER(Scene)]),
+    "mne_render_backward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 11
+                            + [C.c_int64] + [C.c_void_p] * 4),
+    "mne_decoder_param_floats": (C.c_size_t, [C.POINTER(Scene)]),
+    "mne_wgrad_partial_floats": (C.c_size_t, [C.POINTER(Scene)]),
+    "mne_decoder_wgrad": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.c_void_p]),
+    "mne_query_points": (C.c_int, [C.POINTER(Scene), C.c_int64] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
+    "mne_encode_oneblob": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load(path=None):
+    """Load (once) and return the library.  ``path`` overrides the in-tree location; the test-suite
+    uses it to inject its host-emulation build -- the package itself never looks anywhere else."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise RuntimeError(
+                f"{p} not found: the HIP library is the only backend of mneslam_amd. "
+                "Build it with `python -m mneslam_amd.build` (needs hipcc; cross-compiles gfx950 without a GPU).")
+        lib = C.CDLL(p)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(lib, name)          # AttributeError = the library does not export the ABI
+            fn.restype, fn.argtypes = res, args
+        if lib.mne_abi_version() != 1:
+            raise RuntimeError("libmneslam_hip ABI version mismatch")
+        for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
+                       (lib.mne_sizeof_adam_seg, AdamSeg)):
+            if fn() != C.sizeof(st):
+                raise RuntimeError(f"struct layout mismatch for {st.__name__}: C {fn()} vs ctypes {C.sizeof(st)}")
+        _lib = lib
+        return lib
+
+
+def unload():
+    global _lib
+    with _lock:
+        _lib = None
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mne_last_error()
+        raise RuntimeError(f"libmneslam_hip {what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host, under the test emulator) address of a tensor, or None."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_for(t):
+    """The caller's current HIP stream (kernels must run on the mapping
+    thread's current stream)."""
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None

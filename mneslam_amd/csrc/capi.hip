@@ -1,0 +1,240 @@
+// capi.hip -- extern "C" entry points of libmneslam_hip.so (declared in include/mneslam_hip.h).
+// Argument validation, derivation of the fp32 constants from the YAML doubles, kernel launches on
+// the caller's stream.  No device allocation, no synchronisation, no state kept between calls.
+#include <cmath>
+#include <cstdio>
+#include <string>
+
+#include "mne_launch.h"
+
+long long mne_adam_blocks_for(long long n);
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-10, std::string(what) + ": " + hipGetErrorString(e));
+    return 0;
+}
+
+static int check_scene(const mne_scene_t* sc, bool need_grad) {
+    if (!sc) return fail(-1, "scene is NULL");
+    if (sc->n_sets != 1 && sc->n_sets != 2) return fail(-1, "n_sets must be 1 (oneGrid) or 2 (with colour planes)");
+    if (sc->c_dim != 32) return fail(-1, "model.c_dim must be 32 in this build");
+    if (sc->n_bins != 16) return fail(-1, "pos.n_bins must be 16 in this build");
+    if (sc->geo_feat_dim != 15) return fail(-1, "decoder.geo_feat_dim must be 15 in this build");
+    if (!((sc->hidden == 32 && sc->hidden_color == 32) || (sc->hidden == 64 && sc->hidden_color == 64)))
+        return fail(-2, "decoder hidden_dim/hidden_dim_color must both be 32 or both 64 in this build");
+    for (int s = 0; s < sc->n_sets; ++s)
+        for (int o = 0; o < 3; ++o)
+            for (int l = 0; l < 2; ++l) {
+                const mne_plane_t& p = sc->plane[s][o][l];
+                if (!p.data || p.h < 1 || p.w < 1) return fail(-1, "plane pointer/shape missing");
+                if (need_grad && !p.grad) return fail(-1, "plane gradient buffer missing");
+                if ((long long)p.h * p.w * sc->c_dim >= (1ll << 31)) return fail(-1, "plane too large for 32-bit offsets");
+            }
+    if (!sc->w_sdf0 || !sc->w_sdf1 || !sc->w_col0 || !sc->w_col1) return fail(-1, "decoder weight pointer missing");
+    return 0;
+}
+
+static void fill_render_consts(RenderArgs& a, const mne_render_cfg_t* cfg) {
+    a.trunc_f = (float)cfg->trunc;
+    a.win_f = (float)(cfg->sc_factor * cfg->trunc);       // python: sc_factor * trunc, then fp32
+    a.e_T = (float)cfg->truncation;
+    a.e_T04 = (float)(0.4 * cfg->truncation);
+    a.depth_trunc = (float)cfg->depth_trunc;
+}
+
+static size_t render_lds(int S, int nsets) {
+    const int Spad = (S + 3) & ~3;
+    return (size_t)(64 * 4 + nsets * 64 * 68 + 2 * Spad) * sizeof(float) + (size_t)((S + 1) & ~1) * 2;
+}
+
+extern "C" {
+
+int mne_abi_version(void) { return MNE_ABI_VERSION; }
+const char* mne_last_error(void) { return g_err.c_str(); }
+size_t mne_sizeof_scene(void) { return sizeof(mne_scene_t); }
+size_t mne_sizeof_render_cfg(void) { return sizeof(mne_render_cfg_t); }
+size_t mne_sizeof_adam_seg(void) { return sizeof(mne_adam_seg_t); }
+
+int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d) {
+    if (!cfg) return fail(-1, "cfg is NULL");
+    return has_target_d ? cfg->n_range_d + cfg->n_samples_d : cfg->n_samples;
+}
+
+int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d, const float* u,
+                 const float* lin_tables, uint64_t seed, uint64_t offset, float* z_vals, int32_t* counts,
+                 void* stream) {
+    if (!cfg || !z_vals || !lin_tables) return fail(-1, "mne_sample_z: NULL argument");
+    if (n_rays <= 0) return 0;
+    ZArgs a;
+    a.R = n_rays;
+    a.has_d = target_d != nullptr;
+    a.n_a = a.has_d ? cfg->n_samples_d : 0;
+    a.n_b = a.has_d ? cfg->n_range_d : 0;
+    a.S = a.has_d ? a.n_a + a.n_b : cfg->n_samples;
+    if (a.S < 1 || a.S > 16384) return fail(-1, "mne_sample_z: samples per ray out of range [1,16384]");
+    a.perturb = (float)cfg->perturb;
+    a.e_T = (float)cfg->truncation;
+    a.e_T04 = (float)(0.4 * cfg->truncation);
+    a.co_T = (float)(cfg->trunc * cfg->sc_factor);
+    a.depth_trunc = (float)cfg->depth_trunc;
+    a.target_d = target_d;
+    a.u = u;
+    a.tables = lin_tables;
+    a.seed = seed;
+    a.offset = offset;
+    a.z_vals = z_vals;
+    a.counts = counts;
+    hipStream_t st = (hipStream_t)stream;
+    if (counts) {
+        if (hipMemsetAsync(counts, 0, MNE_N_COUNT * sizeof(int32_t), st) != hipSuccess) return fail(-10, "memset(counts) failed");
+    } else if (a.has_d) {
+        return fail(-1, "mne_sample_z: counts buffer required when target_d is given");
+    }
+    mne_launch_sample_z(a, st);
+    return check_launch("sample_z");
+}
+
+size_t mne_packed_decoder_floats(const mne_scene_t* scene) { return scene ? mne_dims_packed(*scene) : 0; }
+size_t mne_tape_row_floats(const mne_scene_t* scene) { return scene ? mne_dims_tape_row(*scene) : 0; }
+size_t mne_decoder_param_floats(const mne_scene_t* scene) { return scene ? mne_dims_nparam(*scene) : 0; }
+size_t mne_wgrad_partial_floats(const mne_scene_t* scene) {
+    return scene ? mne_dims_nparam(*scene) * (size_t)mne_wgrad_waves() : 0;
+}
+
+int mne_pack_decoder(const mne_scene_t* scene, float* packed, void* stream) {
+    if (int rc = check_scene(scene, false)) return rc;
+    if (!packed) return fail(-1, "mne_pack_decoder: packed is NULL");
+    if (int rc = mne_launch_pack(*scene, packed, (hipStream_t)stream)) return fail(rc, "unsupported decoder shape");
+    return check_launch("pack_decoder");
+}
+
+int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                       const float* rays_o, const float* rays_d, const float* target_rgb,
+                       const float* target_d, const float* z_vals, const float* packed_decoder,
+                       float* rgb, float* depth, float* disp, float* acc, float* depth_var,
+                       float* raw, float* ray_sums, void* stream) {
+    if (int rc = check_scene(scene, false)) return rc;
+    if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw) return fail(-1, "mne_render_forward: NULL argument");
+    if (n_rays <= 0) return 0;
+    if (n_samples < 1 || n_samples > 16384) return fail(-1, "samples per ray out of range");
+    if (render_lds(n_samples, scene->n_sets) > 64 * 1024) return fail(-1, "samples per ray too large for the LDS staging");
+    if (ray_sums && (!target_rgb || !target_d)) return fail(-1, "ray_sums needs target_rgb and target_d");
+    RenderArgs a = {};
+    a.sc = *scene;
+    a.R = n_rays; a.S = n_samples;
+    fill_render_consts(a, cfg);
+    a.rays_o = rays_o; a.rays_d = rays_d; a.target_rgb = target_rgb; a.target_d = target_d;
+    a.z_vals = z_vals; a.packed = packed_decoder;
+    a.rgb = rgb; a.depth = depth; a.disp = disp; a.acc = acc; a.depth_var = depth_var; a.raw = raw;
+    a.ray_sums = ray_sums;
+    if (int rc = mne_launch_render(a, 1, 0, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    return check_launch("render_forward");
+}
+
+int mne_loss_finalize(int n_rays, int n_samples, const float* ray_sums, const int32_t* counts, float* losses,
+                      void* stream) {
+    if (!ray_sums || !counts || !losses) return fail(-1, "mne_loss_finalize: NULL argument");
+    LossArgs a = {};
+    a.R = n_rays; a.S = n_samples; a.ray_sums = ray_sums; a.counts = counts; a.losses = losses;
+    mne_launch_loss_finalize(a, (hipStream_t)stream);
+    return check_launch("loss_finalize");
+}
+
+int mne_loss_coef(const mne_render_cfg_t* cfg, int n_rays, int n_samples, const int32_t* counts,
+                  const float* grad_losses, float* coef, void* stream) {
+    if (!cfg || !counts || !grad_losses || !coef) return fail(-1, "mne_loss_coef: NULL argument");
+    LossArgs a = {};
+    a.R = n_rays; a.S = n_samples; a.counts = counts; a.grad_losses = grad_losses; a.coef = coef;
+    a.e_T = (float)cfg->truncation;
+    a.co_T = (float)(cfg->trunc * cfg->sc_factor);
+    mne_launch_loss_coef(a, (hipStream_t)stream);
+    return check_launch("loss_coef");
+}
+
+int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                        const float* rays_o, const float* rays_d, const float* target_rgb,
+                        const float* target_d, const float* z_vals, const float* packed_decoder,
+                        const float* raw, const float* coef, const float* g_rgb, const float* g_depth,
+                        float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                        float* d_rays_o, float* d_rays_d, void* stream) {
+    if (int rc = check_scene(scene, true)) return rc;
+    if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows)
+        return fail(-1, "mne_render_backward: NULL argument");
+    if (n_rays <= 0) return 0;
+    if (n_samples < 1 || render_lds(n_samples, scene->n_sets) > 64 * 1024) return fail(-1, "samples per ray out of range");
+    if (tape_capacity_rows < (int64_t)n_rays * n_samples) return fail(-1, "tape must hold n_rays*n_samples rows");
+    if (coef && (!target_rgb || !target_d)) return fail(-1, "loss coefficients need target_rgb and target_d");
+    if (d_rays_o || d_rays_d) return fail(-3, "ray gradients are not available in this build yet");
+    RenderArgs a = {};
+    a.sc = *scene;
+    a.R = n_rays; a.S = n_samples;
+    fill_render_consts(a, cfg);
+    a.rays_o = rays_o; a.rays_d = rays_d; a.target_rgb = target_rgb; a.target_d = target_d;
+    a.z_vals = z_vals; a.packed = packed_decoder; a.raw_in = raw;
+    a.coef = coef; a.g_rgb = g_rgb; a.g_depth = g_depth;
+    a.tape = tape; a.tape_cap = tape_capacity_rows; a.tape_rows = tape_rows;
+    a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d;
+    if (int rc = mne_launch_render(a, 0, 1, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    return check_launch("render_backward");
+}
+
+int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* tape_rows, float* partials,
+                      float* grad_out, int impl, void* stream) {
+    if (int rc = check_scene(scene, false)) return rc;
+    if (!tape || !tape_rows || !grad_out || (impl == 0 && !partials)) return fail(-1, "mne_decoder_wgrad: NULL argument");
+    WgradArgs a = {};
+    a.tape = tape; a.tape_rows = tape_rows; a.partials = partials; a.grad_out = grad_out;
+    if (int rc = mne_launch_wgrad(*scene, a, impl, (hipStream_t)stream)) return fail(rc, "unsupported decoder shape");
+    return check_launch("decoder_wgrad");
+}
+
+int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* stream) {
+    if (n_seg < 0 || n_seg > 32) return fail(-1, "mne_adam_step: n_seg must be in [0,32]");
+    if (n_seg == 0) return 0;
+    if (!segs) return fail(-1, "mne_adam_step: segs is NULL");
+    AdamArgs a = {};
+    a.n_seg = n_seg;
+    a.zero_grad = zero_grad;
+    a.blk_start[0] = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        const mne_adam_seg_t& g = segs[s];
+        if (!g.p || !g.g || !g.m || !g.v || g.n < 0 || g.step < 1) return fail(-1, "mne_adam_step: bad segment");
+        a.seg[s] = g;
+        const double bc1 = 1.0 - std::pow(g.beta1, (double)g.step);
+        const double bc2 = 1.0 - std::pow(g.beta2, (double)g.step);
+        a.step_size[s] = (float)(g.lr / bc1);
+        a.bc2_sqrt[s] = (float)std::sqrt(bc2);
+        a.blk_start[s + 1] = a.blk_start[s] + mne_adam_blocks_for(g.n);
+    }
+    mne_launch_adam(a, (hipStream_t)stream);
+    return check_launch("adam_step");
+}
+
+int mne_encode_oneblob(int64_t n_pts, int dims, const float* x, float* out, void* stream) {
+    if (!x || !out || dims < 1) return fail(-1, "mne_encode_oneblob: bad argument");
+    if (n_pts <= 0) return 0;
+    mne_launch_oneblob(n_pts, dims, x, out, (hipStream_t)stream);
+    return check_launch("encode_oneblob");
+}
+
+int mne_query_points(const mne_scene_t* scene, int64_t n_pts, const float* pts, const float* packed_decoder,
+                     float* raw, float* geo, float* feat, int flags, void* stream) {
+    if (int rc = check_scene(scene, false)) return rc;
+    if (!pts || ((raw || geo) && !packed_decoder)) return fail(-1, "mne_query_points: NULL argument");
+    if (n_pts <= 0) return 0;
+    QueryArgs a = {};
+    a.sc = *scene; a.n = n_pts; a.pts = pts; a.packed = packed_decoder; a.raw = raw; a.geo = geo; a.feat_out = feat; a.flags = flags;
+    if ((flags & MNE_QUERY_PTS_NORMALISED) && (raw || geo)) return fail(-1, "normalised points only support the feature output");
+    if (int rc = mne_launch_query(a, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    return check_launch("query_points");
+}
+
+}  // extern "C"

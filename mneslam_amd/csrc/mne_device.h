@@ -1,0 +1,288 @@
+// mne_device.h -- device helpers shared by the mapping-path kernels (gfx950 / wave64).
+//
+// Numerics policy: the translation units are compiled with -ffp-contract=off, so the coordinate
+// pipeline (points, normalisation, bilinear indices/weights, z jitter) rounds exactly like the
+// reference's eager fp32 torch ops; FMAs appear only where written as fmaf() (feature
+// accumulation, MLP dot products).
+#pragma once
+#include "mne_platform.h"
+#include "mneslam_hip.h"
+
+#define MNE_WAVE 64
+#define MNE_C 32      // channels per plane (model.c_dim)
+#define MNE_NB 16     // OneBlob bins per dim (pos.n_bins)
+#define MNE_POS 48    // 3 * MNE_NB
+#define MNE_FEAT 64   // 2 levels * MNE_C
+#define MNE_GEO 15    // decoder.geo_feat_dim
+#define MNE_OUT1 16   // 1 sdf + 15 geo
+#define MNE_FS 68     // LDS feature-row stride in floats (64 + 4: 16-B aligned, b128 reads conflict-free)
+#define MNE_IN1 112   // MNE_FEAT + MNE_POS
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- Philox4x32-10 (counter-based RNG for the on-device jitter) -------------------------------
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t elem) {
+    uint64_t ctr = offset + (elem >> 2);
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    uint32_t w = (elem & 3) == 0 ? c0 : (elem & 3) == 1 ? c1 : (elem & 3) == 2 ? c2 : c3;
+    return (float)(w >> 8) * (1.0f / 16777216.0f);      // [0,1), 24 bits like torch.rand
+}
+
+// ---- coordinates --------------------------------------------------------------------------------
+// Plane lookup uses the EXTENDED bound -> [-1,1] (model/utils.py:38-40); OneBlob uses the RAW
+// bounding box -> [0,1], in fp64 when the box is float64 (model/scene_rep.py:292).
+__device__ __forceinline__ void point_coords(const mne_scene_t& sc, const float p[3], float pn[3], float u[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pn[k] = ((p[k] - sc.bound_lo[k]) / (sc.bound_hi[k] - sc.bound_lo[k])) * 2.0f - 1.0f;
+        if (sc.bb_is_f64) {
+            u[k] = (float)(((double)p[k] - sc.bb_lo[k]) / (sc.bb_hi[k] - sc.bb_lo[k]));
+        } else {
+            float lo = (float)sc.bb_lo[k], hi = (float)sc.bb_hi[k];
+            u[k] = (p[k] - lo) / (hi - lo);
+        }
+    }
+}
+
+// ---- bilinear corner set (ATen grid_sampler_2d: bilinear, align_corners=True, border) ----------
+struct Bilin {
+    int o00, o01, o10, o11;       // float offsets of the corner rows (nw, ne, sw, se), clamped in-range
+    float w00, w01, w10, w11;     // weights; 0 for corners outside the plane (skipped by ATen)
+    int ix0, iy0;                 // the integer NW corner ("bit-exact indices" of this path)
+};
+
+__device__ __forceinline__ float unnormalize_clip(float g, int size) {
+    float v = ((g + 1.0f) / 2.0f) * (float)(size - 1);
+    return fminf((float)(size - 1), fmaxf(v, 0.0f));
+}
+
+__device__ __forceinline__ void bilin_setup(float gx, float gy, int H, int W, Bilin& b) {
+    float fx = unnormalize_clip(gx, W), fy = unnormalize_clip(gy, H);
+    float x0 = floorf(fx), y0 = floorf(fy);
+    float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    float nw = (x1 - fx) * (y1 - fy), ne = (fx - x0) * (y1 - fy);
+    float sw = (x1 - fx) * (fy - y0), se = (fx - x0) * (fy - y0);
+    int ix0 = (int)x0, iy0 = (int)y0;
+    bool xin = ix0 + 1 < W, yin = iy0 + 1 < H;
+    int ix1 = xin ? ix0 + 1 : ix0, iy1 = yin ? iy0 + 1 : iy0;
+    b.ix0 = ix0; b.iy0 = iy0;
+    b.o00 = (iy0 * W + ix0) * MNE_C; b.o01 = (iy0 * W + ix1) * MNE_C;
+    b.o10 = (iy1 * W + ix0) * MNE_C; b.o11 = (iy1 * W + ix1) * MNE_C;
+    b.w00 = nw; b.w01 = xin ? ne : 0.0f; b.w10 = yin ? sw : 0.0f; b.w11 = (xin && yin) ? se : 0.0f;
+}
+
+__device__ __forceinline__ void orient_coords(int orient, float px, float py, float pz, float& gx, float& gy) {
+    // xy -> (x,y); xz -> (x,z); yz -> (y,z): first coordinate indexes W (model/scene_rep.py:43-47)
+    gx = orient == MNE_YZ ? py : px;
+    gy = orient == MNE_XY ? py : pz;
+}
+
+// ---- OneBlob (oracle/oneblob.py is the spec; tinycudann's published quartic-kernel OneBlob) ----
+__device__ __forceinline__ float quartic_cdf(float t) {
+    float u = t * 16.0f;
+    float u2 = u * u;
+    float u4 = u2 * u2;
+    float poly = (0.9375f * u) * ((1.0f - 0.6666666666666666f * u2) + 0.2f * u4) + 0.5f;
+    return fminf(1.0f, fmaxf(poly, 0.0f));
+}
+
+__device__ __forceinline__ void oneblob16(float x, float* out /*16*/) {
+    float c[MNE_NB];
+#pragma unroll
+    for (int b = 0; b < MNE_NB; ++b) {
+        float t = (float)b * 0.0625f - x;
+        c[b] = (quartic_cdf(t) + quartic_cdf(t - 1.0f)) + quartic_cdf(t + 1.0f);
+    }
+#pragma unroll
+    for (int b = 0; b < MNE_NB - 1; ++b) out[b] = c[b + 1] - c[b];
+    out[MNE_NB - 1] = (c[0] + 1.0f) - c[MNE_NB - 1];
+}
+
+// ---- gather: tri-plane features of the 64 staged points -> LDS rows ---------------------------
+// Lane layout: 8 lanes x float4 cover one 128-B corner row, 8 points per pass (coalesced rows).
+// pn: LDS [64][4] normalised points; feat: LDS [64][MNE_FS]; set s uses rows of `feat + s*64*MNE_FS`.
+template <int NSETS>
+__device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane) {
+    const int cg = lane & 7;
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const int slot = it * 8 + (lane >> 3);
+        const float px = pn[slot * 4 + 0], py = pn[slot * 4 + 1], pz = pn[slot * 4 + 2];
+#pragma unroll
+        for (int set = 0; set < NSETS; ++set) {
+#pragma unroll
+            for (int lvl = 0; lvl < 2; ++lvl) {
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ori = 0; ori < 3; ++ori) {
+                    const mne_plane_t& pl = sc.plane[set][ori][lvl];
+                    float gx, gy;
+                    orient_coords(ori, px, py, pz, gx, gy);
+                    Bilin b;
+                    bilin_setup(gx, gy, pl.h, pl.w, b);
+                    const float* base = pl.data + cg * 4;
+                    const float4 v00 = *(const float4*)(base + b.o00);
+                    const float4 v01 = *(const float4*)(base + b.o01);
+                    const float4 v10 = *(const float4*)(base + b.o10);
+                    const float4 v11 = *(const float4*)(base + b.o11);
+                    float4 acc;
+                    acc.x = v00.x * b.w00; acc.y = v00.y * b.w00; acc.z = v00.z * b.w00; acc.w = v00.w * b.w00;
+                    acc.x = fmaf(v01.x, b.w01, acc.x); acc.y = fmaf(v01.y, b.w01, acc.y);
+                    acc.z = fmaf(v01.z, b.w01, acc.z); acc.w = fmaf(v01.w, b.w01, acc.w);
+                    acc.x = fmaf(v10.x, b.w10, acc.x); acc.y = fmaf(v10.y, b.w10, acc.y);
+                    acc.z = fmaf(v10.z, b.w10, acc.z); acc.w = fmaf(v10.w, b.w10, acc.w);
+                    acc.x = fmaf(v11.x, b.w11, acc.x); acc.y = fmaf(v11.y, b.w11, acc.y);
+                    acc.z = fmaf(v11.z, b.w11, acc.z); acc.w = fmaf(v11.w, b.w11, acc.w);
+                    sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;   // xy + xz + yz
+                }
+                *(float4*)(feat + set * 64 * MNE_FS + slot * MNE_FS + lvl * MNE_C + cg * 4) = sum;
+            }
+        }
+    }
+}
+
+// ---- scatter: d(feature) rows in LDS -> atomic adds into the plane gradients -------------------
+// Lane layout: 32 lanes = the 32 channels of one corner row (one 128-B line per half-wave).
+template <int NSETS>
+__device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float* pn, const float* dfeat,
+                                              int n_valid, int lane) {
+    const int c = lane & 31, half = lane >> 5;
+#pragma unroll 1
+    for (int it = 0; it < 32; ++it) {
+        const int slot = it * 2 + half;
+        if (slot < n_valid) {
+            const float px = pn[slot * 4 + 0], py = pn[slot * 4 + 1], pz = pn[slot * 4 + 2];
+#pragma unroll
+            for (int set = 0; set < NSETS; ++set) {
+#pragma unroll
+                for (int lvl = 0; lvl < 2; ++lvl) {
+                    const float g = dfeat[set * 64 * MNE_FS + slot * MNE_FS + lvl * MNE_C + c];
+#pragma unroll
+                    for (int ori = 0; ori < 3; ++ori) {
+                        const mne_plane_t& pl = sc.plane[set][ori][lvl];
+                        float gx, gy;
+                        orient_coords(ori, px, py, pz, gx, gy);
+                        Bilin b;
+                        bilin_setup(gx, gy, pl.h, pl.w, b);
+                        float* base = pl.grad + c;
+                        unsafeAtomicAdd(base + b.o00, g * b.w00);
+                        if (b.w01 != 0.0f) unsafeAtomicAdd(base + b.o01, g * b.w01);
+                        if (b.w10 != 0.0f) unsafeAtomicAdd(base + b.o10, g * b.w10);
+                        if (b.w11 != 0.0f) unsafeAtomicAdd(base + b.o11, g * b.w11);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- decoder dimensions --------------------------------------------------------------------------
+template <int HID, int HIDC, bool CP>
+struct DecDims {
+    static constexpr int CINB = CP ? (MNE_POS + MNE_FEAT) : MNE_POS;   // where geo starts in the colour input
+    static constexpr int CIN = CINB + MNE_GEO;                           // 63 or 127
+    static constexpr int CINP = CP ? 128 : 64;                           // padded (tape)
+    // packed (transposed) decoder: W1T [112][HID] | W2T [HID][16] | V1T [CIN][HIDC] | V2T [HIDC][4]
+    static constexpr int OFF_W1T = 0;
+    static constexpr int OFF_W2T = OFF_W1T + MNE_IN1 * HID;
+    static constexpr int OFF_V1T = OFF_W2T + HID * MNE_OUT1;
+    static constexpr int OFF_V2T = OFF_V1T + CIN * HIDC;
+    static constexpr int PACKED = OFF_V2T + HIDC * 4;
+    // tape row: X[112] | H[HID] | DH[HID] | DOUT[16] | CIN[CINP] | HC[HIDC] | DHC[HIDC] | DC[4]
+    static constexpr int T_X = 0;
+    static constexpr int T_H = T_X + MNE_IN1;
+    static constexpr int T_DH = T_H + HID;
+    static constexpr int T_DOUT = T_DH + HID;
+    static constexpr int T_CIN = T_DOUT + MNE_OUT1;
+    static constexpr int T_HC = T_CIN + CINP;
+    static constexpr int T_DHC = T_HC + HIDC;
+    static constexpr int T_DC = T_DHC + HIDC;
+    static constexpr int ROW = T_DC + 4;
+    // decoder parameter buffer (order of decoder.parameters()): col0 | col1 | sdf0 | sdf1
+    static constexpr int P_COL0 = 0;
+    static constexpr int P_COL1 = P_COL0 + HIDC * CIN;
+    static constexpr int P_SDF0 = P_COL1 + 3 * HIDC;
+    static constexpr int P_SDF1 = P_SDF0 + HID * MNE_IN1;
+    static constexpr int NPARAM = P_SDF1 + MNE_OUT1 * HID;
+};
+
+// ---- tiny-MLP forward for one point per lane ---------------------------------------------------
+// frow / cfrow: this lane's LDS feature rows (64 floats each); pos: OneBlob(48) in registers.
+// Weights come through the constant address space (scalar loads -> SGPR operands of the FMAs).
+template <int HID, int HIDC, bool CP>
+__device__ __forceinline__ void mlp_forward(const float* frow, const float* cfrow, const float (&pos)[MNE_POS],
+                                            mne_cptr pk, float (&h)[HID], float (&out)[MNE_OUT1],
+                                            float (&hc)[HIDC], float (&rgb)[3]) {
+    typedef DecDims<HID, HIDC, CP> D;
+    mne_cptr w1t = pk + D::OFF_W1T, w2t = pk + D::OFF_W2T, v1t = pk + D::OFF_V1T, v2t = pk + D::OFF_V2T;
+#pragma unroll
+    for (int j = 0; j < HID; ++j) h[j] = 0.0f;
+#pragma unroll
+    for (int k4 = 0; k4 < MNE_FEAT / 4; ++k4) {
+        const float4 x = *(const float4*)(frow + 4 * k4);
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < HID; ++j) h[j] = fmaf(w1t[(4 * k4 + kk) * HID + j], xs[kk], h[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < MNE_POS; ++k)
+#pragma unroll
+        for (int j = 0; j < HID; ++j) h[j] = fmaf(w1t[(MNE_FEAT + k) * HID + j], pos[k], h[j]);
+#pragma unroll
+    for (int j = 0; j < HID; ++j) h[j] = fmaxf(h[j], 0.0f);
+#pragma unroll
+    for (int m = 0; m < MNE_OUT1; ++m) out[m] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < HID; ++j)
+#pragma unroll
+        for (int m = 0; m < MNE_OUT1; ++m) out[m] = fmaf(w2t[j * MNE_OUT1 + m], h[j], out[m]);
+    // colour net input = [pos(48), (colour-plane features 64), geo(15)]  (model/decoder.py:137,170)
+#pragma unroll
+    for (int j = 0; j < HIDC; ++j) hc[j] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MNE_POS; ++k)
+#pragma unroll
+        for (int j = 0; j < HIDC; ++j) hc[j] = fmaf(v1t[k * HIDC + j], pos[k], hc[j]);
+    if (CP) {
+#pragma unroll
+        for (int k4 = 0; k4 < MNE_FEAT / 4; ++k4) {
+            const float4 x = *(const float4*)(cfrow + 4 * k4);
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < HIDC; ++j)
+                    hc[j] = fmaf(v1t[(MNE_POS + 4 * k4 + kk) * HIDC + j], xs[kk], hc[j]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < MNE_GEO; ++g)
+#pragma unroll
+        for (int j = 0; j < HIDC; ++j) hc[j] = fmaf(v1t[(D::CINB + g) * HIDC + j], out[1 + g], hc[j]);
+#pragma unroll
+    for (int j = 0; j < HIDC; ++j) hc[j] = fmaxf(hc[j], 0.0f);
+    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < HIDC; ++j) {
+        rgb[0] = fmaf(v2t[j * 4 + 0], hc[j], rgb[0]);
+        rgb[1] = fmaf(v2t[j * 4 + 1], hc[j], rgb[1]);
+        rgb[2] = fmaf(v2t[j * 4 + 2], hc[j], rgb[2]);
+    }
+}

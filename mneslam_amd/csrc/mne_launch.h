@@ -1,0 +1,84 @@
+// mne_launch.h -- kernel argument blocks and host-side launchers shared by the .hip translation
+// units and the C ABI (capi.cpp).  Internal; the public surface is include/mneslam_hip.h.
+#pragma once
+#include "mne_platform.h"
+#include "mneslam_hip.h"
+
+struct ZArgs {
+    int R, S, n_a, n_b, has_d;
+    float perturb;
+    float e_T, e_T04, co_T, depth_trunc;
+    const float* target_d;
+    const float* u;
+    const float* tables;     // has_d: uniform[n_a] | surface offsets[n_b] | invalid-depth[n_b];  else full[S]
+    uint64_t seed, offset;
+    float* z_vals;
+    int* counts;
+};
+
+struct RenderArgs {
+    mne_scene_t sc;
+    int R, S;
+    float trunc_f;        // (float)training.trunc                  (sdf / trunc)
+    float win_f;          // (float)(data.sc_factor*training.trunc) (render window, Co-SLAM truncation)
+    float e_T, e_T04;     // (float)model.truncation, (float)(0.4*model.truncation)
+    float depth_trunc;
+    const float *rays_o, *rays_d, *target_rgb, *target_d, *z_vals, *packed;
+    float *rgb, *depth, *disp, *acc, *depth_var, *raw, *ray_sums;
+    const float* raw_in;
+    const float *coef, *g_rgb, *g_depth;
+    float* tape;
+    long long tape_cap;
+    int* tape_rows;
+    float *d_rays_o, *d_rays_d;
+};
+
+struct LossArgs {
+    int R, S;
+    const float* ray_sums;
+    const int* counts;
+    float* losses;
+    const float* grad_losses;
+    float* coef;
+    float e_T, co_T;
+};
+
+struct QueryArgs {
+    mne_scene_t sc;
+    long long n;
+    const float* pts;
+    const float* packed;
+    float *raw, *geo, *feat_out;
+    int flags;
+};
+
+struct WgradArgs {
+    const float* tape;
+    const int* tape_rows;
+    float* partials;      // [n_waves][NPARAM]
+    float* grad_out;      // [NPARAM]
+    int n_waves;
+};
+
+struct AdamArgs {
+    mne_adam_seg_t seg[32];
+    float step_size[32];      // lr / (1 - beta1^t)
+    float bc2_sqrt[32];       // sqrt(1 - beta2^t)
+    long long blk_start[33];  // prefix sum of blocks per segment
+    int n_seg;
+    int zero_grad;
+};
+
+int mne_launch_sample_z(const ZArgs& a, hipStream_t st);
+int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
+int mne_launch_render(const RenderArgs& a, int pass1, int bwd, hipStream_t st);
+int mne_launch_query(const QueryArgs& a, hipStream_t st);
+int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStream_t st);
+int mne_launch_loss_finalize(const LossArgs& a, hipStream_t st);
+int mne_launch_loss_coef(const LossArgs& a, hipStream_t st);
+int mne_launch_wgrad(const mne_scene_t& sc, WgradArgs a, int impl, hipStream_t st);
+int mne_launch_adam(const AdamArgs& a, hipStream_t st);
+size_t mne_dims_packed(const mne_scene_t& sc);
+size_t mne_dims_tape_row(const mne_scene_t& sc);
+size_t mne_dims_nparam(const mne_scene_t& sc);
+int mne_wgrad_waves(void);

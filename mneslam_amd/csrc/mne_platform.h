@@ -1,0 +1,16 @@
+// mne_platform.h -- the one place that decides between the real HIP toolchain (the product:
+// hipcc --offload-arch=gfx950) and the test-only host emulator (tests/hostemu/hip_emu.h, used by
+// the CPU test-suite to run these same kernel sources without a GPU).
+#pragma once
+#ifdef MNE_HOST_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define MNE_LAUNCH(kern, grid, block, lds, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
+#define MNE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+// Decoder weights are wave-uniform: reading them through the constant address space makes the
+// compiler use scalar (SMEM) loads, so the tiny-MLP FMAs take their weight operand from SGPRs.
+typedef const __attribute__((address_space(4))) float* mne_cptr;
+#define MNE_CPTR(p) ((mne_cptr)(unsigned long long)(p))
+#endif

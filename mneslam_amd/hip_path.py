@@ -1,0 +1,209 @@
+"""Glue between PyTorch tensors and the C ABI for the render path: struct marshalling, scratch
+allocation (through torch's caching allocator, on the caller's stream) and the autograd node that
+makes ``JointEncoding.forward / render_rays`` differentiable exactly like the reference's graph
+(planes, decoder weights; rays when requested).
+
+Nothing here computes per-sample math in PyTorch: every tensor op below is allocation, a view, or a
+layout conversion of a caller-provided plane.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+# --------------------------------------------------------------------------------------------------
+# marshalling
+# --------------------------------------------------------------------------------------------------
+def render_cfg_struct(config):
+    tr, cam = config["training"], config["cam"]
+    rc = _lib.RenderCfg()
+    rc.near_z, rc.far_z = float(cam["near"]), float(cam["far"])
+    rc.range_d = float(tr["range_d"])
+    rc.perturb = float(tr["perturb"])
+    rc.trunc = float(tr["trunc"])
+    rc.sc_factor = float(config["data"]["sc_factor"])
+    rc.truncation = float(config["model"]["truncation"])
+    rc.depth_trunc = float(cam["depth_trunc"])
+    rc.n_samples = int(tr.get("n_samples", 0) or 0)
+    rc.n_samples_d = int(tr["n_samples_d"])
+    rc.n_range_d = int(tr["n_range_d"])
+    return rc
+
+
+def as_channels_last(plane):
+    """Physical [H][W][C] view of a logical [1,C,H,W] plane (copy only if the caller handed us a
+    plane in another layout, e.g. a peer's NCHW checkpoint; the copy stays in the autograd graph)."""
+    if plane.dim() != 4 or plane.shape[0] != 1:
+        raise ValueError(f"plane must be [1,C,H,W], got {tuple(plane.shape)}")
+    if plane.dtype != torch.float32:
+        raise TypeError("planes must be float32")
+    if plane.is_contiguous(memory_format=torch.channels_last) and plane.stride(1) == 1:
+        return plane
+    return plane.contiguous(memory_format=torch.channels_last)
+
+
+def scene_struct(model_info, planes_cl, dec_w, grads=None):
+    """Fill mne_scene_t.  ``planes_cl``: flat list in all_planes order
+    (xy[coarse,fine], xz[...], yz[...], then the colour planes); ``grads``: same order or None."""
+    sc = _lib.Scene()
+    n_sets = len(planes_cl) // 6
+    sc.n_sets = n_sets
+    sc.c_dim = model_info["c_dim"]
+    sc.hidden, sc.hidden_color = model_info["hidden"], model_info["hidden_color"]
+    sc.geo_feat_dim, sc.n_bins = model_info["geo_feat_dim"], model_info["n_bins"]
+    sc.bb_is_f64 = 1 if model_info["bb_is_f64"] else 0
+    for s in range(n_sets):
+        for o in range(3):
+            for l in range(2):
+                p = planes_cl[s * 6 + o * 2 + l]
+                pl = sc.plane[s][o][l]
+                pl.data = p.data_ptr()
+                pl.h, pl.w = p.shape[2], p.shape[3]
+                pl.grad = grads[s * 6 + o * 2 + l].data_ptr() if grads is not None else None
+    for k in range(3):
+        sc.bound_lo[k], sc.bound_hi[k] = model_info["bound_lo"][k], model_info["bound_hi"][k]
+        sc.bb_lo[k], sc.bb_hi[k] = model_info["bb_lo"][k], model_info["bb_hi"][k]
+    w_sdf0, w_sdf1, w_col0, w_col1 = dec_w
+    sc.w_sdf0, sc.w_sdf1 = w_sdf0.data_ptr(), w_sdf1.data_ptr()
+    sc.w_col0, sc.w_col1 = w_col0.data_ptr(), w_col1.data_ptr()
+    return sc
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def linspace_tables(config, has_depth, device):
+    """The linspace values the reference computes on the CPU with torch.linspace
+    (model/scene_rep.py:363-373), uploaded once per call (a few hundred bytes)."""
+    tr, cam = config["training"], config["cam"]
+    if has_depth:
+        parts = [torch.linspace(cam["near"], cam["far"], tr["n_samples_d"]),
+                 torch.linspace(-tr["range_d"], tr["range_d"], steps=tr["n_range_d"]),
+                 torch.linspace(cam["near"], cam["far"], steps=tr["n_range_d"])]
+        return torch.cat(parts).to(device)
+    return torch.linspace(cam["near"], cam["far"], tr["n_samples"]).to(device)
+
+
+# --------------------------------------------------------------------------------------------------
+# the autograd node
+# --------------------------------------------------------------------------------------------------
+class RenderFunction(torch.autograd.Function):
+    """(rays, targets, jitter, planes..., decoder weights...) ->
+       rgb[R,3], depth[R], disp[R], acc[R], depth_var[R], z_vals[R,S], raw[R,S,4], losses[8].
+
+    forward  = mne_sample_z + mne_pack_decoder + mne_render_forward (+ mne_loss_finalize)
+    backward = mne_loss_coef + mne_render_backward + mne_decoder_wgrad
+    z_vals, raw, disp, acc and depth_var are returned as non-differentiable (the reference's losses
+    on raw/z are computed inside the node)."""
+
+    @staticmethod
+    def forward(ctx, info, tables, rays_o, rays_d, target_rgb, target_d, u, seed_offset, *params):
+        lib = _lib.load()
+        n_planes = info["n_planes"]
+        planes = params[:n_planes]
+        dec_w = params[n_planes:]
+        dev = rays_o.device
+        st = _lib.stream_for(rays_o)
+        rc = info["render_cfg"]
+        R = rays_o.shape[0]
+        has_d = target_d is not None
+        S = lib.mne_num_samples(C.byref(rc), 1 if has_d else 0)
+        rays_o_c, rays_d_c = _f32c(rays_o.detach(), "rays_o"), _f32c(rays_d.detach(), "rays_d")
+        tgt_rgb = _f32c(target_rgb, "target_rgb")
+        tgt_d = _f32c(target_d.reshape(-1), "target_d") if has_d else None
+        u_c = _f32c(u, "u")
+        opts = dict(device=dev, dtype=torch.float32)
+        z_vals = torch.empty(R, S, **opts)
+        counts = torch.zeros(_lib.N_COUNT, device=dev, dtype=torch.int32)
+        seed, offset = seed_offset
+        _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u_c), _lib.ptr(tables), seed, offset,
+                                    _lib.ptr(z_vals), _lib.ptr(counts), st), "mne_sample_z")
+        sc = scene_struct(info, [p.detach() for p in planes], [w.detach() for w in dec_w])
+        packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
+        _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
+        rgb, depth = torch.empty(R, 3, **opts), torch.empty(R, **opts)
+        disp, acc, var = torch.empty(R, **opts), torch.empty(R, **opts), torch.empty(R, **opts)
+        raw = torch.empty(R, S, 4, **opts)
+        want_losses = has_d and target_rgb is not None
+        ray_sums = torch.empty(R, _lib.N_LOSS, **opts) if want_losses else None
+        _lib.check(lib.mne_render_forward(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o_c), _lib.ptr(rays_d_c),
+                                          _lib.ptr(tgt_rgb) if want_losses else None, _lib.ptr(tgt_d),
+                                          _lib.ptr(z_vals), _lib.ptr(packed), _lib.ptr(rgb), _lib.ptr(depth),
+                                          _lib.ptr(disp), _lib.ptr(acc), _lib.ptr(var), _lib.ptr(raw),
+                                          _lib.ptr(ray_sums), st), "mne_render_forward")
+        losses = torch.zeros(_lib.N_LOSS, **opts)
+        if want_losses:
+            _lib.check(lib.mne_loss_finalize(R, S, _lib.ptr(ray_sums), _lib.ptr(counts), _lib.ptr(losses), st),
+                       "mne_loss_finalize")
+        ctx.info, ctx.S, ctx.want_losses = info, S, want_losses
+        ctx.save_for_backward(rays_o_c, rays_d_c, tgt_rgb, tgt_d, z_vals, raw, counts, packed, *params)
+        ctx.mark_non_differentiable(disp, acc, var, z_vals, raw)
+        return rgb, depth, disp, acc, var, z_vals, raw, losses
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_disp, g_acc, g_var, g_z, g_raw, g_losses):
+        lib = _lib.load()
+        info, S = ctx.info, ctx.S
+        rays_o, rays_d, tgt_rgb, tgt_d, z_vals, raw, counts, packed, *params = ctx.saved_tensors
+        n_planes = info["n_planes"]
+        planes, dec_w = params[:n_planes], params[n_planes:]
+        dev, st = rays_o.device, _lib.stream_for(rays_o)
+        rc = info["render_cfg"]
+        R = rays_o.shape[0]
+        opts = dict(device=dev, dtype=torch.float32)
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            raise NotImplementedError("gradients w.r.t. rays (pose optimisation) are not available in this build yet")
+        grads = [torch.zeros_like(p) for p in planes]          # channels_last preserved
+        sc = scene_struct(info, list(planes), list(dec_w), grads)
+        coef = None
+        if ctx.want_losses and g_losses is not None:
+            coef = torch.empty(_lib.N_LOSS, **opts)
+            _lib.check(lib.mne_loss_coef(C.byref(rc), R, S, _lib.ptr(counts), _lib.ptr(_f32c(g_losses, "g")),
+                                         _lib.ptr(coef), st), "mne_loss_coef")
+        row = lib.mne_tape_row_floats(C.byref(sc))
+        tape = torch.empty(R * S, row, **opts)
+        tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        _lib.check(lib.mne_render_backward(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                                           _lib.ptr(tgt_rgb) if coef is not None else None,
+                                           _lib.ptr(tgt_d), _lib.ptr(z_vals), _lib.ptr(packed), _lib.ptr(raw),
+                                           _lib.ptr(coef), _lib.ptr(_f32c(g_rgb, "g_rgb")),
+                                           _lib.ptr(_f32c(g_depth, "g_depth")), _lib.ptr(tape), R * S,
+                                           _lib.ptr(tape_rows), None, None, st), "mne_render_backward")
+        nparam = lib.mne_decoder_param_floats(C.byref(sc))
+        partials = torch.empty(lib.mne_wgrad_partial_floats(C.byref(sc)), **opts)
+        dgrad = torch.empty(nparam, **opts)
+        _lib.check(lib.mne_decoder_wgrad(C.byref(sc), _lib.ptr(tape), _lib.ptr(tape_rows), _lib.ptr(partials),
+                                         _lib.ptr(dgrad), info.get("wgrad_impl", 0), st), "mne_decoder_wgrad")
+        w_sdf0, w_sdf1, w_col0, w_col1 = dec_w
+        n0, n1, n2 = w_col0.numel(), w_col1.numel(), w_sdf0.numel()
+        g_col0 = dgrad[:n0].view_as(w_col0)
+        g_col1 = dgrad[n0:n0 + n1].view_as(w_col1)
+        g_sdf0 = dgrad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0)
+        g_sdf1 = dgrad[n0 + n1 + n2:].view_as(w_sdf1)
+        return (None, None, None, None, None, None, None, None, *grads, g_sdf0, g_sdf1, g_col0, g_col1)
+
+
+def query_points(info, planes, dec_w, pts, want_raw=True, want_geo=False, want_feat=False, normalised=False):
+    """Forward-only point query (no autograd): raw [N,4], geo [N,15], feat [N,64]."""
+    lib = _lib.load()
+    flat = _f32c(pts.reshape(-1, 3).detach(), "pts")
+    n = flat.shape[0]
+    opts = dict(device=flat.device, dtype=torch.float32)
+    st = _lib.stream_for(flat)
+    planes_cl = [as_channels_last(p.detach()) for p in planes]
+    sc = scene_struct(info, planes_cl, [w.detach() for w in dec_w])
+    packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
+    _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
+    raw = torch.empty(n, 4, **opts) if want_raw else None
+    geo = torch.empty(n, info["geo_feat_dim"], **opts) if want_geo else None
+    feat = torch.empty(n, 2 * info["c_dim"], **opts) if want_feat else None
+    _lib.check(lib.mne_query_points(C.byref(sc), n, _lib.ptr(flat), _lib.ptr(packed), _lib.ptr(raw), _lib.ptr(geo),
+                                    _lib.ptr(feat), 1 if normalised else 0, st), "mne_query_points")
+    return raw, geo, feat

@@ -1,0 +1,82 @@
+"""FusedAdam -- ``torch.optim.Adam``-compatible optimizer over the param groups of
+MNESLAM.create_optimizer (mneslam_mp.py:459-469) whose ``step()`` is one HIP launch
+(mne_adam_step: single pass over p, g, m, v for every tensor of every group).
+
+Semantics are torch.optim.Adam's (amsgrad=False, maximize=False): L2 weight decay folded into the
+gradient, bias correction by the per-parameter step count, dense update of every element (cells
+with zero gradient still move while their first moment is non-zero -- required for parity,
+SURVEY.md section 7).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _dense_like(p, t):
+    """``t`` laid out exactly like ``p`` (same strides), copying only if needed."""
+    if t.stride() == p.stride() and t.dtype == p.dtype:
+        return t
+    out = torch.empty_like(p)            # preserve_format
+    out.copy_(t)
+    return out
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+
+    def _state(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p)          # preserve_format: same physical layout as p
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        return st
+
+    def segments(self, zero_grad_buffers=None):
+        """ctypes segment array for every parameter that has a gradient (advances the step counts)."""
+        segs = []
+        keep = []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                g = p.grad if zero_grad_buffers is None else zero_grad_buffers.get(p)
+                if g is None:
+                    continue
+                if p.dtype != torch.float32:
+                    raise TypeError("FusedAdam supports float32 parameters")
+                if not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)):
+                    raise ValueError("FusedAdam needs dense parameters")
+                st = self._state(p)
+                st["step"] += 1
+                g = _dense_like(p, g)
+                keep.append(g)
+                s = _lib.AdamSeg()
+                s.p, s.g = p.data_ptr(), g.data_ptr()
+                s.m, s.v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                s.n = p.numel()
+                s.lr, s.beta1, s.beta2 = float(group["lr"]), float(b1), float(b2)
+                s.eps, s.weight_decay = float(group["eps"]), float(group["weight_decay"])
+                s.step = st["step"]
+                segs.append((s, p))
+        return segs, keep
+
+    @torch.no_grad()
+    def step(self, closure=None, zero_grad=False, grad_buffers=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        segs, keep = self.segments(grad_buffers)
+        if not segs:
+            return loss
+        lib = _lib.load()
+        for i in range(0, len(segs), 32):
+            chunk = segs[i:i + 32]
+            arr = (_lib.AdamSeg * len(chunk))(*[s for s, _ in chunk])
+            _lib.check(lib.mne_adam_step(arr, len(chunk), 1 if zero_grad else 0, _lib.stream_for(chunk[0][1])),
+                       "mne_adam_step")
+        return loss

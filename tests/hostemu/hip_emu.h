@@ -1,0 +1,195 @@
+// hip_emu.h -- TEST-ONLY host emulation of the small HIP subset the mneslam kernels use.
+//
+// Purpose: the build container has no GPU, and GPU time is scarce.  Compiling the *same* kernel
+// sources with g++ -DMNE_HOST_EMU against this header lets tests/ run them on CPU tensors (slowly):
+// one workgroup at a time, one OS thread per work-item, wave64 collectives (__shfl*, __ballot,
+// MFMA) and __syncthreads implemented with barriers.  It is never part of the shipped library:
+// mneslam_amd/ loads only the hipcc-built libmneslam_hip.so and fails loudly without it.
+//
+// Emulated semantics follow /opt/skills/guides (wave = 64 lanes; MFMA f32 32x32x2 fragment layout:
+// A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D col=l&31,row=(reg&3)+8*(reg>>2)+4*(l>>5)).
+#pragma once
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+#define __shared__ static
+
+struct emu_dim3 { unsigned x = 1, y = 1, z = 1; };
+inline thread_local emu_dim3 threadIdx, blockIdx;
+inline emu_dim3 blockDim, gridDim;
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+inline float2 make_float2(float a, float b) { return float2{a, b}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return 0; }
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToDevice 3
+
+namespace hipemu {
+constexpr int WAVE = 64;
+struct BlockCtx {
+    unsigned nthreads;
+    std::unique_ptr<std::barrier<>> block_bar;
+    std::unique_ptr<std::barrier<>> end_bar;
+    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
+    std::vector<uint64_t> xchg;      // one 8-byte slot per work-item
+    std::vector<uint64_t> xchg2;
+    std::vector<unsigned char> dyn_lds;
+};
+inline BlockCtx* g_ctx = nullptr;
+
+inline int lane() { return threadIdx.x & 63; }
+inline int wave() { return threadIdx.x >> 6; }
+inline int wave_lanes() {           // live lanes in this (possibly partial) wave
+    int base = wave() * WAVE;
+    int n = (int)g_ctx->nthreads - base;
+    return n > WAVE ? WAVE : n;
+}
+inline void wave_sync() { g_ctx->wave_bar[wave()]->arrive_and_wait(); }
+
+template <class T> inline uint64_t to_bits(T v) { uint64_t b = 0; std::memcpy(&b, &v, sizeof(T)); return b; }
+template <class T> inline T from_bits(uint64_t b) { T v; std::memcpy(&v, &b, sizeof(T)); return v; }
+
+template <class T> inline T shfl_idx(T v, int src) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    int base = wave() * WAVE;
+    g_ctx->xchg[threadIdx.x] = to_bits(v);
+    wave_sync();
+    int s = src & 63;
+    T r = (s < wave_lanes()) ? from_bits<T>(g_ctx->xchg[base + s]) : v;
+    wave_sync();
+    return r;
+}
+
+template <class K, class... A>
+void launch(K kern, unsigned grid, unsigned block, size_t lds, A... args) {
+    BlockCtx ctx;
+    ctx.nthreads = block;
+    ctx.block_bar = std::make_unique<std::barrier<>>(block);
+    ctx.end_bar = std::make_unique<std::barrier<>>(block);
+    unsigned nw = (block + WAVE - 1) / WAVE;
+    for (unsigned w = 0; w < nw; ++w) {
+        unsigned n = std::min<unsigned>(WAVE, block - w * WAVE);
+        ctx.wave_bar.emplace_back(std::make_unique<std::barrier<>>(n));
+    }
+    ctx.xchg.assign(block, 0);
+    ctx.xchg2.assign(block, 0);
+    ctx.dyn_lds.assign(lds + 64, 0);
+    g_ctx = &ctx;
+    blockDim.x = block;
+    gridDim.x = grid;
+    std::vector<std::thread> pool;
+    pool.reserve(block);
+    for (unsigned t = 0; t < block; ++t) {
+        pool.emplace_back([&, t]() {
+            for (unsigned b = 0; b < grid; ++b) {
+                threadIdx.x = t;
+                blockIdx.x = b;
+                kern(args...);
+                ctx.end_bar->arrive_and_wait();        // static __shared__ is reused by the next block
+            }
+        });
+    }
+    for (auto& th : pool) th.join();
+    g_ctx = nullptr;
+}
+}  // namespace hipemu
+
+#define MNE_LAUNCH(kern, grid, block, lds, stream, ...) hipemu::launch(kern, (unsigned)(grid), (unsigned)(block), (size_t)(lds), __VA_ARGS__)
+#define MNE_DYN_LDS(name) unsigned char* name = (unsigned char*)(((uintptr_t)hipemu::g_ctx->dyn_lds.data() + 15) & ~(uintptr_t)15)
+typedef const float* mne_cptr;
+#define MNE_CPTR(p) ((const float*)(p))
+
+inline void __syncthreads() { hipemu::g_ctx->block_bar->arrive_and_wait(); }
+template <class T> inline T __shfl(T v, int src, int = 64) { return hipemu::shfl_idx(v, src); }
+template <class T> inline T __shfl_xor(T v, int m, int = 64) { return hipemu::shfl_idx(v, hipemu::lane() ^ m); }
+template <class T> inline T __shfl_down(T v, unsigned d, int = 64) {
+    int s = hipemu::lane() + (int)d;
+    return hipemu::shfl_idx(v, s < 64 ? s : hipemu::lane());
+}
+template <class T> inline T __shfl_up(T v, unsigned d, int = 64) {
+    int s = hipemu::lane() - (int)d;
+    return hipemu::shfl_idx(v, s >= 0 ? s : hipemu::lane());
+}
+inline unsigned long long __ballot(int pred) {
+    using namespace hipemu;
+    int base = wave() * WAVE;
+    g_ctx->xchg2[threadIdx.x] = pred ? 1 : 0;
+    wave_sync();
+    unsigned long long m = 0;
+    for (int l = 0; l < wave_lanes(); ++l) m |= (unsigned long long)(g_ctx->xchg2[base + l] & 1) << l;
+    wave_sync();
+    return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+
+template <class T> inline T atomic_add_impl(T* addr, T val) {
+    static_assert(sizeof(T) == 4, "4-byte atomics only");
+    auto* a = reinterpret_cast<std::atomic<uint32_t>*>(addr);
+    uint32_t old = a->load(std::memory_order_relaxed);
+    for (;;) {
+        T cur; std::memcpy(&cur, &old, 4);
+        T nv = cur + val;
+        uint32_t nb; std::memcpy(&nb, &nv, 4);
+        if (a->compare_exchange_weak(old, nb, std::memory_order_relaxed)) return cur;
+    }
+}
+inline float atomicAdd(float* a, float v) { return atomic_add_impl(a, v); }
+inline int atomicAdd(int* a, int v) { return atomic_add_impl(a, v); }
+inline unsigned atomicAdd(unsigned* a, unsigned v) { return atomic_add_impl(a, v); }
+inline float unsafeAtomicAdd(float* a, float v) { return atomic_add_impl(a, v); }
+
+// MFMA f32 32x32x2: every lane of a full wave must call it together.
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+inline emu_f32x16 emu_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c) {
+    using namespace hipemu;
+    int base = wave() * WAVE, l = lane();
+    g_ctx->xchg[threadIdx.x] = to_bits(a);
+    g_ctx->xchg2[threadIdx.x] = to_bits(b);
+    wave_sync();
+    int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av = from_bits<float>(g_ctx->xchg[base + i + 32 * k]);
+            float bv = from_bits<float>(g_ctx->xchg2[base + j + 32 * k]);
+            acc = std::fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32(a, b, c)

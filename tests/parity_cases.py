@@ -1,0 +1,278 @@
+"""Parity checks of the HIP path against the oracle and the golden fixtures, written once and run on
+two backends: the real library on an MI355X (tests/test_hip_parity_gpu.py, ``-m gpu``) and the
+test-only host emulation of the same kernel sources (tests/test_kernels_hostemu.py, CPU).
+Every function takes the torch device to run on."""
+import random
+import types
+
+import numpy as np
+import torch
+
+from mneslam_amd import configs, slam_glue
+from mneslam_amd.model.keyframe import KeyFrameDatabase
+from mneslam_amd.model.scene_rep import JointEncoding
+from mneslam_amd.mp_slam.mapper import Mapper
+from mneslam_amd.optim import FusedAdam
+from oracle import mapping as omap
+from oracle.oneblob import oneblob
+from oracle.scene_rep import OracleScene
+
+from helpers import (DEC_KEYS, assert_close, fixture_inputs, load_golden, n_plane_sets,
+                     oracle_scene_from_golden)
+
+FWD_CASES = {"fwd_onegrid": dict(one_grid=True), "fwd_colorplanes": dict(one_grid=False, depth_trunc=3.0)}
+LOSS_KEYS = ("rgb_loss", "depth_loss", "co_sdf_loss", "co_fs_loss", "e_fs_loss", "e_center_loss", "e_tail_loss", "psnr")
+
+
+def model_from_golden(g, cfg, device, prefix=""):
+    """JointEncoding holding the fixture's planes/decoder (planes channels_last on ``device``)."""
+    torch.manual_seed(0)
+    m = JointEncoding(cfg, torch.from_numpy(g["bounding_box"]).to(device))
+    m.device = torch.device(device)
+    for s in range(n_plane_sets(g, prefix)):
+        for l in range(2):
+            t = torch.from_numpy(g[f"{prefix}plane_{s}_{l}"]).to(device)
+            m.all_planes[s][l] = t.contiguous(memory_format=torch.channels_last)
+    sd = {k: torch.from_numpy(g[f"{prefix}dec.{k}"]) for k in DEC_KEYS}
+    m.decoder.load_state_dict(sd)
+    return m.to(device)
+
+
+def to_dev(ts, device):
+    return [t.to(device) if t is not None else None for t in ts]
+
+
+def check_forward(name, device):
+    g = load_golden(name)
+    cfg = configs.small_test_config(**FWD_CASES[name])
+    m = model_from_golden(g, cfg, device).train()
+    rays_o, rays_d, rgb, d, U = to_dev(fixture_inputs(g), device)
+    out = m._render(rays_o, rays_d, rgb, d, u=U)
+    o_rgb, o_depth, o_disp, o_acc, o_var, o_z, o_raw, o_losses = [t.detach().cpu() for t in out]
+    assert_close(o_z, g["rr.z_vals"], rtol=0, atol=0, what="z_vals (bit-exact)")
+    assert_close(o_raw, g["rr.raw"], rtol=1e-4, atol=1e-5, what="raw")
+    assert_close(o_rgb, g["ret.rgb"], rtol=1e-4, atol=1e-5, what="rgb")
+    assert_close(o_depth, g["ret.depth"], rtol=1e-4, atol=1e-5, what="depth")
+    assert_close(o_var, g["rr.depth_var"], rtol=1e-3, atol=1e-5, what="depth_var")
+    assert_close(o_acc, g["rr.acc_map"], rtol=1e-4, atol=1e-5, what="acc")
+    assert_close(o_disp, g["rr.disp_map"], rtol=1e-4, atol=1e-5, what="disp")
+    for k, key in enumerate(LOSS_KEYS):
+        assert_close(o_losses[k], g[f"ret.{key}"].reshape(()), rtol=1e-4, atol=1e-6, what=key)
+    # north-star tolerance: depth/colour L1 within 1e-4
+    assert float(np.abs(o_rgb.numpy() - g["ret.rgb"]).mean()) < 1e-4
+    assert float(np.abs(o_depth.numpy() - g["ret.depth"]).mean()) < 1e-4
+    # forward() dict surface
+    ret = m.forward(rays_o, rays_d, rgb, d)
+    assert set(ret) == {"rgb", "depth", "rgb_loss", "depth_loss", "co_sdf_loss", "co_fs_loss", "e_fs_loss",
+                        "e_center_loss", "e_tail_loss", "psnr"}
+    assert ret["psnr"].shape == (1,) and ret["rgb_loss"].dim() == 0
+
+
+def check_backward(name, co, device, wgrad_impl=0):
+    g = load_golden(name)
+    cfg = configs.small_test_config(**FWD_CASES[name])
+    m = model_from_golden(g, cfg, device).train()
+    m.wgrad_impl = wgrad_impl
+    opt = slam_glue.create_optimizer(m, cfg)
+    rays_o, rays_d, rgb, d, U = to_dev(fixture_inputs(g), device)
+    out = m._render(rays_o, rays_d, rgb, d, u=U)
+    losses = out[-1]
+    L = {k: losses[i] for i, k in enumerate(LOSS_KEYS)}
+    loss = slam_glue.get_loss_from_ret(cfg, L, is_co_sdf=co)
+    assert_close(loss.detach().cpu(), g[f"loss.co{int(co)}"], rtol=1e-4, what="total loss")
+    loss.backward()
+    tag = f"grad.co{int(co)}."
+    for s in range(n_plane_sets(g)):
+        for l in range(2):
+            ref = g[f"{tag}plane_{s}_{l}"]
+            got = m.all_planes[s][l].grad
+            assert got is not None, "plane got no gradient"
+            assert_close(got.cpu(), ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()), what=f"plane grad {s},{l}")
+    sd = dict(m.decoder.named_parameters())
+    for k in DEC_KEYS:
+        ref = g[f"{tag}dec.{k}"]
+        assert_close(sd[k].grad.cpu(), ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()), what=f"decoder grad {k}")
+    return opt
+
+
+def check_all_invalid(device):
+    g = load_golden("fwd_all_invalid")
+    cfg = configs.small_test_config()
+    m = model_from_golden(g, cfg, device).train()
+    rays_o, rays_d, rgb, d, U = to_dev(fixture_inputs(g), device)
+    losses = m._render(rays_o, rays_d, rgb, d, u=U)[-1].detach().cpu()
+    for k, key in enumerate(LOSS_KEYS):
+        assert_close(losses[k], g[f"ret.{key}"].reshape(()), rtol=1e-4, atol=1e-6, what=key)
+    assert torch.isnan(losses[1]) and torch.isnan(losses[4])
+
+
+def check_render_nodepth(device):
+    g = load_golden("render_nodepth")
+    cfg = configs.small_test_config()
+    m = model_from_golden(g, cfg, device).eval()
+    rays_o, rays_d, rgb, d, U = to_dev(fixture_inputs(g), device)
+    out = m._render(rays_o, rays_d, None, None, u=U)
+    assert_close(out[5].cpu(), g["rr.z_vals"], rtol=0, atol=0, what="z_vals")
+    assert_close(out[0].detach().cpu(), g["rr.rgb"], rtol=1e-4, atol=1e-5, what="rgb")
+    assert_close(out[1].detach().cpu(), g["rr.depth"], rtol=1e-4, atol=1e-5, what="depth")
+    assert_close(out[6].cpu(), g["rr.raw"], rtol=1e-4, atol=1e-5, what="raw")
+    rr = m.render_rays(rays_o, rays_d, target_d=None)
+    assert set(rr) == {"rgb", "depth", "disp_map", "acc_map", "depth_var", "z_vals", "raw"}
+
+
+def check_mapping3(name, one_grid, co, seed, device):
+    """Three drop-in Mapper.mapping_optimize iterations (host RNG sampling, autograd path, FusedAdam)
+    against the parameters the REFERENCE reached from the same state and seeds."""
+    g = load_golden(name)
+    cfg = configs.small_test_config(one_grid=one_grid, is_co_sdf=co)
+    cfg["mapping"].update(sample=64, min_pixels_cur=10, iters=3, n_pixels=0.25)
+    H, W, n_save = int(g["H"]), int(g["W"]), int(g["n_save"])
+    m = model_from_golden(g, cfg, device, prefix="init.").train()
+    opt = slam_glue.create_optimizer(m, cfg)
+    direction = torch.from_numpy(g["direction"])
+    frames = [dict(frame_id=k, c2w=torch.from_numpy(g[f"frame{k}.c2w"]), rgb=torch.from_numpy(g[f"frame{k}.rgb"]),
+                   depth=torch.from_numpy(g[f"frame{k}.depth"]), direction=direction) for k in range(4)]
+    random.seed(seed)
+    torch.manual_seed(seed)
+    kfdb = KeyFrameDatabase(cfg, H, W, 8, n_save, device)
+    for k in range(3):
+        kfdb.add_keyframe(frames[k], k + 1)
+    assert_close(kfdb.rays[:3], g["kf.rays"], rtol=0, atol=0, what="keyframe ray DB")
+    slam = types.SimpleNamespace(
+        config=cfg, model=m, map_optimizer=opt, device=torch.device(device),
+        dataset=types.SimpleNamespace(H=H, W=W), video=types.SimpleNamespace(keyframe=kfdb),
+        get_loss_from_ret=lambda ret, **kw: slam_glue.get_loss_from_ret(cfg, ret, **kw),
+        select_samples=slam_glue.select_samples)
+    mapper = Mapper(cfg, slam)
+    poses = torch.stack([f["c2w"] for f in frames]).to(device)
+    random.seed(seed + 1)
+    torch.manual_seed(seed + 1)
+    mapper.optimize_map(frames[3], poses)
+    for s in range(n_plane_sets(g, "init.")):
+        for l in range(2):
+            assert_close(m.all_planes[s][l].detach().cpu(), g[f"final.plane_{s}_{l}"], rtol=1e-3, atol=1e-4,
+                         what=f"plane {s},{l} after 3 iterations")
+    sd = dict(m.decoder.named_parameters())
+    for k in DEC_KEYS:
+        assert_close(sd[k].detach().cpu(), g[f"final.dec.{k}"], rtol=1e-3, atol=1e-4, what=f"decoder {k} after 3 iterations")
+
+
+def check_adam(device):
+    """mne_adam_step against the written-out Adam of the oracle, incl. weight decay, odd sizes,
+    channels_last tensors and gradient zeroing."""
+    torch.manual_seed(3)
+    shapes = [(1, 32, 9, 7), (16, 32), (3, 33), (5,)]
+    ps = [torch.randn(s) for s in shapes]
+    ps[0] = ps[0].contiguous(memory_format=torch.channels_last)
+    ref_p = [p.clone() for p in ps]
+    dev_p = [torch.nn.Parameter(p.clone().to(device)) for p in ps]
+    opt = FusedAdam([{"params": dev_p[:2], "lr": 0.005, "eps": 1e-15},
+                     {"params": dev_p[2:], "lr": 0.01, "weight_decay": 1e-6}], betas=(0.9, 0.99))
+    grp = [omap.AdamGroup(ref_p[:2], 0.005, eps=1e-15), omap.AdamGroup(ref_p[2:], 0.01, eps=1e-8, weight_decay=1e-6)]
+    for it in range(4):
+        gs = [torch.randn(s) * (0.0 if (it == 2 and k == 1) else 1.0) for k, s in enumerate(shapes)]
+        gs[0] = gs[0].contiguous(memory_format=torch.channels_last)
+        for p, gr in zip(dev_p, gs):
+            p.grad = gr.clone().to(device)
+        opt.step(zero_grad=(it == 3))
+        for gq in grp:
+            gq.t += 1
+        for k, (p, gr) in enumerate(zip(ref_p, gs)):
+            q = grp[0] if k < 2 else grp[1]
+            j = k if k < 2 else k - 2
+            b1, b2 = q.betas
+            gg = gr + q.wd * p if q.wd else gr
+            q.m[j].add_((gg - q.m[j]) * (1 - b1))
+            q.v[j].mul_(b2).add_(gg * gg * (1 - b2))
+            den = q.v[j].sqrt() / np.sqrt(1 - b2 ** q.t) + q.eps
+            p.add_(-(q.lr / (1 - b1 ** q.t)) * (q.m[j] / den))
+    for p, r in zip(dev_p, ref_p):
+        assert_close(p.detach().cpu(), r, rtol=1e-5, atol=1e-6, what="adam param")
+        assert float(p.grad.abs().max()) == 0.0, "zero_grad=True must clear the gradient buffer"
+
+
+def check_oneblob(device):
+    from mneslam_amd.model.encodings import get_encoder
+    enc, dim = get_encoder("OneBlob", n_bins=16)
+    assert dim == 48 and enc.params.numel() == 0
+    torch.manual_seed(0)
+    x = torch.cat([torch.rand(200, 3), torch.tensor([[0.0, 1.0, 0.5], [-0.3, 1.7, 0.03125], [0.999, 0.001, 0.0625]])])
+    got = enc(x.double().to(device)).cpu()          # double input is cast to fp32 like tinycudann
+    assert_close(got, oneblob(x, 16), rtol=0, atol=0, what="OneBlob (bit-exact vs spec)")
+
+
+def check_queries(device):
+    g = load_golden("fwd_colorplanes")
+    cfg = configs.small_test_config(one_grid=False, depth_trunc=3.0)
+    m = model_from_golden(g, cfg, device).eval()
+    sc = oracle_scene_from_golden(g, cfg)
+    torch.manual_seed(1)
+    pts = (torch.rand(150, 3) * 2.4 - 1.2)          # some points outside the bound (border clamp)
+    raw = m.query_color_sdf(pts.to(device)).cpu()
+    ref, parts = sc.query_color_sdf(pts, return_parts=True)
+    assert_close(raw, ref, rtol=1e-4, atol=1e-5, what="query_color_sdf")
+    sdf, geo = m.query_sdf(pts.reshape(10, 15, 3).to(device), return_geo=True)
+    rs, rg = sc.query_sdf(pts.reshape(10, 15, 3), return_geo=True)
+    assert_close(sdf.cpu(), rs, rtol=1e-4, atol=1e-5, what="query_sdf")
+    assert_close(geo.cpu(), rg, rtol=1e-4, atol=1e-5, what="query_sdf geo")
+    emb = m.query_sdf(pts.to(device), embed=True).cpu()
+    assert_close(emb, parts["feat"], rtol=1e-5, atol=1e-6, what="embed")
+    feat = m.sample_plane_feature(parts["p_nor"].to(device), *m.all_planes[:3]).cpu()
+    assert_close(feat, parts["feat"], rtol=1e-5, atol=1e-6, what="sample_plane_feature")
+    assert_close(m.query_color(pts.to(device)).cpu(), torch.sigmoid(ref[..., :3]), rtol=1e-4, atol=1e-5, what="query_color")
+
+
+def check_oracle_random_scene(device, hidden=32, one_grid=True, n_rays=24, S_d=20, S_r=9, seed=5):
+    """Seeded random scene at a configuration without fixture (e.g. hidden 64): HIP vs oracle,
+    forward and gradients."""
+    cfg = configs.small_test_config(one_grid=one_grid, n_samples_d=S_d, n_range_d=S_r)
+    cfg["decoder"]["hidden_dim"] = cfg["decoder"]["hidden_dim_color"] = hidden
+    gen = torch.Generator().manual_seed(seed)
+    bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
+    sc = OracleScene(cfg, bb, generator=gen)
+    for lst in sc.all_planes:
+        for i in range(len(lst)):
+            lst[i] = lst[i] * 20.0
+    sc.requires_grad_(True)
+    torch.manual_seed(seed)
+    m = JointEncoding(cfg, bb.to(device))
+    m.device = torch.device(device)
+    for s, lst in enumerate(sc.all_planes):
+        for l, p in enumerate(lst):
+            m.all_planes[s][l] = p.detach().clone().to(device).contiguous(memory_format=torch.channels_last)
+    m.decoder.load_state_dict(dict(zip(DEC_KEYS, [w.detach().clone() for w in sc.col_w + sc.sdf_w])))
+    m = m.to(device).train()
+    slam_glue.create_optimizer(m, cfg)
+    rays_o = (torch.rand(n_rays, 3, generator=gen) - 0.5) * 0.6
+    rays_d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=-1) * 0.7
+    rgb = torch.rand(n_rays, 3, generator=gen)
+    d = torch.rand(n_rays, 1, generator=gen) * 2.0 + 0.2
+    d[::5] = 0.0
+    U = torch.rand(n_rays, S_d + S_r, generator=gen)
+    ref = sc.forward(rays_o, rays_d, rgb, d, u=U)
+    out = m._render(*to_dev([rays_o, rays_d, rgb, d], device), u=U.to(device))
+    assert_close(out[5].cpu(), ref["z_vals"], rtol=0, atol=0, what="z_vals")
+    assert_close(out[6].cpu(), ref["raw"].detach(), rtol=1e-4, atol=1e-5, what="raw")
+    assert_close(out[0].detach().cpu(), ref["rgb"].detach(), rtol=1e-4, atol=1e-5, what="rgb")
+    assert_close(out[1].detach().cpu(), ref["depth"].detach(), rtol=1e-4, atol=1e-5, what="depth")
+    for co in (False, True):
+        for t in sc.plane_list() + sc.decoder_list():
+            t.grad = None
+        m.zero_grad()
+        for lst in m.all_planes:
+            for p in lst:
+                p.grad = None
+        ref = sc.forward(rays_o, rays_d, rgb, d, u=U)
+        omap.loss_from_ret(cfg, ref, is_co_sdf=co).backward()
+        out = m._render(*to_dev([rays_o, rays_d, rgb, d], device), u=U.to(device))
+        L = {k: out[-1][i] for i, k in enumerate(LOSS_KEYS)}
+        slam_glue.get_loss_from_ret(cfg, L, is_co_sdf=co).backward()
+        for s, lst in enumerate(sc.all_planes):
+            for l, p in enumerate(lst):
+                r = p.grad.numpy()
+                assert_close(m.all_planes[s][l].grad.cpu(), r, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(r).max()),
+                             what=f"plane grad {s},{l} co={co}")
+        got = dict(m.decoder.named_parameters())
+        for k, w in zip(DEC_KEYS, sc.col_w + sc.sdf_w):
+            r = w.grad.numpy()
+            assert_close(got[k].grad.cpu(), r, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(r).max()), what=f"dec grad {k} co={co}")
