@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- mapping iterations / second of the MNE-SLAM mapping hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one mapping iteration (R1-R12): sample 2048 global keyframe rays
++ the current frame's share -> z sampling -> tri-plane/OneBlob/MLP/compositing forward -> losses ->
+backward -> dense Adam over planes + decoder.  Workload = BASELINE.json configs[1] in its as-wired
+form: Replica office0 tri-planes (0.02/0.01 m, 38.4 M fp32 params), 2x32 MLPs, 2048 rays x 128
+samples (n_range_d 32 + n_samples_d 96), synthetic 1200x680 RGB-D frames, 20 keyframes.  All inputs
+(keyframe ray database, current frame, poses, parameters) are resident in HBM before timing.
+
+Multi-GPU: one agent per GPU (the reference's own decomposition, multi_agents.py:43-52), no data-path
+collective (the reference has none); value = iterations of all agents / max-over-ranks time (weak).
+"""
+import argparse
+import json
+import math
+import os
+import random
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from mneslam_amd import configs, slam_glue, synthetic  # noqa: E402
+from mneslam_amd.model.keyframe import KeyFrameDatabase  # noqa: E402
+from mneslam_amd.model.scene_rep import JointEncoding  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--keyframes", type=int, default=20)
+    ap.add_argument("--hidden", type=int, default=32, choices=[32, 64])
+    ap.add_argument("--path", default="autograd", choices=["autograd"])
+    ap.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
+    ap.add_argument("--small", action="store_true", help="tiny planes/frames (functional check, not a benchmark)")
+    return ap.parse_args()
+
+
+class Agent:
+    """One mapping agent: scene model + optimizer + device-resident keyframe rays."""
+
+    def __init__(self, cfg, device, seed, n_keyframes, small=False):
+        self.cfg, self.device = cfg, device
+        cam = dict(synthetic.REPLICA_CAM)
+        if small:
+            cam = dict(H=68, W=120, fx=60.0, fy=60.0, cx=59.0, cy=33.0)
+        self.H, self.W = cam["H"], cam["W"]
+        room = synthetic.OFFICE0_ROOM if not small else [[-0.8, 0.8], [-1.0, 0.9], [-0.6, 0.7]]
+        random.seed(seed)
+        torch.manual_seed(seed)
+        frames = synthetic.make_frames(n_keyframes + 1, self.H, self.W, cam["fx"], cam["fy"], cam["cx"], cam["cy"],
+                                       room, seed=seed)
+        n_save = int(self.H * self.W * cfg["mapping"]["n_pixels"])
+        self.kfdb = KeyFrameDatabase(cfg, self.H, self.W, n_keyframes + 1, n_save, device)
+        for k in range(n_keyframes):
+            self.kfdb.add_keyframe(frames[k], k + 1)
+        self.n_kf, self.n_save = n_keyframes, n_save
+        self.kf_rays = self.kfdb.device_rays(device)[:n_keyframes].reshape(-1, 7).contiguous()
+        cur = frames[n_keyframes]
+        self.cur_rays = torch.cat([cur["direction"], cur["rgb"], cur["depth"][..., None]], -1).reshape(-1, 7).to(device)
+        self.poses = torch.stack([f["c2w"] for f in frames]).to(device)          # [n_kf+1,4,4]; last = current
+        bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64, device=device)
+        self.model = JointEncoding(cfg, bb).to(device).train()
+        self.model.jitter_rng = "device"
+        self.opt = slam_glue.create_optimizer(self.model, cfg)
+        self.n_cur = max(cfg["mapping"]["sample"] // n_keyframes, cfg["mapping"]["min_pixels_cur"])
+        self.n_plane_params = sum(p.numel() for lst in self.model.all_planes for p in lst)
+        self.n_dec_params = sum(p.numel() for p in self.model.decoder.parameters())
+        self.ev = None
+        self.last = None
+
+    def sample_rays(self):
+        """R1/R2 ray assembly on the device (mp_slam/mapper.py:135-153): `sample` rows without
+        replacement over all stored keyframe rays + n_cur pixels of the current frame."""
+        n = self.cfg["mapping"]["sample"]
+        idx = torch.randperm(self.kf_rays.shape[0], device=self.device)[:n]
+        ids = torch.div(idx, self.n_save, rounding_mode="trunc")
+        idc = torch.randperm(self.cur_rays.shape[0], device=self.device)[:self.n_cur]
+        rays = torch.cat([self.kf_rays[idx], self.cur_rays[idc]], 0)
+        ids_all = torch.cat([ids, torch.full((self.n_cur,), self.n_kf, device=self.device, dtype=ids.dtype)])
+        rot = self.poses[ids_all, :3, :3]
+        rays_d = torch.sum(rays[:, None, :3] * rot, -1)
+        rays_o = self.poses[ids_all, :3, 3]
+        return rays_o, rays_d, rays[:, 3:6], rays[:, 6:7]
+
+    def step(self, timers=None):
+        rays_o, rays_d, tgt_rgb, tgt_d = self.sample_rays()
+        ret = self.model.forward(rays_o, rays_d, tgt_rgb, tgt_d)
+        loss = slam_glue.get_loss_from_ret(self.cfg, ret, is_co_sdf=self.cfg["is_co_sdf"])
+        loss.backward()
+        if timers is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.opt.step(zero_grad=False)
+        if timers is not None:
+            e1.record()
+            timers.append((e0, e1))
+        self.opt.zero_grad(set_to_none=True)
+        self.last = (ret, tgt_rgb, tgt_d)
+
+    def quality(self):
+        ret, tgt_rgb, tgt_d = self.last
+        d = tgt_d.squeeze(-1)
+        valid = (d > 0) & (d < self.cfg["cam"]["depth_trunc"])
+        l1 = (ret["depth"].detach()[valid] - d[valid]).abs().mean()
+        return float(ret["psnr"].detach()[0]), float(l1)
+
+
+def cpu_baseline(cfg, n_keyframes, iters, seed=0):
+    """The oracle (CPU restatement of the reference's PyTorch path; checker code, reported baseline
+    only) timed on this box's host cores on the same workload shape."""
+    from oracle import mapping as omap
+    from oracle.scene_rep import OracleScene
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(seed)
+    bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
+    sc = OracleScene(cfg, bb, generator=gen).requires_grad_(True)
+    opt = omap.OracleAdam(sc, cfg)
+    n = cfg["mapping"]["sample"] + max(cfg["mapping"]["sample"] // n_keyframes, cfg["mapping"]["min_pixels_cur"])
+    frames = synthetic.make_frames(1, 68, 120, 60.0, 60.0, 59.0, 33.0, synthetic.OFFICE0_ROOM, seed=seed)
+    fr = frames[0]
+    idx = torch.randint(0, 68 * 120, (n,), generator=gen)
+    d_cam = fr["direction"].reshape(-1, 3)[idx]
+    rays_d = torch.sum(d_cam[:, None, :] * fr["c2w"][:3, :3], -1)
+    rays_o = fr["c2w"][None, :3, 3].repeat(n, 1)
+    rgb, dep = fr["rgb"].reshape(-1, 3)[idx], fr["depth"].reshape(-1, 1)[idx]
+    times = []
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        ret = sc.forward(rays_o, rays_d, rgb, dep, impl="grid_sample")
+        omap.loss_from_ret(cfg, ret, is_co_sdf=cfg["is_co_sdf"]).backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / max(len(times) - 1, 1)
+    return {"value": 1.0 / t, "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} mapping iterations (1 warm-up) of the same workload ({n} rays x "
+                      f"{cfg['training']['n_range_d'] + cfg['training']['n_samples_d']} samples, "
+                      f"{sum(p.numel() for p in sc.plane_list())} plane params) with the CPU oracle, torch "
+                      f"{torch.__version__}, {cores} threads"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP library is the only backend)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    cfg = configs.bench_office0(hidden=args.hidden)
+    if args.small:
+        cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+        cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
+    agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        agent.step()
+    timers = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agent.step(timers)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    adam_ms = sum(a.elapsed_time(b) for a, b in timers) / max(len(timers), 1)
+    psnr, depth_l1 = agent.quality()
+    if rank == 0:
+        S = cfg["training"]["n_range_d"] + cfg["training"]["n_samples_d"]
+        R = cfg["mapping"]["sample"] + agent.n_cur
+        n_par = agent.n_plane_params + agent.n_dec_params
+        adam_bytes = 32.0 * n_par                 # r p,g,m,v + w p,m,v (+ g re-zeroed by the next backward)
+        achieved = adam_bytes / (adam_ms * 1e-3) / 1e9 if adam_ms > 0 else 0.0
+        out = {
+            "metric": "mapping iters/sec (2048 rays x 128 samples)", "value": world * args.steps / elapsed,
+            "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "replica_office0_triplane_asWired_2048x128" + ("_SMALL" if args.small else ""),
+                       "rays_per_iter": R, "samples_per_ray": S, "plane_params": agent.n_plane_params,
+                       "decoder_params": agent.n_dec_params, "mlp_hidden": args.hidden, "keyframes": args.keyframes,
+                       "frame": f"{agent.W}x{agent.H}", "path": args.path, "agents": world,
+                       "parallelism": f"agent-per-gpu x{world}, no data-path collective"},
+            "psnr_last_iter": psnr, "depth_l1_last_iter": depth_l1,
+            "roofline": {"kernel": "adam_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": adam_bytes, "avg_launch_ms": adam_ms},
+        }
+        if world == 1 and args.cpu_iters > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.keyframes, args.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

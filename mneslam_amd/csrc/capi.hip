@@ -50,10 +50,7 @@ static void fill_render_consts(RenderArgs& a, const mne_render_cfg_t* cfg) {
     a.depth_trunc = (float)cfg->depth_trunc;
 }
 
-static size_t render_lds(int S, int nsets) {
-    const int Spad = (S + 3) & ~3;
-    return (size_t)(64 * 4 + nsets * 64 * 68 + 2 * Spad) * sizeof(float) + (size_t)((S + 1) & ~1) * 2;
-}
+static size_t render_lds(int S, int nsets) { return mne_render_lds_bytes(S, nsets); }
 
 extern "C" {
 
@@ -125,7 +122,7 @@ int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, in
     if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw) return fail(-1, "mne_render_forward: NULL argument");
     if (n_rays <= 0) return 0;
     if (n_samples < 1 || n_samples > 16384) return fail(-1, "samples per ray out of range");
-    if (render_lds(n_samples, scene->n_sets) > 64 * 1024) return fail(-1, "samples per ray too large for the LDS staging");
+    if (render_lds(n_samples, scene->n_sets) > 160 * 1024) return fail(-1, "samples per ray too large for the LDS staging");
     if (ray_sums && (!target_rgb || !target_d)) return fail(-1, "ray_sums needs target_rgb and target_d");
     RenderArgs a = {};
     a.sc = *scene;
@@ -169,7 +166,7 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
     if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows)
         return fail(-1, "mne_render_backward: NULL argument");
     if (n_rays <= 0) return 0;
-    if (n_samples < 1 || render_lds(n_samples, scene->n_sets) > 64 * 1024) return fail(-1, "samples per ray out of range");
+    if (n_samples < 1 || render_lds(n_samples, scene->n_sets) > 160 * 1024) return fail(-1, "samples per ray out of range");
     if (tape_capacity_rows < (int64_t)n_rays * n_samples) return fail(-1, "tape must hold n_rays*n_samples rows");
     if (coef && (!target_rgb || !target_d)) return fail(-1, "loss coefficients need target_rgb and target_d");
     if (d_rays_o || d_rays_d) return fail(-3, "ray gradients are not available in this build yet");

@@ -1,0 +1,266 @@
+// mlp_mfma.h -- the tiny decoder MLPs on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+// Formulation: every layer is computed TRANSPOSED,  Y^T[out][point] = W[out][in] . X^T[in][point],
+// so the point index stays lane-local across the whole chain (the CDNA analogue of the swapped
+// QK^T trick).  A 32-point tile is owned by one wave with TWO LANES PER POINT: lane l and l+32 both
+// belong to point (l & 31); for the MFMA B operand (B[k = l>>5][col = l&31]) lane l<32 supplies
+// input channel c_lo(s) of its point at k-step s and lane l+32 supplies channel c_hi(s).  The
+// reduction order over input channels is free, so channels are paired the way the data is laid out:
+//   plane features : lanes<32 hold the coarse level (channels 0..31), lanes>=32 the fine level
+//   OneBlob        : lanes<32 hold pos[0..23], lanes>=32 pos[24..47]
+//   hidden vectors : the MFMA C/D layout itself -- lane l holds rows (r&3)+8(r>>2)+4(l>>5) of its
+//                    point for r = 0..15, i.e. exactly a (lo, hi) pairing with k-step = register r,
+//                    so the next layer consumes the accumulator registers directly as B operands.
+// The A operand (A[row = l&31][k = l>>5]) is a weight; all weights are pre-permuted once per call by
+// pack_decoder_kernel into "A tables": 64 floats per k-step in lane order, read with one coalesced
+// 256-B load per MFMA (L1/L2 resident, shared by every wave).
+//
+// Reference semantics: model/decoder.py:143-175 (ColorSDFNet_v2) / :110-141 (ColorSDFNet), bias-free
+// Linear -> ReLU -> Linear for both nets.
+#pragma once
+#include "mne_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MNE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// row of a 32-row MFMA tile held in accumulator register r by a lane of half h (= lane >> 5)
+__host__ __device__ constexpr int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int HID, int HIDC, bool CP>
+struct ATab {
+    typedef DecDims<HID, HIDC, CP> D;
+    static constexpr int NT = HID / 32, NTC = HIDC / 32;
+    static constexpr int L1S = 56;                                   // 32 feature + 24 OneBlob steps
+    static constexpr int C1S = 24 + (CP ? 32 : 0) + 8;               // OneBlob + (colour features) + geo
+    static constexpr int OFF_L1 = 0;                                 // [NT][L1S]
+    static constexpr int OFF_L2 = OFF_L1 + NT * L1S;                 // [16*NT]
+    static constexpr int OFF_C1 = OFF_L2 + 16 * NT;                  // [NTC][C1S]
+    static constexpr int OFF_C2 = OFF_C1 + NTC * C1S;                // [16*NTC]
+    static constexpr int FWD_STEPS = OFF_C2 + 16 * NTC;
+    static constexpr int OFF_B1 = FWD_STEPS;                         // [NTC][2]     d hc   = V2^T dc
+    static constexpr int OFF_B2 = OFF_B1 + NTC * 2;                  // [16*NTC]     d out16 rows m (geo part of V1^T dhc)
+    static constexpr int OFF_B2C = OFF_B2 + 16 * NTC;                // CP: [2][16*NTC]  d colour features
+    static constexpr int OFF_B3 = OFF_B2C + (CP ? 2 * 16 * NTC : 0); // [NT][8]      d h    = W2^T dout
+    static constexpr int OFF_B4 = OFF_B3 + NT * 8;                   // [2][16*NT]   d features = W1^T dh
+    static constexpr int TOTAL = OFF_B4 + 2 * 16 * NT;
+};
+
+// hidden-unit index consumed at k-step s (0..HID/2-1) by half h when the B operand is an accumulator
+__host__ __device__ constexpr int hid_of_step(int s, int h) { return 32 * (s >> 4) + mfma_row(s & 15, h); }
+
+// One element of the A tables: step in [0, TOTAL), lane l in [0, 64).
+template <int HID, int HIDC, bool CP>
+__device__ inline float atab_value(const mne_scene_t& sc, int step, int l) {
+    typedef ATab<HID, HIDC, CP> T;
+    typedef DecDims<HID, HIDC, CP> D;
+    const int i = l & 31, h = l >> 5;
+    const float* W1 = sc.w_sdf0;   // [HID][112]
+    const float* W2 = sc.w_sdf1;   // [16][HID]
+    const float* V1 = sc.w_col0;   // [HIDC][CIN]
+    const float* V2 = sc.w_col1;   // [3][HIDC]
+    if (step < T::OFF_L2) {                                   // sdf layer 1
+        const int t = step / T::L1S, s = step % T::L1S;
+        const int ch = s < 32 ? h * 32 + s : MNE_FEAT + h * 24 + (s - 32);
+        return W1[(32 * t + i) * MNE_IN1 + ch];
+    }
+    if (step < T::OFF_C1) {                                   // sdf layer 2 (16 valid rows)
+        const int s = step - T::OFF_L2;
+        return i < MNE_OUT1 ? W2[i * HID + hid_of_step(s, h)] : 0.0f;
+    }
+    if (step < T::OFF_C2) {                                   // colour layer 1
+        const int t = (step - T::OFF_C1) / T::C1S, s = (step - T::OFF_C1) % T::C1S;
+        const int row = 32 * t + i;
+        if (s < 24) return V1[row * D::CIN + h * 24 + s];
+        if (CP && s < 56) return V1[row * D::CIN + MNE_POS + h * 32 + (s - 24)];
+        const int m = mfma_row(s - (CP ? 56 : 24), h);        // row of out16: 0 = sdf (not an input)
+        return m >= 1 ? V1[row * D::CIN + D::CINB + m - 1] : 0.0f;
+    }
+    if (step < T::FWD_STEPS) {                                // colour layer 2 (3 valid rows)
+        const int s = step - T::OFF_C2;
+        return i < 3 ? V2[i * HIDC + hid_of_step(s, h)] : 0.0f;
+    }
+    if (step < T::OFF_B2) {                                   // d hc[j] = sum_c V2[c][j] dc[c]
+        const int t = (step - T::OFF_B1) / 2, s = (step - T::OFF_B1) % 2;
+        const int c = 2 * s + h;
+        return c < 3 ? V2[c * HIDC + 32 * t + i] : 0.0f;
+    }
+    if (step < T::OFF_B2C) {                                  // d out16[m] = sum_j V1[j][CINB+m-1] dhc[j]
+        const int s = step - T::OFF_B2;
+        return (i >= 1 && i < MNE_OUT1) ? V1[hid_of_step(s, h) * D::CIN + D::CINB + i - 1] : 0.0f;
+    }
+    if (CP && step < T::OFF_B3) {                             // d colour feature[k] = sum_j V1[j][48+k] dhc[j]
+        const int rt = (step - T::OFF_B2C) / (16 * T::NTC), s = (step - T::OFF_B2C) % (16 * T::NTC);
+        return V1[hid_of_step(s, h) * D::CIN + MNE_POS + 32 * rt + i];
+    }
+    if (step < T::OFF_B4) {                                   // d h[j] = sum_m W2[m][j] dout[m]
+        const int t = (step - T::OFF_B3) / 8, s = (step - T::OFF_B3) % 8;
+        return W2[mfma_row(s, h) * HID + 32 * t + i];
+    }
+    {                                                         // d feature[k] = sum_j W1[j][k] dh[j]
+        const int rt = (step - T::OFF_B4) / (16 * T::NT), s = (step - T::OFF_B4) % (16 * T::NT);
+        return W1[hid_of_step(s, h) * MNE_IN1 + 32 * rt + i];
+    }
+}
+
+// Register state of one 32-point tile after the forward chain.
+template <int HID, int HIDC>
+struct MlpState {
+    f32x16 h[HID / 32];     // relu(W1 x)           rows = hidden units
+    f32x16 out;             // W2 h                 rows 0..15 = (sdf, geo15)
+    f32x16 hc[HIDC / 32];   // relu(V1 [pos,(cf),geo])
+    f32x16 rgb;             // V2 hc                rows 0..2 = raw rgb
+};
+
+// OneBlob of this lane's half of the 48 channels: half 0 -> pos[0..23] = dim0 (16) + dim1 bins 0..7,
+// half 1 -> pos[24..47] = dim1 bins 8..15 + dim2 (16).
+__device__ __forceinline__ void oneblob_half(const float u[3], int h, float (&pos)[24]) {
+    float full[MNE_NB], part[MNE_NB];
+    oneblob16(h == 0 ? u[0] : u[2], full);
+    oneblob16(u[1], part);
+    // static register indices only (a lane-dependent index would put pos[] in scratch)
+#pragma unroll
+    for (int idx = 0; idx < 24; ++idx) {
+        const float lo = idx < 16 ? full[idx & 15] : part[(idx - 16) & 15];      // half 0: dim0 | dim1[0..7]
+        const float hi = idx < 8 ? part[(8 + idx) & 15] : full[(idx - 8) & 15];   // half 1: dim1[8..15] | dim2
+        pos[idx] = h == 0 ? lo : hi;
+    }
+}
+
+// frow / cfrow: LDS feature rows of this lane's POINT (64 floats each); the lane reads its level half.
+template <int HID, int HIDC, bool CP>
+__device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float* cfrow, const float (&pos)[24],
+                                                 const float* atab, int lane, MlpState<HID, HIDC>& S) {
+    typedef ATab<HID, HIDC, CP> T;
+    const int h = lane >> 5;
+    const float* A = atab + lane;
+    const float* fh = frow + h * 32;
+    const float* ch = cfrow + h * 32;
+#pragma unroll
+    for (int t = 0; t < T::NT; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 x = *(const float4*)(fh + 4 * q);
+            acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 4 * q + 0) * 64], x.x, acc);
+            acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 4 * q + 1) * 64], x.y, acc);
+            acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 4 * q + 2) * 64], x.z, acc);
+            acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 4 * q + 3) * 64], x.w, acc);
+        }
+#pragma unroll
+        for (int s = 0; s < 24; ++s) acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 32 + s) * 64], pos[s], acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = fmaxf(acc[e], 0.0f);
+        S.h[t] = acc;
+    }
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16 * T::NT; ++s) acc = MNE_MFMA(A[(T::OFF_L2 + s) * 64], S.h[s >> 4][s & 15], acc);
+        S.out = acc;
+    }
+#pragma unroll
+    for (int t = 0; t < T::NTC; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        const int base = T::OFF_C1 + t * T::C1S;
+#pragma unroll
+        for (int s = 0; s < 24; ++s) acc = MNE_MFMA(A[(base + s) * 64], pos[s], acc);
+        if (CP) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 x = *(const float4*)(ch + 4 * q);
+                acc = MNE_MFMA(A[(base + 24 + 4 * q + 0) * 64], x.x, acc);
+                acc = MNE_MFMA(A[(base + 24 + 4 * q + 1) * 64], x.y, acc);
+                acc = MNE_MFMA(A[(base + 24 + 4 * q + 2) * 64], x.z, acc);
+                acc = MNE_MFMA(A[(base + 24 + 4 * q + 3) * 64], x.w, acc);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = MNE_MFMA(A[(base + 24 + (CP ? 32 : 0) + s) * 64], S.out[s], acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = fmaxf(acc[e], 0.0f);
+        S.hc[t] = acc;
+    }
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16 * T::NTC; ++s) acc = MNE_MFMA(A[(T::OFF_C2 + s) * 64], S.hc[s >> 4][s & 15], acc);
+        S.rgb = acc;
+    }
+}
+
+// Backward data path.  ds/dc: d(total)/d(sdf), d(total)/d(raw rgb) of this lane's point (identical on
+// both lanes of the pair).  Outputs: dh, dout, dhc (tape) and d(feature) rows written to LDS
+// (dfrow / dcfrow = the point's rows; each lane writes the rows it holds).
+template <int HID, int HIDC, bool CP>
+__device__ __forceinline__ void mlp_backward_mfma(const MlpState<HID, HIDC>& S, float ds, const float (&dc)[3],
+                                                  const float* atab, int lane, f32x16 (&dh)[HID / 32],
+                                                  f32x16& dout, f32x16 (&dhc)[HIDC / 32], float* dfrow, float* dcfrow) {
+    typedef ATab<HID, HIDC, CP> T;
+    const int h = lane >> 5;
+    const float* A = atab + lane;
+#pragma unroll
+    for (int t = 0; t < T::NTC; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        acc = MNE_MFMA(A[(T::OFF_B1 + 2 * t + 0) * 64], h ? dc[1] : dc[0], acc);
+        acc = MNE_MFMA(A[(T::OFF_B1 + 2 * t + 1) * 64], h ? 0.0f : dc[2], acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = S.hc[t][e] > 0.0f ? acc[e] : 0.0f;
+        dhc[t] = acc;
+    }
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16 * T::NTC; ++s) acc = MNE_MFMA(A[(T::OFF_B2 + s) * 64], dhc[s >> 4][s & 15], acc);
+        if (h == 0) acc[0] = ds;            // row m = 0 is the sdf output
+        dout = acc;
+    }
+    if (CP) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16 * T::NTC; ++s)
+                acc = MNE_MFMA(A[(T::OFF_B2C + rt * 16 * T::NTC + s) * 64], dhc[s >> 4][s & 15], acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4*)(dcfrow + 32 * rt + 8 * q + 4 * h) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T::NT; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = MNE_MFMA(A[(T::OFF_B3 + 8 * t + s) * 64], dout[s], acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = S.h[t][e] > 0.0f ? acc[e] : 0.0f;
+        dh[t] = acc;
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16 * T::NT; ++s)
+            acc = MNE_MFMA(A[(T::OFF_B4 + rt * 16 * T::NT + s) * 64], dh[s >> 4][s & 15], acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(float4*)(dfrow + 32 * rt + 8 * q + 4 * h) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+}

@@ -115,12 +115,12 @@ __device__ __forceinline__ void oneblob16(float x, float* out /*16*/) {
 
 // ---- gather: tri-plane features of the 64 staged points -> LDS rows ---------------------------
 // Lane layout: 8 lanes x float4 cover one 128-B corner row, 8 points per pass (coalesced rows).
-// pn: LDS [64][4] normalised points; feat: LDS [64][MNE_FS]; set s uses rows of `feat + s*64*MNE_FS`.
-template <int NSETS>
+// pn: LDS [NPTS][4] normalised points; feat: LDS [NSETS][NPTS][MNE_FS].
+template <int NSETS, int NPTS>
 __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane) {
     const int cg = lane & 7;
 #pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NPTS / 8; ++it) {
         const int slot = it * 8 + (lane >> 3);
         const float px = pn[slot * 4 + 0], py = pn[slot * 4 + 1], pz = pn[slot * 4 + 2];
 #pragma unroll
@@ -150,7 +150,7 @@ __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float*
                     acc.z = fmaf(v11.z, b.w11, acc.z); acc.w = fmaf(v11.w, b.w11, acc.w);
                     sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;   // xy + xz + yz
                 }
-                *(float4*)(feat + set * 64 * MNE_FS + slot * MNE_FS + lvl * MNE_C + cg * 4) = sum;
+                *(float4*)(feat + set * NPTS * MNE_FS + slot * MNE_FS + lvl * MNE_C + cg * 4) = sum;
             }
         }
     }
@@ -158,12 +158,12 @@ __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float*
 
 // ---- scatter: d(feature) rows in LDS -> atomic adds into the plane gradients -------------------
 // Lane layout: 32 lanes = the 32 channels of one corner row (one 128-B line per half-wave).
-template <int NSETS>
+template <int NSETS, int NPTS>
 __device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float* pn, const float* dfeat,
                                               int n_valid, int lane) {
     const int c = lane & 31, half = lane >> 5;
 #pragma unroll 1
-    for (int it = 0; it < 32; ++it) {
+    for (int it = 0; it < NPTS / 2; ++it) {
         const int slot = it * 2 + half;
         if (slot < n_valid) {
             const float px = pn[slot * 4 + 0], py = pn[slot * 4 + 1], pz = pn[slot * 4 + 2];
@@ -171,7 +171,7 @@ __device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float
             for (int set = 0; set < NSETS; ++set) {
 #pragma unroll
                 for (int lvl = 0; lvl < 2; ++lvl) {
-                    const float g = dfeat[set * 64 * MNE_FS + slot * MNE_FS + lvl * MNE_C + c];
+                    const float g = dfeat[set * NPTS * MNE_FS + slot * MNE_FS + lvl * MNE_C + c];
 #pragma unroll
                     for (int ori = 0; ori < 3; ++ori) {
                         const mne_plane_t& pl = sc.plane[set][ori][lvl];
@@ -196,14 +196,9 @@ template <int HID, int HIDC, bool CP>
 struct DecDims {
     static constexpr int CINB = CP ? (MNE_POS + MNE_FEAT) : MNE_POS;   // where geo starts in the colour input
     static constexpr int CIN = CINB + MNE_GEO;                           // 63 or 127
-    static constexpr int CINP = CP ? 128 : 64;                           // padded (tape)
-    // packed (transposed) decoder: W1T [112][HID] | W2T [HID][16] | V1T [CIN][HIDC] | V2T [HIDC][4]
-    static constexpr int OFF_W1T = 0;
-    static constexpr int OFF_W2T = OFF_W1T + MNE_IN1 * HID;
-    static constexpr int OFF_V1T = OFF_W2T + HID * MNE_OUT1;
-    static constexpr int OFF_V2T = OFF_V1T + CIN * HIDC;
-    static constexpr int PACKED = OFF_V2T + HIDC * 4;
+    static constexpr int CINP = CINB + MNE_OUT1;                         // tape: [pos | (colour feat) | out16]
     // tape row: X[112] | H[HID] | DH[HID] | DOUT[16] | CIN[CINP] | HC[HIDC] | DHC[HIDC] | DC[4]
+    // (CIN holds the whole out16 = (sdf, geo15); the sdf slot is skipped by the weight-gradient GEMM)
     static constexpr int T_X = 0;
     static constexpr int T_H = T_X + MNE_IN1;
     static constexpr int T_DH = T_H + HID;
@@ -220,69 +215,3 @@ struct DecDims {
     static constexpr int P_SDF1 = P_SDF0 + HID * MNE_IN1;
     static constexpr int NPARAM = P_SDF1 + MNE_OUT1 * HID;
 };
-
-// ---- tiny-MLP forward for one point per lane ---------------------------------------------------
-// frow / cfrow: this lane's LDS feature rows (64 floats each); pos: OneBlob(48) in registers.
-// Weights come through the constant address space (scalar loads -> SGPR operands of the FMAs).
-template <int HID, int HIDC, bool CP>
-__device__ __forceinline__ void mlp_forward(const float* frow, const float* cfrow, const float (&pos)[MNE_POS],
-                                            mne_cptr pk, float (&h)[HID], float (&out)[MNE_OUT1],
-                                            float (&hc)[HIDC], float (&rgb)[3]) {
-    typedef DecDims<HID, HIDC, CP> D;
-    mne_cptr w1t = pk + D::OFF_W1T, w2t = pk + D::OFF_W2T, v1t = pk + D::OFF_V1T, v2t = pk + D::OFF_V2T;
-#pragma unroll
-    for (int j = 0; j < HID; ++j) h[j] = 0.0f;
-#pragma unroll
-    for (int k4 = 0; k4 < MNE_FEAT / 4; ++k4) {
-        const float4 x = *(const float4*)(frow + 4 * k4);
-        const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int j = 0; j < HID; ++j) h[j] = fmaf(w1t[(4 * k4 + kk) * HID + j], xs[kk], h[j]);
-    }
-#pragma unroll
-    for (int k = 0; k < MNE_POS; ++k)
-#pragma unroll
-        for (int j = 0; j < HID; ++j) h[j] = fmaf(w1t[(MNE_FEAT + k) * HID + j], pos[k], h[j]);
-#pragma unroll
-    for (int j = 0; j < HID; ++j) h[j] = fmaxf(h[j], 0.0f);
-#pragma unroll
-    for (int m = 0; m < MNE_OUT1; ++m) out[m] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < HID; ++j)
-#pragma unroll
-        for (int m = 0; m < MNE_OUT1; ++m) out[m] = fmaf(w2t[j * MNE_OUT1 + m], h[j], out[m]);
-    // colour net input = [pos(48), (colour-plane features 64), geo(15)]  (model/decoder.py:137,170)
-#pragma unroll
-    for (int j = 0; j < HIDC; ++j) hc[j] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < MNE_POS; ++k)
-#pragma unroll
-        for (int j = 0; j < HIDC; ++j) hc[j] = fmaf(v1t[k * HIDC + j], pos[k], hc[j]);
-    if (CP) {
-#pragma unroll
-        for (int k4 = 0; k4 < MNE_FEAT / 4; ++k4) {
-            const float4 x = *(const float4*)(cfrow + 4 * k4);
-            const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int j = 0; j < HIDC; ++j)
-                    hc[j] = fmaf(v1t[(MNE_POS + 4 * k4 + kk) * HIDC + j], xs[kk], hc[j]);
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < MNE_GEO; ++g)
-#pragma unroll
-        for (int j = 0; j < HIDC; ++j) hc[j] = fmaf(v1t[(D::CINB + g) * HIDC + j], out[1 + g], hc[j]);
-#pragma unroll
-    for (int j = 0; j < HIDC; ++j) hc[j] = fmaxf(hc[j], 0.0f);
-    rgb[0] = rgb[1] = rgb[2] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < HIDC; ++j) {
-        rgb[0] = fmaf(v2t[j * 4 + 0], hc[j], rgb[0]);
-        rgb[1] = fmaf(v2t[j * 4 + 1], hc[j], rgb[1]);
-        rgb[2] = fmaf(v2t[j * 4 + 2], hc[j], rgb[2]);
-    }
-}

@@ -82,3 +82,4 @@ size_t mne_dims_packed(const mne_scene_t& sc);
 size_t mne_dims_tape_row(const mne_scene_t& sc);
 size_t mne_dims_nparam(const mne_scene_t& sc);
 int mne_wgrad_waves(void);
+size_t mne_render_lds_bytes(int S, int nsets);

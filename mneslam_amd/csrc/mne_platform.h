@@ -8,9 +8,18 @@
 #include <hip/hip_runtime.h>
 #define MNE_LAUNCH(kern, grid, block, lds, stream, ...) \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
+#define MNE_SET_MAX_LDS(kern, bytes) hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 #define MNE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 // Decoder weights are wave-uniform: reading them through the constant address space makes the
 // compiler use scalar (SMEM) loads, so the tiny-MLP FMAs take their weight operand from SGPRs.
 typedef const __attribute__((address_space(4))) float* mne_cptr;
 #define MNE_CPTR(p) ((mne_cptr)(unsigned long long)(p))
+// LDS hand-off between the lanes of ONE wave (each wave owns a private LDS region): DS operations of
+// a wave complete in issue order, so draining lgkmcnt and pinning the compiler's order is enough --
+// no s_barrier, the four waves of a workgroup never wait for each other.
+#define MNE_WAVE_SYNC()                                         \
+    do {                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
 #endif

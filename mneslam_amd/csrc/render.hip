@@ -1,69 +1,78 @@
-// render.hip -- z sampling, fused tri-plane gather -> OneBlob -> tiny MLP -> SDF compositing
-// (forward), and its backward (loss gradients -> MLP backward -> plane-gradient scatter + decoder
-// tape), for the MNE-SLAM mapping iteration on gfx950.
+// render.hip -- z sampling, fused tri-plane gather -> OneBlob -> MFMA tiny-MLP -> SDF compositing
+// (forward) and its backward (loss gradients -> MFMA MLP backward -> plane-gradient scatter +
+// decoder tape) for the MNE-SLAM mapping iteration on gfx950.
 //
-// Work decomposition: ONE WAVE (64 lanes, a 64-thread workgroup) PER RAY.
-//   pass 1  all S samples in chunks of 64: coalesced gather (8 lanes x 16 B per 128-B corner row)
-//           -> per-point feature rows in LDS -> lane-per-point OneBlob + MLP (weights via scalar
-//           loads) -> raw[R][S][4].
-//   pass 2  per-ray reductions with wave shuffles/ballot: first SDF sign change, truncated
-//           sigmoid-product weights, rgb/depth/acc/var maps, per-ray loss partial sums.
-//   pass 3  (backward) ballot/prefix-sum compaction of the samples that receive gradient
-//           (render window or loss masks; SURVEY.md section 7 "early termination must be exact"),
-//           forward recompute on the compacted samples, loss/compositing gradients, MLP backward,
-//           one tape row per sample for the decoder weight-gradient GEMM, and half-wave-per-row
-//           atomic scatter into the plane gradients.
+// Work decomposition: ONE WAVE PER RAY, four independent waves per 256-thread workgroup (they never
+// barrier with each other; each owns a private LDS region and hands data between its own lanes
+// with MNE_WAVE_SYNC).  Samples are processed in tiles of 32 points, two lanes per point:
+//   pass 1  all S samples: coalesced gather (8 lanes x 16 B per 128-B corner row, 12 rows in flight
+//           per lane) -> per-point feature rows in LDS -> OneBlob in registers -> MFMA chain
+//           (mlp_mfma.h) -> raw (r,g,b,sdf) to global and to LDS.
+//   pass 2  per-ray reductions with shuffles/ballot (lane per sample): first SDF sign change,
+//           truncated sigmoid-product weights, rgb/depth/acc/var maps, loss partial sums.
+//   pass 3  (backward) ballot/prefix-sum compaction of the samples that can receive gradient
+//           (render window or loss masks), forward recompute on the compacted tiles, loss and
+//           compositing gradients, MFMA backward chain, one tape row per sample for the decoder
+//           weight-gradient GEMM, half-wave-per-row atomic scatter into the plane gradients.
 //
-// Reference semantics: model/scene_rep.py:28-53,183-230,351-419,475-611; model/decoder.py:143-175;
-// model/utils.py:27-41,117-185 (see include/mneslam_hip.h for the per-entry-point mapping).
-#include "mne_device.h"
+// Reference semantics: model/scene_rep.py:28-53,183-230,351-419,475-611; model/decoder.py:110-175;
+// model/utils.py:27-41,117-185 (include/mneslam_hip.h maps each entry point).
+#include "mlp_mfma.h"
 #include "mne_launch.h"
 
-// -----------------------------------------------------------------------------------------------
-// z sampling + mask counts
-// -----------------------------------------------------------------------------------------------
+#define RAYS_PER_WG 4
+#define TILE 32
 
-__global__ __launch_bounds__(64) void sample_z_kernel(ZArgs a) {
+// -----------------------------------------------------------------------------------------------
+// z sampling + mask counts: one wave per ray, linspace tables staged in LDS once per workgroup
+// -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
     MNE_DYN_LDS(lds_raw);
-    float* vals = (float*)lds_raw;                 // [S] sorted samples of this ray
-    const int lane = threadIdx.x, r = blockIdx.x, S = a.S;
+    const int S = a.S, n_tab = a.has_d ? a.n_a + 2 * a.n_b : S;
+    float* tab = (float*)lds_raw;                                   // [n_tab]
+    for (int i = threadIdx.x; i < n_tab; i += blockDim.x) tab[i] = a.tables[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * RAYS_PER_WG + w;
+    if (r >= a.R) return;                                           // whole wave leaves together
+    float* vals = tab + ((n_tab + 3) & ~3) + w * ((S + 3) & ~3);    // [S] sorted samples of this ray
     float d = 0.0f;
     if (a.has_d) {
         d = a.target_d[r];
-        const float* uni = a.tables;
-        const float* surf = a.tables + a.n_a;
-        const float* inval = a.tables + a.n_a + a.n_b;
-        const bool invalid = d <= 0.0f;            // scene_rep.py:365
+        const float* uni = tab;
+        const float* surf = tab + a.n_a;
+        const float* inval = tab + a.n_a + a.n_b;
+        const bool invalid = d <= 0.0f;                             // scene_rep.py:365
         // stable merge of two ascending sequences by rank (== torch.sort of their concatenation)
         for (int e = lane; e < S; e += MNE_WAVE) {
             if (e < a.n_a) {
                 const float v = uni[e];
-                int lo = 0, hi = a.n_b;             // #b strictly below v
+                int lo = 0, hi = a.n_b;                             // #b strictly below v
                 while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    float bv = invalid ? inval[mid] : surf[mid] + d;
+                    const int mid = (lo + hi) >> 1;
+                    const float bv = invalid ? inval[mid] : surf[mid] + d;
                     if (bv < v) lo = mid + 1; else hi = mid;
                 }
                 vals[e + lo] = v;
             } else {
                 const int j = e - a.n_a;
                 const float v = invalid ? inval[j] : surf[j] + d;
-                int lo = 0, hi = a.n_a;             // #a at or below v
+                int lo = 0, hi = a.n_a;                             // #a at or below v
                 while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
+                    const int mid = (lo + hi) >> 1;
                     if (uni[mid] <= v) lo = mid + 1; else hi = mid;
                 }
                 vals[j + lo] = v;
             }
         }
     } else {
-        for (int e = lane; e < S; e += MNE_WAVE) vals[e] = a.tables[e];
+        for (int e = lane; e < S; e += MNE_WAVE) vals[e] = tab[e];
     }
-    __syncthreads();
+    MNE_WAVE_SYNC();
     int n_front = 0, n_center = 0, n_tail = 0, n_cofs = 0, n_cosdf = 0;
     for (int i = lane; i < S; i += MNE_WAVE) {
         float z = vals[i];
-        if (a.perturb > 0.0f) {                     // scene_rep.py:377-381
+        if (a.perturb > 0.0f) {                                     // scene_rep.py:377-381
             const float zm = vals[i > 0 ? i - 1 : 0], zp = vals[i < S - 1 ? i + 1 : S - 1];
             const float lower = i > 0 ? 0.5f * (z + zm) : z;
             const float upper = i < S - 1 ? 0.5f * (zp + z) : z;
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(64) void sample_z_kernel(ZArgs a) {
         }
         a.z_vals[(size_t)r * S + i] = z;
         if (a.has_d) {
-            if (d > 0.0f) {                         // ESLAM masks, scene_rep.py:489-499 (rays with d>0, :589)
+            if (d > 0.0f) {                                         // ESLAM masks, scene_rep.py:489-499 (d>0 rays, :589)
                 const bool front = z < (d - a.e_T), back = z > (d + a.e_T);
                 const bool center = (z > (d - a.e_T04)) && (z < (d + a.e_T04));
                 n_front += front;
@@ -102,22 +111,17 @@ __global__ __launch_bounds__(64) void sample_z_kernel(ZArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------------
-// decoder packing (transposes so that the forward's inner loop reads contiguous weight rows)
+// decoder packing: the MFMA A-operand tables of mlp_mfma.h (one 64-float row per k-step)
 // -----------------------------------------------------------------------------------------------
 template <int HID, int HIDC, bool CP>
-__global__ void pack_decoder_kernel(mne_scene_t sc, float* pk) {
-    typedef DecDims<HID, HIDC, CP> D;
+__global__ __launch_bounds__(256) void pack_decoder_kernel(mne_scene_t sc, float* pk) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < MNE_IN1 * HID) { int k = t / HID, j = t % HID; pk[D::OFF_W1T + t] = sc.w_sdf0[j * MNE_IN1 + k]; }
-    if (t < HID * MNE_OUT1) { int j = t / MNE_OUT1, m = t % MNE_OUT1; pk[D::OFF_W2T + t] = sc.w_sdf1[m * HID + j]; }
-    if (t < D::CIN * HIDC) { int k = t / HIDC, j = t % HIDC; pk[D::OFF_V1T + t] = sc.w_col0[j * D::CIN + k]; }
-    if (t < HIDC * 4) { int j = t / 4, c = t % 4; pk[D::OFF_V2T + t] = c < 3 ? sc.w_col1[c * HIDC + j] : 0.0f; }
+    if (t < ATab<HID, HIDC, CP>::TOTAL * 64) pk[t] = atab_value<HID, HIDC, CP>(sc, t >> 6, t & 63);
 }
 
 // -----------------------------------------------------------------------------------------------
 // render kernel
 // -----------------------------------------------------------------------------------------------
-
 struct SampleMasks { bool e_front, e_center, e_tail, co_fs, co_sdf; };
 
 __device__ __forceinline__ SampleMasks sample_masks(float z, float d, bool has_t, const RenderArgs& a) {
@@ -134,88 +138,101 @@ __device__ __forceinline__ SampleMasks sample_masks(float z, float d, bool has_t
     return m;
 }
 
+// per-wave LDS: pn[32][4] | feat[NSETS][32][FS] | raws[Spad][4] | list[Spad] (ushort)
+__host__ __device__ inline size_t render_wave_lds_bytes(int S, int nsets) {
+    const size_t Spad = (size_t)((S + 3) & ~3);
+    size_t b = (size_t)(TILE * 4 + nsets * TILE * MNE_FS) * sizeof(float) + Spad * 4 * sizeof(float) + Spad * sizeof(unsigned short);
+    return (b + 15) & ~(size_t)15;
+}
+
 template <int HID, int HIDC, bool CP, bool PASS1, bool BWD>
-__global__ __launch_bounds__(64) void render_kernel(RenderArgs a) {
+__global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     typedef DecDims<HID, HIDC, CP> D;
     constexpr int NSETS = CP ? 2 : 1;
+    constexpr int NT = HID / 32, NTC = HIDC / 32;
     MNE_DYN_LDS(lds_raw);
-    const int lane = threadIdx.x, r = blockIdx.x, S = a.S;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * RAYS_PER_WG + wv;
+    if (r >= a.R) return;                                  // whole wave leaves together; no block barriers below
+    const int S = a.S;
     const int Spad = (S + 3) & ~3;
-    float* pn = (float*)lds_raw;                     // [64][4]
-    float* feat = pn + 64 * 4;                       // [NSETS][64][MNE_FS]
-    float* zs = feat + NSETS * 64 * MNE_FS;          // [Spad]
-    float* sdfs = zs + Spad;                         // [Spad]
-    unsigned short* list = (unsigned short*)(sdfs + Spad);   // [S] compacted sample ids (backward)
-    const mne_cptr pk = MNE_CPTR(a.packed);
+    unsigned char* my = lds_raw + (size_t)wv * render_wave_lds_bytes(S, NSETS);
+    float* pn = (float*)my;                                // [32][4]
+    float* feat = pn + TILE * 4;                           // [NSETS][32][MNE_FS]
+    float* raws = feat + NSETS * TILE * MNE_FS;            // [Spad][4]  (r,g,b,sdf)
+    unsigned short* list = (unsigned short*)(raws + Spad * 4);   // [S] compacted sample ids (backward)
+    const int pt = lane & 31, hf = lane >> 5;
 
     const float o[3] = {a.rays_o[r * 3 + 0], a.rays_o[r * 3 + 1], a.rays_o[r * 3 + 2]};
     const float dv[3] = {a.rays_d[r * 3 + 0], a.rays_d[r * 3 + 1], a.rays_d[r * 3 + 2]};
     const bool has_t = a.target_d != nullptr;
     const float td = has_t ? a.target_d[r] : 0.0f;
-    const float* rawp = PASS1 ? a.raw : a.raw_in;
+    const float* zr = a.z_vals + (size_t)r * S;
 
-    for (int i = lane; i < S; i += MNE_WAVE) zs[i] = a.z_vals[(size_t)r * S + i];
-    if (!PASS1)
-        for (int i = lane; i < S; i += MNE_WAVE) sdfs[i] = rawp[((size_t)r * S + i) * 4 + 3];
-    __syncthreads();
+    if (!PASS1) {
+        const float4* src = (const float4*)(a.raw_in + (size_t)r * S * 4);
+        for (int i = lane; i < S; i += MNE_WAVE) *(float4*)(raws + 4 * i) = src[i];
+    }
 
     // ------------------------------------------------------------------ pass 1: decode all samples
     if (PASS1) {
-        const int nchunk = (S + MNE_WAVE - 1) / MNE_WAVE;
+        const int ntile = (S + TILE - 1) / TILE;
 #pragma unroll 1
-        for (int c = 0; c < nchunk; ++c) {
-            const int i = c * MNE_WAVE + lane;
+        for (int c = 0; c < ntile; ++c) {
+            const int i = c * TILE + pt;
             const bool valid = i < S;
-            const float z = zs[valid ? i : S - 1];
+            const float z = zr[valid ? i : S - 1];
             float p[3], pnv[3], u[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) p[k] = o[k] + dv[k] * z;         // scene_rep.py:384
+            for (int k = 0; k < 3; ++k) p[k] = o[k] + dv[k] * z;          // scene_rep.py:384
             point_coords(a.sc, p, pnv, u);
-            pn[lane * 4 + 0] = pnv[0]; pn[lane * 4 + 1] = pnv[1]; pn[lane * 4 + 2] = pnv[2];
-            __syncthreads();
-            gather_chunk<NSETS>(a.sc, pn, feat, lane);
-            __syncthreads();
-            float pos[MNE_POS];
-            oneblob16(u[0], pos); oneblob16(u[1], pos + 16); oneblob16(u[2], pos + 32);
-            float h[HID], out[MNE_OUT1], hc[HIDC], rgbr[3];
-            mlp_forward<HID, HIDC, CP>(feat + lane * MNE_FS, feat + 64 * MNE_FS + lane * MNE_FS, pos, pk, h, out, hc, rgbr);
-            if (valid) {
-                *(float4*)(a.raw + ((size_t)r * S + i) * 4) = make_float4(rgbr[0], rgbr[1], rgbr[2], out[0]);
-                sdfs[i] = out[0];
+            if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+            MNE_WAVE_SYNC();
+            gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+            MNE_WAVE_SYNC();
+            float pos[24];
+            oneblob_half(u, hf, pos);
+            MlpState<HID, HIDC> st;
+            mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, a.packed, lane, st);
+            if (valid && hf == 0) {                                        // rows 0..3 live in the lower half
+                const float4 rw = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);
+                *(float4*)(a.raw + ((size_t)r * S + i) * 4) = rw;
+                *(float4*)(raws + 4 * i) = rw;
             }
-            __syncthreads();
+            MNE_WAVE_SYNC();
         }
     }
+    MNE_WAVE_SYNC();
 
-    // ------------------------------------------------------------------ pass 2: compositing
+    // ------------------------------------------------------------------ pass 2: compositing (lane per sample)
     // first adjacent sign change (argmax of a 0/1 mask = first occurrence, 0 when none), scene_rep.py:195-199
     int first = 0;
     {
         const int nchunk = (S + MNE_WAVE - 1) / MNE_WAVE;
         for (int c = 0; c < nchunk; ++c) {
             const int i = c * MNE_WAVE + lane;
-            const bool cr = (i < S - 1) && (sdfs[i + 1] * sdfs[i] < 0.0f);
+            const bool cr = (i < S - 1) && (raws[4 * (i + 1) + 3] * raws[4 * i + 3] < 0.0f);
             const unsigned long long m = __ballot(cr);
             if (m) { first = c * MNE_WAVE + __ffsll(m) - 1; break; }
         }
     }
-    const float z_min = zs[first];
+    const float z_min = zr[first];
     const float z_lim = z_min + a.win_f;                                   // scene_rep.py:200
     float wsum = 0.0f;
     for (int i = lane; i < S; i += MNE_WAVE) {
-        const float s = sdfs[i];
+        const float s = raws[4 * i + 3];
         const float wt = sigmoidf_(s / a.trunc_f) * sigmoidf_(-s / a.trunc_f);
-        wsum += (zs[i] < z_lim) ? wt : 0.0f;
+        wsum += (zr[i] < z_lim) ? wt : 0.0f;
     }
     wsum = wave_sum(wsum);
     const float denom = wsum + 1e-8f;                                       // scene_rep.py:203
     float m_rgb[3] = {0.f, 0.f, 0.f}, m_depth = 0.f, m_acc = 0.f;
     float l_efs = 0.f, l_ec = 0.f, l_et = 0.f, l_cofs = 0.f, l_cosdf = 0.f;
     for (int i = lane; i < S; i += MNE_WAVE) {
-        const float s = sdfs[i], z = zs[i];
+        const float4 rw = *(const float4*)(raws + 4 * i);
+        const float s = rw.w, z = zr[i];
         const float wt = sigmoidf_(s / a.trunc_f) * sigmoidf_(-s / a.trunc_f);
         const float w = ((z < z_lim) ? wt : 0.0f) / denom;
-        const float4 rw = *(const float4*)(rawp + ((size_t)r * S + i) * 4);
         m_rgb[0] += w * sigmoidf_(rw.x); m_rgb[1] += w * sigmoidf_(rw.y); m_rgb[2] += w * sigmoidf_(rw.z);
         m_depth += w * z;
         m_acc += w;
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(64) void render_kernel(RenderArgs a) {
     if (a.depth_var || a.disp) {
         float var = 0.f;
         for (int i = lane; i < S; i += MNE_WAVE) {
-            const float s = sdfs[i], z = zs[i];
+            const float s = raws[4 * i + 3], z = zr[i];
             const float wt = sigmoidf_(s / a.trunc_f) * sigmoidf_(-s / a.trunc_f);
             const float w = ((z < z_lim) ? wt : 0.0f) / denom;
             const float dz = z - m_depth;
@@ -281,10 +298,10 @@ __global__ __launch_bounds__(64) void render_kernel(RenderArgs a) {
         for (int k = 0; k < 3; ++k)
             g_rgb[k] = (a.target_rgb ? cf[MNE_L_RGB] * (m_rgb[k] - trgb[k]) : 0.0f) + (a.g_rgb ? a.g_rgb[r * 3 + k] : 0.0f);
         g_dep = (valid_ray ? cf[MNE_L_DEPTH] * (m_depth - td) : 0.0f) + (a.g_depth ? a.g_depth[r] : 0.0f);
-        const float A = g_rgb[0] * m_rgb[0] + g_rgb[1] * m_rgb[1] + g_rgb[2] * m_rgb[2] + g_dep * m_depth;
+        const float Aq = g_rgb[0] * m_rgb[0] + g_rgb[1] * m_rgb[1] + g_rgb[2] * m_rgb[2] + g_dep * m_depth;
         const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
         const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
-        // compaction of the samples that can receive a non-zero gradient
+        // compaction of the samples that can receive a non-zero gradient (wave ballot + prefix popcount)
         int n_contrib = 0;
         {
             const int nchunk = (S + MNE_WAVE - 1) / MNE_WAVE;
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(64) void render_kernel(RenderArgs a) {
                 const int i = c * MNE_WAVE + lane;
                 bool f = false;
                 if (i < S) {
-                    const float z = zs[i];
+                    const float z = zr[i];
                     const SampleMasks mk = sample_masks(z, td, has_t, a);
                     f = (z < z_lim) || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) ||
                         (use_co && (mk.co_fs || mk.co_sdf));
@@ -302,43 +319,43 @@ __global__ __launch_bounds__(64) void render_kernel(RenderArgs a) {
                 n_contrib += __popcll(m);
             }
         }
-        __syncthreads();
+        MNE_WAVE_SYNC();
         int tape_base = 0;
         if (lane == 0 && n_contrib > 0) tape_base = atomicAdd(a.tape_rows, n_contrib);
         tape_base = __shfl(tape_base, 0);
-        float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
-        const int nck = (n_contrib + MNE_WAVE - 1) / MNE_WAVE;
+        const int ntile = (n_contrib + TILE - 1) / TILE;
 #pragma unroll 1
-        for (int cc = 0; cc < nck; ++cc) {
-            const int k = cc * MNE_WAVE + lane;
+        for (int cc = 0; cc < ntile; ++cc) {
+            const int k = cc * TILE + pt;
             const bool valid = k < n_contrib;
             const int i = list[valid ? k : n_contrib - 1];
-            const float z = zs[i];
+            const float z = zr[i];
             float p[3], pnv[3], u[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) p[q] = o[q] + dv[q] * z;
             point_coords(a.sc, p, pnv, u);
-            pn[lane * 4 + 0] = pnv[0]; pn[lane * 4 + 1] = pnv[1]; pn[lane * 4 + 2] = pnv[2];
-            __syncthreads();
-            gather_chunk<NSETS>(a.sc, pn, feat, lane);
-            __syncthreads();
-            float* frow = feat + lane * MNE_FS;
-            float* cfrow = feat + 64 * MNE_FS + lane * MNE_FS;
-            float pos[MNE_POS];
-            oneblob16(u[0], pos); oneblob16(u[1], pos + 16); oneblob16(u[2], pos + 32);
-            float h[HID], out[MNE_OUT1], hc[HIDC], rgbr[3];
-            mlp_forward<HID, HIDC, CP>(frow, cfrow, pos, pk, h, out, hc, rgbr);
-            // ---- d(total)/d(raw) for this sample
-            const float s = out[0];
+            if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+            MNE_WAVE_SYNC();
+            gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+            MNE_WAVE_SYNC();
+            float* frow = feat + pt * MNE_FS;
+            float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
+            float pos[24];
+            oneblob_half(u, hf, pos);
+            MlpState<HID, HIDC> st;
+            mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, a.packed, lane, st);
+            // ---- d(total)/d(raw) of this point (both lanes of the pair compute the same values)
+            const float4 rw = *(const float4*)(raws + 4 * i);
+            const float s = rw.w;
             float ds = 0.0f, dc[3] = {0.f, 0.f, 0.f};
             if (valid) {
                 if (z < z_lim) {
                     const float pp = sigmoidf_(s / a.trunc_f), qq = sigmoidf_(-s / a.trunc_f);
                     const float wt = pp * qq;
                     const float w = wt / denom;
-                    const float sg[3] = {sigmoidf_(rgbr[0]), sigmoidf_(rgbr[1]), sigmoidf_(rgbr[2])};
+                    const float sg[3] = {sigmoidf_(rw.x), sigmoidf_(rw.y), sigmoidf_(rw.z)};
                     const float dLdw = g_rgb[0] * sg[0] + g_rgb[1] * sg[1] + g_rgb[2] * sg[2] + g_dep * z;
-                    ds += ((dLdw - A) / denom) * (wt * (qq - pp) / a.trunc_f);
+                    ds += ((dLdw - Aq) / denom) * (wt * (qq - pp) / a.trunc_f);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) dc[q] = g_rgb[q] * w * (sg[q] * (1.0f - sg[q]));
                 }
@@ -350,111 +367,72 @@ __global__ __launch_bounds__(64) void render_kernel(RenderArgs a) {
                 if (mk.co_fs) ds += cf[MNE_L_CO_FS] * (s - 1.0f);
                 if (mk.co_sdf) ds += cf[MNE_L_CO_SDF] * c_res;
             }
-            // ---- MLP backward (weights in nn.Linear layout [out][in], scalar loads)
-            const mne_cptr W1 = MNE_CPTR(a.sc.w_sdf0), W2 = MNE_CPTR(a.sc.w_sdf1);
-            const mne_cptr V1 = MNE_CPTR(a.sc.w_col0), V2 = MNE_CPTR(a.sc.w_col1);
-            float dhc[HIDC];
-#pragma unroll
-            for (int j = 0; j < HIDC; ++j) {
-                float t = V2[0 * HIDC + j] * dc[0];
-                t = fmaf(V2[1 * HIDC + j], dc[1], t);
-                t = fmaf(V2[2 * HIDC + j], dc[2], t);
-                dhc[j] = hc[j] > 0.0f ? t : 0.0f;
-            }
-            float dout[MNE_OUT1];
-            dout[0] = ds;
-#pragma unroll
-            for (int g = 0; g < MNE_GEO; ++g) dout[1 + g] = 0.0f;
-#pragma unroll
-            for (int j = 0; j < HIDC; ++j)
-#pragma unroll
-                for (int g = 0; g < MNE_GEO; ++g)
-                    dout[1 + g] = fmaf(V1[j * D::CIN + D::CINB + g], dhc[j], dout[1 + g]);
-            float dh[HID];
-#pragma unroll
-            for (int j = 0; j < HID; ++j) dh[j] = 0.0f;
-#pragma unroll
-            for (int m = 0; m < MNE_OUT1; ++m)
-#pragma unroll
-                for (int j = 0; j < HID; ++j) dh[j] = fmaf(W2[m * HID + j], dout[m], dh[j]);
-#pragma unroll
-            for (int j = 0; j < HID; ++j) dh[j] = h[j] > 0.0f ? dh[j] : 0.0f;
-            // ---- tape row for the decoder weight-gradient GEMM
+            // ---- tape: forward activations of this point (each lane writes the part it holds)
+            float* row = a.tape + (size_t)(tape_base + (valid ? k : 0)) * D::ROW;
             if (valid) {
-                float* row = a.tape + (size_t)(tape_base + k) * D::ROW;
 #pragma unroll
-                for (int q = 0; q < MNE_FEAT / 4; ++q) *(float4*)(row + D::T_X + 4 * q) = *(const float4*)(frow + 4 * q);
+                for (int q = 0; q < 8; ++q)
+                    *(float4*)(row + D::T_X + hf * 32 + 4 * q) = *(const float4*)(frow + hf * 32 + 4 * q);
 #pragma unroll
-                for (int q = 0; q < MNE_POS / 4; ++q)
-                    *(float4*)(row + D::T_X + MNE_FEAT + 4 * q) = make_float4(pos[4 * q], pos[4 * q + 1], pos[4 * q + 2], pos[4 * q + 3]);
-#pragma unroll
-                for (int q = 0; q < HID / 4; ++q) {
-                    *(float4*)(row + D::T_H + 4 * q) = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
-                    *(float4*)(row + D::T_DH + 4 * q) = make_float4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]);
+                for (int q = 0; q < 6; ++q) {
+                    const float4 pv = make_float4(pos[4 * q], pos[4 * q + 1], pos[4 * q + 2], pos[4 * q + 3]);
+                    *(float4*)(row + D::T_X + MNE_FEAT + hf * 24 + 4 * q) = pv;
+                    *(float4*)(row + D::T_CIN + hf * 24 + 4 * q) = pv;
                 }
-#pragma unroll
-                for (int q = 0; q < MNE_OUT1 / 4; ++q)
-                    *(float4*)(row + D::T_DOUT + 4 * q) = make_float4(dout[4 * q], dout[4 * q + 1], dout[4 * q + 2], dout[4 * q + 3]);
-                // colour-net input [pos | (colour features) | geo | 0-pad]
-#pragma unroll
-                for (int q = 0; q < MNE_POS / 4; ++q)
-                    *(float4*)(row + D::T_CIN + 4 * q) = make_float4(pos[4 * q], pos[4 * q + 1], pos[4 * q + 2], pos[4 * q + 3]);
                 if (CP) {
 #pragma unroll
-                    for (int q = 0; q < MNE_FEAT / 4; ++q)
-                        *(float4*)(row + D::T_CIN + MNE_POS + 4 * q) = *(const float4*)(cfrow + 4 * q);
+                    for (int q = 0; q < 8; ++q)
+                        *(float4*)(row + D::T_CIN + MNE_POS + hf * 32 + 4 * q) = *(const float4*)(cfrow + hf * 32 + 4 * q);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int b = 1 + 4 * q;      // geo index base (out[1..15]) + one zero pad
-                    *(float4*)(row + D::T_CIN + D::CINB + 4 * q) =
-                        make_float4(out[b], out[b + 1], out[b + 2], (b + 3 < MNE_OUT1) ? out[(b + 3) & 15] : 0.0f);
-                }
+                for (int q = 0; q < 2; ++q)
+                    *(float4*)(row + D::T_CIN + D::CINB + 8 * q + 4 * hf) =
+                        make_float4(st.out[4 * q], st.out[4 * q + 1], st.out[4 * q + 2], st.out[4 * q + 3]);
 #pragma unroll
-                for (int q = 0; q < HIDC / 4; ++q) {
-                    *(float4*)(row + D::T_HC + 4 * q) = make_float4(hc[4 * q], hc[4 * q + 1], hc[4 * q + 2], hc[4 * q + 3]);
-                    *(float4*)(row + D::T_DHC + 4 * q) = make_float4(dhc[4 * q], dhc[4 * q + 1], dhc[4 * q + 2], dhc[4 * q + 3]);
-                }
-                *(float4*)(row + D::T_DC) = make_float4(dc[0], dc[1], dc[2], 0.0f);
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(float4*)(row + D::T_H + 32 * t + 8 * q + 4 * hf) =
+                            make_float4(st.h[t][4 * q], st.h[t][4 * q + 1], st.h[t][4 * q + 2], st.h[t][4 * q + 3]);
+#pragma unroll
+                for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(float4*)(row + D::T_HC + 32 * t + 8 * q + 4 * hf) =
+                            make_float4(st.hc[t][4 * q], st.hc[t][4 * q + 1], st.hc[t][4 * q + 2], st.hc[t][4 * q + 3]);
+                if (hf == 0) *(float4*)(row + D::T_DC) = make_float4(dc[0], dc[1], dc[2], 0.0f);
             }
-            // ---- d(feature): geometry planes via sdf-net layer 1, colour planes via colour-net layer 1
-            {
-                float dx[MNE_FEAT];
+            // ---- MFMA backward chain; d(feature) rows overwrite this point's LDS feature rows
+            f32x16 dh[NT], dout, dhc[NTC];
+            mlp_backward_mfma<HID, HIDC, CP>(st, ds, dc, a.packed, lane, dh, dout, dhc, frow, cfrow);
+            if (valid) {
 #pragma unroll
-                for (int q = 0; q < MNE_FEAT; ++q) dx[q] = 0.0f;
+                for (int q = 0; q < 2; ++q)
+                    *(float4*)(row + D::T_DOUT + 8 * q + 4 * hf) = make_float4(dout[4 * q], dout[4 * q + 1], dout[4 * q + 2], dout[4 * q + 3]);
 #pragma unroll
-                for (int j = 0; j < HID; ++j)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int q = 0; q < MNE_FEAT; ++q) dx[q] = fmaf(W1[j * MNE_IN1 + q], dh[j], dx[q]);
+                    for (int q = 0; q < 4; ++q)
+                        *(float4*)(row + D::T_DH + 32 * t + 8 * q + 4 * hf) =
+                            make_float4(dh[t][4 * q], dh[t][4 * q + 1], dh[t][4 * q + 2], dh[t][4 * q + 3]);
 #pragma unroll
-                for (int q = 0; q < MNE_FEAT / 4; ++q)
-                    *(float4*)(frow + 4 * q) = make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+                for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(float4*)(row + D::T_DHC + 32 * t + 8 * q + 4 * hf) =
+                            make_float4(dhc[t][4 * q], dhc[t][4 * q + 1], dhc[t][4 * q + 2], dhc[t][4 * q + 3]);
             }
-            if (CP) {
-                float dx[MNE_FEAT];
-#pragma unroll
-                for (int q = 0; q < MNE_FEAT; ++q) dx[q] = 0.0f;
-#pragma unroll
-                for (int j = 0; j < HIDC; ++j)
-#pragma unroll
-                    for (int q = 0; q < MNE_FEAT; ++q) dx[q] = fmaf(V1[j * D::CIN + MNE_POS + q], dhc[j], dx[q]);
-#pragma unroll
-                for (int q = 0; q < MNE_FEAT / 4; ++q)
-                    *(float4*)(cfrow + 4 * q) = make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
-            }
-            __syncthreads();
-            const int n_here = n_contrib - cc * MNE_WAVE;
-            scatter_chunk<NSETS>(a.sc, pn, feat, n_here < MNE_WAVE ? n_here : MNE_WAVE, lane);
-            __syncthreads();
+            MNE_WAVE_SYNC();
+            const int n_here = n_contrib - cc * TILE;
+            scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane);
+            MNE_WAVE_SYNC();
         }
-        (void)go; (void)gd;
     }
 }
 
 // -----------------------------------------------------------------------------------------------
 // loss scalars / coefficients (single small block; deterministic summation order)
 // -----------------------------------------------------------------------------------------------
-
 __global__ __launch_bounds__(256) void loss_finalize_kernel(LossArgs a) {
     __shared__ double part[256][MNE_N_LOSS];
     const int t = threadIdx.x;
@@ -507,40 +485,49 @@ __global__ void loss_coef_kernel(LossArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------------
-// point queries (forward only): lane per point, same gather/MLP building blocks
+// point queries (forward only): 32 points per wave, same gather / MFMA building blocks
 // -----------------------------------------------------------------------------------------------
-
 template <int HID, int HIDC, bool CP>
-__global__ __launch_bounds__(64) void query_kernel(QueryArgs a) {
+__global__ __launch_bounds__(256) void query_kernel(QueryArgs a) {
     constexpr int NSETS = CP ? 2 : 1;
     MNE_DYN_LDS(lds_raw);
-    float* pn = (float*)lds_raw;
-    float* feat = pn + 64 * 4;
-    const int lane = threadIdx.x;
-    const long long i = (long long)blockIdx.x * MNE_WAVE + lane;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long tile = (long long)blockIdx.x * RAYS_PER_WG + wv;
+    if (tile * TILE >= a.n) return;
+    float* pn = (float*)lds_raw + (size_t)wv * (TILE * 4 + NSETS * TILE * MNE_FS);
+    float* feat = pn + TILE * 4;
+    const int pt = lane & 31, hf = lane >> 5;
+    const long long i = tile * TILE + pt;
     const bool valid = i < a.n;
     const long long ii = valid ? i : a.n - 1;
     const float p[3] = {a.pts[ii * 3 + 0], a.pts[ii * 3 + 1], a.pts[ii * 3 + 2]};
     float pnv[3], u[3];
     point_coords(a.sc, p, pnv, u);
     if (a.flags & MNE_QUERY_PTS_NORMALISED) { pnv[0] = p[0]; pnv[1] = p[1]; pnv[2] = p[2]; }
-    pn[lane * 4 + 0] = pnv[0]; pn[lane * 4 + 1] = pnv[1]; pn[lane * 4 + 2] = pnv[2];
-    __syncthreads();
-    gather_chunk<NSETS>(a.sc, pn, feat, lane);
-    __syncthreads();
+    if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+    MNE_WAVE_SYNC();
+    gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+    MNE_WAVE_SYNC();
     if (a.feat_out && valid) {
-        for (int q = 0; q < MNE_FEAT / 4; ++q)
-            *(float4*)(a.feat_out + i * MNE_FEAT + 4 * q) = *(const float4*)(feat + lane * MNE_FS + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            *(float4*)(a.feat_out + i * MNE_FEAT + hf * 32 + 4 * q) = *(const float4*)(feat + pt * MNE_FS + hf * 32 + 4 * q);
     }
     if (a.raw || a.geo) {
-        float pos[MNE_POS];
-        oneblob16(u[0], pos); oneblob16(u[1], pos + 16); oneblob16(u[2], pos + 32);
-        float h[HID], out[MNE_OUT1], hc[HIDC], rgbr[3];
-        mlp_forward<HID, HIDC, CP>(feat + lane * MNE_FS, feat + 64 * MNE_FS + lane * MNE_FS, pos, MNE_CPTR(a.packed), h, out, hc, rgbr);
+        float pos[24];
+        oneblob_half(u, hf, pos);
+        MlpState<HID, HIDC> st;
+        mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, a.packed, lane, st);
         if (valid) {
-            if (a.raw) *(float4*)(a.raw + i * 4) = make_float4(rgbr[0], rgbr[1], rgbr[2], out[0]);
-            if (a.geo)
-                for (int g = 0; g < MNE_GEO; ++g) a.geo[i * MNE_GEO + g] = out[1 + g];
+            if (a.raw && hf == 0) *(float4*)(a.raw + i * 4) = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);
+            if (a.geo) {
+                // out16 rows held by this lane: m = (r&3) + 8(r>>2) + 4 hf, r = 0..7; geo index = m-1
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int m = mfma_row(rr, 0) + 4 * hf;
+                    if (m >= 1) a.geo[i * MNE_GEO + m - 1] = st.out[rr];
+                }
+            }
         }
     }
 }
@@ -567,37 +554,43 @@ int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStr
 // -----------------------------------------------------------------------------------------------
 // host-side launchers (called from capi.hip)
 // -----------------------------------------------------------------------------------------------
-static size_t render_lds_bytes(int S, int nsets) {
-    const int Spad = (S + 3) & ~3;
-    return (size_t)(64 * 4 + nsets * 64 * MNE_FS + 2 * Spad) * sizeof(float) + (size_t)((S + 1) & ~1) * sizeof(unsigned short);
-}
+size_t mne_render_lds_bytes(int S, int nsets) { return RAYS_PER_WG * render_wave_lds_bytes(S, nsets); }
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
-    MNE_LAUNCH(sample_z_kernel, a.R, 64, (size_t)a.S * sizeof(float), st, a);
+    const int n_tab = a.has_d ? a.n_a + 2 * a.n_b : a.S;
+    const size_t lds = (size_t)(((n_tab + 3) & ~3) + RAYS_PER_WG * ((a.S + 3) & ~3)) * sizeof(float);
+    MNE_LAUNCH(sample_z_kernel, (a.R + RAYS_PER_WG - 1) / RAYS_PER_WG, 256, lds, st, a);
     return 0;
 }
 
 template <int HID, int HIDC, bool CP>
 static int launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
-    const int n = MNE_IN1 * HID > DecDims<HID, HIDC, CP>::CIN * HIDC ? MNE_IN1 * HID : DecDims<HID, HIDC, CP>::CIN * HIDC;
+    const int n = ATab<HID, HIDC, CP>::TOTAL * 64;
     MNE_LAUNCH((pack_decoder_kernel<HID, HIDC, CP>), (n + 255) / 256, 256, 0, st, sc, pk);
     return 0;
 }
 
 template <int HID, int HIDC, bool CP>
 static int launch_render(const RenderArgs& a, int pass1, int bwd, hipStream_t st) {
-    const size_t lds = render_lds_bytes(a.S, CP ? 2 : 1);
-    if (pass1 && !bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, false>), a.R, 64, lds, st, a);
-    else if (!pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true>), a.R, 64, lds, st, a);
-    else if (pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, true>), a.R, 64, lds, st, a);
+    const size_t lds = mne_render_lds_bytes(a.S, CP ? 2 : 1);
+    const int grid = (a.R + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    if (lds > 64 * 1024) {          // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, false>), 160 * 1024);
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, false, true>), 160 * 1024);
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, true>), 160 * 1024);
+    }
+    if (pass1 && !bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, false>), grid, 256, lds, st, a);
+    else if (!pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true>), grid, 256, lds, st, a);
+    else if (pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, true>), grid, 256, lds, st, a);
     else return -1;
     return 0;
 }
 
 template <int HID, int HIDC, bool CP>
 static int launch_query(const QueryArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)(64 * 4 + (CP ? 2 : 1) * 64 * MNE_FS) * sizeof(float);
-    MNE_LAUNCH((query_kernel<HID, HIDC, CP>), (unsigned)((a.n + 63) / 64), 64, lds, st, a);
+    const size_t lds = (size_t)RAYS_PER_WG * (TILE * 4 + (CP ? 2 : 1) * TILE * MNE_FS) * sizeof(float);
+    const long long tiles = (a.n + TILE - 1) / TILE;
+    MNE_LAUNCH((query_kernel<HID, HIDC, CP>), (unsigned)((tiles + RAYS_PER_WG - 1) / RAYS_PER_WG), 256, lds, st, a);
     return 0;
 }
 
@@ -641,7 +634,7 @@ int mne_launch_loss_coef(const LossArgs& a, hipStream_t st) {
 }
 
 size_t mne_dims_packed(const mne_scene_t& sc) {
-#define CALL(H, HC, CPV) return (size_t)DecDims<H, HC, CPV>::PACKED
+#define CALL(H, HC, CPV) return (size_t)ATab<H, HC, CPV>::TOTAL * 64
     MNE_DISPATCH(sc, CALL, 0);
 #undef CALL
     return 0;

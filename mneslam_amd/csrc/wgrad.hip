@@ -2,15 +2,21 @@
 //     dW[o][i] = sum_t dY[t][o] * X[t][i]          (K = number of contributing samples, ~1e5)
 // on the matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32 at the vector rate).  Operands are
 // loaded straight from the tape in fragment layout -- lane l reads dY[t0+(l>>5)][o0+(l&31)] and
-// X[t0+(l>>5)][i0+(l&31)], i.e. two coalesced 128-B row segments per instruction, no LDS.
-// Each wave owns a contiguous slice of tape rows and writes one partial result; a second tiny
-// kernel sums the partials in a fixed order (deterministic given the tape).
+// X[t0+(l>>5)][i0+(l&31)], i.e. two coalesced 128-B row segments per instruction, no LDS.  Eight
+// tape rows (4 k-steps) are loaded per loop trip before their MFMAs issue, so each wave keeps
+// 4*(TM+TN) loads in flight.  Each wave owns a contiguous slice of tape rows and writes one partial
+// result; a second small kernel sums the partials in a fixed order (deterministic given the tape).
 #include "mne_device.h"
 #include "mne_launch.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct GemmDesc { int offA, OUT, offB, IN, poff; };
+// offA/OUT: tape column and width of dY; offB/IN: tape column and width of X; skip: one tape column
+// of X that is not a weight input (the sdf slot inside the colour-net input), -1 = none;
+// poff/ld: offset and row length of the matrix inside the decoder parameter buffer.
+struct GemmDesc { int offA, OUT, offB, IN, skip, poff, ld; };
+
+#define WG_KSTEPS 4
 
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, GemmDesc g, int row_stride, int nparam) {
@@ -19,7 +25,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, GemmDesc g
     const int nw = gridDim.x * (blockDim.x >> 6);
     const int n = *a.tape_rows;
     int per = (n + nw - 1) / nw;
-    per = (per + 1) & ~1;
+    per = (per + 2 * WG_KSTEPS - 1) / (2 * WG_KSTEPS) * (2 * WG_KSTEPS);
     const int t0 = gw * per;
     const int t1 = (t0 + per < n) ? t0 + per : n;
     f32x16 acc[TM][TN];
@@ -30,26 +36,31 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, GemmDesc g
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][q][e] = 0.0f;
     const int col = lane & 31, kk = lane >> 5;
-    for (int t = t0; t < t1; t += 2) {
-        const int tt = t + kk;
-        const bool ok = tt < t1;
-        const float* row = a.tape + (size_t)(ok ? tt : t) * row_stride;
-        float av[TM], bv[TN];
+    for (int t = t0; t < t1; t += 2 * WG_KSTEPS) {
+        float av[WG_KSTEPS][TM], bv[WG_KSTEPS][TN];
 #pragma unroll
-        for (int m = 0; m < TM; ++m) {
-            const int o = 32 * m + col;
-            av[m] = (ok && o < g.OUT) ? row[g.offA + o] : 0.0f;
+        for (int ks = 0; ks < WG_KSTEPS; ++ks) {
+            const int tt = t + 2 * ks + kk;
+            const bool ok = tt < t1;
+            const float* row = a.tape + (size_t)(ok ? tt : t0) * row_stride;
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                const int o = 32 * m + col;
+                av[ks][m] = (ok && o < g.OUT) ? row[g.offA + o] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < TN; ++q) {
+                const int i = 32 * q + col;
+                bv[ks][q] = (ok && i < g.IN) ? row[g.offB + i] : 0.0f;
+            }
         }
 #pragma unroll
-        for (int q = 0; q < TN; ++q) {
-            const int i = 32 * q + col;
-            bv[q] = (ok && i < g.IN) ? row[g.offB + i] : 0.0f;
-        }
+        for (int ks = 0; ks < WG_KSTEPS; ++ks)
 #pragma unroll
-        for (int m = 0; m < TM; ++m)
+            for (int m = 0; m < TM; ++m)
 #pragma unroll
-            for (int q = 0; q < TN; ++q)
-                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[q], acc[m][q], 0, 0, 0);
+                for (int q = 0; q < TN; ++q)
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][m], bv[ks][q], acc[m][q], 0, 0, 0);
     }
     float* out = a.partials + (size_t)gw * nparam + g.poff;
 #pragma unroll
@@ -60,23 +71,35 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, GemmDesc g
             for (int e = 0; e < 16; ++e) {
                 const int o = 32 * m + (e & 3) + 8 * (e >> 2) + 4 * kk;
                 const int i = 32 * q + col;
-                if (o < g.OUT && i < g.IN) out[o * g.IN + i] = acc[m][q][e];
+                if (o < g.OUT && i < g.IN && i != g.skip) out[o * g.ld + (g.skip >= 0 && i > g.skip ? i - 1 : i)] = acc[m][q][e];
             }
 }
 
+// 32 parameters per block, 8 groups of partials per parameter, fixed summation order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int nparam) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nparam) return;
+    __shared__ float part[8][32];
+    const int e = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
     float s = 0.0f;
-    for (int w = 0; w < a.n_waves; ++w) s += a.partials[(size_t)w * nparam + e];
-    a.grad_out[e] = s;
+    if (e < nparam) {
+#pragma unroll 8
+        for (int w = grp; w < a.n_waves; w += 8) s += a.partials[(size_t)w * nparam + e];
+    }
+    part[grp][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (grp == 0 && e < nparam) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += part[k][threadIdx.x];
+        a.grad_out[e] = tot;
+    }
 }
 
 // scalar cross-check of the MFMA path (impl = 1): one thread per output element
 __global__ __launch_bounds__(256) void wgrad_scalar_kernel(WgradArgs a, GemmDesc g, int row_stride) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= g.OUT * g.IN) return;
-    const int o = e / g.IN, i = e % g.IN;
+    if (e >= g.OUT * g.ld) return;
+    const int o = e / g.ld, c = e % g.ld;
+    const int i = (g.skip >= 0 && c >= g.skip) ? c + 1 : c;       // tape column of parameter column c
     const int n = *a.tape_rows;
     float s = 0.0f;
     for (int t = 0; t < n; ++t) {
@@ -86,21 +109,21 @@ __global__ __launch_bounds__(256) void wgrad_scalar_kernel(WgradArgs a, GemmDesc
     a.grad_out[g.poff + e] = s;
 }
 
-#define MNE_WGRAD_BLOCKS 128      // x 4 waves = 512 partial results
+#define MNE_WGRAD_BLOCKS 256      // x 4 waves = 1024 partial results
 
 int mne_wgrad_waves(void) { return MNE_WGRAD_BLOCKS * 4; }
 
 template <int HID, int HIDC, bool CP>
 static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
     typedef DecDims<HID, HIDC, CP> D;
-    const GemmDesc g1 = {D::T_DH, HID, D::T_X, MNE_IN1, D::P_SDF0};
-    const GemmDesc g2 = {D::T_DOUT, MNE_OUT1, D::T_H, HID, D::P_SDF1};
-    const GemmDesc g3 = {D::T_DHC, HIDC, D::T_CIN, D::CIN, D::P_COL0};
-    const GemmDesc g4 = {D::T_DC, 3, D::T_HC, HIDC, D::P_COL1};
+    const GemmDesc g1 = {D::T_DH, HID, D::T_X, MNE_IN1, -1, D::P_SDF0, MNE_IN1};
+    const GemmDesc g2 = {D::T_DOUT, MNE_OUT1, D::T_H, HID, -1, D::P_SDF1, HID};
+    const GemmDesc g3 = {D::T_DHC, HIDC, D::T_CIN, D::CINP, D::CINB, D::P_COL0, D::CIN};
+    const GemmDesc g4 = {D::T_DC, 3, D::T_HC, HIDC, -1, D::P_COL1, HIDC};
     if (impl == 1) {
         const GemmDesc gs[4] = {g1, g2, g3, g4};
         for (int k = 0; k < 4; ++k)
-            MNE_LAUNCH(wgrad_scalar_kernel, (gs[k].OUT * gs[k].IN + 255) / 256, 256, 0, st, a, gs[k], D::ROW);
+            MNE_LAUNCH(wgrad_scalar_kernel, (gs[k].OUT * gs[k].ld + 255) / 256, 256, 0, st, a, gs[k], D::ROW);
         return 0;
     }
     a.n_waves = MNE_WGRAD_BLOCKS * 4;
@@ -108,7 +131,7 @@ static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
     MNE_LAUNCH((wgrad_mfma_kernel<1, HID / 32>), MNE_WGRAD_BLOCKS, 256, 0, st, a, g2, D::ROW, D::NPARAM);
     MNE_LAUNCH((wgrad_mfma_kernel<HIDC / 32, D::CINP / 32>), MNE_WGRAD_BLOCKS, 256, 0, st, a, g3, D::ROW, D::NPARAM);
     MNE_LAUNCH((wgrad_mfma_kernel<1, HIDC / 32>), MNE_WGRAD_BLOCKS, 256, 0, st, a, g4, D::ROW, D::NPARAM);
-    MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 255) / 256, 256, 0, st, a, D::NPARAM);
+    MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
     return 0;
 }
 

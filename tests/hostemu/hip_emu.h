@@ -123,6 +123,8 @@ void launch(K kern, unsigned grid, unsigned block, size_t lds, A... args) {
 typedef const float* mne_cptr;
 #define MNE_CPTR(p) ((const float*)(p))
 
+#define MNE_WAVE_SYNC() hipemu::wave_sync()
+#define MNE_SET_MAX_LDS(kern, bytes) ((void)0)
 inline void __syncthreads() { hipemu::g_ctx->block_bar->arrive_and_wait(); }
 template <class T> inline T __shfl(T v, int src, int = 64) { return hipemu::shfl_idx(v, src); }
 template <class T> inline T __shfl_xor(T v, int m, int = 64) { return hipemu::shfl_idx(v, hipemu::lane() ^ m); }
