@@ -30,6 +30,7 @@ if REPO not in sys.path:
 
 from mneslam_amd import configs, slam_glue, synthetic  # noqa: E402
 from mneslam_amd.model.keyframe import KeyFrameDatabase  # noqa: E402
+from mneslam_amd.fused import FusedStep  # noqa: E402
 from mneslam_amd.model.scene_rep import JointEncoding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -42,7 +43,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--keyframes", type=int, default=20)
     ap.add_argument("--hidden", type=int, default=32, choices=[32, 64])
-    ap.add_argument("--path", default="autograd", choices=["autograd"])
+    ap.add_argument("--path", default="fused", choices=["fused", "autograd"],
+                    help="fused = FusedStep + device sampler (default); autograd = the reference's call sequence")
     ap.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--small", action="store_true", help="tiny planes/frames (functional check, not a benchmark)")
     return ap.parse_args()
@@ -51,8 +53,8 @@ def parse_args():
 class Agent:
     """One mapping agent: scene model + optimizer + device-resident keyframe rays."""
 
-    def __init__(self, cfg, device, seed, n_keyframes, small=False):
-        self.cfg, self.device = cfg, device
+    def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused"):
+        self.cfg, self.device, self.path = cfg, device, path
         cam = dict(synthetic.REPLICA_CAM)
         if small:
             cam = dict(H=68, W=120, fx=60.0, fy=60.0, cx=59.0, cy=33.0)
@@ -78,8 +80,11 @@ class Agent:
         self.n_cur = max(cfg["mapping"]["sample"] // n_keyframes, cfg["mapping"]["min_pixels_cur"])
         self.n_plane_params = sum(p.numel() for lst in self.model.all_planes for p in lst)
         self.n_dec_params = sum(p.numel() for p in self.model.decoder.parameters())
-        self.ev = None
         self.last = None
+        self.fused = None
+        if path == "fused":
+            self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device)
+            self.fused.seed = seed
 
     def sample_rays(self):
         """R1/R2 ray assembly on the device (mp_slam/mapper.py:135-153): `sample` rows without
@@ -96,6 +101,11 @@ class Agent:
         return rays_o, rays_d, rays[:, 3:6], rays[:, 6:7]
 
     def step(self, timers=None):
+        if self.fused is not None:
+            self.fused.events = timers
+            self.fused.step(self.kf_rays, self.kf_rays.shape[0], self.n_save, self.cur_rays, self.poses,
+                            self.cfg["mapping"]["sample"], self.n_cur)
+            return
         rays_o, rays_d, tgt_rgb, tgt_d = self.sample_rays()
         ret = self.model.forward(rays_o, rays_d, tgt_rgb, tgt_d)
         loss = slam_glue.get_loss_from_ret(self.cfg, ret, is_co_sdf=self.cfg["is_co_sdf"])
@@ -106,12 +116,16 @@ class Agent:
         self.opt.step(zero_grad=False)
         if timers is not None:
             e1.record()
-            timers.append((e0, e1))
+            timers.setdefault("adam", []).append((e0, e1))
         self.opt.zero_grad(set_to_none=True)
         self.last = (ret, tgt_rgb, tgt_d)
 
     def quality(self):
-        ret, tgt_rgb, tgt_d = self.last
+        if self.fused is not None:
+            f = self.fused
+            ret, tgt_rgb, tgt_d = f.loss_dict(), f.tgt_rgb, f.tgt_d[:, None]
+        else:
+            ret, tgt_rgb, tgt_d = self.last
         d = tgt_d.squeeze(-1)
         valid = (d > 0) & (d < self.cfg["cam"]["depth_trunc"])
         l1 = (ret["depth"].detach()[valid] - d[valid]).abs().mean()
@@ -123,7 +137,7 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0):
     only) timed on this box's host cores on the same workload shape."""
     from oracle import mapping as omap
     from oracle.scene_rep import OracleScene
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)      # more threads only add contention on the scatter-heavy backward
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(seed)
     bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
@@ -138,7 +152,10 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0):
     rays_o = fr["c2w"][None, :3, 3].repeat(n, 1)
     rgb, dep = fr["rgb"].reshape(-1, 3)[idx], fr["depth"].reshape(-1, 1)[idx]
     times = []
+    t_start = time.perf_counter()
     for it in range(iters + 1):
+        if it >= 2 and time.perf_counter() - t_start > 25.0:     # keep the default run bounded
+            break
         t0 = time.perf_counter()
         opt.zero_grad()
         ret = sc.forward(rays_o, rays_d, rgb, dep, impl="grid_sample")
@@ -147,7 +164,7 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0):
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / max(len(times) - 1, 1)
     return {"value": 1.0 / t, "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} mapping iterations (1 warm-up) of the same workload ({n} rays x "
+            "sample": f"{len(times) - 1} mapping iterations (1 warm-up) of the same workload ({n} rays x "
                       f"{cfg['training']['n_range_d'] + cfg['training']['n_samples_d']} samples, "
                       f"{sum(p.numel() for p in sc.plane_list())} plane params) with the CPU oracle, torch "
                       f"{torch.__version__}, {cores} threads"}
@@ -170,7 +187,7 @@ def main():
     if args.small:
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
-    agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small)
+    agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path)
 
     def barrier():
         if world > 1:
@@ -179,7 +196,7 @@ def main():
 
     for _ in range(args.warmup):
         agent.step()
-    timers = []
+    timers = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -190,14 +207,21 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    adam_ms = sum(a.elapsed_time(b) for a, b in timers) / max(len(timers), 1)
+    avg_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timers.items()}
     psnr, depth_l1 = agent.quality()
     if rank == 0:
         S = cfg["training"]["n_range_d"] + cfg["training"]["n_samples_d"]
         R = cfg["mapping"]["sample"] + agent.n_cur
         n_par = agent.n_plane_params + agent.n_dec_params
-        adam_bytes = 32.0 * n_par                 # r p,g,m,v + w p,m,v (+ g re-zeroed by the next backward)
-        achieved = adam_bytes / (adam_ms * 1e-3) / 1e9 if adam_ms > 0 else 0.0
+        # algorithmic bytes per launch (stated in DESIGN.md):
+        #   adam   : 32 B/param = read p,g,m,v + write p,m,v + zero g
+        #   render : gather + scatter of every sample, G = 6 planes x 4 corners x 32 ch x 4 B per set
+        G = 3072.0 * (1 if cfg["grid"]["oneGrid"] else 2)
+        alg = {"adam": 32.0 * n_par, "render": 2.0 * R * S * G}
+        kern = {"adam": "adam_kernel", "render": "render_kernel<pass1,bwd> (fused forward+backward)"}
+        dom = max(avg_ms, key=avg_ms.get) if avg_ms else "adam"
+        dom_ms = avg_ms.get(dom, 0.0)
+        achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         out = {
             "metric": "mapping iters/sec (2048 rays x 128 samples)", "value": world * args.steps / elapsed,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,9 +233,12 @@ def main():
                        "frame": f"{agent.W}x{agent.H}", "path": args.path, "agents": world,
                        "parallelism": f"agent-per-gpu x{world}, no data-path collective"},
             "psnr_last_iter": psnr, "depth_l1_last_iter": depth_l1,
-            "roofline": {"kernel": "adam_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": kern[dom], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": adam_bytes, "avg_launch_ms": adam_ms},
+                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms,
+                         "other_kernels_avg_ms": {kern[k]: v for k, v in avg_ms.items() if k != dom},
+                         "iteration_algorithmic_bytes": alg["adam"] + alg["render"],
+                         "iteration_hbm_frac": (alg["adam"] + alg["render"]) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, args.keyframes, args.cpu_iters)

@@ -101,6 +101,22 @@ size_t mne_sizeof_adam_seg(void);
  * (model/scene_rep.py:362-374). */
 int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d);
 
+/* ---- R1/R2: per-iteration ray batch --------------------------------------------------------- */
+/* Replaces KeyFrameDatabase.sample_global_rays (model/keyframe.py:91-103) + the ray assembly of
+ * Mapper.mapping_optimize (mp_slam/mapper.py:135-153) with device-resident data: n_global rows
+ * sampled without replacement from kf_rays [n_kf_rays][7] (dir3,rgb3,depth1; owner keyframe =
+ * index / n_save, its pose = poses[kf_pose_ids ? kf_pose_ids[owner] : owner]) plus n_cur pixels of
+ * cur_rays [n_cur_rays][7] (pose = poses[n_poses-1], the reference's id -1), directions rotated
+ * into the world frame.  idx_global / idx_cur (int64, device) supply explicit indices -- e.g. the
+ * host RNG's draws, which makes the batch identical to the reference's; NULL = keyed Feistel
+ * permutation of (seed, iteration) on the device.  Outputs are [R][3], [R][3], [R][3], [R] with
+ * R = n_global + n_cur; out_idx (optional, int64 [R]) receives the indices used. */
+int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const int32_t* kf_pose_ids,
+                    const float* cur_rays, int64_t n_cur_rays, const float* poses, int n_poses,
+                    int n_global, int n_cur, const int64_t* idx_global, const int64_t* idx_cur,
+                    uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
+                    float* target_d, int64_t* out_idx, void* stream);
+
 /* ---- R3: z sampling -------------------------------------------------------------------- */
 /* Replaces render_rays' sampling block, model/scene_rep.py:362-381: near-surface linspace around
  * target_d (rays with d<=0 get linspace(near,far)), merged with the uniform samples, sorted, then
@@ -111,10 +127,11 @@ int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d);
  * on the CPU, :363-373): with depth  [linspace(near,far,n_samples_d) | linspace(-range_d,range_d,
  * n_range_d) | linspace(near,far,n_range_d)], without  [linspace(near,far,n_samples)].  Also counts the loss masks that depend only on
  * z and target_d (scene_rep.py:489-499, :570; model/utils.py:131-145) into counts[MNE_N_COUNT]
- * (int32; zeroed by the call).  `target_d` is [R]. */
+ * (int32; overwritten by the call) via the scratch ray_counts [R][MNE_N_COUNT] (per-ray counts,
+ * summed in a fixed order; both may be NULL when target_d is NULL).  `target_d` is [R]. */
 int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d, const float* u,
                  const float* lin_tables, uint64_t seed, uint64_t offset, float* z_vals,
-                 int32_t* counts, void* stream);
+                 int32_t* counts, int32_t* ray_counts, void* stream);
 
 /* ---- R8 helper: decoder weights in the kernels' packed form ------------------------------ */
 size_t mne_packed_decoder_floats(const mne_scene_t* scene);
@@ -162,6 +179,16 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
                         const float* raw, const float* coef, const float* g_rgb, const float* g_depth,
                         float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
                         float* d_rays_o, float* d_rays_d, void* stream);
+
+/* Fused training form of the two calls above (what Mapper.mapping_optimize runs per iteration):
+ * one launch that decodes all samples (writes raw, rgb, depth, ray_sums like mne_render_forward)
+ * and immediately back-propagates with the loss coefficients `coef` (mne_loss_coef), without
+ * re-reading raw. */
+int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                     const float* rays_o, const float* rays_d, const float* target_rgb,
+                     const float* target_d, const float* z_vals, const float* packed_decoder,
+                     const float* coef, float* rgb, float* depth, float* raw, float* ray_sums,
+                     float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, void* stream);
 
 /* Decoder weight gradients from the tape: dW = sum_rows outer(d_out, in) for the four matrices,
  * written as [w_col0 | w_col1 | w_sdf0 | w_sdf1] (the order of decoder.parameters(),

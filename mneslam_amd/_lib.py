@@ -53,7 +53,7 @@ _PROTOS = {
     "mne_sizeof_adam_seg": (C.c_size_t, []),
     "mne_num_samples": (C.c_int, [C.POINTER(RenderCfg), C.c_int]),
     "mne_sample_z": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
-                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_packed_decoder_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_pack_decoder": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p]),
     "mne_render_forward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 14),
@@ -62,6 +62,10 @@ _PROTOS = {
     "mne_tape_row_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_render_backward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 11
                             + [C.c_int64] + [C.c_void_p] * 4),
+    "mne_render_fused": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 12
+                         + [C.c_int64] + [C.c_void_p] * 2),
+    "mne_sample_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 6),
     "mne_decoder_param_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_wgrad_partial_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_decoder_wgrad": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

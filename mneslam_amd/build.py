@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libmneslam_hip.so")
-SOURCES = ["capi.hip", "render.hip", "wgrad.hip", "adam.hip"]
-HEADERS = ["mne_device.h", "mne_launch.h", "mne_platform.h"]
+SOURCES = ["capi.hip", "render.hip", "wgrad.hip", "adam.hip", "sampler.hip"]
+HEADERS = ["mne_device.h", "mne_launch.h", "mne_platform.h", "mlp_mfma.h"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-munsafe-fp-atomics", "-fgpu-rdc-off-placeholder"]
@@ -43,9 +43,10 @@ def build(force=False, verbose=False):
         return LIB
     flags = [f for f in HIPCC_FLAGS if f != "-fgpu-rdc-off-placeholder"]
     objs = []
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "mneslam_hip.h")]
     for s in srcs:
         obj = s[:-4] + ".o"
-        if force or _stale(obj, deps):
+        if force or _stale(obj, [s] + hdrs):
             cmd = [_hipcc(), *flags, "-I", INCLUDE, "-I", CSRC, "-c", s, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -50,7 +50,6 @@ static void fill_render_consts(RenderArgs& a, const mne_render_cfg_t* cfg) {
     a.depth_trunc = (float)cfg->depth_trunc;
 }
 
-static size_t render_lds(int S, int nsets) { return mne_render_lds_bytes(S, nsets); }
 
 extern "C" {
 
@@ -67,7 +66,7 @@ int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d) {
 
 int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d, const float* u,
                  const float* lin_tables, uint64_t seed, uint64_t offset, float* z_vals, int32_t* counts,
-                 void* stream) {
+                 int32_t* ray_counts, void* stream) {
     if (!cfg || !z_vals || !lin_tables) return fail(-1, "mne_sample_z: NULL argument");
     if (n_rays <= 0) return 0;
     ZArgs a;
@@ -89,12 +88,9 @@ int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d,
     a.offset = offset;
     a.z_vals = z_vals;
     a.counts = counts;
+    a.ray_counts = ray_counts;
     hipStream_t st = (hipStream_t)stream;
-    if (counts) {
-        if (hipMemsetAsync(counts, 0, MNE_N_COUNT * sizeof(int32_t), st) != hipSuccess) return fail(-10, "memset(counts) failed");
-    } else if (a.has_d) {
-        return fail(-1, "mne_sample_z: counts buffer required when target_d is given");
-    }
+    if (a.has_d && (!counts || !ray_counts)) return fail(-1, "mne_sample_z: counts and ray_counts buffers required when target_d is given");
     mne_launch_sample_z(a, st);
     return check_launch("sample_z");
 }
@@ -122,7 +118,7 @@ int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, in
     if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw) return fail(-1, "mne_render_forward: NULL argument");
     if (n_rays <= 0) return 0;
     if (n_samples < 1 || n_samples > 16384) return fail(-1, "samples per ray out of range");
-    if (render_lds(n_samples, scene->n_sets) > 160 * 1024) return fail(-1, "samples per ray too large for the LDS staging");
+    if (mne_render_lds_bytes(*scene, n_samples, 0) > 160 * 1024) return fail(-1, "samples per ray too large for the LDS staging");
     if (ray_sums && (!target_rgb || !target_d)) return fail(-1, "ray_sums needs target_rgb and target_d");
     RenderArgs a = {};
     a.sc = *scene;
@@ -166,7 +162,7 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
     if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows)
         return fail(-1, "mne_render_backward: NULL argument");
     if (n_rays <= 0) return 0;
-    if (n_samples < 1 || render_lds(n_samples, scene->n_sets) > 160 * 1024) return fail(-1, "samples per ray out of range");
+    if (n_samples < 1 || mne_render_lds_bytes(*scene, n_samples, 1) > 160 * 1024) return fail(-1, "samples per ray out of range");
     if (tape_capacity_rows < (int64_t)n_rays * n_samples) return fail(-1, "tape must hold n_rays*n_samples rows");
     if (coef && (!target_rgb || !target_d)) return fail(-1, "loss coefficients need target_rgb and target_d");
     if (d_rays_o || d_rays_d) return fail(-3, "ray gradients are not available in this build yet");
@@ -181,6 +177,50 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d;
     if (int rc = mne_launch_render(a, 0, 1, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_backward");
+}
+
+int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                     const float* rays_o, const float* rays_d, const float* target_rgb,
+                     const float* target_d, const float* z_vals, const float* packed_decoder,
+                     const float* coef, float* rgb, float* depth, float* raw, float* ray_sums,
+                     float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, void* stream) {
+    if (int rc = check_scene(scene, true)) return rc;
+    if (!cfg || !rays_o || !rays_d || !target_rgb || !target_d || !z_vals || !packed_decoder || !coef || !raw ||
+        !tape || !tape_rows)
+        return fail(-1, "mne_render_fused: NULL argument");
+    if (n_rays <= 0) return 0;
+    if (n_samples < 1 || mne_render_lds_bytes(*scene, n_samples, 1) > 160 * 1024) return fail(-1, "samples per ray out of range");
+    if (tape_capacity_rows < (int64_t)n_rays * n_samples) return fail(-1, "tape must hold n_rays*n_samples rows");
+    RenderArgs a = {};
+    a.sc = *scene;
+    a.R = n_rays; a.S = n_samples;
+    fill_render_consts(a, cfg);
+    a.rays_o = rays_o; a.rays_d = rays_d; a.target_rgb = target_rgb; a.target_d = target_d;
+    a.z_vals = z_vals; a.packed = packed_decoder; a.coef = coef;
+    a.rgb = rgb; a.depth = depth; a.raw = raw; a.ray_sums = ray_sums;
+    a.tape = tape; a.tape_cap = tape_capacity_rows; a.tape_rows = tape_rows;
+    if (int rc = mne_launch_render(a, 1, 1, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    return check_launch("render_fused");
+}
+
+int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const int32_t* kf_pose_ids,
+                    const float* cur_rays, int64_t n_cur_rays, const float* poses, int n_poses,
+                    int n_global, int n_cur, const int64_t* idx_global, const int64_t* idx_cur,
+                    uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
+                    float* target_d, int64_t* out_idx, void* stream) {
+    if (!poses || !rays_o || !rays_d || !target_rgb || !target_d || n_poses < 1) return fail(-1, "mne_sample_rays: NULL argument");
+    if (n_global < 0 || n_cur < 0) return fail(-1, "mne_sample_rays: negative count");
+    if (n_global > 0 && (!kf_rays || n_save < 1 || n_kf_rays < n_global)) return fail(-1, "mne_sample_rays: cannot draw n_global distinct keyframe rays");
+    if (n_cur > 0 && (!cur_rays || n_cur_rays < n_cur)) return fail(-1, "mne_sample_rays: cannot draw n_cur distinct current-frame rays");
+    if (n_global + n_cur == 0) return 0;
+    SampleRaysArgs a = {};
+    a.kf_rays = kf_rays; a.n_kf_rays = n_kf_rays; a.n_save = n_save; a.kf_pose_ids = kf_pose_ids;
+    a.cur_rays = cur_rays; a.n_cur_rays = n_cur_rays; a.poses = poses; a.n_poses = n_poses;
+    a.n_global = n_global; a.n_cur = n_cur;
+    a.idx_global = (const long long*)idx_global; a.idx_cur = (const long long*)idx_cur; a.out_idx = (long long*)out_idx;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.target_rgb = target_rgb; a.target_d = target_d;
+    mne_launch_sample_rays(a, seed, iteration, (hipStream_t)stream);
+    return check_launch("sample_rays");
 }
 
 int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* tape_rows, float* partials,

@@ -14,6 +14,7 @@ struct ZArgs {
     uint64_t seed, offset;
     float* z_vals;
     int* counts;
+    int* ray_counts;     // [R][MNE_N_COUNT] scratch
 };
 
 struct RenderArgs {
@@ -52,6 +53,23 @@ struct QueryArgs {
     int flags;
 };
 
+struct SampleRaysArgs {
+    const float* kf_rays;        // [n_kf_rays][7]  (dir3, rgb3, depth1), keyframe-major
+    long long n_kf_rays;
+    int n_save;                  // rays stored per keyframe (owner keyframe = idx / n_save)
+    const int* kf_pose_ids;      // optional map keyframe slot -> row of `poses` (NULL = identity)
+    const float* cur_rays;       // [n_cur_rays][7] current frame
+    long long n_cur_rays;
+    const float* poses;          // [n_poses][4][4] c2w; the current frame's pose is the LAST row
+    int n_poses, n_global, n_cur;
+    const long long* idx_global; // optional explicit indices (host RNG) instead of the device permutation
+    const long long* idx_cur;
+    long long* out_idx;          // optional [R]: the indices used
+    float *rays_o, *rays_d, *target_rgb, *target_d;
+    int half_bits_kf, half_bits_cur;
+    unsigned long long key_kf, key_cur;
+};
+
 struct WgradArgs {
     const float* tape;
     const int* tape_rows;
@@ -78,8 +96,9 @@ int mne_launch_loss_finalize(const LossArgs& a, hipStream_t st);
 int mne_launch_loss_coef(const LossArgs& a, hipStream_t st);
 int mne_launch_wgrad(const mne_scene_t& sc, WgradArgs a, int impl, hipStream_t st);
 int mne_launch_adam(const AdamArgs& a, hipStream_t st);
+int mne_launch_sample_rays(SampleRaysArgs a, unsigned long long seed, unsigned long long iteration, hipStream_t st);
 size_t mne_dims_packed(const mne_scene_t& sc);
 size_t mne_dims_tape_row(const mne_scene_t& sc);
 size_t mne_dims_nparam(const mne_scene_t& sc);
 int mne_wgrad_waves(void);
-size_t mne_render_lds_bytes(int S, int nsets);
+size_t mne_render_lds_bytes(const mne_scene_t& sc, int S, int bwd);

@@ -99,15 +99,30 @@ __global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)
             for (int m = 32; m >= 1; m >>= 1) sums[k] += __shfl_xor(sums[k], m);
-        if (lane == 0) {
-            if (d > 0.0f && d < a.depth_trunc) atomicAdd(a.counts + MNE_C_VALID, 1);   // scene_rep.py:570
-            if (sums[0]) atomicAdd(a.counts + MNE_C_E_FRONT, sums[0]);
-            if (sums[1]) atomicAdd(a.counts + MNE_C_E_CENTER, sums[1]);
-            if (sums[2]) atomicAdd(a.counts + MNE_C_E_TAIL, sums[2]);
-            if (sums[3]) atomicAdd(a.counts + MNE_C_CO_FS, sums[3]);
-            if (sums[4]) atomicAdd(a.counts + MNE_C_CO_SDF, sums[4]);
+        if (lane == 0) {                 // per-ray counts; summed by counts_reduce_kernel (no same-address atomics)
+            int* rc = a.ray_counts + (size_t)r * MNE_N_COUNT;
+            rc[MNE_C_VALID] = (d > 0.0f && d < a.depth_trunc) ? 1 : 0;          // scene_rep.py:570
+            rc[MNE_C_E_FRONT] = sums[0]; rc[MNE_C_E_CENTER] = sums[1]; rc[MNE_C_E_TAIL] = sums[2];
+            rc[MNE_C_CO_FS] = sums[3]; rc[MNE_C_CO_SDF] = sums[4]; rc[6] = 0; rc[7] = 0;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void counts_reduce_kernel(ZArgs a) {
+    __shared__ int part[256][MNE_N_COUNT];
+    const int t = threadIdx.x;
+    int acc[MNE_N_COUNT];
+    for (int k = 0; k < MNE_N_COUNT; ++k) acc[k] = 0;
+    for (int r = t; r < a.R; r += 256)
+        for (int k = 0; k < MNE_N_COUNT; ++k) acc[k] += a.ray_counts[(size_t)r * MNE_N_COUNT + k];
+    for (int k = 0; k < MNE_N_COUNT; ++k) part[t][k] = acc[k];
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (t < st)
+            for (int k = 0; k < MNE_N_COUNT; ++k) part[t][k] += part[t + st][k];
+        __syncthreads();
+    }
+    if (t < MNE_N_COUNT) a.counts[t] = part[0][t];
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -145,18 +160,29 @@ __host__ __device__ inline size_t render_wave_lds_bytes(int S, int nsets) {
     return (b + 15) & ~(size_t)15;
 }
 
-template <int HID, int HIDC, bool CP, bool PASS1, bool BWD>
-__global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
+// RPW = rays (= waves) per workgroup; ALDS = the MFMA A-operand tables are staged in LDS once per
+// workgroup (one ds_read_b32 per MFMA) instead of being re-read from global memory per MFMA.
+template <int HID, int HIDC, bool CP, bool PASS1, bool BWD, int RPW, bool ALDS>
+__global__ __launch_bounds__(64 * RPW) void render_kernel(RenderArgs a) {
     typedef DecDims<HID, HIDC, CP> D;
+    typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
     constexpr int NT = HID / 32, NTC = HIDC / 32;
+    constexpr int TAB_FLOATS = ALDS ? (BWD ? T::TOTAL : T::FWD_STEPS) * 64 : 0;
     MNE_DYN_LDS(lds_raw);
+    if (ALDS) {                                            // stage the A tables: the only block-wide step
+        float4* dst = (float4*)lds_raw;
+        const float4* src = (const float4*)a.packed;
+        for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += 64 * RPW) dst[i] = src[i];
+        __syncthreads();
+    }
+    const float* atab = ALDS ? (const float*)lds_raw : a.packed;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = blockIdx.x * RAYS_PER_WG + wv;
+    const int r = blockIdx.x * RPW + wv;
     if (r >= a.R) return;                                  // whole wave leaves together; no block barriers below
     const int S = a.S;
     const int Spad = (S + 3) & ~3;
-    unsigned char* my = lds_raw + (size_t)wv * render_wave_lds_bytes(S, NSETS);
+    unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * render_wave_lds_bytes(S, NSETS);
     float* pn = (float*)my;                                // [32][4]
     float* feat = pn + TILE * 4;                           // [NSETS][32][MNE_FS]
     float* raws = feat + NSETS * TILE * MNE_FS;            // [Spad][4]  (r,g,b,sdf)
@@ -193,7 +219,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             float pos[24];
             oneblob_half(u, hf, pos);
             MlpState<HID, HIDC> st;
-            mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, a.packed, lane, st);
+            mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, atab, lane, st);
             if (valid && hf == 0) {                                        // rows 0..3 live in the lower half
                 const float4 rw = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);
                 *(float4*)(a.raw + ((size_t)r * S + i) * 4) = rw;
@@ -343,7 +369,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             float pos[24];
             oneblob_half(u, hf, pos);
             MlpState<HID, HIDC> st;
-            mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, a.packed, lane, st);
+            mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, atab, lane, st);
             // ---- d(total)/d(raw) of this point (both lanes of the pair compute the same values)
             const float4 rw = *(const float4*)(raws + 4 * i);
             const float s = rw.w;
@@ -404,7 +430,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             }
             // ---- MFMA backward chain; d(feature) rows overwrite this point's LDS feature rows
             f32x16 dh[NT], dout, dhc[NTC];
-            mlp_backward_mfma<HID, HIDC, CP>(st, ds, dc, a.packed, lane, dh, dout, dhc, frow, cfrow);
+            mlp_backward_mfma<HID, HIDC, CP>(st, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
             if (valid) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
@@ -554,12 +580,26 @@ int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStr
 // -----------------------------------------------------------------------------------------------
 // host-side launchers (called from capi.hip)
 // -----------------------------------------------------------------------------------------------
-size_t mne_render_lds_bytes(int S, int nsets) { return RAYS_PER_WG * render_wave_lds_bytes(S, nsets); }
+// Workgroup shape per decoder configuration: 8 rays per workgroup when tables + 8 private regions
+// fit the 160 KiB LDS (2 waves per SIMD), otherwise 4; the largest decoder keeps its tables in L2.
+template <int HID, int HIDC, bool CP> struct WgShape {
+    static constexpr int RPW = (HID == 32 && !CP) ? 8 : 4;
+    static constexpr bool ALDS = !(HID == 64 && CP);
+};
+
+template <int HID, int HIDC, bool CP>
+static size_t render_lds_total(int S, bool bwd) {
+    typedef WgShape<HID, HIDC, CP> W;
+    typedef ATab<HID, HIDC, CP> T;
+    const size_t tab = W::ALDS ? (size_t)(bwd ? T::TOTAL : T::FWD_STEPS) * 64 * sizeof(float) : 0;
+    return tab + W::RPW * render_wave_lds_bytes(S, CP ? 2 : 1);
+}
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
     const int n_tab = a.has_d ? a.n_a + 2 * a.n_b : a.S;
     const size_t lds = (size_t)(((n_tab + 3) & ~3) + RAYS_PER_WG * ((a.S + 3) & ~3)) * sizeof(float);
     MNE_LAUNCH(sample_z_kernel, (a.R + RAYS_PER_WG - 1) / RAYS_PER_WG, 256, lds, st, a);
+    if (a.has_d) MNE_LAUNCH(counts_reduce_kernel, 1, 256, 0, st, a);
     return 0;
 }
 
@@ -572,16 +612,18 @@ static int launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
 
 template <int HID, int HIDC, bool CP>
 static int launch_render(const RenderArgs& a, int pass1, int bwd, hipStream_t st) {
-    const size_t lds = mne_render_lds_bytes(a.S, CP ? 2 : 1);
-    const int grid = (a.R + RAYS_PER_WG - 1) / RAYS_PER_WG;
+    typedef WgShape<HID, HIDC, CP> W;
+    const size_t lds = render_lds_total<HID, HIDC, CP>(a.S, bwd != 0);
+    if (lds > 160 * 1024) return -4;
+    const int grid = (a.R + W::RPW - 1) / W::RPW;
     if (lds > 64 * 1024) {          // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, false>), 160 * 1024);
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, false, true>), 160 * 1024);
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, true>), 160 * 1024);
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, false, W::RPW, W::ALDS>), 160 * 1024);
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, false, true, W::RPW, W::ALDS>), 160 * 1024);
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, true, W::RPW, W::ALDS>), 160 * 1024);
     }
-    if (pass1 && !bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, false>), grid, 256, lds, st, a);
-    else if (!pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true>), grid, 256, lds, st, a);
-    else if (pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, true>), grid, 256, lds, st, a);
+    if (pass1 && !bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, false, W::RPW, W::ALDS>), grid, 64 * W::RPW, lds, st, a);
+    else if (!pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true, W::RPW, W::ALDS>), grid, 64 * W::RPW, lds, st, a);
+    else if (pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, true, W::RPW, W::ALDS>), grid, 64 * W::RPW, lds, st, a);
     else return -1;
     return 0;
 }
@@ -630,6 +672,13 @@ int mne_launch_loss_finalize(const LossArgs& a, hipStream_t st) {
 
 int mne_launch_loss_coef(const LossArgs& a, hipStream_t st) {
     MNE_LAUNCH(loss_coef_kernel, 1, 64, 0, st, a);
+    return 0;
+}
+
+size_t mne_render_lds_bytes(const mne_scene_t& sc, int S, int bwd) {
+#define CALL(H, HC, CPV) return render_lds_total<H, HC, CPV>(S, bwd != 0)
+    MNE_DISPATCH(sc, CALL, 0);
+#undef CALL
     return 0;
 }
 

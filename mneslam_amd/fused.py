@@ -1,0 +1,121 @@
+"""The fused mapping iteration: sample rays -> z -> forward+backward in one kernel -> decoder
+weight-gradient GEMM -> one Adam launch over planes + decoder (gradients zeroed in the same pass).
+No autograd graph, no per-iteration allocation, no host synchronisation: every buffer is allocated
+once per ``FusedStep`` and the ~9 C-ABI calls of an iteration are asynchronous launches on the
+caller's stream.
+
+Semantically one ``step`` equals the reference's
+``forward -> get_loss_from_ret -> backward -> map_optimizer.step() -> zero_grad()``
+(mp_slam/mapper.py:155-162) on the same ray batch; tests run both paths against the reference's
+golden parameters.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, hip_path, slam_glue
+from .optim import FusedAdam
+
+
+class FusedStep:
+    def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, with_depth=True):
+        if not isinstance(optimizer, FusedAdam):
+            raise TypeError("the fused mapping step needs mneslam_amd.optim.FusedAdam "
+                            "(slam_glue.create_optimizer builds it with the reference's groups)")
+        self.lib = _lib.load()
+        self.model, self.opt, self.cfg, self.R = model, optimizer, config, int(n_rays)
+        self.device = torch.device(device)
+        dev, f32 = self.device, torch.float32
+        self.info = model._info()
+        self.rc = self.info["render_cfg"]
+        self.S = self.lib.mne_num_samples(C.byref(self.rc), 1)
+        R, S = self.R, self.S
+        self.planes = [p for lst in model.all_planes for p in lst]
+        for p in self.planes:
+            if not isinstance(p, torch.nn.Parameter):
+                raise ValueError("planes must be nn.Parameters (call create_optimizer first)")
+            if not (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and p.stride(1) == 1) \
+                    or p.device.type != dev.type:
+                raise ValueError("fused step needs channels_last planes on the compute device")
+        self.dec_w = model.decoder.hip_weights()
+        # persistent gradient accumulators (zeroed by the Adam kernel itself after each use)
+        self.grads = []
+        for p in self.planes:
+            st = optimizer._state(p)
+            if "grad_buffer" not in st:
+                st["grad_buffer"] = torch.zeros_like(p.data)
+            self.grads.append(st["grad_buffer"])
+        self.scene = hip_path.scene_struct(self.info, [p.data for p in self.planes], [w.data for w in self.dec_w], self.grads)
+        e = lambda *shape, dtype=f32: torch.empty(*shape, device=dev, dtype=dtype)
+        self.rays_o, self.rays_d, self.tgt_rgb, self.tgt_d = e(R, 3), e(R, 3), e(R, 3), e(R)
+        self.idx = e(R, dtype=torch.int64)
+        self.z_vals, self.raw = e(R, S), e(R, S, 4)
+        self.counts, self.ray_counts = e(_lib.N_COUNT, dtype=torch.int32), e(R, _lib.N_COUNT, dtype=torch.int32)
+        self.coef, self.ray_sums, self.losses = e(_lib.N_LOSS), e(R, _lib.N_LOSS), torch.zeros(_lib.N_LOSS, device=dev)
+        self.rgb, self.depth = e(R, 3), e(R)
+        self.packed = e(self.lib.mne_packed_decoder_floats(C.byref(self.scene)))
+        self.tape = e(R * S, self.lib.mne_tape_row_floats(C.byref(self.scene)))
+        self.tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.partials = e(self.lib.mne_wgrad_partial_floats(C.byref(self.scene)))
+        self.dec_grad = e(self.lib.mne_decoder_param_floats(C.byref(self.scene)))
+        co = config["is_co_sdf"] if is_co_sdf is None else is_co_sdf
+        self.loss_w = torch.tensor(slam_glue.loss_weight_vector(config, co) + [0.0], device=dev, dtype=f32)
+        self.tables = hip_path.linspace_tables(config, True, dev)
+        w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
+        n0, n1, n2 = w_col0.numel(), w_col1.numel(), w_sdf0.numel()
+        self.dec_grad_views = {w_col0: self.dec_grad[:n0].view_as(w_col0), w_col1: self.dec_grad[n0:n0 + n1].view_as(w_col1),
+                               w_sdf0: self.dec_grad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0),
+                               w_sdf1: self.dec_grad[n0 + n1 + n2:].view_as(w_sdf1)}
+        self.grad_map = {p: g for p, g in zip(self.planes, self.grads)}
+        self.grad_map.update(self.dec_grad_views)
+        self.events = None          # set to {} to record HIP events around the two dominant launches
+        self.iteration = 0
+        self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+
+    def step(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global=None, idx_cur=None, u=None):
+        """One mapping iteration.  kf_rays [*,7] / cur_rays [H*W,7] / poses [N,4,4] live on the device;
+        idx_global / idx_cur (int64 device tensors) and u [R,S] reproduce a host-RNG batch."""
+        lib, P, st = self.lib, _lib.ptr, _lib.stream_for(self.rays_o)
+        R, S = self.R, self.S
+        if n_global + n_cur != R:
+            raise ValueError(f"this FusedStep was built for {R} rays, got {n_global}+{n_cur}")
+        _lib.check(lib.mne_sample_rays(P(kf_rays), int(n_kf_rays), int(n_save), None, P(cur_rays), cur_rays.shape[0],
+                                       P(poses), poses.shape[0], n_global, n_cur, P(idx_global), P(idx_cur),
+                                       self.seed, self.iteration, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb),
+                                       P(self.tgt_d), P(self.idx), st), "mne_sample_rays")
+        _lib.check(lib.mne_sample_z(C.byref(self.rc), R, P(self.tgt_d), P(u), P(self.tables), self.seed,
+                                    self.iteration * ((R * S + 3) // 4), P(self.z_vals), P(self.counts),
+                                    P(self.ray_counts), st), "mne_sample_z")
+        _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
+        _lib.check(lib.mne_loss_coef(C.byref(self.rc), R, S, P(self.counts), P(self.loss_w), P(self.coef), st),
+                   "mne_loss_coef")
+        self.tape_rows.zero_()
+        ev = self._mark("render")
+        _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
+                                        P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals), P(self.packed), P(self.coef),
+                                        P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape),
+                                        R * S, P(self.tape_rows), st), "mne_render_fused")
+        self._mark("render", ev)
+        _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), P(self.partials),
+                                         P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
+        ev = self._mark("adam")
+        self.opt.step(zero_grad=True, grad_buffers=self.grad_map)
+        self._mark("adam", ev)
+        _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
+        self.iteration += 1
+
+    def _mark(self, name, start=None):
+        """HIP events on the launch stream around one launch (bench.py's live kernel timing)."""
+        if self.events is None or not self.rays_o.is_cuda:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if start is not None:
+            self.events.setdefault(name, []).append((start, e))
+        return e
+
+    def loss_dict(self):
+        L = self.losses
+        return {"rgb": self.rgb, "depth": self.depth, "rgb_loss": L[_lib.L_RGB], "depth_loss": L[_lib.L_DEPTH],
+                "co_sdf_loss": L[_lib.L_CO_SDF], "co_fs_loss": L[_lib.L_CO_FS], "e_fs_loss": L[_lib.L_E_FS],
+                "e_center_loss": L[_lib.L_E_CENTER], "e_tail_loss": L[_lib.L_E_TAIL], "psnr": L[_lib.L_PSNR:_lib.L_PSNR + 1]}

@@ -11,9 +11,23 @@ import random
 
 import torch
 
+from ..fused import FusedStep
+
 
 class Mapper():
-    def __init__(self, config, SLAM) -> None:
+    """``compute``: "autograd" = the reference's own sequence (model.forward -> get_loss_from_ret ->
+    backward -> map_optimizer.step/zero_grad) through the autograd node; "fused" = FusedStep (same
+    math, one forward+backward kernel, no graph).  ``sampler``: "host" = python ``random`` draws in
+    the reference's order (seed-for-seed identical batches); "device" = keyed permutation on the GPU
+    (no host work per iteration).  Defaults reproduce the reference exactly."""
+
+    def __init__(self, config, SLAM, compute="autograd", sampler="host") -> None:
+        if compute not in ("autograd", "fused") or sampler not in ("host", "device"):
+            raise ValueError("compute must be autograd|fused and sampler host|device")
+        if sampler == "device" and compute != "fused":
+            raise ValueError("the device sampler is part of the fused path")
+        self.compute, self.sampler = compute, sampler
+        self._fused = {}
         self.config = config
         self.slam = SLAM
         self.model = SLAM.model
@@ -33,6 +47,8 @@ class Mapper():
         c2w = batch["c2w"].to(self.device)
         self.model.train()
         H, n = self.slam.dataset.H, self.config["mapping"]["sample"]
+        if self.compute == "fused":
+            return self._first_frame_fused(batch, c2w, n_iters)
         for _ in range(n_iters):
             self.map_optimizer.zero_grad()
             indice = self.slam.select_samples(self.slam.dataset.H, self.slam.dataset.W, n)
@@ -56,6 +72,8 @@ class Mapper():
         current_rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
         current_rays = current_rays.reshape(-1, current_rays.shape[-1])
         n = self.config["mapping"]["sample"]
+        if self.compute == "fused":
+            return self._mapping_optimize_fused(current_rays, poses)
         for _ in range(self.config["mapping"]["iters"]):
             rays, ids = self.video.keyframe.sample_global_rays(n)
             idx_cur = random.sample(range(0, self.slam.dataset.H * self.slam.dataset.W),
@@ -75,3 +93,48 @@ class Mapper():
             self.map_optimizer.zero_grad()
 
     optimize_map = mapping_optimize
+
+    # ------------------------------------------------------------------ fused path
+    def _fused_step(self, n_rays):
+        key = (n_rays, id(self.map_optimizer))
+        if key not in self._fused:
+            self._fused[key] = FusedStep(self.model, self.map_optimizer, self.config, n_rays, self.device)
+        return self._fused[key]
+
+    def _jitter(self, fs):
+        if self.sampler == "host" and self.config["training"]["perturb"] > 0.0:
+            return torch.rand(fs.R, fs.S).to(self.device)        # the reference's CPU draw (scene_rep.py:381)
+        return None
+
+    def _mapping_optimize_fused(self, current_rays, poses):
+        kf = self.video.keyframe
+        n, n_kf = self.config["mapping"]["sample"], len(kf.frame_ids)
+        n_cur = max(n // n_kf, self.config["mapping"]["min_pixels_cur"])
+        fs = self._fused_step(n + n_cur)
+        kf_rays = kf.device_rays(self.device)
+        cur = current_rays.to(self.device, torch.float32).contiguous()
+        poses = poses.to(self.device, torch.float32).contiguous()
+        n_pix = self.slam.dataset.H * self.slam.dataset.W
+        for _ in range(self.config["mapping"]["iters"]):
+            idx_g = idx_c = None
+            if self.sampler == "host":                               # same draws, same order as the reference
+                idx_g = torch.tensor(random.sample(range(n_kf * kf.num_rays_to_save), n)).to(self.device)
+                idx_c = torch.tensor(random.sample(range(0, n_pix), n_cur)).to(self.device)
+            fs.step(kf_rays, n_kf * kf.num_rays_to_save, kf.num_rays_to_save, cur, poses, n, n_cur,
+                    idx_global=idx_g, idx_cur=idx_c, u=self._jitter(fs))
+        self.last_losses = fs.loss_dict()
+
+    def _first_frame_fused(self, batch, c2w, n_iters):
+        H, W, n = self.slam.dataset.H, self.slam.dataset.W, self.config["mapping"]["sample"]
+        fs = self._fused_step(n)
+        cur = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
+        cur = cur.reshape(-1, 7).to(self.device, torch.float32).contiguous()
+        poses = c2w.reshape(1, 4, 4).to(torch.float32).contiguous()
+        for _ in range(n_iters):
+            idx_c = None
+            if self.sampler == "host":
+                ind = self.slam.select_samples(H, W, n)
+                # the reference indexes [H,W] images with (ind % H, ind // H)  (mp_slam/mapper.py:76-77)
+                idx_c = ((ind % H) * W + torch.div(ind, H, rounding_mode="trunc")).to(self.device)
+            fs.step(None, 0, 1, cur, poses, 0, n, idx_cur=idx_c, u=self._jitter(fs))
+        self.last_losses = fs.loss_dict()

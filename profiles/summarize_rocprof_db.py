@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel count / total / average duration.
+usage: summarize_rocprof_db.py results.db [n_iters]   (n_iters divides totals into per-iteration time)"""
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+cur = db.cursor()
+rows = cur.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, "
+                   "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) "
+                   "from kernels group by name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+print(f"total kernel time {tot:.1f} us over {iters} iterations = {tot / iters:.1f} us/iter")
+print(f"{'us/iter':>9} {'%':>5} {'calls':>6} {'avg us':>9} {'min':>8} {'max':>8} {'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'lds':>7} {'scr':>5}  kernel")
+for r in rows[:28]:
+    print(f"{r[2] / iters:9.1f} {100 * r[2] / tot:5.1f} {r[1]:6d} {r[3]:9.1f} {r[4]:8.1f} {r[5]:8.1f} {r[6]:5d} {r[7]:5d} {r[8]:5d} {r[9]:7d} {r[10]:5d}  {r[0][:100]}")

@@ -120,7 +120,7 @@ def check_render_nodepth(device):
     assert set(rr) == {"rgb", "depth", "disp_map", "acc_map", "depth_var", "z_vals", "raw"}
 
 
-def check_mapping3(name, one_grid, co, seed, device):
+def check_mapping3(name, one_grid, co, seed, device, compute="autograd"):
     """Three drop-in Mapper.mapping_optimize iterations (host RNG sampling, autograd path, FusedAdam)
     against the parameters the REFERENCE reached from the same state and seeds."""
     g = load_golden(name)
@@ -143,7 +143,7 @@ def check_mapping3(name, one_grid, co, seed, device):
         dataset=types.SimpleNamespace(H=H, W=W), video=types.SimpleNamespace(keyframe=kfdb),
         get_loss_from_ret=lambda ret, **kw: slam_glue.get_loss_from_ret(cfg, ret, **kw),
         select_samples=slam_glue.select_samples)
-    mapper = Mapper(cfg, slam)
+    mapper = Mapper(cfg, slam, compute=compute, sampler="host")
     poses = torch.stack([f["c2w"] for f in frames]).to(device)
     random.seed(seed + 1)
     torch.manual_seed(seed + 1)
@@ -155,6 +155,58 @@ def check_mapping3(name, one_grid, co, seed, device):
     sd = dict(m.decoder.named_parameters())
     for k in DEC_KEYS:
         assert_close(sd[k].detach().cpu(), g[f"final.dec.{k}"], rtol=1e-3, atol=1e-4, what=f"decoder {k} after 3 iterations")
+
+
+def check_device_sampler(device):
+    """mne_sample_rays: explicit indices reproduce the reference's ray assembly bit-exactly; the
+    device permutation draws distinct, in-range, well-spread indices, reproducibly per (seed, it)."""
+    import ctypes as C
+    from mneslam_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(4)
+    n_kf, n_save, HW, n_g, n_c = 5, 300, 777, 256, 40
+    kf_rays = torch.randn(n_kf * n_save, 7, generator=gen)
+    cur = torch.randn(HW, 7, generator=gen)
+    poses = torch.randn(n_kf + 1, 4, 4, generator=gen)
+    idx_g = torch.randperm(n_kf * n_save, generator=gen)[:n_g]
+    idx_c = torch.randperm(HW, generator=gen)[:n_c]
+    rays7 = torch.cat([kf_rays[idx_g], cur[idx_c]], 0)
+    ids = torch.cat([torch.div(idx_g, n_save, rounding_mode="trunc"), -torch.ones(n_c, dtype=torch.int64)])
+    ref_o, ref_d, ref_rgb, ref_dep = omap.assemble_rays(rays7, ids, poses)
+    R = n_g + n_c
+    d = lambda t: t.to(device).contiguous()
+    out = [torch.empty(R, 3, device=device), torch.empty(R, 3, device=device), torch.empty(R, 3, device=device),
+           torch.empty(R, device=device)]
+    oidx = torch.empty(R, dtype=torch.int64, device=device)
+    a = [d(kf_rays), d(cur), d(poses), d(idx_g), d(idx_c)]
+    P = _lib.ptr
+    _lib.check(lib.mne_sample_rays(P(a[0]), n_kf * n_save, n_save, None, P(a[1]), HW, P(a[2]), n_kf + 1, n_g, n_c,
+                                   P(a[3]), P(a[4]), 0, 0, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(oidx),
+                                   _lib.stream_for(out[0])))
+    assert_close(out[0].cpu(), ref_o, rtol=0, atol=0, what="rays_o (bit-exact)")
+    assert_close(out[1].cpu(), ref_d, rtol=0, atol=0, what="rays_d (bit-exact)")
+    assert_close(out[2].cpu(), ref_rgb, rtol=0, atol=0, what="target rgb")
+    assert_close(out[3].cpu(), ref_dep[:, 0], rtol=0, atol=0, what="target depth")
+    seen = []
+    for it in range(3):
+        _lib.check(lib.mne_sample_rays(P(a[0]), n_kf * n_save, n_save, None, P(a[1]), HW, P(a[2]), n_kf + 1, n_g, n_c,
+                                       None, None, 1234, it, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(oidx),
+                                       _lib.stream_for(out[0])))
+        ii = oidx.cpu()
+        g, c = ii[:n_g], ii[n_g:]
+        assert g.unique().numel() == n_g and int(g.min()) >= 0 and int(g.max()) < n_kf * n_save
+        assert c.unique().numel() == n_c and int(c.min()) >= 0 and int(c.max()) < HW
+        assert_close(out[3].cpu(), torch.cat([kf_rays[g, 6], cur[c, 6]]), rtol=0, atol=0, what="gathered depth")
+        seen.append(ii.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    _lib.check(lib.mne_sample_rays(P(a[0]), n_kf * n_save, n_save, None, P(a[1]), HW, P(a[2]), n_kf + 1, n_g, n_c,
+                                   None, None, 1234, 0, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(oidx),
+                                   _lib.stream_for(out[0])))
+    assert torch.equal(oidx.cpu(), seen[0]), "same (seed, iteration) must give the same batch"
+    # spread: owners of the global rows cover every keyframe roughly evenly
+    own = torch.bincount(torch.div(torch.cat(seen)[: 3 * n_g].reshape(3, -1)[:, :n_g].reshape(-1), n_save, rounding_mode="trunc"),
+                         minlength=n_kf).float()
+    assert own.min() > 0.5 * own.mean()
 
 
 def check_adam(device):

@@ -67,3 +67,11 @@ def test_queries():
 
 def test_mapping3_onegrid():
     pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV)
+
+
+def test_device_sampler():
+    pc.check_device_sampler(DEV)
+
+
+def test_mapping3_fused_path():
+    pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV, compute="fused")
