@@ -3,6 +3,7 @@
 // the caller's stream.  No device allocation, no synchronisation, no state kept between calls.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "mne_launch.h"
@@ -43,6 +44,8 @@ static int check_scene(const mne_scene_t* sc, bool need_grad) {
 }
 
 static void fill_render_consts(RenderArgs& a, const mne_render_cfg_t* cfg) {
+    const char* dbg = getenv("MNE_DBG_FLAGS");
+    a.dbg = dbg ? atoi(dbg) : 0;
     a.trunc_f = (float)cfg->trunc;
     a.win_f = (float)(cfg->sc_factor * cfg->trunc);       // python: sc_factor * trunc, then fp32
     a.e_T = (float)cfg->truncation;

@@ -117,7 +117,7 @@ __device__ __forceinline__ void oneblob16(float x, float* out /*16*/) {
 // Lane layout: 8 lanes x float4 cover one 128-B corner row, 8 points per pass (coalesced rows).
 // pn: LDS [NPTS][4] normalised points; feat: LDS [NSETS][NPTS][MNE_FS].
 template <int NSETS, int NPTS>
-__device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane) {
+__device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane, int dbg = 0) {
     const int cg = lane & 7;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 8; ++it) {
@@ -135,6 +135,7 @@ __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float*
                     orient_coords(ori, px, py, pz, gx, gy);
                     Bilin b;
                     bilin_setup(gx, gy, pl.h, pl.w, b);
+                    if (dbg & 4) { b.o00 = b.o01 = b.o10 = b.o11 = 0; }      // ablation: every load hits one line
                     const float* base = pl.data + cg * 4;
                     const float4 v00 = *(const float4*)(base + b.o00);
                     const float4 v01 = *(const float4*)(base + b.o01);
@@ -160,8 +161,9 @@ __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float*
 // Lane layout: 32 lanes = the 32 channels of one corner row (one 128-B line per half-wave).
 template <int NSETS, int NPTS>
 __device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float* pn, const float* dfeat,
-                                              int n_valid, int lane) {
+                                              int n_valid, int lane, int dbg = 0) {
     const int c = lane & 31, half = lane >> 5;
+    if (dbg & 1) return;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 2; ++it) {
         const int slot = it * 2 + half;

@@ -32,6 +32,8 @@ struct RenderArgs {
     long long tape_cap;
     int* tape_rows;
     float *d_rays_o, *d_rays_d;
+    int rpw;              // rays (= waves) per workgroup, set by the launcher
+    int dbg;              // MNE_DBG_FLAGS (timing ablations only; results are wrong when non-zero)
 };
 
 struct LossArgs {

@@ -160,10 +160,13 @@ __host__ __device__ inline size_t render_wave_lds_bytes(int S, int nsets) {
     return (b + 15) & ~(size_t)15;
 }
 
-// RPW = rays (= waves) per workgroup; ALDS = the MFMA A-operand tables are staged in LDS once per
+// a.rpw = rays (= waves) per workgroup (chosen at launch so that one round of workgroups covers
+// the batch); ALDS = the MFMA A-operand tables are staged in LDS once per
 // workgroup (one ds_read_b32 per MFMA) instead of being re-read from global memory per MFMA.
-template <int HID, int HIDC, bool CP, bool PASS1, bool BWD, int RPW, bool ALDS>
-__global__ __launch_bounds__(64 * RPW) void render_kernel(RenderArgs a) {
+#define MAX_RPW 10
+template <int HID, int HIDC, bool CP, bool PASS1, bool BWD, bool ALDS>
+__global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
+    const int RPW = a.rpw;                                 // waves (= rays) in this workgroup
     typedef DecDims<HID, HIDC, CP> D;
     typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(64 * RPW) void render_kernel(RenderArgs a) {
     if (ALDS) {                                            // stage the A tables: the only block-wide step
         float4* dst = (float4*)lds_raw;
         const float4* src = (const float4*)a.packed;
-        for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += 64 * RPW) dst[i] = src[i];
+        for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
     const float* atab = ALDS ? (const float*)lds_raw : a.packed;
@@ -214,12 +217,13 @@ __global__ __launch_bounds__(64 * RPW) void render_kernel(RenderArgs a) {
             point_coords(a.sc, p, pnv, u);
             if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
             MNE_WAVE_SYNC();
-            gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+            gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane, a.dbg);
             MNE_WAVE_SYNC();
             float pos[24];
             oneblob_half(u, hf, pos);
             MlpState<HID, HIDC> st;
-            mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, atab, lane, st);
+            if (!(a.dbg & 8)) mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, atab, lane, st);
+            else { st.rgb[0] = st.rgb[1] = st.rgb[2] = pos[0]; st.out[0] = pos[1]; }
             if (valid && hf == 0) {                                        // rows 0..3 live in the lower half
                 const float4 rw = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);
                 *(float4*)(a.raw + ((size_t)r * S + i) * 4) = rw;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(64 * RPW) void render_kernel(RenderArgs a) {
         int tape_base = 0;
         if (lane == 0 && n_contrib > 0) tape_base = atomicAdd(a.tape_rows, n_contrib);
         tape_base = __shfl(tape_base, 0);
-        const int ntile = (n_contrib + TILE - 1) / TILE;
+        const int ntile = (a.dbg & 16) ? 0 : (n_contrib + TILE - 1) / TILE;
 #pragma unroll 1
         for (int cc = 0; cc < ntile; ++cc) {
             const int k = cc * TILE + pt;
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(64 * RPW) void render_kernel(RenderArgs a) {
             point_coords(a.sc, p, pnv, u);
             if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
             MNE_WAVE_SYNC();
-            gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+            gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane, a.dbg);
             MNE_WAVE_SYNC();
             float* frow = feat + pt * MNE_FS;
             float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
@@ -395,7 +399,8 @@ __global__ __launch_bounds__(64 * RPW) void render_kernel(RenderArgs a) {
             }
             // ---- tape: forward activations of this point (each lane writes the part it holds)
             float* row = a.tape + (size_t)(tape_base + (valid ? k : 0)) * D::ROW;
-            if (valid) {
+            const bool tape_on = valid && !(a.dbg & 2);
+            if (tape_on) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     *(float4*)(row + D::T_X + hf * 32 + 4 * q) = *(const float4*)(frow + hf * 32 + 4 * q);
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(64 * RPW) void render_kernel(RenderArgs a) {
             // ---- MFMA backward chain; d(feature) rows overwrite this point's LDS feature rows
             f32x16 dh[NT], dout, dhc[NTC];
             mlp_backward_mfma<HID, HIDC, CP>(st, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
-            if (valid) {
+            if (tape_on) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
                     *(float4*)(row + D::T_DOUT + 8 * q + 4 * hf) = make_float4(dout[4 * q], dout[4 * q + 1], dout[4 * q + 2], dout[4 * q + 3]);
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(64 * RPW) void render_kernel(RenderArgs a) {
             }
             MNE_WAVE_SYNC();
             const int n_here = n_contrib - cc * TILE;
-            scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane);
+            scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane, a.dbg);
             MNE_WAVE_SYNC();
         }
     }
@@ -580,19 +585,32 @@ int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStr
 // -----------------------------------------------------------------------------------------------
 // host-side launchers (called from capi.hip)
 // -----------------------------------------------------------------------------------------------
-// Workgroup shape per decoder configuration: 8 rays per workgroup when tables + 8 private regions
-// fit the 160 KiB LDS (2 waves per SIMD), otherwise 4; the largest decoder keeps its tables in L2.
+// Workgroup shape: the A tables (staged in LDS except for the largest decoder, which reads them
+// through L2) plus one private region per ray.  Rays per workgroup are chosen at launch: enough that
+// ONE round of workgroups (<= 256, one per CU) covers the batch when the 160 KiB LDS allows it --
+// a second, nearly empty round would double the kernel time -- otherwise as many as fit.
+#define MNE_LDS_MAX (160 * 1024)
+#define MNE_NUM_CU 256
 template <int HID, int HIDC, bool CP> struct WgShape {
-    static constexpr int RPW = (HID == 32 && !CP) ? 8 : 4;
     static constexpr bool ALDS = !(HID == 64 && CP);
 };
 
 template <int HID, int HIDC, bool CP>
-static size_t render_lds_total(int S, bool bwd) {
+static size_t render_lds_total(int S, bool bwd, int rpw) {
     typedef WgShape<HID, HIDC, CP> W;
     typedef ATab<HID, HIDC, CP> T;
     const size_t tab = W::ALDS ? (size_t)(bwd ? T::TOTAL : T::FWD_STEPS) * 64 * sizeof(float) : 0;
-    return tab + W::RPW * render_wave_lds_bytes(S, CP ? 2 : 1);
+    return tab + (size_t)rpw * render_wave_lds_bytes(S, CP ? 2 : 1);
+}
+
+template <int HID, int HIDC, bool CP>
+static int choose_rpw(int R, int S, bool bwd) {
+    int fit = 0;
+    for (int k = 1; k <= MAX_RPW; ++k)
+        if (render_lds_total<HID, HIDC, CP>(S, bwd, k) <= MNE_LDS_MAX) fit = k;
+    if (fit == 0) return 0;
+    const int want = (R + MNE_NUM_CU - 1) / MNE_NUM_CU;      // rays per CU for a single round
+    return want <= fit ? (want < 1 ? 1 : want) : fit;
 }
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
@@ -611,19 +629,20 @@ static int launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
 }
 
 template <int HID, int HIDC, bool CP>
-static int launch_render(const RenderArgs& a, int pass1, int bwd, hipStream_t st) {
+static int launch_render(RenderArgs a, int pass1, int bwd, hipStream_t st) {
     typedef WgShape<HID, HIDC, CP> W;
-    const size_t lds = render_lds_total<HID, HIDC, CP>(a.S, bwd != 0);
-    if (lds > 160 * 1024) return -4;
-    const int grid = (a.R + W::RPW - 1) / W::RPW;
+    a.rpw = choose_rpw<HID, HIDC, CP>(a.R, a.S, bwd != 0);
+    if (a.rpw < 1) return -4;
+    const size_t lds = render_lds_total<HID, HIDC, CP>(a.S, bwd != 0, a.rpw);
+    const int grid = (a.R + a.rpw - 1) / a.rpw;
     if (lds > 64 * 1024) {          // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, false, W::RPW, W::ALDS>), 160 * 1024);
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, false, true, W::RPW, W::ALDS>), 160 * 1024);
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, true, W::RPW, W::ALDS>), 160 * 1024);
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, false, W::ALDS>), MNE_LDS_MAX);
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, false, true, W::ALDS>), MNE_LDS_MAX);
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, true, W::ALDS>), MNE_LDS_MAX);
     }
-    if (pass1 && !bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, false, W::RPW, W::ALDS>), grid, 64 * W::RPW, lds, st, a);
-    else if (!pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true, W::RPW, W::ALDS>), grid, 64 * W::RPW, lds, st, a);
-    else if (pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, true, W::RPW, W::ALDS>), grid, 64 * W::RPW, lds, st, a);
+    if (pass1 && !bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, false, W::ALDS>), grid, 64 * a.rpw, lds, st, a);
+    else if (!pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true, W::ALDS>), grid, 64 * a.rpw, lds, st, a);
+    else if (pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, true, W::ALDS>), grid, 64 * a.rpw, lds, st, a);
     else return -1;
     return 0;
 }
@@ -676,7 +695,7 @@ int mne_launch_loss_coef(const LossArgs& a, hipStream_t st) {
 }
 
 size_t mne_render_lds_bytes(const mne_scene_t& sc, int S, int bwd) {
-#define CALL(H, HC, CPV) return render_lds_total<H, HC, CPV>(S, bwd != 0)
+#define CALL(H, HC, CPV) return render_lds_total<H, HC, CPV>(S, bwd != 0, 1)
     MNE_DISPATCH(sc, CALL, 0);
 #undef CALL
     return 0;
