@@ -81,6 +81,26 @@ typedef struct mne_render_cfg {
     int32_t reserved;
 } mne_render_cfg_t;
 
+/* Per-tile sample lists of the binned scatter (mne_render_fused -> mne_tile_adam).  All buffers are
+ * caller-owned device memory; counts and *spill_count must be zero before the first use (each
+ * mne_tile_adam call leaves counts zeroed again; mne_render_fused zeroes *spill_count itself). */
+typedef struct mne_tile_bins {
+    uint32_t* lists;       /* [mne_tile_count()][cap] */
+    int32_t* counts;       /* [mne_tile_count()] */
+    uint32_t* spill;       /* [spill_cap][2] overflow entries (tile id, tape row) */
+    int32_t* spill_count;  /* [1] */
+    int32_t cap, spill_cap;
+} mne_tile_bins_t;
+
+/* Adam state and hyper-parameters of one plane, in JointEncoding.all_planes order
+ * ([set][xy,xz,yz][coarse,fine]) for mne_tile_adam. */
+typedef struct mne_plane_opt {
+    float* m; float* v;                            /* exp_avg, exp_avg_sq: same layout as the plane */
+    double lr, beta1, beta2, eps, weight_decay;
+    int32_t step;                                  /* 1-based */
+    int32_t reserved;
+} mne_plane_opt_t;
+
 /* Per-tensor view for the fused Adam step. */
 typedef struct mne_adam_seg {
     float* p; float* g; float* m; float* v;
@@ -188,7 +208,19 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
                      const float* rays_o, const float* rays_d, const float* target_rgb,
                      const float* target_d, const float* z_vals, const float* packed_decoder,
                      const float* coef, float* rgb, float* depth, float* raw, float* ray_sums,
-                     float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, void* stream);
+                     float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                     const mne_tile_bins_t* bins, void* stream);
+
+/* Binned scatter + Adam for the planes (see csrc/tile_adam.hip): with `bins` given, mne_render_fused
+ * does not touch plane[].grad; it appends every contributing sample to the lists of the 16x16-cell
+ * plane tiles it touches, and mne_tile_adam then (per tile) sums the samples' d(feature) x bilinear
+ * weights in LDS and applies torch.optim.Adam's update to the tile -- i.e. it replaces
+ * grid_sampler_2d_backward + Adam.step() + zero_grad() for the plane groups
+ * (mneslam_mp.py:459-469) with no gradient buffer and no global atomics.  opt[] has 6*n_sets entries.
+ * tape_rows is zeroed by mne_render_fused itself in every mode. */
+size_t mne_tile_count(const mne_scene_t* scene);
+int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
+                  const mne_tile_bins_t* bins, void* stream);
 
 /* Decoder weight gradients from the tape: dW = sum_rows outer(d_out, in) for the four matrices,
  * written as [w_col0 | w_col1 | w_sdf0 | w_sdf1] (the order of decoder.parameters(),

@@ -43,6 +43,16 @@ class AdamSeg(C.Structure):
                 ("weight_decay", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
 
 
+class TileBins(C.Structure):
+    _fields_ = [("lists", C.c_void_p), ("counts", C.c_void_p), ("spill", C.c_void_p), ("spill_count", C.c_void_p),
+                ("cap", C.c_int32), ("spill_cap", C.c_int32)]
+
+
+class PlaneOpt(C.Structure):
+    _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
+
+
 # Plane * 2 * 3 * 2 builds [2][3][2] read right-to-left: ((Plane*2)*3)*2 == plane[2][3][2]  (set, orient, level)
 
 _PROTOS = {
@@ -63,7 +73,9 @@ _PROTOS = {
     "mne_render_backward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 11
                             + [C.c_int64] + [C.c_void_p] * 4),
     "mne_render_fused": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 12
-                         + [C.c_int64] + [C.c_void_p] * 2),
+                         + [C.c_int64, C.c_void_p, C.POINTER(TileBins), C.c_void_p]),
+    "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
+    "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.c_void_p]),
     "mne_sample_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 6),
     "mne_decoder_param_floats": (C.c_size_t, [C.POINTER(Scene)]),

@@ -186,8 +186,11 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
                      const float* rays_o, const float* rays_d, const float* target_rgb,
                      const float* target_d, const float* z_vals, const float* packed_decoder,
                      const float* coef, float* rgb, float* depth, float* raw, float* ray_sums,
-                     float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, void* stream) {
-    if (int rc = check_scene(scene, true)) return rc;
+                     float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                     const mne_tile_bins_t* bins, void* stream) {
+    if (int rc = check_scene(scene, bins == nullptr)) return rc;
+    if (bins && (!bins->lists || !bins->counts || !bins->spill || !bins->spill_count || bins->cap < 1 || bins->spill_cap < 1))
+        return fail(-1, "mne_render_fused: incomplete tile bins");
     if (!cfg || !rays_o || !rays_d || !target_rgb || !target_d || !z_vals || !packed_decoder || !coef || !raw ||
         !tape || !tape_rows)
         return fail(-1, "mne_render_fused: NULL argument");
@@ -202,8 +205,52 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
     a.z_vals = z_vals; a.packed = packed_decoder; a.coef = coef;
     a.rgb = rgb; a.depth = depth; a.raw = raw; a.ray_sums = ray_sums;
     a.tape = tape; a.tape_cap = tape_capacity_rows; a.tape_rows = tape_rows;
-    if (int rc = mne_launch_render(a, 1, 1, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(tape_rows, 0, sizeof(int32_t), st) != hipSuccess) return fail(-10, "memset(tape_rows) failed");
+    if (bins) {
+        a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
+        a.bins.spill_count = bins->spill_count; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
+        mne_tile_geometry(*scene, a.bins);
+        if (hipMemsetAsync(bins->spill_count, 0, sizeof(int32_t), st) != hipSuccess) return fail(-10, "memset(spill_count) failed");
+    }
+    if (int rc = mne_launch_render(a, 1, 1, st)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_fused");
+}
+
+size_t mne_tile_count(const mne_scene_t* scene) {
+    if (!scene || (scene->n_sets != 1 && scene->n_sets != 2)) return 0;
+    TileBins b = {};
+    mne_tile_geometry(*scene, b);
+    return (size_t)b.tile_base[scene->n_sets * 6];
+}
+
+int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
+                  const mne_tile_bins_t* bins, void* stream) {
+    if (int rc = check_scene(scene, false)) return rc;
+    if (!opt || !tape || !bins || !bins->lists || !bins->counts || !bins->spill || !bins->spill_count)
+        return fail(-1, "mne_tile_adam: NULL argument");
+    TileAdamArgs a = {};
+    a.sc = *scene;
+    a.n_planes = scene->n_sets * 6;
+    a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
+    a.bins.spill_count = bins->spill_count; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
+    mne_tile_geometry(*scene, a.bins);
+    for (int k = 0; k < a.n_planes; ++k) {
+        const mne_plane_opt_t& g = opt[k];
+        if (!g.m || !g.v || g.step < 1) return fail(-1, "mne_tile_adam: bad plane optimizer state");
+        PlaneOpt& o = a.opt[k];
+        o.m = g.m; o.v = g.v;
+        o.omb1 = (float)(1.0 - g.beta1); o.b2 = (float)g.beta2; o.omb2 = (float)(1.0 - g.beta2);
+        o.eps = (float)g.eps; o.wd = (float)g.weight_decay;
+        o.step_size = (float)(g.lr / (1.0 - std::pow(g.beta1, (double)g.step)));
+        o.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(g.beta2, (double)g.step));
+    }
+    a.tape = tape;
+    a.row_stride = (int)mne_dims_tape_row(*scene);
+    a.t_dfeat = (int)mne_dims_tape_dfeat(*scene);
+    a.t_pn = (int)mne_dims_tape_pn(*scene);
+    mne_launch_tile_adam(a, (hipStream_t)stream);
+    return check_launch("tile_adam");
 }
 
 int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const int32_t* kf_pose_ids,

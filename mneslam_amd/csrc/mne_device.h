@@ -199,7 +199,7 @@ struct DecDims {
     static constexpr int CINB = CP ? (MNE_POS + MNE_FEAT) : MNE_POS;   // where geo starts in the colour input
     static constexpr int CIN = CINB + MNE_GEO;                           // 63 or 127
     static constexpr int CINP = CINB + MNE_OUT1;                         // tape: [pos | (colour feat) | out16]
-    // tape row: X[112] | H[HID] | DH[HID] | DOUT[16] | CIN[CINP] | HC[HIDC] | DHC[HIDC] | DC[4]
+    // tape row: X[112] | H[HID] | DH[HID] | DOUT[16] | CIN[CINP] | HC[HIDC] | DHC[HIDC] | DC[4] | DFEAT | PN[4]
     // (CIN holds the whole out16 = (sdf, geo15); the sdf slot is skipped by the weight-gradient GEMM)
     static constexpr int T_X = 0;
     static constexpr int T_H = T_X + MNE_IN1;
@@ -209,7 +209,10 @@ struct DecDims {
     static constexpr int T_HC = T_CIN + CINP;
     static constexpr int T_DHC = T_HC + HIDC;
     static constexpr int T_DC = T_DHC + HIDC;
-    static constexpr int ROW = T_DC + 4;
+    // binned scatter (tile_adam.hip): d(feature) rows [set][64] and the normalised point
+    static constexpr int T_DFEAT = T_DC + 4;
+    static constexpr int T_PN = T_DFEAT + (CP ? 2 : 1) * MNE_FEAT;
+    static constexpr int ROW = T_PN + 4;
     // decoder parameter buffer (order of decoder.parameters()): col0 | col1 | sdf0 | sdf1
     static constexpr int P_COL0 = 0;
     static constexpr int P_COL1 = P_COL0 + HIDC * CIN;

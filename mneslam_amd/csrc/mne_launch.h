@@ -17,6 +17,19 @@ struct ZArgs {
     int* ray_counts;     // [R][MNE_N_COUNT] scratch
 };
 
+#define MNE_TILE 16            // plane tile edge (cells) of the binned scatter
+#define MNE_MAX_PLANES 12
+
+struct TileBins {
+    unsigned* lists;          // [n_tiles][cap] tape-row ids
+    int* counts;              // [n_tiles] cursors (reset by tile_adam_kernel)
+    unsigned* spill;          // [spill_cap][2] (tile, tape row) overflow entries
+    int* spill_count;
+    int cap, spill_cap;
+    int tile_base[MNE_MAX_PLANES + 1];   // first tile id of each plane ([set][orient][level] order)
+    int ntx[MNE_MAX_PLANES];             // tiles per plane row
+};
+
 struct RenderArgs {
     mne_scene_t sc;
     int R, S;
@@ -32,6 +45,7 @@ struct RenderArgs {
     long long tape_cap;
     int* tape_rows;
     float *d_rays_o, *d_rays_d;
+    TileBins bins;        // bins.lists != NULL: binned scatter instead of atomics into plane[].grad
     int rpw;              // rays (= waves) per workgroup, set by the launcher
     int dbg;              // MNE_DBG_FLAGS (timing ablations only; results are wrong when non-zero)
 };
@@ -80,6 +94,17 @@ struct WgradArgs {
     int n_waves;
 };
 
+struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, bc2_sqrt; };
+
+struct TileAdamArgs {
+    mne_scene_t sc;
+    TileBins bins;
+    PlaneOpt opt[MNE_MAX_PLANES];
+    const float* tape;
+    int row_stride, t_dfeat, t_pn;
+    int n_planes;
+};
+
 struct AdamArgs {
     mne_adam_seg_t seg[32];
     float step_size[32];      // lr / (1 - beta1^t)
@@ -98,9 +123,13 @@ int mne_launch_loss_finalize(const LossArgs& a, hipStream_t st);
 int mne_launch_loss_coef(const LossArgs& a, hipStream_t st);
 int mne_launch_wgrad(const mne_scene_t& sc, WgradArgs a, int impl, hipStream_t st);
 int mne_launch_adam(const AdamArgs& a, hipStream_t st);
+int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st);
+void mne_tile_geometry(const mne_scene_t& sc, TileBins& b);
 int mne_launch_sample_rays(SampleRaysArgs a, unsigned long long seed, unsigned long long iteration, hipStream_t st);
 size_t mne_dims_packed(const mne_scene_t& sc);
 size_t mne_dims_tape_row(const mne_scene_t& sc);
 size_t mne_dims_nparam(const mne_scene_t& sc);
+size_t mne_dims_tape_dfeat(const mne_scene_t& sc);
+size_t mne_dims_tape_pn(const mne_scene_t& sc);
 int mne_wgrad_waves(void);
 size_t mne_render_lds_bytes(const mne_scene_t& sc, int S, int bwd);

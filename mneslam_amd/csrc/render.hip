@@ -455,7 +455,49 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
             }
             MNE_WAVE_SYNC();
             const int n_here = n_contrib - cc * TILE;
-            scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane, a.dbg);
+            if (a.bins.lists) {
+                // binned scatter: d(feature) + normalised point go to the tape row, and the sample is
+                // appended to the list of every plane tile its 2x2 footprint touches (tile_adam.hip)
+                if (tape_on) {
+#pragma unroll
+                    for (int set = 0; set < NSETS; ++set)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            *(float4*)(row + D::T_DFEAT + set * MNE_FEAT + hf * 32 + 4 * q) =
+                                *(const float4*)(feat + set * TILE * MNE_FS + pt * MNE_FS + hf * 32 + 4 * q);
+                    if (hf == 0) *(float4*)(row + D::T_PN) = *(const float4*)(pn + pt * 4);
+                }
+                if (valid && !(a.dbg & 1)) {
+                    const unsigned trow = (unsigned)(tape_base + k);
+#pragma unroll
+                    for (int j = 0; j < NSETS * 3; ++j) {
+                        const int pidx = 2 * j + hf;                       // planes in [set][orient][level] order
+                        const int set = pidx / 6, ori = (pidx % 6) / 2, lvl = pidx % 2;
+                        const mne_plane_t& pl = a.sc.plane[set][ori][lvl];
+                        float gx, gy;
+                        orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
+                        Bilin b;
+                        bilin_setup(gx, gy, pl.h, pl.w, b);
+                        const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
+                        const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
+                        const int base = a.bins.tile_base[pidx], ntx = a.bins.ntx[pidx];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
+                            if (((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0)) continue;   // same tile again
+                            const int tile = base + ty * ntx + tx;
+                            const int slot = atomicAdd(a.bins.counts + tile, 1);
+                            if (slot < a.bins.cap) a.bins.lists[(size_t)tile * a.bins.cap + slot] = trow;
+                            else {
+                                const int sp = atomicAdd(a.bins.spill_count, 1);
+                                if (sp < a.bins.spill_cap) { a.bins.spill[2 * sp] = (unsigned)tile; a.bins.spill[2 * sp + 1] = trow; }
+                            }
+                        }
+                    }
+                }
+            } else {
+                scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane, a.dbg);
+            }
             MNE_WAVE_SYNC();
         }
     }
@@ -709,6 +751,18 @@ size_t mne_dims_packed(const mne_scene_t& sc) {
 }
 size_t mne_dims_tape_row(const mne_scene_t& sc) {
 #define CALL(H, HC, CPV) return (size_t)DecDims<H, HC, CPV>::ROW
+    MNE_DISPATCH(sc, CALL, 0);
+#undef CALL
+    return 0;
+}
+size_t mne_dims_tape_dfeat(const mne_scene_t& sc) {
+#define CALL(H, HC, CPV) return (size_t)DecDims<H, HC, CPV>::T_DFEAT
+    MNE_DISPATCH(sc, CALL, 0);
+#undef CALL
+    return 0;
+}
+size_t mne_dims_tape_pn(const mne_scene_t& sc) {
+#define CALL(H, HC, CPV) return (size_t)DecDims<H, HC, CPV>::T_PN
     MNE_DISPATCH(sc, CALL, 0);
 #undef CALL
     return 0;

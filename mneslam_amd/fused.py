@@ -18,7 +18,14 @@ from .optim import FusedAdam
 
 
 class FusedStep:
-    def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, with_depth=True):
+    def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
+                 tile_capacity=1024, spill_capacity=1 << 16):
+        """scatter="binned": plane gradients are accumulated per 16x16-cell tile in LDS and Adam is applied
+        in the same kernel (csrc/tile_adam.hip; no gradient buffers).  scatter="atomics": global
+        atomic adds into persistent gradient buffers + the streaming Adam kernel."""
+        if scatter not in ("binned", "atomics"):
+            raise ValueError("scatter must be binned|atomics")
+        self.scatter = scatter
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("the fused mapping step needs mneslam_amd.optim.FusedAdam "
                             "(slam_glue.create_optimizer builds it with the reference's groups)")
@@ -38,13 +45,16 @@ class FusedStep:
                     or p.device.type != dev.type:
                 raise ValueError("fused step needs channels_last planes on the compute device")
         self.dec_w = model.decoder.hip_weights()
-        # persistent gradient accumulators (zeroed by the Adam kernel itself after each use)
-        self.grads = []
-        for p in self.planes:
-            st = optimizer._state(p)
-            if "grad_buffer" not in st:
-                st["grad_buffer"] = torch.zeros_like(p.data)
-            self.grads.append(st["grad_buffer"])
+        self.group_of = {p: g for g in optimizer.param_groups for p in g["params"]}
+        self.grads = None
+        if scatter == "atomics":
+            # persistent gradient accumulators (zeroed by the Adam kernel itself after each use)
+            self.grads = []
+            for p in self.planes:
+                st = optimizer._state(p)
+                if "grad_buffer" not in st:
+                    st["grad_buffer"] = torch.zeros_like(p.data)
+                self.grads.append(st["grad_buffer"])
         self.scene = hip_path.scene_struct(self.info, [p.data for p in self.planes], [w.data for w in self.dec_w], self.grads)
         e = lambda *shape, dtype=f32: torch.empty(*shape, device=dev, dtype=dtype)
         self.rays_o, self.rays_d, self.tgt_rgb, self.tgt_d = e(R, 3), e(R, 3), e(R, 3), e(R)
@@ -66,8 +76,28 @@ class FusedStep:
         self.dec_grad_views = {w_col0: self.dec_grad[:n0].view_as(w_col0), w_col1: self.dec_grad[n0:n0 + n1].view_as(w_col1),
                                w_sdf0: self.dec_grad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0),
                                w_sdf1: self.dec_grad[n0 + n1 + n2:].view_as(w_sdf1)}
-        self.grad_map = {p: g for p, g in zip(self.planes, self.grads)}
-        self.grad_map.update(self.dec_grad_views)
+        self.grad_map = dict(self.dec_grad_views)
+        self.bins = None
+        if scatter == "atomics":
+            self.grad_map.update({p: g for p, g in zip(self.planes, self.grads)})
+        else:
+            n_tiles = self.lib.mne_tile_count(C.byref(self.scene))
+            self.tile_lists = torch.zeros(n_tiles, tile_capacity, device=dev, dtype=torch.int32)
+            self.tile_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
+            self.spill = torch.zeros(spill_capacity, 2, device=dev, dtype=torch.int32)
+            self.spill_count = torch.zeros(1, device=dev, dtype=torch.int32)
+            b = _lib.TileBins()
+            b.lists, b.counts = self.tile_lists.data_ptr(), self.tile_counts.data_ptr()
+            b.spill, b.spill_count = self.spill.data_ptr(), self.spill_count.data_ptr()
+            b.cap, b.spill_cap = tile_capacity, spill_capacity
+            self.bins = b
+            self.plane_opt = (_lib.PlaneOpt * len(self.planes))()
+            for k, p in enumerate(self.planes):
+                st, grp = optimizer._state(p), self.group_of[p]
+                o = self.plane_opt[k]
+                o.m, o.v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
+                o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
         self.events = None          # set to {} to record HIP events around the two dominant launches
         self.iteration = 0
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
@@ -89,18 +119,28 @@ class FusedStep:
         _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
         _lib.check(lib.mne_loss_coef(C.byref(self.rc), R, S, P(self.counts), P(self.loss_w), P(self.coef), st),
                    "mne_loss_coef")
-        self.tape_rows.zero_()
         ev = self._mark("render")
         _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
                                         P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals), P(self.packed), P(self.coef),
                                         P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape),
-                                        R * S, P(self.tape_rows), st), "mne_render_fused")
+                                        R * S, P(self.tape_rows), C.byref(self.bins) if self.bins is not None else None, st),
+                   "mne_render_fused")
         self._mark("render", ev)
         _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), P(self.partials),
                                          P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
         ev = self._mark("adam")
-        self.opt.step(zero_grad=True, grad_buffers=self.grad_map)
-        self._mark("adam", ev)
+        if self.bins is not None:
+            for k, p in enumerate(self.planes):
+                stt = self.opt._state(p)
+                stt["step"] += 1
+                self.plane_opt[k].step = stt["step"]
+            _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), st),
+                       "mne_tile_adam")
+            self._mark("adam", ev)
+            self.opt.step(zero_grad=False, grad_buffers=self.grad_map)      # decoder tensors
+        else:
+            self.opt.step(zero_grad=True, grad_buffers=self.grad_map)
+            self._mark("adam", ev)
         _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
         self.iteration += 1
 

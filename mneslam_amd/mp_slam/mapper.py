@@ -21,12 +21,12 @@ class Mapper():
     the reference's order (seed-for-seed identical batches); "device" = keyed permutation on the GPU
     (no host work per iteration).  Defaults reproduce the reference exactly."""
 
-    def __init__(self, config, SLAM, compute="autograd", sampler="host") -> None:
+    def __init__(self, config, SLAM, compute="autograd", sampler="host", scatter="binned") -> None:
         if compute not in ("autograd", "fused") or sampler not in ("host", "device"):
             raise ValueError("compute must be autograd|fused and sampler host|device")
         if sampler == "device" and compute != "fused":
             raise ValueError("the device sampler is part of the fused path")
-        self.compute, self.sampler = compute, sampler
+        self.compute, self.sampler, self.scatter = compute, sampler, scatter
         self._fused = {}
         self.config = config
         self.slam = SLAM
@@ -98,7 +98,8 @@ class Mapper():
     def _fused_step(self, n_rays):
         key = (n_rays, id(self.map_optimizer))
         if key not in self._fused:
-            self._fused[key] = FusedStep(self.model, self.map_optimizer, self.config, n_rays, self.device)
+            self._fused[key] = FusedStep(self.model, self.map_optimizer, self.config, n_rays, self.device,
+                                         scatter=self.scatter)
         return self._fused[key]
 
     def _jitter(self, fs):

@@ -43,7 +43,7 @@ class FusedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
-                g = p.grad if zero_grad_buffers is None else zero_grad_buffers.get(p)
+                g = p.grad if zero_grad_buffers is None else zero_grad_buffers.get(p)   # explicit map: only those params
                 if g is None:
                     continue
                 if p.dtype != torch.float32:

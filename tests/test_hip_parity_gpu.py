@@ -70,8 +70,9 @@ def test_device_sampler():
 
 @pytest.mark.parametrize("name,one_grid,co,seed", [("mapping3_onegrid_esdf", True, False, 21),
                                                    ("mapping3_colorplanes_cosdf", False, True, 22)])
-def test_three_fused_mapping_iterations_match_reference(name, one_grid, co, seed):
-    pc.check_mapping3(name, one_grid, co, seed, DEV, compute="fused")
+@pytest.mark.parametrize("scatter", ["binned", "atomics"])
+def test_three_fused_mapping_iterations_match_reference(name, one_grid, co, seed, scatter):
+    pc.check_mapping3(name, one_grid, co, seed, DEV, compute="fused", scatter=scatter)
 
 
 @pytest.mark.parametrize("hidden,one_grid", [(64, True), (64, False), (32, True)])

@@ -73,5 +73,10 @@ def test_device_sampler():
     pc.check_device_sampler(DEV)
 
 
-def test_mapping3_fused_path():
-    pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV, compute="fused")
+@pytest.mark.parametrize("scatter", ["binned", "atomics"])
+def test_mapping3_fused_path(scatter):
+    pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV, compute="fused", scatter=scatter)
+
+
+def test_mapping3_fused_binned_colorplanes():
+    pc.check_mapping3("mapping3_colorplanes_cosdf", False, True, 22, DEV, compute="fused", scatter="binned")
