@@ -249,6 +249,7 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
     a.row_stride = (int)mne_dims_tape_row(*scene);
     a.t_dfeat = (int)mne_dims_tape_dfeat(*scene);
     a.t_pn = (int)mne_dims_tape_pn(*scene);
+    { const char* dbg = getenv("MNE_DBG_FLAGS"); a.dbg = dbg ? atoi(dbg) : 0; }
     mne_launch_tile_adam(a, (hipStream_t)stream);
     return check_launch("tile_adam");
 }

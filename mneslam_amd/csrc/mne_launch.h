@@ -19,11 +19,13 @@ struct ZArgs {
 
 #define MNE_TILE 16            // plane tile edge (cells) of the binned scatter
 #define MNE_MAX_PLANES 12
+#define MNE_ENTRY_WORDS 6       // list entry: tape row | (lx+1)|(ly+1)<<8 | 4 bilinear weights
+#define MNE_SPILL_WORDS 8       // spill entry: tile id | entry | pad
 
 struct TileBins {
-    unsigned* lists;          // [n_tiles][cap] tape-row ids
+    unsigned* lists;          // [n_tiles][cap][MNE_ENTRY_WORDS]
     int* counts;              // [n_tiles] cursors (reset by tile_adam_kernel)
-    unsigned* spill;          // [spill_cap][2] (tile, tape row) overflow entries
+    unsigned* spill;          // [spill_cap][MNE_SPILL_WORDS] overflow entries
     int* spill_count;
     int cap, spill_cap;
     int tile_base[MNE_MAX_PLANES + 1];   // first tile id of each plane ([set][orient][level] order)
@@ -103,6 +105,7 @@ struct TileAdamArgs {
     const float* tape;
     int row_stride, t_dfeat, t_pn;
     int n_planes;
+    int dbg;
 };
 
 struct AdamArgs {

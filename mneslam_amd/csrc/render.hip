@@ -486,11 +486,21 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
                             const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
                             if (((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0)) continue;   // same tile again
                             const int tile = base + ty * ntx + tx;
+                            unsigned ent[MNE_ENTRY_WORDS];
+                            ent[0] = trow;
+                            ent[1] = (unsigned)(b.ix0 - tx * MNE_TILE + 1) | ((unsigned)(b.iy0 - ty * MNE_TILE + 1) << 8);
+                            ent[2] = __float_as_uint(b.w00); ent[3] = __float_as_uint(b.w01);
+                            ent[4] = __float_as_uint(b.w10); ent[5] = __float_as_uint(b.w11);
                             const int slot = atomicAdd(a.bins.counts + tile, 1);
-                            if (slot < a.bins.cap) a.bins.lists[(size_t)tile * a.bins.cap + slot] = trow;
+                            unsigned* dst = nullptr;
+                            if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)tile * a.bins.cap + slot) * MNE_ENTRY_WORDS;
                             else {
                                 const int sp = atomicAdd(a.bins.spill_count, 1);
-                                if (sp < a.bins.spill_cap) { a.bins.spill[2 * sp] = (unsigned)tile; a.bins.spill[2 * sp + 1] = trow; }
+                                if (sp < a.bins.spill_cap) { dst = a.bins.spill + (size_t)sp * MNE_SPILL_WORDS; *dst++ = (unsigned)tile; }
+                            }
+                            if (dst) {
+#pragma unroll
+                                for (int w = 0; w < MNE_ENTRY_WORDS; ++w) dst[w] = ent[w];
                             }
                         }
                     }

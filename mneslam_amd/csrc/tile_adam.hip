@@ -25,61 +25,114 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p = p - o.step_size * (m / denom);
 }
 
-// one (tape row, plane) contribution into the LDS tile; executed by a half-wave, lane = channel
-__device__ __forceinline__ void tile_accumulate(const TileAdamArgs& a, const mne_plane_t& pl, int set, int ori, int lvl,
-                                                int tx0, int ty0, unsigned t, int c, float* g) {
-    const float* row = a.tape + (size_t)t * a.row_stride;
-    const float px = row[a.t_pn + 0], py = row[a.t_pn + 1], pz = row[a.t_pn + 2];
-    float gx, gy;
-    orient_coords(ori, px, py, pz, gx, gy);
-    Bilin b;
-    bilin_setup(gx, gy, pl.h, pl.w, b);
-    const float gc = row[a.t_dfeat + set * MNE_FEAT + lvl * MNE_C + c];
-    const int lx = b.ix0 - tx0 * MNE_TILE, ly = b.iy0 - ty0 * MNE_TILE;     // NW corner relative to the tile
-    const bool x0in = lx >= 0 && lx < MNE_TILE, x1in = lx + 1 >= 0 && lx + 1 < MNE_TILE;
-    const bool y0in = ly >= 0 && ly < MNE_TILE, y1in = ly + 1 >= 0 && ly + 1 < MNE_TILE;
-    if (x0in && y0in && b.w00 != 0.0f) atomicAdd(g + ((ly * MNE_TILE + lx) * MNE_C + c), gc * b.w00);
-    if (x1in && y0in && b.w01 != 0.0f) atomicAdd(g + ((ly * MNE_TILE + lx + 1) * MNE_C + c), gc * b.w01);
-    if (x0in && y1in && b.w10 != 0.0f) atomicAdd(g + (((ly + 1) * MNE_TILE + lx) * MNE_C + c), gc * b.w10);
-    if (x1in && y1in && b.w11 != 0.0f) atomicAdd(g + (((ly + 1) * MNE_TILE + lx + 1) * MNE_C + c), gc * b.w11);
-}
+// One list entry = MNE_ENTRY_WORDS uint32 written by the backward kernel: the tape row, the footprint's
+// NW corner relative to the tile (+1, so 0 means "one cell before the tile") and the four bilinear
+// weights (0 for corners outside the plane).  The tile kernel therefore does no coordinate math.
+//
+// LDS fp32 atomics (ds_add_f32) measured ~0.25 op/clk/CU here (profiles/r01_ablation_tile_adam.txt), so
+// the accumulation avoids them: per pass of PASS_ENTRIES list entries the workgroup first copies the
+// entries into LDS and files each into the queues of the (at most two) tile rows it touches (integer
+// LDS counters only); then every half-wave owns one tile row (or half of one), lane = channel, and
+// applies its row queue with plain read-add-write: single owner, DS operations of a wave complete in
+// order.  The gradient-row loads of QB queue items are issued together.
+#ifndef TILE_THREADS
+#define TILE_THREADS 1024
+#endif
+#ifndef PASS_ENTRIES
+#define PASS_ENTRIES 512
+#endif
+#ifndef QB
+#define QB 8
+#endif
+#define TILE_HW (TILE_THREADS / 32)           // half-waves: 16 rows x TILE_SIDES
+#define TILE_SIDES (TILE_HW / MNE_TILE)
+#define SIDE_CELLS (MNE_TILE / TILE_SIDES)
 
-__global__ __launch_bounds__(256) void tile_adam_kernel(TileAdamArgs a) {
-    __shared__ __attribute__((aligned(16))) float g[MNE_TILE * MNE_TILE * MNE_C];     // 32 KiB
+__global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a) {
+    __shared__ __attribute__((aligned(16))) float g[MNE_TILE * MNE_TILE * MNE_C];     // 32 KiB gradient tile
+    __shared__ unsigned short rowq[MNE_TILE][PASS_ENTRIES];                           // row queues of this pass
+    __shared__ unsigned ents[PASS_ENTRIES][MNE_ENTRY_WORDS];                          // entries of this pass
+    __shared__ int rowq_n[MNE_TILE];
     const int tile = blockIdx.x, tid = threadIdx.x;
     int pidx = 0;
     while (pidx + 1 < a.n_planes && tile >= a.bins.tile_base[pidx + 1]) ++pidx;
-    const int set = pidx / 6, ori = (pidx % 6) / 2, lvl = pidx % 2;           // [set][orient][level]
-    const mne_plane_t& pl = a.sc.plane[set][ori][lvl];
+    const int set = pidx / 6, lvl = pidx % 2;                                 // [set][orient][level]
+    const mne_plane_t& pl = a.sc.plane[set][(pidx % 6) / 2][lvl];
     const int local = tile - a.bins.tile_base[pidx];
     const int tx0 = local % a.bins.ntx[pidx], ty0 = local / a.bins.ntx[pidx];
-    for (int i = tid; i < MNE_TILE * MNE_TILE * MNE_C / 4; i += 256) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    for (int i = tid; i < MNE_TILE * MNE_TILE * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int cnt = a.bins.counts[tile];
-    const int n = cnt < a.bins.cap ? cnt : a.bins.cap;
-    const int c = tid & 31, hw = tid >> 5;                                     // 8 half-waves
-    const unsigned* lst = a.bins.lists + (size_t)tile * a.bins.cap;
-    for (int e = hw; e < n; e += 8) tile_accumulate(a, pl, set, ori, lvl, tx0, ty0, lst[e], c, g);
-    const int ns = *a.bins.spill_count;
-    if (ns > 0) {                                                              // rare: entries beyond a list's capacity
-        const int nsp = ns < a.bins.spill_cap ? ns : a.bins.spill_cap;
-        for (int e = hw; e < nsp; e += 8)
-            if (a.bins.spill[2 * e] == (unsigned)tile) tile_accumulate(a, pl, set, ori, lvl, tx0, ty0, a.bins.spill[2 * e + 1], c, g);
+    const int n_list = (a.dbg & 32) ? 0 : (cnt < a.bins.cap ? cnt : a.bins.cap);
+    int n_spill = 0;
+    if (cnt > a.bins.cap) {                     // only a tile whose list overflowed has entries in the spill area
+        const int ns = *a.bins.spill_count;
+        n_spill = ns < a.bins.spill_cap ? ns : a.bins.spill_cap;
+    }
+    const unsigned* lst = a.bins.lists + (size_t)tile * a.bins.cap * MNE_ENTRY_WORDS;
+    const int c = tid & 31, hw = tid >> 5;
+    const int my_row = hw / TILE_SIDES, my_lo = (hw % TILE_SIDES) * SIDE_CELLS;   // cells [my_lo, my_lo+SIDE_CELLS) of my_row
+    // passes over the list, then over the spill area (spill entries of other tiles are skipped when filing)
+    const int n_total = n_list + n_spill;
+    for (int p0 = 0; p0 < n_total; p0 += PASS_ENTRIES) {
+        if (tid < MNE_TILE) rowq_n[tid] = 0;
+        __syncthreads();
+        const int p1 = p0 + PASS_ENTRIES < n_total ? p0 + PASS_ENTRIES : n_total;
+        for (int e = p0 + tid; e < p1; e += TILE_THREADS) {
+            const unsigned* ent;
+            if (e < n_list) ent = lst + (size_t)e * MNE_ENTRY_WORDS;
+            else {
+                const unsigned* sp = a.bins.spill + (size_t)(e - n_list) * MNE_SPILL_WORDS;
+                if (sp[0] != (unsigned)tile) continue;
+                ent = sp + 1;
+            }
+            const unsigned short item = (unsigned short)(e - p0);
+#pragma unroll
+            for (int w = 0; w < MNE_ENTRY_WORDS; ++w) ents[item][w] = ent[w];
+            const int ly = (int)((ent[1] >> 8) & 0xff) - 1;
+            if (ly >= 0) rowq[ly][atomicAdd(&rowq_n[ly], 1)] = item;
+            if (ly + 1 < MNE_TILE) rowq[ly + 1][atomicAdd(&rowq_n[ly + 1], 1)] = item;
+        }
+        __syncthreads();
+        const int nq = rowq_n[my_row];
+        float* grow = g + my_row * MNE_TILE * MNE_C + c;
+        for (int q0 = 0; q0 < nq; q0 += QB) {
+            unsigned hdr[QB];
+            float w0[QB], w1[QB], gc[QB];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                const unsigned* ent = ents[rowq[my_row][q0 + j < nq ? q0 + j : q0]];
+                hdr[j] = ent[1];
+                const bool bottom = ((int)((hdr[j] >> 8) & 0xff) - 1) != my_row;     // this row is the footprint's lower row
+                w0[j] = __uint_as_float(ent[bottom ? 4 : 2]);
+                w1[j] = __uint_as_float(ent[bottom ? 5 : 3]);
+                gc[j] = (a.dbg & 256) ? 1.0f : a.tape[(size_t)ent[0] * a.row_stride + a.t_dfeat + set * MNE_FEAT + lvl * MNE_C + c];
+            }
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                if (q0 + j < nq) {
+                    const int lx = (int)(hdr[j] & 0xff) - 1;
+                    if (lx >= my_lo && lx < my_lo + SIDE_CELLS && w0[j] != 0.0f) grow[lx * MNE_C] += gc[j] * w0[j];
+                    if (lx + 1 >= my_lo && lx + 1 < my_lo + SIDE_CELLS && w1[j] != 0.0f) grow[(lx + 1) * MNE_C] += gc[j] * w1[j];
+                }
+            }
+        }
+        __syncthreads();
     }
     __syncthreads();
-    // ---- Adam on the tile: 16 rows x (16 cells x 32 ch) = 2048 float4, 8 per thread
+    // ---- Adam on the tile: 16 rows x (16 cells x 32 ch) = 2048 float4
     const PlaneOpt& o = a.opt[pidx];
     float* P = (float*)pl.data;
 #pragma unroll
-    for (int it = 0; it < (MNE_TILE * MNE_TILE * MNE_C / 4) / 256; ++it) {
-        const int i4 = it * 256 + tid;
+    for (int it = 0; it < (MNE_TILE * MNE_TILE * MNE_C / 4) / TILE_THREADS; ++it) {
+        if (a.dbg & 64) break;
+        const int i4 = it * TILE_THREADS + tid;
         const int y = i4 / (MNE_TILE * MNE_C / 4), x4 = i4 % (MNE_TILE * MNE_C / 4);
         const int cell = x4 / (MNE_C / 4), ch4 = x4 % (MNE_C / 4);
         const int gy = ty0 * MNE_TILE + y, gx = tx0 * MNE_TILE + cell;
         if (gy < pl.h && gx < pl.w) {
             const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + ch4 * 4;
             float4 p = *(float4*)(P + off), m = *(float4*)(o.m + off), v = *(float4*)(o.v + off);
-            const float4 gg = *(const float4*)(g + ((y * MNE_TILE + cell) * MNE_C + ch4 * 4));
+            const float4 gg = ((const float4*)g)[i4];
             adam_elem(p.x, gg.x, m.x, v.x, o); adam_elem(p.y, gg.y, m.y, v.y, o);
             adam_elem(p.z, gg.z, m.z, v.z, o); adam_elem(p.w, gg.w, m.w, v.w, o);
             *(float4*)(P + off) = p; *(float4*)(o.m + off) = m; *(float4*)(o.v + off) = v;
@@ -106,6 +159,6 @@ void mne_tile_geometry(const mne_scene_t& sc, TileBins& b) {
 int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st) {
     const int n_tiles = a.bins.tile_base[a.n_planes];
     if (n_tiles <= 0) return 0;
-    MNE_LAUNCH(tile_adam_kernel, n_tiles, 256, 0, st, a);
+    MNE_LAUNCH(tile_adam_kernel, n_tiles, TILE_THREADS, 0, st, a);
     return 0;
 }

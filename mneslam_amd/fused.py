@@ -19,7 +19,7 @@ from .optim import FusedAdam
 
 class FusedStep:
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
-                 tile_capacity=1024, spill_capacity=1 << 16):
+                 tile_capacity=4096, spill_capacity=1 << 18):
         """scatter="binned": plane gradients are accumulated per 16x16-cell tile in LDS and Adam is applied
         in the same kernel (csrc/tile_adam.hip; no gradient buffers).  scatter="atomics": global
         atomic adds into persistent gradient buffers + the streaming Adam kernel."""
@@ -82,9 +82,9 @@ class FusedStep:
             self.grad_map.update({p: g for p, g in zip(self.planes, self.grads)})
         else:
             n_tiles = self.lib.mne_tile_count(C.byref(self.scene))
-            self.tile_lists = torch.zeros(n_tiles, tile_capacity, device=dev, dtype=torch.int32)
+            self.tile_lists = torch.zeros(n_tiles, tile_capacity, 6, device=dev, dtype=torch.int32)
             self.tile_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
-            self.spill = torch.zeros(spill_capacity, 2, device=dev, dtype=torch.int32)
+            self.spill = torch.zeros(spill_capacity, 8, device=dev, dtype=torch.int32)
             self.spill_count = torch.zeros(1, device=dev, dtype=torch.int32)
             b = _lib.TileBins()
             b.lists, b.counts = self.tile_lists.data_ptr(), self.tile_counts.data_ptr()

@@ -28,6 +28,7 @@ class Mapper():
             raise ValueError("the device sampler is part of the fused path")
         self.compute, self.sampler, self.scatter = compute, sampler, scatter
         self._fused = {}
+        self.fused_kwargs = {}          # extra FusedStep options (e.g. tile_capacity)
         self.config = config
         self.slam = SLAM
         self.model = SLAM.model
@@ -99,7 +100,7 @@ class Mapper():
         key = (n_rays, id(self.map_optimizer))
         if key not in self._fused:
             self._fused[key] = FusedStep(self.model, self.map_optimizer, self.config, n_rays, self.device,
-                                         scatter=self.scatter)
+                                         scatter=self.scatter, **self.fused_kwargs)
         return self._fused[key]
 
     def _jitter(self, fs):

@@ -120,7 +120,7 @@ def check_render_nodepth(device):
     assert set(rr) == {"rgb", "depth", "disp_map", "acc_map", "depth_var", "z_vals", "raw"}
 
 
-def check_mapping3(name, one_grid, co, seed, device, compute="autograd", scatter="binned"):
+def check_mapping3(name, one_grid, co, seed, device, compute="autograd", scatter="binned", **fused_kwargs):
     """Three drop-in Mapper.mapping_optimize iterations (host RNG sampling, autograd path, FusedAdam)
     against the parameters the REFERENCE reached from the same state and seeds."""
     g = load_golden(name)
@@ -144,6 +144,7 @@ def check_mapping3(name, one_grid, co, seed, device, compute="autograd", scatter
         get_loss_from_ret=lambda ret, **kw: slam_glue.get_loss_from_ret(cfg, ret, **kw),
         select_samples=slam_glue.select_samples)
     mapper = Mapper(cfg, slam, compute=compute, sampler="host", scatter=scatter)
+    mapper.fused_kwargs = fused_kwargs
     poses = torch.stack([f["c2w"] for f in frames]).to(device)
     random.seed(seed + 1)
     torch.manual_seed(seed + 1)

@@ -75,6 +75,10 @@ def test_three_fused_mapping_iterations_match_reference(name, one_grid, co, seed
     pc.check_mapping3(name, one_grid, co, seed, DEV, compute="fused", scatter=scatter)
 
 
+def test_binned_scatter_with_list_overflow():
+    pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV, compute="fused", scatter="binned", tile_capacity=8)
+
+
 @pytest.mark.parametrize("hidden,one_grid", [(64, True), (64, False), (32, True)])
 def test_random_scene_vs_oracle(hidden, one_grid):
     pc.check_oracle_random_scene(DEV, hidden=hidden, one_grid=one_grid, n_rays=96, S_d=96, S_r=32)

@@ -78,5 +78,10 @@ def test_mapping3_fused_path(scatter):
     pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV, compute="fused", scatter=scatter)
 
 
+def test_mapping3_fused_binned_with_list_overflow():
+    """tile lists of 8 entries: most contributions go through the spill area"""
+    pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV, compute="fused", scatter="binned", tile_capacity=8)
+
+
 def test_mapping3_fused_binned_colorplanes():
     pc.check_mapping3("mapping3_colorplanes_cosdf", False, True, 22, DEV, compute="fused", scatter="binned")
