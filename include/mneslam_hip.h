@@ -89,6 +89,7 @@ typedef struct mne_tile_bins {
     int32_t* counts;       /* [mne_tile_count()] */
     uint32_t* spill;       /* [spill_cap][8] overflow entries (tile id, entry, pad) */
     int32_t* spill_count;  /* [1] */
+    int32_t* order;        /* [mne_tile_count()] scratch: tile processing order (heaviest first) */
     int32_t cap, spill_cap;
 } mne_tile_bins_t;
 

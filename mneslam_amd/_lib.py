@@ -45,7 +45,7 @@ class AdamSeg(C.Structure):
 
 class TileBins(C.Structure):
     _fields_ = [("lists", C.c_void_p), ("counts", C.c_void_p), ("spill", C.c_void_p), ("spill_count", C.c_void_p),
-                ("cap", C.c_int32), ("spill_cap", C.c_int32)]
+                ("order", C.c_void_p), ("cap", C.c_int32), ("spill_cap", C.c_int32)]
 
 
 class PlaneOpt(C.Structure):

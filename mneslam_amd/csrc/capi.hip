@@ -189,7 +189,7 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
                      float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
                      const mne_tile_bins_t* bins, void* stream) {
     if (int rc = check_scene(scene, bins == nullptr)) return rc;
-    if (bins && (!bins->lists || !bins->counts || !bins->spill || !bins->spill_count || bins->cap < 1 || bins->spill_cap < 1))
+    if (bins && (!bins->lists || !bins->counts || !bins->spill || !bins->spill_count || !bins->order || bins->cap < 1 || bins->spill_cap < 1))
         return fail(-1, "mne_render_fused: incomplete tile bins");
     if (!cfg || !rays_o || !rays_d || !target_rgb || !target_d || !z_vals || !packed_decoder || !coef || !raw ||
         !tape || !tape_rows)
@@ -209,7 +209,7 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
     if (hipMemsetAsync(tape_rows, 0, sizeof(int32_t), st) != hipSuccess) return fail(-10, "memset(tape_rows) failed");
     if (bins) {
         a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
-        a.bins.spill_count = bins->spill_count; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
+        a.bins.spill_count = bins->spill_count; a.bins.order = bins->order; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
         mne_tile_geometry(*scene, a.bins);
         if (hipMemsetAsync(bins->spill_count, 0, sizeof(int32_t), st) != hipSuccess) return fail(-10, "memset(spill_count) failed");
     }
@@ -227,13 +227,13 @@ size_t mne_tile_count(const mne_scene_t* scene) {
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
                   const mne_tile_bins_t* bins, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
-    if (!opt || !tape || !bins || !bins->lists || !bins->counts || !bins->spill || !bins->spill_count)
+    if (!opt || !tape || !bins || !bins->lists || !bins->counts || !bins->spill || !bins->spill_count || !bins->order)
         return fail(-1, "mne_tile_adam: NULL argument");
     TileAdamArgs a = {};
     a.sc = *scene;
     a.n_planes = scene->n_sets * 6;
     a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
-    a.bins.spill_count = bins->spill_count; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
+    a.bins.spill_count = bins->spill_count; a.bins.order = bins->order; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
     mne_tile_geometry(*scene, a.bins);
     for (int k = 0; k < a.n_planes; ++k) {
         const mne_plane_opt_t& g = opt[k];

@@ -27,6 +27,7 @@ struct TileBins {
     int* counts;              // [n_tiles] cursors (reset by tile_adam_kernel)
     unsigned* spill;          // [spill_cap][MNE_SPILL_WORDS] overflow entries
     int* spill_count;
+    int* order;               // [n_tiles] processing order of tile_adam_kernel (heaviest lists first)
     int cap, spill_cap;
     int tile_base[MNE_MAX_PLANES + 1];   // first tile id of each plane ([set][orient][level] order)
     int ntx[MNE_MAX_PLANES];             // tiles per plane row

@@ -36,10 +36,10 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
 // applies its row queue with plain read-add-write: single owner, DS operations of a wave complete in
 // order.  The gradient-row loads of QB queue items are issued together.
 #ifndef TILE_THREADS
-#define TILE_THREADS 1024
+#define TILE_THREADS 512
 #endif
 #ifndef PASS_ENTRIES
-#define PASS_ENTRIES 512
+#define PASS_ENTRIES 256
 #endif
 #ifndef QB
 #define QB 8
@@ -48,12 +48,30 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
 #define TILE_SIDES (TILE_HW / MNE_TILE)
 #define SIDE_CELLS (MNE_TILE / TILE_SIDES)
 
+// Processing order: tiles bucketed by floor(log2(list length + 1)), heaviest bucket first, so the few
+// very long lists (every ray of a keyframe passes through the tile holding its camera centre) start
+// at once instead of forming the tail of the launch.
+__global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_tiles) {
+    __shared__ int hist[32], start[32];
+    const int tid = threadIdx.x;
+    if (tid < 32) hist[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < n_tiles; t += 1024) atomicAdd(&hist[31 - __clz(a.bins.counts[t] + 1)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int b = 31; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < n_tiles; t += 1024) a.bins.order[atomicAdd(&start[31 - __clz(a.bins.counts[t] + 1)], 1)] = t;
+}
+
 __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a) {
     __shared__ __attribute__((aligned(16))) float g[MNE_TILE * MNE_TILE * MNE_C];     // 32 KiB gradient tile
     __shared__ unsigned short rowq[MNE_TILE][PASS_ENTRIES];                           // row queues of this pass
     __shared__ unsigned ents[PASS_ENTRIES][MNE_ENTRY_WORDS];                          // entries of this pass
     __shared__ int rowq_n[MNE_TILE];
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tile = a.bins.order[blockIdx.x], tid = threadIdx.x;
     int pidx = 0;
     while (pidx + 1 < a.n_planes && tile >= a.bins.tile_base[pidx + 1]) ++pidx;
     const int set = pidx / 6, lvl = pidx % 2;                                 // [set][orient][level]
@@ -159,6 +177,7 @@ void mne_tile_geometry(const mne_scene_t& sc, TileBins& b) {
 int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st) {
     const int n_tiles = a.bins.tile_base[a.n_planes];
     if (n_tiles <= 0) return 0;
+    MNE_LAUNCH(tile_order_kernel, 1, 1024, 0, st, a, n_tiles);
     MNE_LAUNCH(tile_adam_kernel, n_tiles, TILE_THREADS, 0, st, a);
     return 0;
 }

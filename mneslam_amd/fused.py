@@ -89,6 +89,8 @@ class FusedStep:
             b = _lib.TileBins()
             b.lists, b.counts = self.tile_lists.data_ptr(), self.tile_counts.data_ptr()
             b.spill, b.spill_count = self.spill.data_ptr(), self.spill_count.data_ptr()
+            self.tile_order = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
+            b.order = self.tile_order.data_ptr()
             b.cap, b.spill_cap = tile_capacity, spill_capacity
             self.bins = b
             self.plane_opt = (_lib.PlaneOpt * len(self.planes))()

@@ -148,6 +148,7 @@ inline unsigned long long __ballot(int pred) {
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 
 inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
