@@ -115,8 +115,11 @@ struct MlpState {
 // half 1 -> pos[24..47] = dim1 bins 8..15 + dim2 (16).
 __device__ __forceinline__ void oneblob_half(const float u[3], int h, float (&pos)[24]) {
     float full[MNE_NB], part[MNE_NB];
-    oneblob16(h == 0 ? u[0] : u[2], full);
-    oneblob16(u[1], part);
+    const float xf = h == 0 ? u[0] : u[2];
+    const bool in_f = xf >= 0.125f && xf <= 0.875f, in_p = u[1] >= 0.125f && u[1] <= 0.875f;
+    const bool interior = __ballot(!(in_f && in_p)) == 0ull;        // wave-uniform fast path
+    oneblob16(xf, full, interior);
+    oneblob16(u[1], part, interior);
     // static register indices only (a lane-dependent index would put pos[] in scratch)
 #pragma unroll
     for (int idx = 0; idx < 24; ++idx) {

@@ -101,12 +101,15 @@ __device__ __forceinline__ float quartic_cdf(float t) {
     return fminf(1.0f, fmaxf(poly, 0.0f));
 }
 
-__device__ __forceinline__ void oneblob16(float x, float* out /*16*/) {
+// `interior` (wave-uniform): every lane's x lies in [2/16, 14/16], where the two periodic wrap terms are
+// exactly 0 and 1 (|u| >= 2 > 1: the clamp saturates), so only the central kernel is evaluated.
+__device__ __forceinline__ void oneblob16(float x, float* out /*16*/, bool interior = false) {
     float c[MNE_NB];
 #pragma unroll
     for (int b = 0; b < MNE_NB; ++b) {
         float t = (float)b * 0.0625f - x;
-        c[b] = (quartic_cdf(t) + quartic_cdf(t - 1.0f)) + quartic_cdf(t + 1.0f);
+        c[b] = interior ? (quartic_cdf(t) + 0.0f) + 1.0f
+                        : (quartic_cdf(t) + quartic_cdf(t - 1.0f)) + quartic_cdf(t + 1.0f);
     }
 #pragma unroll
     for (int b = 0; b < MNE_NB - 1; ++b) out[b] = c[b + 1] - c[b];

@@ -467,8 +467,11 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
                                 *(const float4*)(feat + set * TILE * MNE_FS + pt * MNE_FS + hf * 32 + 4 * q);
                     if (hf == 0) *(float4*)(row + D::T_PN) = *(const float4*)(pn + pt * 4);
                 }
-                if (valid && !(a.dbg & 1)) {
-                    const unsigned trow = (unsigned)(tape_base + k);
+                if (!(a.dbg & 1)) {
+                    // One returning atomic per DISTINCT tile per wave: lanes that append to the same list
+                    // (consecutive samples of a ray mostly do) are grouped with ballots and the group
+                    // leader reserves the whole run of slots.
+                    const unsigned trow = (unsigned)(tape_base + (valid ? k : 0));
 #pragma unroll
                     for (int j = 0; j < NSETS * 3; ++j) {
                         const int pidx = 2 * j + hf;                       // planes in [set][orient][level] order
@@ -484,23 +487,33 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
-                            if (((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0)) continue;   // same tile again
-                            const int tile = base + ty * ntx + tx;
-                            unsigned ent[MNE_ENTRY_WORDS];
-                            ent[0] = trow;
-                            ent[1] = (unsigned)(b.ix0 - tx * MNE_TILE + 1) | ((unsigned)(b.iy0 - ty * MNE_TILE + 1) << 8);
-                            ent[2] = __float_as_uint(b.w00); ent[3] = __float_as_uint(b.w01);
-                            ent[4] = __float_as_uint(b.w10); ent[5] = __float_as_uint(b.w11);
-                            const int slot = atomicAdd(a.bins.counts + tile, 1);
-                            unsigned* dst = nullptr;
-                            if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)tile * a.bins.cap + slot) * MNE_ENTRY_WORDS;
-                            else {
-                                const int sp = atomicAdd(a.bins.spill_count, 1);
-                                if (sp < a.bins.spill_cap) { dst = a.bins.spill + (size_t)sp * MNE_SPILL_WORDS; *dst++ = (unsigned)tile; }
+                            const bool dup = ((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0);   // same tile again
+                            const int want = (valid && !dup) ? base + ty * ntx + tx : -1;
+                            unsigned long long todo = __ballot(want >= 0);
+                            int slot = -1;
+                            while (todo) {
+                                const int leader = __ffsll(todo) - 1;
+                                const int t = __shfl(want, leader);
+                                const unsigned long long same = __ballot(want == t);
+                                int first = 0;
+                                if (lane == leader) first = atomicAdd(a.bins.counts + t, __popcll(same));
+                                first = __shfl(first, leader);
+                                if (want == t) slot = first + __popcll(same & ((1ull << lane) - 1ull));
+                                todo &= ~same;
                             }
-                            if (dst) {
-#pragma unroll
-                                for (int w = 0; w < MNE_ENTRY_WORDS; ++w) dst[w] = ent[w];
+                            if (want >= 0) {
+                                unsigned* dst = nullptr;
+                                if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want * a.bins.cap + slot) * MNE_ENTRY_WORDS;
+                                else {
+                                    const int sp = atomicAdd(a.bins.spill_count, 1);
+                                    if (sp < a.bins.spill_cap) { dst = a.bins.spill + (size_t)sp * MNE_SPILL_WORDS; *dst++ = (unsigned)want; }
+                                }
+                                if (dst) {
+                                    dst[0] = trow;
+                                    dst[1] = (unsigned)(b.ix0 - tx * MNE_TILE + 1) | ((unsigned)(b.iy0 - ty * MNE_TILE + 1) << 8);
+                                    dst[2] = __float_as_uint(b.w00); dst[3] = __float_as_uint(b.w01);
+                                    dst[4] = __float_as_uint(b.w10); dst[5] = __float_as_uint(b.w11);
+                                }
                             }
                         }
                     }

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-for f in 0 1 2 3 4 7 8 16 20 24 28; do
+for f in 0 1 2 16 24 28; do
   echo "FLAGS=$f" >> gpurun_out/ablate.log
   MNE_DBG_FLAGS=$f python bench.py --steps 40 --warmup 10 --cpu-iters 0 2>/dev/null | python -c "
 import sys, json
