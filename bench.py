@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--path", default="fused", choices=["fused", "autograd"],
                     help="fused = FusedStep + device sampler (default); autograd = the reference's call sequence")
     ap.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
+    ap.add_argument("--scatter", default="binned", choices=["binned", "atomics"],
+                    help="fused path: tile-binned LDS scatter fused with Adam (default) or global atomics + streaming Adam")
     ap.add_argument("--small", action="store_true", help="tiny planes/frames (functional check, not a benchmark)")
     return ap.parse_args()
 
@@ -53,7 +55,7 @@ def parse_args():
 class Agent:
     """One mapping agent: scene model + optimizer + device-resident keyframe rays."""
 
-    def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused"):
+    def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused", scatter="binned"):
         self.cfg, self.device, self.path = cfg, device, path
         cam = dict(synthetic.REPLICA_CAM)
         if small:
@@ -83,7 +85,8 @@ class Agent:
         self.last = None
         self.fused = None
         if path == "fused":
-            self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device)
+            self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device,
+                                   scatter=scatter)
             self.fused.seed = seed
 
     def sample_rays(self):
@@ -187,7 +190,7 @@ def main():
     if args.small:
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
-    agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path)
+    agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter)
 
     def barrier():
         if world > 1:
@@ -217,11 +220,25 @@ def main():
         #   adam   : 32 B/param = read p,g,m,v + write p,m,v + zero g
         #   render : gather + scatter of every sample, G = 6 planes x 4 corners x 32 ch x 4 B per set
         G = 3072.0 * (1 if cfg["grid"]["oneGrid"] else 2)
-        alg = {"adam": 32.0 * n_par, "render": 2.0 * R * S * G}
-        kern = {"adam": "adam_kernel", "render": "render_kernel<pass1,bwd> (fused forward+backward)"}
+        binned = agent.fused is not None and agent.fused.bins is not None
+        if binned:      # gather in the render kernel; scatter + Adam (no gradient buffer) in tile_adam_kernel
+            alg = {"adam": R * S * G + 32.0 * n_par, "render": 1.0 * R * S * G}
+            kern = {"adam": "tile_adam_kernel (binned scatter + Adam)", "render": "render_kernel<pass1,bwd> (fused forward+backward)"}
+        else:
+            alg = {"adam": 32.0 * n_par, "render": 2.0 * R * S * G}
+            kern = {"adam": "adam_kernel", "render": "render_kernel<pass1,bwd> (fused forward+backward)"}
         dom = max(avg_ms, key=avg_ms.get) if avg_ms else "adam"
         dom_ms = avg_ms.get(dom, 0.0)
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM traffic of the same kernel from committed PMC passes (rocprofv3 cannot run inside the timed loop)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            if (pmc["workload"] == "replica_office0_triplane_asWired_2048x128" and not args.small and args.path == "fused"
+                    and pmc["scatter"] == args.scatter and args.hidden == 32):
+                traffic = pmc["hbm_bytes_per_launch"].get(dom)
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "mapping iters/sec (2048 rays x 128 samples)", "value": world * args.steps / elapsed,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -230,13 +247,14 @@ def main():
             "config": {"workload": "replica_office0_triplane_asWired_2048x128" + ("_SMALL" if args.small else ""),
                        "rays_per_iter": R, "samples_per_ray": S, "plane_params": agent.n_plane_params,
                        "decoder_params": agent.n_dec_params, "mlp_hidden": args.hidden, "keyframes": args.keyframes,
-                       "frame": f"{agent.W}x{agent.H}", "path": args.path, "agents": world,
+                       "frame": f"{agent.W}x{agent.H}", "path": args.path, "scatter": args.scatter if args.path == "fused" else "atomics", "agents": world,
                        "parallelism": f"agent-per-gpu x{world}, no data-path collective"},
             "psnr_last_iter": psnr, "depth_l1_last_iter": depth_l1,
             "roofline": {"kernel": kern[dom], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms,
                          "other_kernels_avg_ms": {kern[k]: v for k, v in avg_ms.items() if k != dom},
+                         "other_kernels_algorithmic_bytes": {kern[k]: alg[k] for k in alg if k != dom},
                          "iteration_algorithmic_bytes": alg["adam"] + alg["render"],
                          "iteration_hbm_frac": (alg["adam"] + alg["render"]) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }

@@ -274,12 +274,13 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
     return check_launch("sample_rays");
 }
 
-int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* tape_rows, float* partials,
-                      float* grad_out, int impl, void* stream) {
+int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* tape_rows, int64_t max_rows,
+                      float* partials, float* grad_out, int impl, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
     if (!tape || !tape_rows || !grad_out || (impl == 0 && !partials)) return fail(-1, "mne_decoder_wgrad: NULL argument");
     WgradArgs a = {};
     a.tape = tape; a.tape_rows = tape_rows; a.partials = partials; a.grad_out = grad_out;
+    a.n_waves = (int)(max_rows > 0 ? (max_rows + 63) / 64 : 1);      // >= 64 rows per wave when the tape is full
     if (int rc = mne_launch_wgrad(*scene, a, impl, (hipStream_t)stream)) return fail(rc, "unsupported decoder shape");
     return check_launch("decoder_wgrad");
 }

@@ -126,11 +126,13 @@ static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
             MNE_LAUNCH(wgrad_scalar_kernel, (gs[k].OUT * gs[k].ld + 255) / 256, 256, 0, st, a, gs[k], D::ROW);
         return 0;
     }
-    a.n_waves = MNE_WGRAD_BLOCKS * 4;
-    MNE_LAUNCH((wgrad_mfma_kernel<HID / 32, 4>), MNE_WGRAD_BLOCKS, 256, 0, st, a, g1, D::ROW, D::NPARAM);
-    MNE_LAUNCH((wgrad_mfma_kernel<1, HID / 32>), MNE_WGRAD_BLOCKS, 256, 0, st, a, g2, D::ROW, D::NPARAM);
-    MNE_LAUNCH((wgrad_mfma_kernel<HIDC / 32, D::CINP / 32>), MNE_WGRAD_BLOCKS, 256, 0, st, a, g3, D::ROW, D::NPARAM);
-    MNE_LAUNCH((wgrad_mfma_kernel<1, HIDC / 32>), MNE_WGRAD_BLOCKS, 256, 0, st, a, g4, D::ROW, D::NPARAM);
+    int blocks = (a.n_waves + 3) / 4;                    // caller's bound on the tape length
+    blocks = blocks < 1 ? 1 : (blocks > MNE_WGRAD_BLOCKS ? MNE_WGRAD_BLOCKS : blocks);
+    a.n_waves = blocks * 4;
+    MNE_LAUNCH((wgrad_mfma_kernel<HID / 32, 4>), blocks, 256, 0, st, a, g1, D::ROW, D::NPARAM);
+    MNE_LAUNCH((wgrad_mfma_kernel<1, HID / 32>), blocks, 256, 0, st, a, g2, D::ROW, D::NPARAM);
+    MNE_LAUNCH((wgrad_mfma_kernel<HIDC / 32, D::CINP / 32>), blocks, 256, 0, st, a, g3, D::ROW, D::NPARAM);
+    MNE_LAUNCH((wgrad_mfma_kernel<1, HIDC / 32>), blocks, 256, 0, st, a, g4, D::ROW, D::NPARAM);
     MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
     return 0;
 }

@@ -128,7 +128,7 @@ class FusedStep:
                                         R * S, P(self.tape_rows), C.byref(self.bins) if self.bins is not None else None, st),
                    "mne_render_fused")
         self._mark("render", ev)
-        _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), P(self.partials),
+        _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), R * S, P(self.partials),
                                          P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
         ev = self._mark("adam")
         if self.bins is not None:

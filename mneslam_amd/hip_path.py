@@ -180,7 +180,7 @@ class RenderFunction(torch.autograd.Function):
         nparam = lib.mne_decoder_param_floats(C.byref(sc))
         partials = torch.empty(lib.mne_wgrad_partial_floats(C.byref(sc)), **opts)
         dgrad = torch.empty(nparam, **opts)
-        _lib.check(lib.mne_decoder_wgrad(C.byref(sc), _lib.ptr(tape), _lib.ptr(tape_rows), _lib.ptr(partials),
+        _lib.check(lib.mne_decoder_wgrad(C.byref(sc), _lib.ptr(tape), _lib.ptr(tape_rows), R * S, _lib.ptr(partials),
                                          _lib.ptr(dgrad), info.get("wgrad_impl", 0), st), "mne_decoder_wgrad")
         w_sdf0, w_sdf1, w_col0, w_col1 = dec_w
         n0, n1, n2 = w_col0.numel(), w_col1.numel(), w_sdf0.numel()
