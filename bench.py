@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--scatter", default="binned", choices=["binned", "atomics"],
                     help="fused path: tile-binned LDS scatter fused with Adam (default) or global atomics + streaming Adam")
+    ap.add_argument("--share-decoder", action="store_true",
+                    help="EXTENSION: all-reduce (mean) the decoder gradient over agents each iteration (RCCL)")
     ap.add_argument("--small", action="store_true", help="tiny planes/frames (functional check, not a benchmark)")
     return ap.parse_args()
 
@@ -55,7 +57,7 @@ def parse_args():
 class Agent:
     """One mapping agent: scene model + optimizer + device-resident keyframe rays."""
 
-    def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused", scatter="binned"):
+    def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused", scatter="binned", share_decoder=False):
         self.cfg, self.device, self.path = cfg, device, path
         cam = dict(synthetic.REPLICA_CAM)
         if small:
@@ -86,7 +88,7 @@ class Agent:
         self.fused = None
         if path == "fused":
             self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device,
-                                   scatter=scatter)
+                                   scatter=scatter, shared_decoder=share_decoder)
             self.fused.seed = seed
 
     def sample_rays(self):
@@ -175,22 +177,17 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0):
 
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP library is the only backend)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+    from mneslam_amd import dist as mdist
+    rank, world, device = mdist.init_agents()          # one process per GPU; RCCL when WORLD_SIZE > 1
+    import torch.distributed as dist
     cfg = configs.bench_office0(hidden=args.hidden)
     if args.small:
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
-    agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter)
+    agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter,
+                  share_decoder=args.share_decoder)
 
     def barrier():
         if world > 1:
@@ -206,10 +203,7 @@ def main():
         agent.step(timers)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = mdist.max_over_ranks(elapsed, device)
     avg_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timers.items()}
     psnr, depth_l1 = agent.quality()
     if rank == 0:
@@ -248,7 +242,8 @@ def main():
                        "rays_per_iter": R, "samples_per_ray": S, "plane_params": agent.n_plane_params,
                        "decoder_params": agent.n_dec_params, "mlp_hidden": args.hidden, "keyframes": args.keyframes,
                        "frame": f"{agent.W}x{agent.H}", "path": args.path, "scatter": args.scatter if args.path == "fused" else "atomics", "agents": world,
-                       "parallelism": f"agent-per-gpu x{world}, no data-path collective"},
+                       "parallelism": f"agent-per-gpu x{world}, " + ("decoder-gradient all-reduce (extension)" if args.share_decoder
+                                                                     else "no data-path collective")},
             "psnr_last_iter": psnr, "depth_l1_last_iter": depth_l1,
             "roofline": {"kernel": kern[dom], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -168,7 +168,6 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
     if (n_samples < 1 || mne_render_lds_bytes(*scene, n_samples, 1) > 160 * 1024) return fail(-1, "samples per ray out of range");
     if (tape_capacity_rows < (int64_t)n_rays * n_samples) return fail(-1, "tape must hold n_rays*n_samples rows");
     if (coef && (!target_rgb || !target_d)) return fail(-1, "loss coefficients need target_rgb and target_d");
-    if (d_rays_o || d_rays_d) return fail(-3, "ray gradients are not available in this build yet");
     RenderArgs a = {};
     a.sc = *scene;
     a.R = n_rays; a.S = n_samples;

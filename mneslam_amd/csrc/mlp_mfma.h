@@ -42,7 +42,11 @@ struct ATab {
     static constexpr int OFF_B2C = OFF_B2 + 16 * NTC;                // CP: [2][16*NTC]  d colour features
     static constexpr int OFF_B3 = OFF_B2C + (CP ? 2 * 16 * NTC : 0); // [NT][8]      d h    = W2^T dout
     static constexpr int OFF_B4 = OFF_B3 + NT * 8;                   // [2][16*NT]   d features = W1^T dh
-    static constexpr int TOTAL = OFF_B4 + 2 * 16 * NT;
+    static constexpr int TOTAL = OFF_B4 + 2 * 16 * NT;               // everything the mapping iteration needs
+    // ray gradients only (R13, pose optimisation): d OneBlob[k] = sum_j W1[j][64+k] dh[j] + sum_j V1[j][k] dhc[j]
+    static constexpr int OFF_P1 = TOTAL;                             // [2][16*NT]   sdf-net part, rows = pos channel
+    static constexpr int OFF_P2 = OFF_P1 + 2 * 16 * NT;              // [2][16*NTC]  colour-net part
+    static constexpr int TOTAL_RAYGRAD = OFF_P2 + 2 * 16 * NTC;
 };
 
 // hidden-unit index consumed at k-step s (0..HID/2-1) by half h when the B operand is an accumulator
@@ -96,9 +100,19 @@ __device__ inline float atab_value(const mne_scene_t& sc, int step, int l) {
         const int t = (step - T::OFF_B3) / 8, s = (step - T::OFF_B3) % 8;
         return W2[mfma_row(s, h) * HID + 32 * t + i];
     }
-    {                                                         // d feature[k] = sum_j W1[j][k] dh[j]
+    if (step < T::OFF_P1) {                                   // d feature[k] = sum_j W1[j][k] dh[j]
         const int rt = (step - T::OFF_B4) / (16 * T::NT), s = (step - T::OFF_B4) % (16 * T::NT);
         return W1[hid_of_step(s, h) * MNE_IN1 + 32 * rt + i];
+    }
+    if (step < T::OFF_P2) {                                   // d pos[k] (sdf net): W1[j][64 + k]
+        const int rt = (step - T::OFF_P1) / (16 * T::NT), s = (step - T::OFF_P1) % (16 * T::NT);
+        const int k = 32 * rt + i;
+        return k < MNE_POS ? W1[hid_of_step(s, h) * MNE_IN1 + MNE_FEAT + k] : 0.0f;
+    }
+    {                                                         // d pos[k] (colour net): V1[j][k]
+        const int rt = (step - T::OFF_P2) / (16 * T::NTC), s = (step - T::OFF_P2) % (16 * T::NTC);
+        const int k = 32 * rt + i;
+        return k < MNE_POS ? V1[hid_of_step(s, h) * D::CIN + k] : 0.0f;
     }
 }
 
@@ -266,4 +280,68 @@ __device__ __forceinline__ void mlp_backward_mfma(const MlpState<HID, HIDC>& S, 
         for (int q = 0; q < 4; ++q)
             *(float4*)(dfrow + 32 * rt + 8 * q + 4 * h) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     }
+}
+
+// d(total)/d(OneBlob channel) rows of this lane's point -> LDS row dprow[0..63] (48 used): both nets'
+// first layers, chained into one accumulator per 32-row tile.  Ray-gradient variant only.
+template <int HID, int HIDC, bool CP>
+__device__ __forceinline__ void mlp_backward_dpos(const f32x16 (&dh)[HID / 32], const f32x16 (&dhc)[HIDC / 32],
+                                                  const float* atab, int lane, float* dprow) {
+    typedef ATab<HID, HIDC, CP> T;
+    const int h = lane >> 5;
+    const float* A = atab + lane;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16 * T::NT; ++s)
+            acc = MNE_MFMA(A[(T::OFF_P1 + rt * 16 * T::NT + s) * 64], dh[s >> 4][s & 15], acc);
+#pragma unroll
+        for (int s = 0; s < 16 * T::NTC; ++s)
+            acc = MNE_MFMA(A[(T::OFF_P2 + rt * 16 * T::NTC + s) * 64], dhc[s >> 4][s & 15], acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(float4*)(dprow + 32 * rt + 8 * q + 4 * h) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+}
+
+// d(OneBlob bins of one dim)/dx for this lane's half, laid out like oneblob_half's pos[24]:
+// quartic kernel derivative 15/16 (1-u^2)^2 * 16 on |u| < 1 (u = 16 t), with the periodic wrap terms.
+__device__ __forceinline__ float quartic_pdf(float t) {
+    const float u = t * 16.0f;
+    const float w = 1.0f - u * u;
+    return (u > -1.0f && u < 1.0f) ? 0.9375f * w * w * 16.0f : 0.0f;
+}
+
+__device__ __forceinline__ void oneblob16_dx(float x, float* dout /*16*/) {
+    float c[MNE_NB];
+#pragma unroll
+    for (int b = 0; b < MNE_NB; ++b) {
+        const float t = (float)b * 0.0625f - x;
+        c[b] = -((quartic_pdf(t) + quartic_pdf(t - 1.0f)) + quartic_pdf(t + 1.0f));    // d cdf(l_b - x) / dx
+    }
+#pragma unroll
+    for (int b = 0; b < MNE_NB - 1; ++b) dout[b] = c[b + 1] - c[b];
+    dout[MNE_NB - 1] = c[0] - c[MNE_NB - 1];
+}
+
+// sum_k dpos[k] * d pos[k] / d u[dim] over this lane's 24 channels -> contributions to du[0..2]
+__device__ __forceinline__ void oneblob_half_backward(const float u[3], int h, const float* dprow, float (&du)[3]) {
+    float dfull[MNE_NB], dpart[MNE_NB];
+    oneblob16_dx(h == 0 ? u[0] : u[2], dfull);
+    oneblob16_dx(u[1], dpart);
+    float s_full = 0.0f, s_part = 0.0f;
+#pragma unroll
+    for (int idx = 0; idx < 24; ++idx) {
+        const float g = dprow[h * 24 + idx];
+        const float lo_f = idx < 16 ? dfull[idx & 15] : 0.0f, lo_p = idx < 16 ? 0.0f : dpart[(idx - 16) & 15];
+        const float hi_p = idx < 8 ? dpart[(8 + idx) & 15] : 0.0f, hi_f = idx < 8 ? 0.0f : dfull[(idx - 8) & 15];
+        s_full += g * (h == 0 ? lo_f : hi_f);
+        s_part += g * (h == 0 ? lo_p : hi_p);
+    }
+    du[0] = h == 0 ? s_full : 0.0f;
+    du[1] = s_part;
+    du[2] = h == 0 ? 0.0f : s_full;
 }

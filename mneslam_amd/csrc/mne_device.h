@@ -160,6 +160,64 @@ __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float*
     }
 }
 
+// ---- d(total)/d(normalised point) through the bilinear lookups (ray gradients, R13) -----------------
+// Same lane layout as gather_chunk.  For every staged point: sum over planes/levels of
+//   dfeat . d feat / d (ix, iy) * (size-1)/2   (ATen grid_sampler_2d_backward's grid gradient: zero
+// where the coordinate was clipped, out-of-range corners contribute nothing), reduced over the 8 lanes
+// of a row group; result dpn[slot][0..2] = d/d(p_nor x,y,z).
+template <int NSETS, int NPTS>
+__device__ __forceinline__ void gather_coord_grad(const mne_scene_t& sc, const float* pn, const float* dfeat, float* dpn, int lane) {
+    const int cg = lane & 7;
+#pragma unroll 1
+    for (int it = 0; it < NPTS / 8; ++it) {
+        const int slot = it * 8 + (lane >> 3);
+        const float px = pn[slot * 4 + 0], py = pn[slot * 4 + 1], pz = pn[slot * 4 + 2];
+        float g3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int set = 0; set < NSETS; ++set) {
+#pragma unroll
+            for (int lvl = 0; lvl < 2; ++lvl) {
+                const float4 df = *(const float4*)(dfeat + set * NPTS * MNE_FS + slot * MNE_FS + lvl * MNE_C + cg * 4);
+#pragma unroll
+                for (int ori = 0; ori < 3; ++ori) {
+                    const mne_plane_t& pl = sc.plane[set][ori][lvl];
+                    float gx, gy;
+                    orient_coords(ori, px, py, pz, gx, gy);
+                    Bilin b;
+                    bilin_setup(gx, gy, pl.h, pl.w, b);
+                    const float ux = ((gx + 1.0f) / 2.0f) * (float)(pl.w - 1), uy = ((gy + 1.0f) / 2.0f) * (float)(pl.h - 1);
+                    const float fx = fminf((float)(pl.w - 1), fmaxf(ux, 0.0f)), fy = fminf((float)(pl.h - 1), fmaxf(uy, 0.0f));
+                    const float x0 = floorf(fx), y0 = floorf(fy);
+                    const float* base = pl.data + cg * 4;
+                    const float4 v00 = *(const float4*)(base + b.o00), v01 = *(const float4*)(base + b.o01);
+                    const float4 v10 = *(const float4*)(base + b.o10), v11 = *(const float4*)(base + b.o11);
+                    const bool xin = b.ix0 + 1 < pl.w, yin = b.iy0 + 1 < pl.h;
+                    // dot(dfeat, corner) over this lane's 4 channels; absent corners count as zero
+                    const float d00 = df.x * v00.x + df.y * v00.y + df.z * v00.z + df.w * v00.w;
+                    const float d01 = xin ? df.x * v01.x + df.y * v01.y + df.z * v01.z + df.w * v01.w : 0.0f;
+                    const float d10 = yin ? df.x * v10.x + df.y * v10.y + df.z * v10.z + df.w * v10.w : 0.0f;
+                    const float d11 = (xin && yin) ? df.x * v11.x + df.y * v11.y + df.z * v11.z + df.w * v11.w : 0.0f;
+                    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+                    float gix = -d00 * (y1 - fy) + d01 * (y1 - fy) - d10 * (fy - y0) + d11 * (fy - y0);
+                    float giy = -d00 * (x1 - fx) - d01 * (fx - x0) + d10 * (x1 - fx) + d11 * (fx - x0);
+                    // clip gradient (ATen clip_coordinates_set_grad): zero at/below 0 and at/above size-1
+                    gix *= (ux <= 0.0f || ux >= (float)(pl.w - 1)) ? 0.0f : (float)(pl.w - 1) / 2.0f;
+                    giy *= (uy <= 0.0f || uy >= (float)(pl.h - 1)) ? 0.0f : (float)(pl.h - 1) / 2.0f;
+                    // xy -> (x,y); xz -> (x,z); yz -> (y,z)
+                    if (ori == MNE_XY) { g3[0] += gix; g3[1] += giy; }
+                    else if (ori == MNE_XZ) { g3[0] += gix; g3[2] += giy; }
+                    else { g3[1] += gix; g3[2] += giy; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            g3[k] += __shfl_xor(g3[k], 1); g3[k] += __shfl_xor(g3[k], 2); g3[k] += __shfl_xor(g3[k], 4);
+        }
+        if (cg == 0) { dpn[slot * 4 + 0] = g3[0]; dpn[slot * 4 + 1] = g3[1]; dpn[slot * 4 + 2] = g3[2]; }
+    }
+}
+
 // ---- scatter: d(feature) rows in LDS -> atomic adds into the plane gradients -------------------
 // Lane layout: 32 lanes = the 32 channels of one corner row (one 128-B line per half-wave).
 template <int NSETS, int NPTS>

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void counts_reduce_kernel(ZArgs a) {
 template <int HID, int HIDC, bool CP>
 __global__ __launch_bounds__(256) void pack_decoder_kernel(mne_scene_t sc, float* pk) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < ATab<HID, HIDC, CP>::TOTAL * 64) pk[t] = atab_value<HID, HIDC, CP>(sc, t >> 6, t & 63);
+    if (t < ATab<HID, HIDC, CP>::TOTAL_RAYGRAD * 64) pk[t] = atab_value<HID, HIDC, CP>(sc, t >> 6, t & 63);
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -154,24 +154,27 @@ __device__ __forceinline__ SampleMasks sample_masks(float z, float d, bool has_t
 }
 
 // per-wave LDS: pn[32][4] | feat[NSETS][32][FS] | raws[Spad][4] | list[Spad] (ushort)
-__host__ __device__ inline size_t render_wave_lds_bytes(int S, int nsets) {
+// (+ ray-gradient variant: dpos[32][64] | dpn[32][4])
+__host__ __device__ inline size_t render_wave_lds_bytes(int S, int nsets, bool raygrad = false) {
     const size_t Spad = (size_t)((S + 3) & ~3);
     size_t b = (size_t)(TILE * 4 + nsets * TILE * MNE_FS) * sizeof(float) + Spad * 4 * sizeof(float) + Spad * sizeof(unsigned short);
-    return (b + 15) & ~(size_t)15;
+    b = (b + 15) & ~(size_t)15;
+    if (raygrad) b += (size_t)(TILE * 64 + TILE * 4) * sizeof(float);
+    return b;
 }
 
 // a.rpw = rays (= waves) per workgroup (chosen at launch so that one round of workgroups covers
 // the batch); ALDS = the MFMA A-operand tables are staged in LDS once per
 // workgroup (one ds_read_b32 per MFMA) instead of being re-read from global memory per MFMA.
 #define MAX_RPW 10
-template <int HID, int HIDC, bool CP, bool PASS1, bool BWD, bool ALDS>
+template <int HID, int HIDC, bool CP, bool PASS1, bool BWD, bool ALDS, bool RAYGRAD = false>
 __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
     const int RPW = a.rpw;                                 // waves (= rays) in this workgroup
     typedef DecDims<HID, HIDC, CP> D;
     typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
     constexpr int NT = HID / 32, NTC = HIDC / 32;
-    constexpr int TAB_FLOATS = ALDS ? (BWD ? T::TOTAL : T::FWD_STEPS) * 64 : 0;
+    constexpr int TAB_FLOATS = ALDS ? (RAYGRAD ? T::TOTAL_RAYGRAD : BWD ? T::TOTAL : T::FWD_STEPS) * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     if (ALDS) {                                            // stage the A tables: the only block-wide step
         float4* dst = (float4*)lds_raw;
@@ -185,11 +188,13 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
     if (r >= a.R) return;                                  // whole wave leaves together; no block barriers below
     const int S = a.S;
     const int Spad = (S + 3) & ~3;
-    unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * render_wave_lds_bytes(S, NSETS);
+    unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * render_wave_lds_bytes(S, NSETS, RAYGRAD);
     float* pn = (float*)my;                                // [32][4]
     float* feat = pn + TILE * 4;                           // [NSETS][32][MNE_FS]
     float* raws = feat + NSETS * TILE * MNE_FS;            // [Spad][4]  (r,g,b,sdf)
     unsigned short* list = (unsigned short*)(raws + Spad * 4);   // [S] compacted sample ids (backward)
+    float* dposL = (float*)(my + render_wave_lds_bytes(S, NSETS, false));   // RAYGRAD: [32][64] d OneBlob rows
+    float* dpnL = dposL + TILE * 64;                                          // RAYGRAD: [32][4]  d normalised point
     const int pt = lane & 31, hf = lane >> 5;
 
     const float o[3] = {a.rays_o[r * 3 + 0], a.rays_o[r * 3 + 1], a.rays_o[r * 3 + 2]};
@@ -353,6 +358,7 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
         int tape_base = 0;
         if (lane == 0 && n_contrib > 0) tape_base = atomicAdd(a.tape_rows, n_contrib);
         tape_base = __shfl(tape_base, 0);
+        float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};       // RAYGRAD: d/d rays_o, d/d rays_d of this lane's points
         const int ntile = (a.dbg & 16) ? 0 : (n_contrib + TILE - 1) / TILE;
 #pragma unroll 1
         for (int cc = 0; cc < ntile; ++cc) {
@@ -453,6 +459,28 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
                         *(float4*)(row + D::T_DHC + 32 * t + 8 * q + 4 * hf) =
                             make_float4(dhc[t][4 * q], dhc[t][4 * q + 1], dhc[t][4 * q + 2], dhc[t][4 * q + 3]);
             }
+            if (RAYGRAD) {
+                // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates
+                float* dprow = dposL + pt * 64;
+                mlp_backward_dpos<HID, HIDC, CP>(dh, dhc, atab, lane, dprow);
+                MNE_WAVE_SYNC();
+                gather_coord_grad<NSETS, TILE>(a.sc, pn, feat, dpnL, lane);
+                MNE_WAVE_SYNC();
+                float du[3];
+                oneblob_half_backward(u, hf, dprow, du);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) du[q] += __shfl_xor(du[q], 32);
+                if (valid && hf == 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const float inv_bb = a.sc.bb_is_f64 ? (float)(1.0 / (a.sc.bb_hi[q] - a.sc.bb_lo[q]))
+                                                            : 1.0f / ((float)a.sc.bb_hi[q] - (float)a.sc.bb_lo[q]);
+                        const float dp = dpnL[pt * 4 + q] * (2.0f / (a.sc.bound_hi[q] - a.sc.bound_lo[q])) + du[q] * inv_bb;
+                        go[q] += dp;
+                        gd[q] += z * dp;
+                    }
+                }
+            }
             MNE_WAVE_SYNC();
             const int n_here = n_contrib - cc * TILE;
             if (a.bins.lists) {
@@ -522,6 +550,17 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
                 scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane, a.dbg);
             }
             MNE_WAVE_SYNC();
+        }
+        if (RAYGRAD) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { go[q] = wave_sum(go[q]); gd[q] = wave_sum(gd[q]); }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (a.d_rays_o) a.d_rays_o[r * 3 + q] = go[q];
+                    if (a.d_rays_d) a.d_rays_d[r * 3 + q] = gd[q];
+                }
+            }
         }
     }
 }
@@ -661,18 +700,18 @@ template <int HID, int HIDC, bool CP> struct WgShape {
 };
 
 template <int HID, int HIDC, bool CP>
-static size_t render_lds_total(int S, bool bwd, int rpw) {
+static size_t render_lds_total(int S, bool bwd, int rpw, bool raygrad = false) {
     typedef WgShape<HID, HIDC, CP> W;
     typedef ATab<HID, HIDC, CP> T;
-    const size_t tab = W::ALDS ? (size_t)(bwd ? T::TOTAL : T::FWD_STEPS) * 64 * sizeof(float) : 0;
-    return tab + (size_t)rpw * render_wave_lds_bytes(S, CP ? 2 : 1);
+    const size_t tab = W::ALDS ? (size_t)(raygrad ? T::TOTAL_RAYGRAD : bwd ? T::TOTAL : T::FWD_STEPS) * 64 * sizeof(float) : 0;
+    return tab + (size_t)rpw * render_wave_lds_bytes(S, CP ? 2 : 1, raygrad);
 }
 
 template <int HID, int HIDC, bool CP>
-static int choose_rpw(int R, int S, bool bwd) {
+static int choose_rpw(int R, int S, bool bwd, bool raygrad = false) {
     int fit = 0;
     for (int k = 1; k <= MAX_RPW; ++k)
-        if (render_lds_total<HID, HIDC, CP>(S, bwd, k) <= MNE_LDS_MAX) fit = k;
+        if (render_lds_total<HID, HIDC, CP>(S, bwd, k, raygrad) <= MNE_LDS_MAX) fit = k;
     if (fit == 0) return 0;
     const int want = (R + MNE_NUM_CU - 1) / MNE_NUM_CU;      // rays per CU for a single round
     return want <= fit ? (want < 1 ? 1 : want) : fit;
@@ -688,7 +727,7 @@ int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
 
 template <int HID, int HIDC, bool CP>
 static int launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
-    const int n = ATab<HID, HIDC, CP>::TOTAL * 64;
+    const int n = ATab<HID, HIDC, CP>::TOTAL_RAYGRAD * 64;
     MNE_LAUNCH((pack_decoder_kernel<HID, HIDC, CP>), (n + 255) / 256, 256, 0, st, sc, pk);
     return 0;
 }
@@ -696,14 +735,21 @@ static int launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
 template <int HID, int HIDC, bool CP>
 static int launch_render(RenderArgs a, int pass1, int bwd, hipStream_t st) {
     typedef WgShape<HID, HIDC, CP> W;
-    a.rpw = choose_rpw<HID, HIDC, CP>(a.R, a.S, bwd != 0);
+    const bool raygrad = a.d_rays_o != nullptr || a.d_rays_d != nullptr;
+    if (raygrad && !(bwd && !pass1)) return -5;
+    a.rpw = choose_rpw<HID, HIDC, CP>(a.R, a.S, bwd != 0, raygrad);
     if (a.rpw < 1) return -4;
-    const size_t lds = render_lds_total<HID, HIDC, CP>(a.S, bwd != 0, a.rpw);
+    const size_t lds = render_lds_total<HID, HIDC, CP>(a.S, bwd != 0, a.rpw, raygrad);
     const int grid = (a.R + a.rpw - 1) / a.rpw;
     if (lds > 64 * 1024) {          // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
         MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, false, W::ALDS>), MNE_LDS_MAX);
         MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, false, true, W::ALDS>), MNE_LDS_MAX);
         MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, true, W::ALDS>), MNE_LDS_MAX);
+        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, false, true, W::ALDS, true>), MNE_LDS_MAX);
+    }
+    if (raygrad) {
+        MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true, W::ALDS, true>), grid, 64 * a.rpw, lds, st, a);
+        return 0;
     }
     if (pass1 && !bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, false, W::ALDS>), grid, 64 * a.rpw, lds, st, a);
     else if (!pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true, W::ALDS>), grid, 64 * a.rpw, lds, st, a);
@@ -767,7 +813,7 @@ size_t mne_render_lds_bytes(const mne_scene_t& sc, int S, int bwd) {
 }
 
 size_t mne_dims_packed(const mne_scene_t& sc) {
-#define CALL(H, HC, CPV) return (size_t)ATab<H, HC, CPV>::TOTAL * 64
+#define CALL(H, HC, CPV) return (size_t)ATab<H, HC, CPV>::TOTAL_RAYGRAD * 64
     MNE_DISPATCH(sc, CALL, 0);
 #undef CALL
     return 0;

@@ -19,13 +19,16 @@ from .optim import FusedAdam
 
 class FusedStep:
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
-                 tile_capacity=4096, spill_capacity=1 << 18):
+                 tile_capacity=4096, spill_capacity=1 << 18, shared_decoder=False):
         """scatter="binned": plane gradients are accumulated per 16x16-cell tile in LDS and Adam is applied
         in the same kernel (csrc/tile_adam.hip; no gradient buffers).  scatter="atomics": global
         atomic adds into persistent gradient buffers + the streaming Adam kernel."""
         if scatter not in ("binned", "atomics"):
             raise ValueError("scatter must be binned|atomics")
         self.scatter = scatter
+        # EXTENSION (BASELINE multi-GPU configs; not reference behaviour): agents share one decoder, so the
+        # decoder gradient is averaged over all ranks (RCCL all-reduce over xGMI) before its Adam step
+        self.shared_decoder = shared_decoder
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("the fused mapping step needs mneslam_amd.optim.FusedAdam "
                             "(slam_glue.create_optimizer builds it with the reference's groups)")
@@ -130,6 +133,9 @@ class FusedStep:
         self._mark("render", ev)
         _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), R * S, P(self.partials),
                                          P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
+        if self.shared_decoder:
+            from . import dist as mdist
+            mdist.allreduce_mean_(self.dec_grad)
         ev = self._mark("adam")
         if self.bins is not None:
             for k, p in enumerate(self.planes):

@@ -159,8 +159,9 @@ class RenderFunction(torch.autograd.Function):
         rc = info["render_cfg"]
         R = rays_o.shape[0]
         opts = dict(device=dev, dtype=torch.float32)
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            raise NotImplementedError("gradients w.r.t. rays (pose optimisation) are not available in this build yet")
+        want_ray = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        d_o = torch.zeros(R, 3, **opts) if want_ray else None
+        d_d = torch.zeros(R, 3, **opts) if want_ray else None
         grads = [torch.zeros_like(p) for p in planes]          # channels_last preserved
         sc = scene_struct(info, list(planes), list(dec_w), grads)
         coef = None
@@ -176,7 +177,7 @@ class RenderFunction(torch.autograd.Function):
                                            _lib.ptr(tgt_d), _lib.ptr(z_vals), _lib.ptr(packed), _lib.ptr(raw),
                                            _lib.ptr(coef), _lib.ptr(_f32c(g_rgb, "g_rgb")),
                                            _lib.ptr(_f32c(g_depth, "g_depth")), _lib.ptr(tape), R * S,
-                                           _lib.ptr(tape_rows), None, None, st), "mne_render_backward")
+                                           _lib.ptr(tape_rows), _lib.ptr(d_o), _lib.ptr(d_d), st), "mne_render_backward")
         nparam = lib.mne_decoder_param_floats(C.byref(sc))
         partials = torch.empty(lib.mne_wgrad_partial_floats(C.byref(sc)), **opts)
         dgrad = torch.empty(nparam, **opts)
@@ -188,7 +189,8 @@ class RenderFunction(torch.autograd.Function):
         g_col1 = dgrad[n0:n0 + n1].view_as(w_col1)
         g_sdf0 = dgrad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0)
         g_sdf1 = dgrad[n0 + n1 + n2:].view_as(w_sdf1)
-        return (None, None, None, None, None, None, None, None, *grads, g_sdf0, g_sdf1, g_col0, g_col1)
+        return (None, None, d_o if ctx.needs_input_grad[2] else None, d_d if ctx.needs_input_grad[3] else None,
+                None, None, None, None, *grads, g_sdf0, g_sdf1, g_col0, g_col1)
 
 
 def query_points(info, planes, dec_w, pts, want_raw=True, want_geo=False, want_feat=False, normalised=False):

@@ -95,6 +95,43 @@ def check_backward(name, co, device, wgrad_impl=0):
     return opt
 
 
+def check_ray_gradients(name, co, device):
+    """R13: d(total)/d rays_o, d rays_d (pose optimisation path) against the reference's autograd."""
+    g = load_golden(name)
+    cfg = configs.small_test_config(**FWD_CASES[name])
+    m = model_from_golden(g, cfg, device).train()
+    slam_glue.create_optimizer(m, cfg)
+    rays_o, rays_d, rgb, d, U = to_dev(fixture_inputs(g), device)
+    rays_o.requires_grad_(True)
+    rays_d.requires_grad_(True)
+    out = m._render(rays_o, rays_d, rgb, d, u=U)
+    L = {k: out[-1][i] for i, k in enumerate(LOSS_KEYS)}
+    slam_glue.get_loss_from_ret(cfg, L, is_co_sdf=co).backward()
+    tag = f"grad.co{int(co)}."
+    for k, t in (("rays_o", rays_o), ("rays_d", rays_d)):
+        ref = g[f"{tag}{k}"]
+        assert_close(t.grad.cpu(), ref, rtol=2e-3, atol=5e-5 * max(1.0, np.abs(ref).max()), what=f"grad {k}")
+
+
+def check_render_nodepth_pose_gradients(device):
+    """Loop-closure usage (mp_slam/mapper.py:388-408): rgb/depth MSE on render_rays(target_d=None),
+    gradients w.r.t. the rays only."""
+    g = load_golden("render_nodepth")
+    cfg = configs.small_test_config()
+    m = model_from_golden(g, cfg, device).eval()
+    rays_o, rays_d, rgb, d, U = to_dev(fixture_inputs(g), device)
+    rays_o.requires_grad_(True)
+    rays_d.requires_grad_(True)
+    out = m._render(rays_o, rays_d, None, None, u=U)
+    loss = (cfg["training"]["rgb_weight"] * torch.nn.functional.mse_loss(out[0], rgb)
+            + cfg["training"]["depth_weight"] * torch.nn.functional.mse_loss(out[1], d.squeeze()))
+    assert_close(loss.detach().cpu(), g["loss"], rtol=1e-4, what="loss")
+    loss.backward()
+    for k, t in (("rays_o", rays_o), ("rays_d", rays_d)):
+        ref = g[f"grad.{k}"]
+        assert_close(t.grad.cpu(), ref, rtol=2e-3, atol=5e-5 * max(1.0, np.abs(ref).max()), what=f"grad {k}")
+
+
 def check_all_invalid(device):
     g = load_golden("fwd_all_invalid")
     cfg = configs.small_test_config()

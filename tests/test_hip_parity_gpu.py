@@ -64,6 +64,15 @@ def test_three_mapping_iterations_match_reference(name, one_grid, co, seed):
     pc.check_mapping3(name, one_grid, co, seed, DEV)
 
 
+@pytest.mark.parametrize("name,co", [("fwd_onegrid", False), ("fwd_onegrid", True), ("fwd_colorplanes", False), ("fwd_colorplanes", True)])
+def test_ray_gradients_match_reference(name, co):
+    pc.check_ray_gradients(name, co, DEV)
+
+
+def test_render_without_depth_pose_gradients():
+    pc.check_render_nodepth_pose_gradients(DEV)
+
+
 def test_device_sampler():
     pc.check_device_sampler(DEV)
 

@@ -103,3 +103,17 @@ def test_mapping3_fused_binned_with_list_overflow():
 @full
 def test_mapping3_fused_binned_colorplanes():
     pc.check_mapping3("mapping3_colorplanes_cosdf", False, True, 22, DEV, compute="fused", scatter="binned")
+
+
+def test_ray_gradients_onegrid():
+    pc.check_ray_gradients("fwd_onegrid", False, DEV)
+
+
+@full
+def test_ray_gradients_colorplanes_cosdf():
+    pc.check_ray_gradients("fwd_colorplanes", True, DEV)
+
+
+@full
+def test_render_nodepth_pose_gradients():
+    pc.check_render_nodepth_pose_gradients(DEV)
