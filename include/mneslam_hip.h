@@ -253,6 +253,26 @@ int mne_query_points(const mne_scene_t* scene, int64_t n_pts, const float* pts,
  * x [N][dims] in [0,1] -> out [N][dims*16], layout [dim0 bins | dim1 bins | ...]. */
 int mne_encode_oneblob(int64_t n_pts, int dims, const float* x, float* out, void* stream);
 
+/* ---- R14: multiresolution hash / dense grid encoding (tinycudann replacement surface) ------ */
+/* Replaces tcnn.Encoding(otype="HashGrid"/"Grid") as configured by get_encoder (model/encodings.py:
+ * 13-46; not executed by the reference's mapping path).  grid_type 0 = Hash, 1 = Dense.  Spec and
+ * parity status: oracle/hashgrid.py (tinycudann is not in the reference tree: parity unpinned). */
+typedef struct mne_grid_cfg {
+    int32_t n_levels, n_features, base_resolution, log2_hashmap_size, grid_type, reserved;
+    double per_level_scale;
+} mne_grid_cfg_t;
+/* per-level constants (host arrays of n_levels entries each; any may be NULL) */
+int mne_grid_level_table(const mne_grid_cfg_t* cfg, float* scale, uint32_t* resolution, uint32_t* size, uint32_t* offset);
+/* number of fp32 parameters of the encoding (all levels) */
+size_t mne_grid_param_count(const mne_grid_cfg_t* cfg);
+/* x [N][3] in [0,1] -> out [N][n_levels*n_features]; idx (optional) [N][n_levels][8] uint32 table
+ * indices within each level (the "integer hash indices" of this encoding) */
+int mne_grid_encode(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, const float* params,
+                    float* out, uint32_t* idx, void* stream);
+/* d(params) += scatter of dout [N][n_levels*n_features] (dparams pre-zeroed by the caller) */
+int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, const float* dout,
+                             float* dparams, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

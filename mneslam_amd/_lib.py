@@ -53,6 +53,12 @@ class PlaneOpt(C.Structure):
                 ("eps", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GridCfg(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("n_features", C.c_int32), ("base_resolution", C.c_int32),
+                ("log2_hashmap_size", C.c_int32), ("grid_type", C.c_int32), ("reserved", C.c_int32),
+                ("per_level_scale", C.c_double)]
+
+
 # Plane * 2 * 3 * 2 builds [2][3][2] read right-to-left: ((Plane*2)*3)*2 == plane[2][3][2]  (set, orient, level)
 
 _PROTOS = {
@@ -83,6 +89,10 @@ _PROTOS = {
     "mne_decoder_wgrad": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.c_void_p]),
     "mne_query_points": (C.c_int, [C.POINTER(Scene), C.c_int64] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
+    "mne_grid_level_table": (C.c_int, [C.POINTER(GridCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_grid_param_count": (C.c_size_t, [C.POINTER(GridCfg)]),
+    "mne_grid_encode": (C.c_int, [C.POINTER(GridCfg), C.c_int64] + [C.c_void_p] * 5),
+    "mne_grid_encode_backward": (C.c_int, [C.POINTER(GridCfg), C.c_int64] + [C.c_void_p] * 4),
     "mne_encode_oneblob": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

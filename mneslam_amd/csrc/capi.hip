@@ -325,4 +325,66 @@ int mne_query_points(const mne_scene_t* scene, int64_t n_pts, const float* pts, 
     return check_launch("query_points");
 }
 
+static int fill_grid(const mne_grid_cfg_t* cfg, GridArgs& a) {
+    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > MNE_GRID_MAX_LEVELS || cfg->n_features < 1 ||
+        cfg->n_features > MNE_GRID_MAX_F || cfg->base_resolution < 1 || cfg->log2_hashmap_size < 1 ||
+        cfg->log2_hashmap_size > 28 || (cfg->grid_type != 0 && cfg->grid_type != 1))
+        return fail(-1, "bad grid encoding configuration");
+    a.n_levels = cfg->n_levels; a.n_features = cfg->n_features; a.out_dim = cfg->n_levels * cfg->n_features;
+    const float l2 = (float)std::log2(cfg->per_level_scale);
+    unsigned long long off = 0;
+    for (int l = 0; l < cfg->n_levels; ++l) {
+        const float scale = std::exp2((float)l * l2) * (float)cfg->base_resolution - 1.0f;
+        const unsigned res = (unsigned)std::ceil(scale) + 1u;
+        unsigned long long n = (unsigned long long)res * res * res;
+        n = (n + 7) / 8 * 8;
+        if (cfg->grid_type == 0 && n > (1ull << cfg->log2_hashmap_size)) n = 1ull << cfg->log2_hashmap_size;
+        if (n >= (1ull << 32) || off + n >= (1ull << 32)) return fail(-1, "grid encoding too large");
+        a.scale[l] = scale; a.res[l] = res; a.size[l] = (unsigned)n; a.offset[l] = (unsigned)off;
+        off += n;
+    }
+    return (int)0;
+}
+
+int mne_grid_level_table(const mne_grid_cfg_t* cfg, float* scale, uint32_t* resolution, uint32_t* size, uint32_t* offset) {
+    GridArgs a = {};
+    if (int rc = fill_grid(cfg, a)) return rc;
+    for (int l = 0; l < cfg->n_levels; ++l) {
+        if (scale) scale[l] = a.scale[l];
+        if (resolution) resolution[l] = a.res[l];
+        if (size) size[l] = a.size[l];
+        if (offset) offset[l] = a.offset[l];
+    }
+    return 0;
+}
+
+size_t mne_grid_param_count(const mne_grid_cfg_t* cfg) {
+    GridArgs a = {};
+    if (fill_grid(cfg, a)) return 0;
+    const int l = cfg->n_levels - 1;
+    return ((size_t)a.offset[l] + a.size[l]) * cfg->n_features;
+}
+
+int mne_grid_encode(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, const float* params,
+                    float* out, uint32_t* idx, void* stream) {
+    GridArgs a = {};
+    if (int rc = fill_grid(cfg, a)) return rc;
+    if (!x || !params || !out) return fail(-1, "mne_grid_encode: NULL argument");
+    if (n_pts <= 0) return 0;
+    a.n = n_pts; a.x = x; a.params = params; a.out = out; a.idx_out = idx;
+    mne_launch_grid(a, 0, (hipStream_t)stream);
+    return check_launch("grid_encode");
+}
+
+int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, const float* dout,
+                             float* dparams, void* stream) {
+    GridArgs a = {};
+    if (int rc = fill_grid(cfg, a)) return rc;
+    if (!x || !dout || !dparams) return fail(-1, "mne_grid_encode_backward: NULL argument");
+    if (n_pts <= 0) return 0;
+    a.n = n_pts; a.x = x; a.dout = dout; a.dparams = dparams;
+    mne_launch_grid(a, 1, (hipStream_t)stream);
+    return check_launch("grid_encode_backward");
+}
+
 }  // extern "C"

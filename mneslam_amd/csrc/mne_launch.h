@@ -89,6 +89,21 @@ struct SampleRaysArgs {
     unsigned long long key_kf, key_cur;
 };
 
+#define MNE_GRID_MAX_LEVELS 32
+#define MNE_GRID_MAX_F 8
+struct GridArgs {
+    long long n;                 // points
+    const float* x;              // [n][3] in [0,1]
+    const float* params;         // flat table, level after level, F floats per entry
+    float* out;                  // [n][n_levels*F]
+    unsigned* idx_out;           // optional [n][n_levels][8] table indices (within the level)
+    const float* dout;           // backward: [n][n_levels*F]
+    float* dparams;              // backward: same layout as params, accumulated into
+    int n_levels, n_features, out_dim;
+    float scale[MNE_GRID_MAX_LEVELS];
+    unsigned res[MNE_GRID_MAX_LEVELS], size[MNE_GRID_MAX_LEVELS], offset[MNE_GRID_MAX_LEVELS];
+};
+
 struct WgradArgs {
     const float* tape;
     const int* tape_rows;
@@ -127,6 +142,7 @@ int mne_launch_loss_finalize(const LossArgs& a, hipStream_t st);
 int mne_launch_loss_coef(const LossArgs& a, hipStream_t st);
 int mne_launch_wgrad(const mne_scene_t& sc, WgradArgs a, int impl, hipStream_t st);
 int mne_launch_adam(const AdamArgs& a, hipStream_t st);
+int mne_launch_grid(const GridArgs& a, int bwd, hipStream_t st);
 int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st);
 void mne_tile_geometry(const mne_scene_t& sc, TileBins& b);
 int mne_launch_sample_rays(SampleRaysArgs a, unsigned long long seed, unsigned long long iteration, hipStream_t st);

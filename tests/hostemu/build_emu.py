@@ -9,7 +9,7 @@ REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
 CSRC = os.path.join(REPO, "mneslam_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libmneslam_emu.so")
-SOURCES = ["capi.hip", "render.hip", "wgrad.hip", "adam.hip", "sampler.hip", "tile_adam.hip"]
+SOURCES = ["capi.hip", "render.hip", "wgrad.hip", "adam.hip", "sampler.hip", "tile_adam.hip", "gridenc.hip"]
 
 
 def _cxx():

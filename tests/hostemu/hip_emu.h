@@ -116,8 +116,20 @@ void launch(K kern, unsigned grid, unsigned block, size_t lds, A... args) {
     for (auto& th : pool) th.join();
     g_ctx = nullptr;
 }
+template <class K, class... A>
+void launch2d(K kern, unsigned gx, unsigned gy, unsigned block, A... args) {
+    // collective-free kernels only: run work-items sequentially on the calling thread
+    blockDim.x = block; gridDim.x = gx; gridDim.y = gy;
+    for (unsigned by = 0; by < gy; ++by)
+        for (unsigned bx = 0; bx < gx; ++bx)
+            for (unsigned t = 0; t < block; ++t) {
+                threadIdx.x = t; blockIdx.x = bx; blockIdx.y = by;
+                kern(args...);
+            }
+}
 }  // namespace hipemu
 
+#define hipLaunchOrEmu2D(kern, gx, gy, block, stream, ...) hipemu::launch2d(kern, (unsigned)(gx), (unsigned)(gy), (unsigned)(block), __VA_ARGS__)
 #define MNE_LAUNCH(kern, grid, block, lds, stream, ...) hipemu::launch(kern, (unsigned)(grid), (unsigned)(block), (size_t)(lds), __VA_ARGS__)
 #define MNE_DYN_LDS(name) unsigned char* name = (unsigned char*)(((uintptr_t)hipemu::g_ctx->dyn_lds.data() + 15) & ~(uintptr_t)15)
 typedef const float* mne_cptr;

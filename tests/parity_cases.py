@@ -291,6 +291,47 @@ def check_oneblob(device):
     assert_close(got, oneblob(x, 16), rtol=0, atol=0, what="OneBlob (bit-exact vs spec)")
 
 
+def check_grid_encoding(device, kind="hash"):
+    """R14 surface: get_encoder('HashGrid'/'dense') vs the frozen spec (oracle/hashgrid.py): uint32 table
+    indices bit-exact, features and parameter gradients to fp32 rounding."""
+    from mneslam_amd.model.encodings import get_encoder
+    from oracle import hashgrid as og
+    torch.manual_seed(7)
+    if kind == "hash":
+        enc, dim = get_encoder("HashGrid", n_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=12,
+                               desired_resolution=256)
+        kw = dict(n_levels=8, n_features=2, base_resolution=16, per_level_scale=float(np.exp2(np.log2(256 / 16) / 7)),
+                  log2_hashmap_size=12, grid_type="hash")
+    else:
+        enc, dim = get_encoder("dense", level_dim=2, base_resolution=16, desired_resolution=16)
+        kw = dict(n_levels=4, n_features=2, base_resolution=16, per_level_scale=1.0, log2_hashmap_size=19, grid_type="dense")
+    assert dim == kw["n_levels"] * 2
+    assert enc.params.numel() == og.n_params(**kw)
+    with torch.no_grad():
+        enc.params.copy_(torch.randn(enc.params.numel()) * 0.3)
+    enc = enc.to(device)
+    x = torch.rand(300, 3)
+    x[:4] = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, 0.25, 0.75], [0.999999, 0.0, 1.0]])
+    p_ref = enc.params.detach().cpu().clone().requires_grad_(True)
+    lib_scales, lib_res, lib_sizes, lib_off = enc.level_table()
+    o_scales, o_res, o_sizes, o_off = og.level_table(kw["n_levels"], kw["base_resolution"], kw["per_level_scale"],
+                                                     kw["log2_hashmap_size"], kw["grid_type"])
+    assert lib_res == o_res and lib_sizes == o_sizes and lib_off == o_off[:-1]
+    assert np.allclose(lib_scales, o_scales, rtol=3e-7, atol=0)          # exp2f of two libms: <= 1 ulp apart
+    ref, ref_idx = og.grid_encode(x, p_ref, return_indices=True, scales=lib_scales, **kw)
+    got = enc(x.to(device))
+    idx = enc.indices(x.to(device)).cpu()
+    assert torch.equal(idx, ref_idx), "integer grid/hash indices must be bit-exact"
+    assert_close(got.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6, what="grid features")
+    wts = torch.randn(300, dim)
+    (ref * wts).sum().backward()
+    (got * wts.to(device)).sum().backward()
+    assert_close(enc.params.grad.cpu(), p_ref.grad, rtol=1e-4, atol=1e-5, what="grid parameter gradients")
+    # the BASELINE configuration's shape: 16 levels, T = 2^19, F = 2 -> 10,492,048 parameters, 32 features
+    big, bdim = get_encoder("HashGrid")
+    assert bdim == 32 and big.params.numel() == 10492048
+
+
 def check_queries(device):
     g = load_golden("fwd_colorplanes")
     cfg = configs.small_test_config(one_grid=False, depth_trunc=3.0)

@@ -73,6 +73,11 @@ def test_render_without_depth_pose_gradients():
     pc.check_render_nodepth_pose_gradients(DEV)
 
 
+@pytest.mark.parametrize("kind", ["hash", "dense"])
+def test_grid_encoding_surface(kind):
+    pc.check_grid_encoding(DEV, kind)
+
+
 def test_device_sampler():
     pc.check_device_sampler(DEV)
 

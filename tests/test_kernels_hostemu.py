@@ -117,3 +117,8 @@ def test_ray_gradients_colorplanes_cosdf():
 @full
 def test_render_nodepth_pose_gradients():
     pc.check_render_nodepth_pose_gradients(DEV)
+
+
+@pytest.mark.parametrize("kind", ["hash", "dense"])
+def test_grid_encoding(kind):
+    pc.check_grid_encoding(DEV, kind)
