@@ -128,6 +128,7 @@ def test_full_size_paths_agree_and_learn():
         d = (a - b).abs()
         assert float(d.mean()) < 1e-7, "binned and atomic scatter disagree"
         assert float((d > 1e-4).float().mean()) < 1e-5 and float(d.max()) < 0.05
-    assert losses["binned"][-1] < losses["binned"][0]
+    for x, y in zip(losses["binned"], losses["atomics"]):
+        assert x == x and abs(x - y) <= 1e-3 * abs(y), "loss histories of the two schedules diverge"
     # the mean absolute update is non-trivial (dense Adam moved the touched cells)
     assert float((finals["binned"][1] != 0).float().mean()) > 0.5
