@@ -227,7 +227,8 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
  * written as [w_col0 | w_col1 | w_sdf0 | w_sdf1] (the order of decoder.parameters(),
  * model/decoder.py:150-159) into grad_out.  `partials` is scratch of
  * mne_wgrad_partial_floats() floats; max_rows = host-known upper bound of *tape_rows (sizes the
- * launch).  impl: 0 = MFMA (v_mfma_f32_32x32x2_f32), 1 = scalar check. */
+ * launch).  impl: 0 = MFMA (v_mfma_f32_32x32x2_f32; one fused pass over the tape for the 2x32 decoders),
+ * 1 = scalar check, 2 = MFMA with one launch per matrix. */
 size_t mne_decoder_param_floats(const mne_scene_t* scene);
 size_t mne_wgrad_partial_floats(const mne_scene_t* scene);
 int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* tape_rows,

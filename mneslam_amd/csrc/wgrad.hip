@@ -75,6 +75,78 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, GemmDesc g
             }
 }
 
+// All four GEMMs in ONE pass over the tape (HID = HIDC = 32): every wave reads each of its tape rows once --
+// A operands dh(32) | dout(16) | dhc(32) | dc(4), B operands x(112) | h(32) | cin(CINP) | hc(32) -- and
+// keeps the 8 (or 10) 32x32 accumulator tiles of dW1, dW2, dV1, dV2 in registers.
+template <int HID, int HIDC, bool CP>
+__global__ __launch_bounds__(256) void wgrad_fused_kernel(WgradArgs a) {
+    typedef DecDims<HID, HIDC, CP> D;
+    static_assert(HID == 32 && HIDC == 32, "fused weight-gradient kernel is built for the 2x32 decoders");
+    constexpr int TNC = D::CINP / 32;
+    constexpr int KS = 2;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nw = gridDim.x * (blockDim.x >> 6);
+    const int n = *a.tape_rows;
+    int per = (n + nw - 1) / nw;
+    per = (per + 2 * KS - 1) / (2 * KS) * (2 * KS);
+    const int t0 = gw * per;
+    const int t1 = (t0 + per < n) ? t0 + per : n;
+    f32x16 w1[4], w2, v1[TNC], v2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        w2[e] = 0.f; v2[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w1[q][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < TNC; ++q) v1[q][e] = 0.f;
+    }
+    const int col = lane & 31, kk = lane >> 5;
+    for (int t = t0; t < t1; t += 2 * KS) {
+        float adh[KS], ado[KS], adc[KS], adq[KS], bx[KS][4], bh[KS], bc[KS][TNC], bhc[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int tt = t + 2 * ks + kk;
+            const bool ok = tt < t1;
+            const float* row = a.tape + (size_t)(ok ? tt : t0) * D::ROW;
+            adh[ks] = ok ? row[D::T_DH + col] : 0.f;
+            ado[ks] = (ok && col < MNE_OUT1) ? row[D::T_DOUT + col] : 0.f;
+            adc[ks] = ok ? row[D::T_DHC + col] : 0.f;
+            adq[ks] = (ok && col < 3) ? row[D::T_DC + col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bx[ks][q] = (ok && 32 * q + col < MNE_IN1) ? row[D::T_X + 32 * q + col] : 0.f;
+            bh[ks] = ok ? row[D::T_H + col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < TNC; ++q) bc[ks][q] = ok ? row[D::T_CIN + 32 * q + col] : 0.f;
+            bhc[ks] = ok ? row[D::T_HC + col] : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w1[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adh[ks], bx[ks][q], w1[q], 0, 0, 0);
+            w2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ado[ks], bh[ks], w2, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TNC; ++q) v1[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adc[ks], bc[ks][q], v1[q], 0, 0, 0);
+            v2 = __builtin_amdgcn_mfma_f32_32x32x2f32(adq[ks], bhc[ks], v2, 0, 0, 0);
+        }
+    }
+    float* out = a.partials + (size_t)gw * D::NPARAM;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int o = (e & 3) + 8 * (e >> 2) + 4 * kk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (32 * q + col < MNE_IN1) out[D::P_SDF0 + o * MNE_IN1 + 32 * q + col] = w1[q][e];
+        if (o < MNE_OUT1) out[D::P_SDF1 + o * HID + col] = w2[e];
+#pragma unroll
+        for (int q = 0; q < TNC; ++q) {
+            const int i = 32 * q + col;                      // tape column of the colour-net input
+            if (i != D::CINB) out[D::P_COL0 + o * D::CIN + (i > D::CINB ? i - 1 : i)] = v1[q][e];
+        }
+        if (o < 3) out[D::P_COL1 + o * HIDC + col] = v2[e];
+    }
+}
+
 // 32 parameters per block, 8 groups of partials per parameter, fixed summation order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int nparam) {
     __shared__ float part[8][32];
@@ -129,6 +201,13 @@ static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
     int blocks = (a.n_waves + 3) / 4;                    // caller's bound on the tape length
     blocks = blocks < 1 ? 1 : (blocks > MNE_WGRAD_BLOCKS ? MNE_WGRAD_BLOCKS : blocks);
     a.n_waves = blocks * 4;
+    if constexpr (HID == 32 && HIDC == 32) {
+        if (impl == 0) {
+            MNE_LAUNCH((wgrad_fused_kernel<HID, HIDC, CP>), blocks, 256, 0, st, a);
+            MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
+            return 0;
+        }
+    }
     MNE_LAUNCH((wgrad_mfma_kernel<HID / 32, 4>), blocks, 256, 0, st, a, g1, D::ROW, D::NPARAM);
     MNE_LAUNCH((wgrad_mfma_kernel<1, HID / 32>), blocks, 256, 0, st, a, g2, D::ROW, D::NPARAM);
     MNE_LAUNCH((wgrad_mfma_kernel<HIDC / 32, D::CINP / 32>), blocks, 256, 0, st, a, g3, D::ROW, D::NPARAM);
