@@ -105,11 +105,11 @@ class Agent:
         rays_o = self.poses[ids_all, :3, 3]
         return rays_o, rays_d, rays[:, 3:6], rays[:, 6:7]
 
-    def step(self, timers=None):
+    def step(self, timers=None, prefetch=False):
         if self.fused is not None:
             self.fused.events = timers
             self.fused.step(self.kf_rays, self.kf_rays.shape[0], self.n_save, self.cur_rays, self.poses,
-                            self.cfg["mapping"]["sample"], self.n_cur)
+                            self.cfg["mapping"]["sample"], self.n_cur, prefetch=prefetch)
             return
         rays_o, rays_d, tgt_rgb, tgt_d = self.sample_rays()
         ret = self.model.forward(rays_o, rays_d, tgt_rgb, tgt_d)
@@ -199,8 +199,8 @@ def main():
     timers = {}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        agent.step(timers)
+    for i in range(args.steps):        # every timed iteration draws its own batch inside the timed region:
+        agent.step(timers, prefetch=i + 1 < args.steps)      # step i+1's batch is drawn while step i's planes update
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = mdist.max_over_ranks(elapsed, device)

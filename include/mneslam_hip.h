@@ -193,24 +193,28 @@ size_t mne_tape_row_floats(const mne_scene_t* scene);
  * optimisation in loop closure, mp_slam/mapper.py:388-408).  `coef` from mne_loss_coef (NULL = no
  * loss terms); g_rgb [R][3] / g_depth [R] are optional extra upstream gradients of the rendered
  * maps (callers that build their own loss on render_rays outputs).  `raw` is the forward's output
- * for the same inputs.  tape_rows (int32 device counter) must be zero on entry. */
+ * for the same inputs.  *tape_rows (int32, device) receives the number of tape rows written; rows are
+ * in (ray, sample) order, so the result does not depend on scheduling.  `workspace` is caller-owned
+ * device scratch of at least mne_render_workspace_bytes(n_rays, n_samples) bytes (per-ray gradient
+ * constants and the compacted lists of contributing samples; contents are meaningless afterwards). */
+size_t mne_render_workspace_bytes(int n_rays, int n_samples);
 int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                         const float* rays_o, const float* rays_d, const float* target_rgb,
                         const float* target_d, const float* z_vals, const float* packed_decoder,
                         const float* raw, const float* coef, const float* g_rgb, const float* g_depth,
                         float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                        float* d_rays_o, float* d_rays_d, void* stream);
+                        float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* Fused training form of the two calls above (what Mapper.mapping_optimize runs per iteration):
- * one launch that decodes all samples (writes raw, rgb, depth, ray_sums like mne_render_forward)
- * and immediately back-propagates with the loss coefficients `coef` (mne_loss_coef), without
- * re-reading raw. */
+ * decodes all samples (writes raw, rgb, depth, ray_sums like mne_render_forward) and back-propagates
+ * with the loss coefficients `coef` (mne_loss_coef) in one call, sharing the compositing pass. */
 int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                      const float* rays_o, const float* rays_d, const float* target_rgb,
                      const float* target_d, const float* z_vals, const float* packed_decoder,
                      const float* coef, float* rgb, float* depth, float* raw, float* ray_sums,
                      float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                     const mne_tile_bins_t* bins, void* stream);
+                     const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Binned scatter + Adam for the planes (see csrc/tile_adam.hip): with `bins` given, mne_render_fused
  * does not touch plane[].grad; it appends every contributing sample to the lists of the 16x16-cell
@@ -218,7 +222,7 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
  * weights in LDS and applies torch.optim.Adam's update to the tile -- i.e. it replaces
  * grid_sampler_2d_backward + Adam.step() + zero_grad() for the plane groups
  * (mneslam_mp.py:459-469) with no gradient buffer and no global atomics.  opt[] has 6*n_sets entries.
- * tape_rows is zeroed by mne_render_fused itself in every mode. */
+ * *tape_rows is written by mne_render_fused itself in every mode. */
 size_t mne_tile_count(const mne_scene_t* scene);
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
                   const mne_tile_bins_t* bins, void* stream);

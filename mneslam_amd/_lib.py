@@ -77,9 +77,10 @@ _PROTOS = {
     "mne_loss_coef": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_tape_row_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_render_backward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 11
-                            + [C.c_int64] + [C.c_void_p] * 4),
+                            + [C.c_int64] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]),
+    "mne_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mne_render_fused": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 12
-                         + [C.c_int64, C.c_void_p, C.POINTER(TileBins), C.c_void_p]),
+                         + [C.c_int64, C.c_void_p, C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.c_void_p]),
     "mne_sample_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,

@@ -131,7 +131,7 @@ int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, in
     a.z_vals = z_vals; a.packed = packed_decoder;
     a.rgb = rgb; a.depth = depth; a.disp = disp; a.acc = acc; a.depth_var = depth_var; a.raw = raw;
     a.ray_sums = ray_sums;
-    if (int rc = mne_launch_render(a, 1, 0, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    if (int rc = mne_launch_render(a, 1, 0, nullptr, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_forward");
 }
 
@@ -155,16 +155,23 @@ int mne_loss_coef(const mne_render_cfg_t* cfg, int n_rays, int n_samples, const 
     return check_launch("loss_coef");
 }
 
+size_t mne_render_workspace_bytes(int n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    return mne_render_workspace(n_rays, n_samples);
+}
+
 int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                         const float* rays_o, const float* rays_d, const float* target_rgb,
                         const float* target_d, const float* z_vals, const float* packed_decoder,
                         const float* raw, const float* coef, const float* g_rgb, const float* g_depth,
                         float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                        float* d_rays_o, float* d_rays_d, void* stream) {
+                        float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
+                        void* stream) {
     if (int rc = check_scene(scene, true)) return rc;
-    if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows)
+    if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows || !workspace)
         return fail(-1, "mne_render_backward: NULL argument");
     if (n_rays <= 0) return 0;
+    if (workspace_bytes < mne_render_workspace(n_rays, n_samples)) return fail(-1, "mne_render_backward: workspace too small");
     if (n_samples < 1 || mne_render_lds_bytes(*scene, n_samples, 1) > 160 * 1024) return fail(-1, "samples per ray out of range");
     if (tape_capacity_rows < (int64_t)n_rays * n_samples) return fail(-1, "tape must hold n_rays*n_samples rows");
     if (coef && (!target_rgb || !target_d)) return fail(-1, "loss coefficients need target_rgb and target_d");
@@ -177,7 +184,7 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
     a.coef = coef; a.g_rgb = g_rgb; a.g_depth = g_depth;
     a.tape = tape; a.tape_cap = tape_capacity_rows; a.tape_rows = tape_rows;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d;
-    if (int rc = mne_launch_render(a, 0, 1, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    if (int rc = mne_launch_render(a, 0, 1, workspace, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_backward");
 }
 
@@ -186,14 +193,15 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
                      const float* target_d, const float* z_vals, const float* packed_decoder,
                      const float* coef, float* rgb, float* depth, float* raw, float* ray_sums,
                      float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                     const mne_tile_bins_t* bins, void* stream) {
+                     const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_scene(scene, bins == nullptr)) return rc;
     if (bins && (!bins->lists || !bins->counts || !bins->spill || !bins->spill_count || !bins->order || bins->cap < 1 || bins->spill_cap < 1))
         return fail(-1, "mne_render_fused: incomplete tile bins");
     if (!cfg || !rays_o || !rays_d || !target_rgb || !target_d || !z_vals || !packed_decoder || !coef || !raw ||
-        !tape || !tape_rows)
+        !tape || !tape_rows || !workspace)
         return fail(-1, "mne_render_fused: NULL argument");
     if (n_rays <= 0) return 0;
+    if (workspace_bytes < mne_render_workspace(n_rays, n_samples)) return fail(-1, "mne_render_fused: workspace too small");
     if (n_samples < 1 || mne_render_lds_bytes(*scene, n_samples, 1) > 160 * 1024) return fail(-1, "samples per ray out of range");
     if (tape_capacity_rows < (int64_t)n_rays * n_samples) return fail(-1, "tape must hold n_rays*n_samples rows");
     RenderArgs a = {};
@@ -205,14 +213,13 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
     a.rgb = rgb; a.depth = depth; a.raw = raw; a.ray_sums = ray_sums;
     a.tape = tape; a.tape_cap = tape_capacity_rows; a.tape_rows = tape_rows;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(tape_rows, 0, sizeof(int32_t), st) != hipSuccess) return fail(-10, "memset(tape_rows) failed");
     if (bins) {
         a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
         a.bins.spill_count = bins->spill_count; a.bins.order = bins->order; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
         mne_tile_geometry(*scene, a.bins);
         if (hipMemsetAsync(bins->spill_count, 0, sizeof(int32_t), st) != hipSuccess) return fail(-10, "memset(spill_count) failed");
     }
-    if (int rc = mne_launch_render(a, 1, 1, st)) return fail(rc, "unsupported scene configuration");
+    if (int rc = mne_launch_render(a, 1, 1, workspace, st)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_fused");
 }
 

@@ -49,7 +49,12 @@ struct RenderArgs {
     int* tape_rows;
     float *d_rays_o, *d_rays_d;
     TileBins bins;        // bins.lists != NULL: binned scatter instead of atomics into plane[].grad
-    int rpw;              // rays (= waves) per workgroup, set by the launcher
+    // backward workspace (mne_render_workspace_bytes): per-ray gradient constants, per-ray compacted
+    // list of contributing samples, its length and the exclusive prefix of the lengths
+    float* ray_ctx;
+    unsigned short* clist;
+    int *ccount, *coffset;
+    int* tile_ray;        // first ray of every 32-row tile of the compacted list
     int dbg;              // MNE_DBG_FLAGS (timing ablations only; results are wrong when non-zero)
 };
 
@@ -135,7 +140,8 @@ struct AdamArgs {
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st);
 int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
-int mne_launch_render(const RenderArgs& a, int pass1, int bwd, hipStream_t st);
+int mne_launch_render(const RenderArgs& a, int pass1, int bwd, void* workspace, hipStream_t st);
+size_t mne_render_workspace(int R, int S);
 int mne_launch_query(const QueryArgs& a, hipStream_t st);
 int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStream_t st);
 int mne_launch_loss_finalize(const LossArgs& a, hipStream_t st);

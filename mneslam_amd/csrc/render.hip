@@ -135,8 +135,18 @@ __global__ __launch_bounds__(256) void pack_decoder_kernel(mne_scene_t sc, float
 }
 
 // -----------------------------------------------------------------------------------------------
-// render kernel
+// render kernels (tile-parallel):
+//   decode_kernel     one wave per 32-sample tile of a ray: gather -> OneBlob -> MFMA forward -> raw
+//   composite_kernel  one wave per ray: SDF compositing, maps, loss partial sums; for the backward also
+//                     the per-ray constants of the gradient and the compacted list of samples that can
+//                     receive gradient (ballot + prefix popcount)
+//   scan_kernel       exclusive prefix of the per-ray counts (deterministic tape order, no atomics)
+//   backward_kernel   one wave per 32 contributing samples, packed ACROSS rays (full tiles): forward
+//                     recompute, loss/compositing gradients, MFMA backward, tape row, scatter/append
+// A ray is therefore never a serial chain of tiles: the batch exposes R*S/32 + P'/32 independent wave tasks.
 // -----------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 f32x16_zero() { f32x16 v; for (int q = 0; q < 16; ++q) v[q] = 0.0f; return v; }
+
 struct SampleMasks { bool e_front, e_center, e_tail, co_fs, co_sdf; };
 
 __device__ __forceinline__ SampleMasks sample_masks(float z, float d, bool has_t, const RenderArgs& a) {
@@ -153,29 +163,26 @@ __device__ __forceinline__ SampleMasks sample_masks(float z, float d, bool has_t
     return m;
 }
 
-// per-wave LDS: pn[32][4] | feat[NSETS][32][FS] | raws[Spad][4] | list[Spad] (ushort)
-// (+ ray-gradient variant: dpos[32][64] | dpn[32][4])
-__host__ __device__ inline size_t render_wave_lds_bytes(int S, int nsets, bool raygrad = false) {
-    const size_t Spad = (size_t)((S + 3) & ~3);
-    size_t b = (size_t)(TILE * 4 + nsets * TILE * MNE_FS) * sizeof(float) + Spad * 4 * sizeof(float) + Spad * sizeof(unsigned short);
-    b = (b + 15) & ~(size_t)15;
+// per-wave LDS of the tile kernels: pn[32][4] | feat[NSETS][32][FS]  (+ ray-gradient variant: dpos[32][64] | dpn[32][4])
+__host__ __device__ inline size_t tile_wave_lds_bytes(int nsets, bool raygrad = false) {
+    size_t b = (size_t)(TILE * 4 + nsets * TILE * MNE_FS) * sizeof(float);
     if (raygrad) b += (size_t)(TILE * 64 + TILE * 4) * sizeof(float);
     return b;
 }
 
-// a.rpw = rays (= waves) per workgroup (chosen at launch so that one round of workgroups covers
-// the batch); ALDS = the MFMA A-operand tables are staged in LDS once per
-// workgroup (one ds_read_b32 per MFMA) instead of being re-read from global memory per MFMA.
-#define MAX_RPW 10
-template <int HID, int HIDC, bool CP, bool PASS1, bool BWD, bool ALDS, bool RAYGRAD = false>
-__global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
-    const int RPW = a.rpw;                                 // waves (= rays) in this workgroup
-    typedef DecDims<HID, HIDC, CP> D;
+// ray_ctx[r][16]: constants of one ray's gradient, written by composite_kernel
+enum { RC_DENOM = 0, RC_ZLIM = 1, RC_AQ = 2, RC_GR = 3, RC_GG = 4, RC_GB = 5, RC_GDEP = 6, RC_N = 16 };
+
+#ifndef MAX_WPB
+#define MAX_WPB 12
+#endif
+template <int HID, int HIDC, bool CP, bool ALDS>
+__global__ __launch_bounds__(64 * MAX_WPB) void decode_kernel(RenderArgs a) {
     typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
-    constexpr int NT = HID / 32, NTC = HIDC / 32;
-    constexpr int TAB_FLOATS = ALDS ? (RAYGRAD ? T::TOTAL_RAYGRAD : BWD ? T::TOTAL : T::FWD_STEPS) * 64 : 0;
+    constexpr int TAB_FLOATS = ALDS ? T::FWD_STEPS * 64 : 0;
     MNE_DYN_LDS(lds_raw);
+    const int wpb = blockDim.x >> 6;
     if (ALDS) {                                            // stage the A tables: the only block-wide step
         float4* dst = (float4*)lds_raw;
         const float4* src = (const float4*)a.packed;
@@ -184,62 +191,53 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
     }
     const float* atab = ALDS ? (const float*)lds_raw : a.packed;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = blockIdx.x * RPW + wv;
-    if (r >= a.R) return;                                  // whole wave leaves together; no block barriers below
-    const int S = a.S;
-    const int Spad = (S + 3) & ~3;
-    unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * render_wave_lds_bytes(S, NSETS, RAYGRAD);
-    float* pn = (float*)my;                                // [32][4]
-    float* feat = pn + TILE * 4;                           // [NSETS][32][MNE_FS]
-    float* raws = feat + NSETS * TILE * MNE_FS;            // [Spad][4]  (r,g,b,sdf)
-    unsigned short* list = (unsigned short*)(raws + Spad * 4);   // [S] compacted sample ids (backward)
-    float* dposL = (float*)(my + render_wave_lds_bytes(S, NSETS, false));   // RAYGRAD: [32][64] d OneBlob rows
-    float* dpnL = dposL + TILE * 64;                                          // RAYGRAD: [32][4]  d normalised point
+    const int S = a.S, ntile = (S + TILE - 1) / TILE;
+    const long long ntask = (long long)a.R * ntile;
+    float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(NSETS));
+    float* feat = pn + TILE * 4;
     const int pt = lane & 31, hf = lane >> 5;
+    // persistent waves: a wave strides over the (ray, tile) tasks; nothing below is block-wide
+    for (long long task = (long long)blockIdx.x * wpb + wv; task < ntask; task += (long long)gridDim.x * wpb) {
+        const int r = (int)(task / ntile), c = (int)(task % ntile);
+        const int i = c * TILE + pt;
+        const bool valid = i < S;
+        const float z = a.z_vals[(size_t)r * S + (valid ? i : S - 1)];
+        float p[3], pnv[3], u[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = a.rays_o[r * 3 + k] + a.rays_d[r * 3 + k] * z;      // scene_rep.py:384
+        point_coords(a.sc, p, pnv, u);
+        MNE_WAVE_SYNC();                                       // previous task's LDS reads are done
+        if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+        MNE_WAVE_SYNC();
+        gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane, a.dbg);
+        MNE_WAVE_SYNC();
+        float pos[24];
+        oneblob_half(u, hf, pos);
+        MlpState<HID, HIDC> st;
+        if (!(a.dbg & 8)) mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, atab, lane, st);
+        else { st.rgb[0] = st.rgb[1] = st.rgb[2] = pos[0]; st.out[0] = pos[1]; }
+        if (valid && hf == 0)                                  // rows 0..3 live in the lower half
+            *(float4*)(a.raw + ((size_t)r * S + i) * 4) = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);
+    }
+}
 
-    const float o[3] = {a.rays_o[r * 3 + 0], a.rays_o[r * 3 + 1], a.rays_o[r * 3 + 2]};
-    const float dv[3] = {a.rays_d[r * 3 + 0], a.rays_d[r * 3 + 1], a.rays_d[r * 3 + 2]};
+// One wave per ray, 4 rays per workgroup.  LDS per wave: raws[Spad][4].
+template <bool BWD>
+__global__ __launch_bounds__(256) void composite_kernel(RenderArgs a) {
+    MNE_DYN_LDS(lds_raw);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= a.R) return;
+    const int S = a.S, Spad = (S + 3) & ~3;
+    float* raws = (float*)lds_raw + (size_t)wv * Spad * 4;
     const bool has_t = a.target_d != nullptr;
     const float td = has_t ? a.target_d[r] : 0.0f;
     const float* zr = a.z_vals + (size_t)r * S;
-
-    if (!PASS1) {
+    {
         const float4* src = (const float4*)(a.raw_in + (size_t)r * S * 4);
         for (int i = lane; i < S; i += MNE_WAVE) *(float4*)(raws + 4 * i) = src[i];
     }
-
-    // ------------------------------------------------------------------ pass 1: decode all samples
-    if (PASS1) {
-        const int ntile = (S + TILE - 1) / TILE;
-#pragma unroll 1
-        for (int c = 0; c < ntile; ++c) {
-            const int i = c * TILE + pt;
-            const bool valid = i < S;
-            const float z = zr[valid ? i : S - 1];
-            float p[3], pnv[3], u[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) p[k] = o[k] + dv[k] * z;          // scene_rep.py:384
-            point_coords(a.sc, p, pnv, u);
-            if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
-            MNE_WAVE_SYNC();
-            gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane, a.dbg);
-            MNE_WAVE_SYNC();
-            float pos[24];
-            oneblob_half(u, hf, pos);
-            MlpState<HID, HIDC> st;
-            if (!(a.dbg & 8)) mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, atab, lane, st);
-            else { st.rgb[0] = st.rgb[1] = st.rgb[2] = pos[0]; st.out[0] = pos[1]; }
-            if (valid && hf == 0) {                                        // rows 0..3 live in the lower half
-                const float4 rw = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);
-                *(float4*)(a.raw + ((size_t)r * S + i) * 4) = rw;
-                *(float4*)(raws + 4 * i) = rw;
-            }
-            MNE_WAVE_SYNC();
-        }
-    }
     MNE_WAVE_SYNC();
-
-    // ------------------------------------------------------------------ pass 2: compositing (lane per sample)
     // first adjacent sign change (argmax of a 0/1 mask = first occurrence, 0 when none), scene_rep.py:195-199
     int first = 0;
     {
@@ -322,8 +320,6 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
             rs[MNE_L_PSNR] = 0.0f;
         }
     }
-
-    // ------------------------------------------------------------------ pass 3: backward
     if (BWD) {
         float cf[MNE_N_LOSS];
 #pragma unroll
@@ -337,230 +333,351 @@ __global__ __launch_bounds__(64 * MAX_RPW) void render_kernel(RenderArgs a) {
         const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
         const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
         // compaction of the samples that can receive a non-zero gradient (wave ballot + prefix popcount)
+        unsigned short* list = a.clist + (size_t)r * Spad;
         int n_contrib = 0;
-        {
-            const int nchunk = (S + MNE_WAVE - 1) / MNE_WAVE;
-            for (int c = 0; c < nchunk; ++c) {
-                const int i = c * MNE_WAVE + lane;
-                bool f = false;
-                if (i < S) {
-                    const float z = zr[i];
-                    const SampleMasks mk = sample_masks(z, td, has_t, a);
-                    f = (z < z_lim) || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) ||
-                        (use_co && (mk.co_fs || mk.co_sdf));
+        const int nchunk = (S + MNE_WAVE - 1) / MNE_WAVE;
+        for (int c = 0; c < nchunk; ++c) {
+            const int i = c * MNE_WAVE + lane;
+            bool f = false;
+            if (i < S) {
+                const float z = zr[i];
+                const SampleMasks mk = sample_masks(z, td, has_t, a);
+                f = (z < z_lim) || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) ||
+                    (use_co && (mk.co_fs || mk.co_sdf));
+            }
+            const unsigned long long m = __ballot(f);
+            if (f) list[n_contrib + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            n_contrib += __popcll(m);
+        }
+        if (lane == 0) {
+            a.ccount[r] = (a.dbg & 16) ? 0 : n_contrib;
+            float* rc = a.ray_ctx + (size_t)r * RC_N;
+            rc[RC_DENOM] = denom; rc[RC_ZLIM] = z_lim; rc[RC_AQ] = Aq;
+            rc[RC_GR] = g_rgb[0]; rc[RC_GG] = g_rgb[1]; rc[RC_GB] = g_rgb[2]; rc[RC_GDEP] = g_dep;
+        }
+    }
+}
+
+// exclusive prefix sum of ccount[R] -> coffset[R+1]; total -> tape_rows (single workgroup)
+__global__ __launch_bounds__(1024) void scan_kernel(RenderArgs a) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (a.R + 1023) / 1024;
+    const int b0 = tid * per, b1 = (b0 + per < a.R) ? b0 + per : a.R;
+    int s = 0;
+    for (int i = b0; i < b1; ++i) s += a.ccount[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;                        // exclusive prefix of this thread's chunk
+    for (int i = b0; i < b1; ++i) {
+        const int c0 = run, c1 = run + a.ccount[i];
+        a.coffset[i] = c0;
+        // ray i owns the 32-row tiles whose first row lies in [c0, c1): backward_kernel starts its search there
+        for (int t = (c0 + TILE - 1) / TILE; t * TILE < c1; ++t) a.tile_ray[t] = i;
+        run = c1;
+    }
+    if (tid == 1023) { a.coffset[a.R] = part[1023]; *a.tape_rows = part[1023]; }
+}
+
+#ifndef MAX_WPB_BWD
+#define MAX_WPB_BWD 8
+#endif
+template <int HID, int HIDC, bool CP, bool ALDS, bool RAYGRAD>
+__global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a) {
+    typedef DecDims<HID, HIDC, CP> D;
+    typedef ATab<HID, HIDC, CP> T;
+    constexpr int NSETS = CP ? 2 : 1;
+    constexpr int NT = HID / 32, NTC = HIDC / 32;
+    constexpr int TAB_FLOATS = ALDS ? (RAYGRAD ? T::TOTAL_RAYGRAD : T::TOTAL) * 64 : 0;
+    MNE_DYN_LDS(lds_raw);
+    const int wpb = blockDim.x >> 6;
+    const int total = a.coffset[a.R];
+    if ((long long)blockIdx.x * wpb * TILE >= total) return;      // whole workgroup beyond the compacted list
+    if (ALDS) {
+        float4* dst = (float4*)lds_raw;
+        const float4* src = (const float4*)a.packed;
+        for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+    const float* atab = ALDS ? (const float*)lds_raw : a.packed;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(NSETS, RAYGRAD);
+    float* pn = (float*)my;
+    float* feat = pn + TILE * 4;
+    float* dposL = feat + NSETS * TILE * MNE_FS;                  // RAYGRAD: [32][64] d OneBlob rows
+    float* dpnL = dposL + TILE * 64;                              // RAYGRAD: [32][4]  d normalised point
+    const int pt = lane & 31, hf = lane >> 5;
+    const int S = a.S, Spad = (S + 3) & ~3;
+    const bool has_t = a.target_d != nullptr;
+    float cf[MNE_N_LOSS];
+#pragma unroll
+    for (int q = 0; q < MNE_N_LOSS; ++q) cf[q] = a.coef ? a.coef[q] : 0.0f;
+    const long long ntile = ((long long)total + TILE - 1) / TILE;
+    // persistent waves over the tiles of the compacted list; nothing below is block-wide
+    for (long long tile = (long long)blockIdx.x * wpb + wv; tile < ntile; tile += (long long)gridDim.x * wpb) {
+        const int k = (int)(tile * TILE) + pt;                    // position in the compacted list = tape row
+        const bool valid = k < total;
+        const int kk = valid ? k : total - 1;
+        // owning ray = last r with coffset[r] <= kk.  The tile's first row belongs to tile_ray[tile]; the
+        // following offsets are fetched with one coalesced load and scanned with wave-uniform reads
+        // (a tile of 32 rows rarely spans more than two or three rays).
+        int lo = a.tile_ray[tile];
+        if (!(a.dbg & 1024)) {
+            const int r0 = lo;
+            const int cnext = a.coffset[(r0 + 1 + lane < a.R) ? r0 + 1 + lane : a.R];     // coffset[R] = total > kk
+            const int k_last = (int)(tile * TILE) + TILE - 1;
+            bool open_end = true;
+            for (int j = 0; j < MNE_WAVE; ++j) {
+                const int v = __shfl(cnext, j);
+                if (v > k_last) { open_end = false; break; }
+                lo += (v <= kk) ? 1 : 0;
+            }
+            if (open_end) {                                       // > 64 rays (mostly empty ones) inside this tile
+                int hi = a.R;
+                if (lo < r0 + MNE_WAVE) hi = lo + 1;              // this lane's ray was already found
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (a.coffset[mid] <= kk) lo = mid; else hi = mid;
                 }
-                const unsigned long long m = __ballot(f);
-                if (f) list[n_contrib + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
-                n_contrib += __popcll(m);
+            }
+        }
+        const int r = lo;
+        const int i = (a.dbg & 1024) ? kk % S : a.clist[(size_t)r * Spad + (kk - a.coffset[r])];
+        const float z = a.z_vals[(size_t)r * S + i];
+        const float td = has_t ? a.target_d[r] : 0.0f;
+        const float* rc = a.ray_ctx + (size_t)r * RC_N;
+        const float denom = rc[RC_DENOM], z_lim = rc[RC_ZLIM], Aq = rc[RC_AQ], g_dep = rc[RC_GDEP];
+        const float g_rgb[3] = {rc[RC_GR], rc[RC_GG], rc[RC_GB]};
+        float p[3], pnv[3], u[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) p[q] = a.rays_o[r * 3 + q] + a.rays_d[r * 3 + q] * z;
+        point_coords(a.sc, p, pnv, u);
+        MNE_WAVE_SYNC();                                          // previous tile's LDS reads are done
+        if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+        MNE_WAVE_SYNC();
+        gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane, a.dbg);
+        MNE_WAVE_SYNC();
+        float* frow = feat + pt * MNE_FS;
+        float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
+        float pos[24];
+        oneblob_half(u, hf, pos);
+        MlpState<HID, HIDC> st;
+        if (!(a.dbg & 512)) mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, atab, lane, st);
+        else {
+            st.out = f32x16_zero(); st.rgb = f32x16_zero(); st.rgb[0] = pos[0];
+            for (int t = 0; t < NT; ++t) st.h[t] = f32x16_zero();
+            for (int t = 0; t < NTC; ++t) st.hc[t] = f32x16_zero();
+        }
+        // ---- d(total)/d(raw) of this point (both lanes of the pair compute the same values)
+        const float4 rw = *(const float4*)(a.raw_in + ((size_t)r * S + i) * 4);
+        const float s = rw.w;
+        float ds = 0.0f, dc[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+            if (z < z_lim) {
+                const float pp = sigmoidf_(s / a.trunc_f), qq = sigmoidf_(-s / a.trunc_f);
+                const float wt = pp * qq;
+                const float w = wt / denom;
+                const float sg[3] = {sigmoidf_(rw.x), sigmoidf_(rw.y), sigmoidf_(rw.z)};
+                const float dLdw = g_rgb[0] * sg[0] + g_rgb[1] * sg[1] + g_rgb[2] * sg[2] + g_dep * z;
+                ds += ((dLdw - Aq) / denom) * (wt * (qq - pp) / a.trunc_f);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dc[q] = g_rgb[q] * w * (sg[q] * (1.0f - sg[q]));
+            }
+            const SampleMasks mk = sample_masks(z, td, has_t, a);
+            const float e_res = (z + s * a.e_T) - td, c_res = (z + s * a.win_f) - td;
+            if (mk.e_front) ds += cf[MNE_L_E_FS] * (s - 1.0f);
+            if (mk.e_center) ds += cf[MNE_L_E_CENTER] * e_res;
+            if (mk.e_tail) ds += cf[MNE_L_E_TAIL] * e_res;
+            if (mk.co_fs) ds += cf[MNE_L_CO_FS] * (s - 1.0f);
+            if (mk.co_sdf) ds += cf[MNE_L_CO_SDF] * c_res;
+        }
+        // ---- tape: forward activations of this point (each lane writes the part it holds)
+        float* row = a.tape + (size_t)kk * D::ROW;
+        const bool tape_on = valid && !(a.dbg & 2);
+        if (tape_on) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *(float4*)(row + D::T_X + hf * 32 + 4 * q) = *(const float4*)(frow + hf * 32 + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const float4 pv = make_float4(pos[4 * q], pos[4 * q + 1], pos[4 * q + 2], pos[4 * q + 3]);
+                *(float4*)(row + D::T_X + MNE_FEAT + hf * 24 + 4 * q) = pv;
+                *(float4*)(row + D::T_CIN + hf * 24 + 4 * q) = pv;
+            }
+            if (CP) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    *(float4*)(row + D::T_CIN + MNE_POS + hf * 32 + 4 * q) = *(const float4*)(cfrow + hf * 32 + 4 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                *(float4*)(row + D::T_CIN + D::CINB + 8 * q + 4 * hf) =
+                    make_float4(st.out[4 * q], st.out[4 * q + 1], st.out[4 * q + 2], st.out[4 * q + 3]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4*)(row + D::T_H + 32 * t + 8 * q + 4 * hf) =
+                        make_float4(st.h[t][4 * q], st.h[t][4 * q + 1], st.h[t][4 * q + 2], st.h[t][4 * q + 3]);
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4*)(row + D::T_HC + 32 * t + 8 * q + 4 * hf) =
+                        make_float4(st.hc[t][4 * q], st.hc[t][4 * q + 1], st.hc[t][4 * q + 2], st.hc[t][4 * q + 3]);
+            if (hf == 0) *(float4*)(row + D::T_DC) = make_float4(dc[0], dc[1], dc[2], 0.0f);
+        }
+        // ---- MFMA backward chain; d(feature) rows overwrite this point's LDS feature rows
+        f32x16 dh[NT], dout, dhc[NTC];
+        if (!(a.dbg & 4096)) mlp_backward_mfma<HID, HIDC, CP>(st, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
+        else {
+            dout = f32x16_zero();
+            for (int t = 0; t < NT; ++t) dh[t] = f32x16_zero();
+            for (int t = 0; t < NTC; ++t) dhc[t] = f32x16_zero();
+        }
+        if (tape_on) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                *(float4*)(row + D::T_DOUT + 8 * q + 4 * hf) = make_float4(dout[4 * q], dout[4 * q + 1], dout[4 * q + 2], dout[4 * q + 3]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4*)(row + D::T_DH + 32 * t + 8 * q + 4 * hf) =
+                        make_float4(dh[t][4 * q], dh[t][4 * q + 1], dh[t][4 * q + 2], dh[t][4 * q + 3]);
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4*)(row + D::T_DHC + 32 * t + 8 * q + 4 * hf) =
+                        make_float4(dhc[t][4 * q], dhc[t][4 * q + 1], dhc[t][4 * q + 2], dhc[t][4 * q + 3]);
+        }
+        if (RAYGRAD) {
+            // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates;
+            // the rays of a tile differ, so each point adds its share to its ray with atomics ([R][3])
+            float* dprow = dposL + pt * 64;
+            mlp_backward_dpos<HID, HIDC, CP>(dh, dhc, atab, lane, dprow);
+            MNE_WAVE_SYNC();
+            gather_coord_grad<NSETS, TILE>(a.sc, pn, feat, dpnL, lane);
+            MNE_WAVE_SYNC();
+            float du[3];
+            oneblob_half_backward(u, hf, dprow, du);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) du[q] += __shfl_xor(du[q], 32);
+            if (valid && hf == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float inv_bb = a.sc.bb_is_f64 ? (float)(1.0 / (a.sc.bb_hi[q] - a.sc.bb_lo[q]))
+                                                        : 1.0f / ((float)a.sc.bb_hi[q] - (float)a.sc.bb_lo[q]);
+                    const float dp = dpnL[pt * 4 + q] * (2.0f / (a.sc.bound_hi[q] - a.sc.bound_lo[q])) + du[q] * inv_bb;
+                    if (a.d_rays_o) unsafeAtomicAdd(a.d_rays_o + r * 3 + q, dp);
+                    if (a.d_rays_d) unsafeAtomicAdd(a.d_rays_d + r * 3 + q, z * dp);
+                }
             }
         }
         MNE_WAVE_SYNC();
-        int tape_base = 0;
-        if (lane == 0 && n_contrib > 0) tape_base = atomicAdd(a.tape_rows, n_contrib);
-        tape_base = __shfl(tape_base, 0);
-        float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};       // RAYGRAD: d/d rays_o, d/d rays_d of this lane's points
-        const int ntile = (a.dbg & 16) ? 0 : (n_contrib + TILE - 1) / TILE;
-#pragma unroll 1
-        for (int cc = 0; cc < ntile; ++cc) {
-            const int k = cc * TILE + pt;
-            const bool valid = k < n_contrib;
-            const int i = list[valid ? k : n_contrib - 1];
-            const float z = zr[i];
-            float p[3], pnv[3], u[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) p[q] = o[q] + dv[q] * z;
-            point_coords(a.sc, p, pnv, u);
-            if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
-            MNE_WAVE_SYNC();
-            gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane, a.dbg);
-            MNE_WAVE_SYNC();
-            float* frow = feat + pt * MNE_FS;
-            float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
-            float pos[24];
-            oneblob_half(u, hf, pos);
-            MlpState<HID, HIDC> st;
-            mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, atab, lane, st);
-            // ---- d(total)/d(raw) of this point (both lanes of the pair compute the same values)
-            const float4 rw = *(const float4*)(raws + 4 * i);
-            const float s = rw.w;
-            float ds = 0.0f, dc[3] = {0.f, 0.f, 0.f};
-            if (valid) {
-                if (z < z_lim) {
-                    const float pp = sigmoidf_(s / a.trunc_f), qq = sigmoidf_(-s / a.trunc_f);
-                    const float wt = pp * qq;
-                    const float w = wt / denom;
-                    const float sg[3] = {sigmoidf_(rw.x), sigmoidf_(rw.y), sigmoidf_(rw.z)};
-                    const float dLdw = g_rgb[0] * sg[0] + g_rgb[1] * sg[1] + g_rgb[2] * sg[2] + g_dep * z;
-                    ds += ((dLdw - Aq) / denom) * (wt * (qq - pp) / a.trunc_f);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) dc[q] = g_rgb[q] * w * (sg[q] * (1.0f - sg[q]));
-                }
-                const SampleMasks mk = sample_masks(z, td, has_t, a);
-                const float e_res = (z + s * a.e_T) - td, c_res = (z + s * a.win_f) - td;
-                if (mk.e_front) ds += cf[MNE_L_E_FS] * (s - 1.0f);
-                if (mk.e_center) ds += cf[MNE_L_E_CENTER] * e_res;
-                if (mk.e_tail) ds += cf[MNE_L_E_TAIL] * e_res;
-                if (mk.co_fs) ds += cf[MNE_L_CO_FS] * (s - 1.0f);
-                if (mk.co_sdf) ds += cf[MNE_L_CO_SDF] * c_res;
-            }
-            // ---- tape: forward activations of this point (each lane writes the part it holds)
-            float* row = a.tape + (size_t)(tape_base + (valid ? k : 0)) * D::ROW;
-            const bool tape_on = valid && !(a.dbg & 2);
+        const int n_here = total - (int)(tile * TILE);
+        if (a.bins.lists) {
+            // binned scatter: d(feature) + normalised point go to the tape row, and the sample is
+            // appended to the list of every plane tile its 2x2 footprint touches (tile_adam.hip)
             if (tape_on) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    *(float4*)(row + D::T_X + hf * 32 + 4 * q) = *(const float4*)(frow + hf * 32 + 4 * q);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const float4 pv = make_float4(pos[4 * q], pos[4 * q + 1], pos[4 * q + 2], pos[4 * q + 3]);
-                    *(float4*)(row + D::T_X + MNE_FEAT + hf * 24 + 4 * q) = pv;
-                    *(float4*)(row + D::T_CIN + hf * 24 + 4 * q) = pv;
-                }
-                if (CP) {
+                for (int set = 0; set < NSETS; ++set)
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        *(float4*)(row + D::T_CIN + MNE_POS + hf * 32 + 4 * q) = *(const float4*)(cfrow + hf * 32 + 4 * q);
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    *(float4*)(row + D::T_CIN + D::CINB + 8 * q + 4 * hf) =
-                        make_float4(st.out[4 * q], st.out[4 * q + 1], st.out[4 * q + 2], st.out[4 * q + 3]);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(float4*)(row + D::T_H + 32 * t + 8 * q + 4 * hf) =
-                            make_float4(st.h[t][4 * q], st.h[t][4 * q + 1], st.h[t][4 * q + 2], st.h[t][4 * q + 3]);
-#pragma unroll
-                for (int t = 0; t < NTC; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(float4*)(row + D::T_HC + 32 * t + 8 * q + 4 * hf) =
-                            make_float4(st.hc[t][4 * q], st.hc[t][4 * q + 1], st.hc[t][4 * q + 2], st.hc[t][4 * q + 3]);
-                if (hf == 0) *(float4*)(row + D::T_DC) = make_float4(dc[0], dc[1], dc[2], 0.0f);
+                        *(float4*)(row + D::T_DFEAT + set * MNE_FEAT + hf * 32 + 4 * q) =
+                            *(const float4*)(feat + set * TILE * MNE_FS + pt * MNE_FS + hf * 32 + 4 * q);
+                if (hf == 0) *(float4*)(row + D::T_PN) = *(const float4*)(pn + pt * 4);
             }
-            // ---- MFMA backward chain; d(feature) rows overwrite this point's LDS feature rows
-            f32x16 dh[NT], dout, dhc[NTC];
-            mlp_backward_mfma<HID, HIDC, CP>(st, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
-            if (tape_on) {
+            if (!(a.dbg & 1)) {
+                // One returning atomic per DISTINCT tile list per wave: lanes that append to the same
+                // list are grouped with ballots and the group leader reserves the whole run of slots.
+                // Three phases so that all reservations of a tile are in flight together: (A) grouping,
+                // registers only; (B) the leaders' atomics, back to back; (C) slots and entry writes.
+                constexpr int NQ = NSETS * 3 * 4;
+                int want[NQ];
+                unsigned meta[NQ];                                 // leader lane | rank << 8 | group size << 16
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    *(float4*)(row + D::T_DOUT + 8 * q + 4 * hf) = make_float4(dout[4 * q], dout[4 * q + 1], dout[4 * q + 2], dout[4 * q + 3]);
+                for (int j = 0; j < NSETS * 3; ++j) {
+                    const int pidx = 2 * j + hf;                   // planes in [set][orient][level] order
+                    const int ori = (pidx % 6) / 2;
+                    const mne_plane_t& pl = a.sc.plane[pidx / 6][ori][pidx % 2];
+                    float gx, gy;
+                    orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
+                    Bilin b;
+                    bilin_setup(gx, gy, pl.h, pl.w, b);
+                    const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
+                    const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
+                    const int base = a.bins.tile_base[pidx], ntx = a.bins.ntx[pidx];
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(float4*)(row + D::T_DH + 32 * t + 8 * q + 4 * hf) =
-                            make_float4(dh[t][4 * q], dh[t][4 * q + 1], dh[t][4 * q + 2], dh[t][4 * q + 3]);
-#pragma unroll
-                for (int t = 0; t < NTC; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(float4*)(row + D::T_DHC + 32 * t + 8 * q + 4 * hf) =
-                            make_float4(dhc[t][4 * q], dhc[t][4 * q + 1], dhc[t][4 * q + 2], dhc[t][4 * q + 3]);
-            }
-            if (RAYGRAD) {
-                // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates
-                float* dprow = dposL + pt * 64;
-                mlp_backward_dpos<HID, HIDC, CP>(dh, dhc, atab, lane, dprow);
-                MNE_WAVE_SYNC();
-                gather_coord_grad<NSETS, TILE>(a.sc, pn, feat, dpnL, lane);
-                MNE_WAVE_SYNC();
-                float du[3];
-                oneblob_half_backward(u, hf, dprow, du);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) du[q] += __shfl_xor(du[q], 32);
-                if (valid && hf == 0) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const float inv_bb = a.sc.bb_is_f64 ? (float)(1.0 / (a.sc.bb_hi[q] - a.sc.bb_lo[q]))
-                                                            : 1.0f / ((float)a.sc.bb_hi[q] - (float)a.sc.bb_lo[q]);
-                        const float dp = dpnL[pt * 4 + q] * (2.0f / (a.sc.bound_hi[q] - a.sc.bound_lo[q])) + du[q] * inv_bb;
-                        go[q] += dp;
-                        gd[q] += z * dp;
+                    for (int q = 0; q < 4; ++q) {
+                        const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
+                        const bool dup = ((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0);   // same tile again
+                        const int w_ = (valid && !dup) ? base + ty * ntx + tx : -1;
+                        unsigned long long todo = __ballot(w_ >= 0);
+                        unsigned m_ = 0;
+                        while (todo) {
+                            const int leader = __ffsll(todo) - 1;
+                            const int t = __shfl(w_, leader);
+                            const unsigned long long same = __ballot(w_ == t);
+                            if (w_ == t)
+                                m_ = (unsigned)leader | ((unsigned)__popcll(same & ((1ull << lane) - 1ull)) << 8) |
+                                     ((unsigned)__popcll(same) << 16);
+                            todo &= ~same;
+                        }
+                        want[j * 4 + q] = w_;
+                        meta[j * 4 + q] = m_;
                     }
                 }
-            }
-            MNE_WAVE_SYNC();
-            const int n_here = n_contrib - cc * TILE;
-            if (a.bins.lists) {
-                // binned scatter: d(feature) + normalised point go to the tape row, and the sample is
-                // appended to the list of every plane tile its 2x2 footprint touches (tile_adam.hip)
-                if (tape_on) {
+                int first[NQ];
 #pragma unroll
-                    for (int set = 0; set < NSETS; ++set)
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            *(float4*)(row + D::T_DFEAT + set * MNE_FEAT + hf * 32 + 4 * q) =
-                                *(const float4*)(feat + set * TILE * MNE_FS + pt * MNE_FS + hf * 32 + 4 * q);
-                    if (hf == 0) *(float4*)(row + D::T_PN) = *(const float4*)(pn + pt * 4);
+                for (int e = 0; e < NQ; ++e) {
+                    first[e] = 0;
+                    if (want[e] >= 0 && (int)(meta[e] & 255u) == lane) first[e] = atomicAdd(a.bins.counts + want[e], (int)(meta[e] >> 16));
                 }
-                if (!(a.dbg & 1)) {
-                    // One returning atomic per DISTINCT tile per wave: lanes that append to the same list
-                    // (consecutive samples of a ray mostly do) are grouped with ballots and the group
-                    // leader reserves the whole run of slots.
-                    const unsigned trow = (unsigned)(tape_base + (valid ? k : 0));
+                const unsigned trow = (unsigned)kk;
 #pragma unroll
-                    for (int j = 0; j < NSETS * 3; ++j) {
-                        const int pidx = 2 * j + hf;                       // planes in [set][orient][level] order
-                        const int set = pidx / 6, ori = (pidx % 6) / 2, lvl = pidx % 2;
-                        const mne_plane_t& pl = a.sc.plane[set][ori][lvl];
-                        float gx, gy;
-                        orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
-                        Bilin b;
-                        bilin_setup(gx, gy, pl.h, pl.w, b);
-                        const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
-                        const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
-                        const int base = a.bins.tile_base[pidx], ntx = a.bins.ntx[pidx];
+                for (int j = 0; j < NSETS * 3; ++j) {
+                    const int pidx = 2 * j + hf;
+                    const int ori = (pidx % 6) / 2;
+                    const mne_plane_t& pl = a.sc.plane[pidx / 6][ori][pidx % 2];
+                    float gx, gy;
+                    orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
+                    Bilin b;
+                    bilin_setup(gx, gy, pl.h, pl.w, b);
+                    const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
+                    const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
-                            const bool dup = ((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0);   // same tile again
-                            const int want = (valid && !dup) ? base + ty * ntx + tx : -1;
-                            unsigned long long todo = __ballot(want >= 0);
-                            int slot = -1;
-                            while (todo) {
-                                const int leader = __ffsll(todo) - 1;
-                                const int t = __shfl(want, leader);
-                                const unsigned long long same = __ballot(want == t);
-                                int first = 0;
-                                if (lane == leader) first = atomicAdd(a.bins.counts + t, __popcll(same));
-                                first = __shfl(first, leader);
-                                if (want == t) slot = first + __popcll(same & ((1ull << lane) - 1ull));
-                                todo &= ~same;
+                    for (int q = 0; q < 4; ++q) {
+                        const int e = j * 4 + q;
+                        const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
+                        const int f0 = __shfl(first[e], (int)(meta[e] & 255u));
+                        if (want[e] >= 0) {
+                            const int slot = f0 + (int)((meta[e] >> 8) & 255u);
+                            unsigned* dst = nullptr;
+                            if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[e] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
+                            else {
+                                const int sp = atomicAdd(a.bins.spill_count, 1);
+                                if (sp < a.bins.spill_cap) { dst = a.bins.spill + (size_t)sp * MNE_SPILL_WORDS; *dst++ = (unsigned)want[e]; }
                             }
-                            if (want >= 0) {
-                                unsigned* dst = nullptr;
-                                if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want * a.bins.cap + slot) * MNE_ENTRY_WORDS;
-                                else {
-                                    const int sp = atomicAdd(a.bins.spill_count, 1);
-                                    if (sp < a.bins.spill_cap) { dst = a.bins.spill + (size_t)sp * MNE_SPILL_WORDS; *dst++ = (unsigned)want; }
-                                }
-                                if (dst) {
-                                    dst[0] = trow;
-                                    dst[1] = (unsigned)(b.ix0 - tx * MNE_TILE + 1) | ((unsigned)(b.iy0 - ty * MNE_TILE + 1) << 8);
-                                    dst[2] = __float_as_uint(b.w00); dst[3] = __float_as_uint(b.w01);
-                                    dst[4] = __float_as_uint(b.w10); dst[5] = __float_as_uint(b.w11);
-                                }
+                            if (dst) {
+                                dst[0] = trow;
+                                dst[1] = (unsigned)(b.ix0 - tx * MNE_TILE + 1) | ((unsigned)(b.iy0 - ty * MNE_TILE + 1) << 8);
+                                dst[2] = __float_as_uint(b.w00); dst[3] = __float_as_uint(b.w01);
+                                dst[4] = __float_as_uint(b.w10); dst[5] = __float_as_uint(b.w11);
                             }
                         }
                     }
                 }
-            } else {
-                scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane, a.dbg);
             }
-            MNE_WAVE_SYNC();
-        }
-        if (RAYGRAD) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { go[q] = wave_sum(go[q]); gd[q] = wave_sum(gd[q]); }
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (a.d_rays_o) a.d_rays_o[r * 3 + q] = go[q];
-                    if (a.d_rays_d) a.d_rays_d[r * 3 + q] = gd[q];
-                }
-            }
+        } else {
+            scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane, a.dbg);
         }
     }
 }
@@ -689,10 +806,9 @@ int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStr
 // -----------------------------------------------------------------------------------------------
 // host-side launchers (called from capi.hip)
 // -----------------------------------------------------------------------------------------------
-// Workgroup shape: the A tables (staged in LDS except for the largest decoder, which reads them
-// through L2) plus one private region per ray.  Rays per workgroup are chosen at launch: enough that
-// ONE round of workgroups (<= 256, one per CU) covers the batch when the 160 KiB LDS allows it --
-// a second, nearly empty round would double the kernel time -- otherwise as many as fit.
+// Workgroup shape of the tile kernels: the A tables (staged in LDS except for the largest decoder,
+// which reads them through L2) plus one private region per wave.  The grid is persistent: at most
+// one workgroup per CU (the LDS footprint allows no more), each wave striding over the tile tasks.
 #define MNE_LDS_MAX (160 * 1024)
 #define MNE_NUM_CU 256
 template <int HID, int HIDC, bool CP> struct WgShape {
@@ -700,21 +816,36 @@ template <int HID, int HIDC, bool CP> struct WgShape {
 };
 
 template <int HID, int HIDC, bool CP>
-static size_t render_lds_total(int S, bool bwd, int rpw, bool raygrad = false) {
+static size_t tile_lds_total(bool bwd, int wpb, bool raygrad = false) {
     typedef WgShape<HID, HIDC, CP> W;
     typedef ATab<HID, HIDC, CP> T;
     const size_t tab = W::ALDS ? (size_t)(raygrad ? T::TOTAL_RAYGRAD : bwd ? T::TOTAL : T::FWD_STEPS) * 64 * sizeof(float) : 0;
-    return tab + (size_t)rpw * render_wave_lds_bytes(S, CP ? 2 : 1, raygrad);
+    return tab + (size_t)wpb * tile_wave_lds_bytes(CP ? 2 : 1, raygrad);
 }
 
 template <int HID, int HIDC, bool CP>
-static int choose_rpw(int R, int S, bool bwd, bool raygrad = false) {
+static int choose_wpb(bool bwd, bool raygrad, int max_wpb) {
     int fit = 0;
-    for (int k = 1; k <= MAX_RPW; ++k)
-        if (render_lds_total<HID, HIDC, CP>(S, bwd, k, raygrad) <= MNE_LDS_MAX) fit = k;
-    if (fit == 0) return 0;
-    const int want = (R + MNE_NUM_CU - 1) / MNE_NUM_CU;      // rays per CU for a single round
-    return want <= fit ? (want < 1 ? 1 : want) : fit;
+    for (int k = 1; k <= max_wpb; ++k)
+        if (tile_lds_total<HID, HIDC, CP>(bwd, k, raygrad) <= MNE_LDS_MAX) fit = k;
+    return fit;
+}
+
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+size_t mne_render_workspace(int R, int S) {
+    const size_t Spad = (size_t)((S + 3) & ~3);
+    return align16((size_t)R * RC_N * sizeof(float)) + align16((size_t)R * sizeof(int)) +
+           align16((size_t)(R + 1) * sizeof(int)) + align16((size_t)R * Spad * sizeof(unsigned short)) +
+           align16(((size_t)R * Spad / TILE + 2) * sizeof(int));
+}
+static void carve_workspace(RenderArgs& a, void* ws) {
+    unsigned char* p = (unsigned char*)ws;
+    const size_t Spad = (size_t)((a.S + 3) & ~3);
+    a.ray_ctx = (float*)p; p += align16((size_t)a.R * RC_N * sizeof(float));
+    a.ccount = (int*)p; p += align16((size_t)a.R * sizeof(int));
+    a.coffset = (int*)p; p += align16((size_t)(a.R + 1) * sizeof(int));
+    a.clist = (unsigned short*)p; p += align16((size_t)a.R * Spad * sizeof(unsigned short));
+    a.tile_ray = (int*)p;
 }
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
@@ -733,28 +864,50 @@ static int launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
 }
 
 template <int HID, int HIDC, bool CP>
-static int launch_render(RenderArgs a, int pass1, int bwd, hipStream_t st) {
+static int launch_render(RenderArgs a, int pass1, int bwd, void* workspace, hipStream_t st) {
     typedef WgShape<HID, HIDC, CP> W;
     const bool raygrad = a.d_rays_o != nullptr || a.d_rays_d != nullptr;
     if (raygrad && !(bwd && !pass1)) return -5;
-    a.rpw = choose_rpw<HID, HIDC, CP>(a.R, a.S, bwd != 0, raygrad);
-    if (a.rpw < 1) return -4;
-    const size_t lds = render_lds_total<HID, HIDC, CP>(a.S, bwd != 0, a.rpw, raygrad);
-    const int grid = (a.R + a.rpw - 1) / a.rpw;
-    if (lds > 64 * 1024) {          // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, false, W::ALDS>), MNE_LDS_MAX);
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, false, true, W::ALDS>), MNE_LDS_MAX);
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, true, true, W::ALDS>), MNE_LDS_MAX);
-        MNE_SET_MAX_LDS((render_kernel<HID, HIDC, CP, false, true, W::ALDS, true>), MNE_LDS_MAX);
+    if (!pass1 && !bwd) return -1;
+    if (pass1) {                                           // raw = decoder(points of every sample)
+        const int wpb = choose_wpb<HID, HIDC, CP>(false, false, MAX_WPB);
+        if (wpb < 1) return -4;
+        const size_t lds = tile_lds_total<HID, HIDC, CP>(false, wpb);
+        if (lds > 64 * 1024)        // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
+            MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS>), MNE_LDS_MAX);
+        const long long ntask = (long long)a.R * ((a.S + TILE - 1) / TILE);
+        long long grid = (ntask + wpb - 1) / wpb;
+        if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
+        MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS>), (unsigned)grid, 64 * wpb, lds, st, a);
+        a.raw_in = a.raw;
     }
-    if (raygrad) {
-        MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true, W::ALDS, true>), grid, 64 * a.rpw, lds, st, a);
+    const size_t clds = (size_t)4 * ((a.S + 3) & ~3) * 4 * sizeof(float);
+    if (clds > MNE_LDS_MAX) return -4;
+    if (clds > 64 * 1024) {
+        MNE_SET_MAX_LDS((composite_kernel<false>), MNE_LDS_MAX);
+        MNE_SET_MAX_LDS((composite_kernel<true>), MNE_LDS_MAX);
+    }
+    if (!bwd) {
+        MNE_LAUNCH((composite_kernel<false>), (a.R + 3) / 4, 256, clds, st, a);
         return 0;
     }
-    if (pass1 && !bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, false, W::ALDS>), grid, 64 * a.rpw, lds, st, a);
-    else if (!pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, false, true, W::ALDS>), grid, 64 * a.rpw, lds, st, a);
-    else if (pass1 && bwd) MNE_LAUNCH((render_kernel<HID, HIDC, CP, true, true, W::ALDS>), grid, 64 * a.rpw, lds, st, a);
-    else return -1;
+    if (!workspace) return -6;
+    carve_workspace(a, workspace);
+    MNE_LAUNCH((composite_kernel<true>), (a.R + 3) / 4, 256, clds, st, a);
+    MNE_LAUNCH(scan_kernel, 1, 1024, 0, st, a);
+    const int wpb = choose_wpb<HID, HIDC, CP>(true, raygrad, MAX_WPB_BWD);
+    if (wpb < 1) return -4;
+    const size_t lds = tile_lds_total<HID, HIDC, CP>(true, wpb, raygrad);
+    const long long ntile = ((long long)a.R * a.S + TILE - 1) / TILE;       // upper bound; the kernel reads the real count
+    long long grid = (ntile + wpb - 1) / wpb;
+    if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
+    if (raygrad) {
+        if (lds > 64 * 1024) MNE_SET_MAX_LDS((backward_kernel<HID, HIDC, CP, W::ALDS, true>), MNE_LDS_MAX);
+        MNE_LAUNCH((backward_kernel<HID, HIDC, CP, W::ALDS, true>), (unsigned)grid, 64 * wpb, lds, st, a);
+    } else {
+        if (lds > 64 * 1024) MNE_SET_MAX_LDS((backward_kernel<HID, HIDC, CP, W::ALDS, false>), MNE_LDS_MAX);
+        MNE_LAUNCH((backward_kernel<HID, HIDC, CP, W::ALDS, false>), (unsigned)grid, 64 * wpb, lds, st, a);
+    }
     return 0;
 }
 
@@ -781,8 +934,8 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
     return -2;
 }
 
-int mne_launch_render(const RenderArgs& a, int pass1, int bwd, hipStream_t st) {
-#define CALL(H, HC, CPV) return launch_render<H, HC, CPV>(a, pass1, bwd, st)
+int mne_launch_render(const RenderArgs& a, int pass1, int bwd, void* workspace, hipStream_t st) {
+#define CALL(H, HC, CPV) return launch_render<H, HC, CPV>(a, pass1, bwd, workspace, st)
     MNE_DISPATCH(a.sc, CALL, -2);
 #undef CALL
     return -2;
@@ -806,10 +959,8 @@ int mne_launch_loss_coef(const LossArgs& a, hipStream_t st) {
 }
 
 size_t mne_render_lds_bytes(const mne_scene_t& sc, int S, int bwd) {
-#define CALL(H, HC, CPV) return render_lds_total<H, HC, CPV>(S, bwd != 0, 1)
-    MNE_DISPATCH(sc, CALL, 0);
-#undef CALL
-    return 0;
+    (void)sc; (void)bwd;
+    return (size_t)4 * ((S + 3) & ~3) * 4 * sizeof(float);      // composite_kernel stages raw[S][4] of 4 rays
 }
 
 size_t mne_dims_packed(const mne_scene_t& sc) {

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     __shared__ unsigned short rowq[MNE_TILE][PASS_ENTRIES];                           // row queues of this pass
     __shared__ unsigned ents[PASS_ENTRIES][MNE_ENTRY_WORDS];                          // entries of this pass
     __shared__ int rowq_n[MNE_TILE];
-    const int tile = a.bins.order[blockIdx.x], tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int tile = a.bins.order[blockIdx.x];
     int pidx = 0;
     while (pidx + 1 < a.n_planes && tile >= a.bins.tile_base[pidx + 1]) ++pidx;
     const int set = pidx / 6, lvl = pidx % 2;                                 // [set][orient][level]

@@ -17,9 +17,17 @@ from . import _lib, hip_path, slam_glue
 from .optim import FusedAdam
 
 
+class _null_ctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 class FusedStep:
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
-                 tile_capacity=4096, spill_capacity=1 << 18, shared_decoder=False):
+                 tile_capacity=4096, spill_capacity=1 << 18, shared_decoder=False, overlap=True):
         """scatter="binned": plane gradients are accumulated per 16x16-cell tile in LDS and Adam is applied
         in the same kernel (csrc/tile_adam.hip; no gradient buffers).  scatter="atomics": global
         atomic adds into persistent gradient buffers + the streaming Adam kernel."""
@@ -69,6 +77,8 @@ class FusedStep:
         self.packed = e(self.lib.mne_packed_decoder_floats(C.byref(self.scene)))
         self.tape = e(R * S, self.lib.mne_tape_row_floats(C.byref(self.scene)))
         self.tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.ws_bytes = self.lib.mne_render_workspace_bytes(R, S)
+        self.ws = e(self.ws_bytes, dtype=torch.uint8)
         self.partials = e(self.lib.mne_wgrad_partial_floats(C.byref(self.scene)))
         self.dec_grad = e(self.lib.mne_decoder_param_floats(C.byref(self.scene)))
         co = config["is_co_sdf"] if is_co_sdf is None else is_co_sdf
@@ -104,16 +114,39 @@ class FusedStep:
                 o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
                 o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
         self.events = None          # set to {} to record HIP events around the two dominant launches
+        self.overlap = overlap
+        self._side, self._ev, self._prefetched = None, None, None
         self.iteration = 0
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
 
-    def step(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global=None, idx_cur=None, u=None):
-        """One mapping iteration.  kf_rays [*,7] / cur_rays [H*W,7] / poses [N,4,4] live on the device;
-        idx_global / idx_cur (int64 device tensors) and u [R,S] reproduce a host-RNG batch."""
-        lib, P, st = self.lib, _lib.ptr, _lib.stream_for(self.rays_o)
-        R, S = self.R, self.S
-        if n_global + n_cur != R:
-            raise ValueError(f"this FusedStep was built for {R} rays, got {n_global}+{n_cur}")
+    # ---------------------------------------------------------------- stream plumbing
+    def _streams(self):
+        """(main, side) as (torch stream, raw handle) pairs.  The plane update (tile_adam_kernel, HBM-bound)
+        and the decoder chain (weight-gradient MFMA pass -> reduce -> decoder Adam -> loss scalars ->
+        next batch's sampling) are independent after the backward kernel, so they run on two HIP
+        streams; with scatter="atomics", or on the host emulator, everything stays on one stream."""
+        main_h = _lib.stream_for(self.rays_o)
+        if not self.rays_o.is_cuda or self.bins is None or not self.overlap:
+            return (None, main_h), (None, main_h)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+            self._ev = [torch.cuda.Event() for _ in range(4)]
+        return (torch.cuda.current_stream(self.device), main_h), (self._side, C.c_void_p(self._side.cuda_stream))
+
+    @staticmethod
+    def _after(waiter, ev, producer):
+        """`waiter` stream continues only after everything enqueued so far on `producer`."""
+        if waiter is not None and producer is not None and waiter is not producer:
+            ev.record(producer)
+            waiter.wait_event(ev)
+
+    def _batch_key(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur):
+        return (None if kf_rays is None else kf_rays.data_ptr(), int(n_kf_rays), int(n_save), cur_rays.data_ptr(),
+                poses.data_ptr(), poses.shape[0], int(n_global), int(n_cur), self.iteration)
+
+    def _sample_batch(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st):
+        """R1-R3 for iteration `self.iteration`: ray batch, z samples (+ mask counts), loss coefficients."""
+        lib, P, R, S = self.lib, _lib.ptr, self.R, self.S
         _lib.check(lib.mne_sample_rays(P(kf_rays), int(n_kf_rays), int(n_save), None, P(cur_rays), cur_rays.shape[0],
                                        P(poses), poses.shape[0], n_global, n_cur, P(idx_global), P(idx_cur),
                                        self.seed, self.iteration, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb),
@@ -121,36 +154,73 @@ class FusedStep:
         _lib.check(lib.mne_sample_z(C.byref(self.rc), R, P(self.tgt_d), P(u), P(self.tables), self.seed,
                                     self.iteration * ((R * S + 3) // 4), P(self.z_vals), P(self.counts),
                                     P(self.ray_counts), st), "mne_sample_z")
-        _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
         _lib.check(lib.mne_loss_coef(C.byref(self.rc), R, S, P(self.counts), P(self.loss_w), P(self.coef), st),
                    "mne_loss_coef")
-        ev = self._mark("render")
+
+    def step(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global=None, idx_cur=None, u=None,
+             prefetch=False):
+        """One mapping iteration.  kf_rays [*,7] / cur_rays [H*W,7] / poses [N,4,4] live on the device;
+        idx_global / idx_cur (int64 device tensors) and u [R,S] reproduce a host-RNG batch.
+        prefetch=True promises that the NEXT call has the same ray sources and poses (the iterations of
+        one keyframe, mp_slam/mapper.py:133): its batch is then drawn on the side stream while this
+        iteration's plane update runs (device sampler only; the batch buffers rays_o/tgt_*/z_vals then
+        already hold the next batch when this call returns -- losses, rgb and depth are this iteration's)."""
+        lib, P = self.lib, _lib.ptr
+        R, S = self.R, self.S
+        if n_global + n_cur != R:
+            raise ValueError(f"this FusedStep was built for {R} rays, got {n_global}+{n_cur}")
+        (main, st), (side, st2) = self._streams()
+        ev = self._ev if side is not None else [None] * 4
+        host_batch = idx_global is not None or idx_cur is not None or u is not None
+        key = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
+        if host_batch or self._prefetched != key:
+            self._after(side, ev[0], main)                        # the caller's inputs were produced on `main`
+            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st2)
+        self._prefetched = None
+        # side stream so far: ... decoder Adam of the previous iteration -> this batch -> pack
+        _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st2), "mne_pack_decoder")
+        self._after(main, ev[1], side)
+        e0 = self._mark("render")
         _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
                                         P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals), P(self.packed), P(self.coef),
                                         P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape),
-                                        R * S, P(self.tape_rows), C.byref(self.bins) if self.bins is not None else None, st),
+                                        R * S, P(self.tape_rows), C.byref(self.bins) if self.bins is not None else None,
+                                        P(self.ws), self.ws_bytes, st),
                    "mne_render_fused")
-        self._mark("render", ev)
+        self._mark("render", e0)
+        self._after(side, ev[2], main)
+        # ---- decoder chain (side stream)
         _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), R * S, P(self.partials),
-                                         P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
-        if self.shared_decoder:
-            from . import dist as mdist
-            mdist.allreduce_mean_(self.dec_grad)
-        ev = self._mark("adam")
+                                         P(self.dec_grad), self.model.wgrad_impl, st2), "mne_decoder_wgrad")
         if self.bins is not None:
+            with (torch.cuda.stream(side) if side is not None else _null_ctx()):
+                if self.shared_decoder:
+                    from . import dist as mdist
+                    mdist.allreduce_mean_(self.dec_grad)
+                self.opt.step(zero_grad=False, grad_buffers=self.grad_map)      # decoder tensors
+            _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st2), "mne_loss_finalize")
+            # ---- plane update (main stream), concurrent with the chain above
             for k, p in enumerate(self.planes):
                 stt = self.opt._state(p)
                 stt["step"] += 1
                 self.plane_opt[k].step = stt["step"]
+            e0 = self._mark("adam")
             _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), st),
                        "mne_tile_adam")
-            self._mark("adam", ev)
-            self.opt.step(zero_grad=False, grad_buffers=self.grad_map)      # decoder tensors
+            self._mark("adam", e0)
         else:
+            if self.shared_decoder:
+                from . import dist as mdist
+                mdist.allreduce_mean_(self.dec_grad)
+            e0 = self._mark("adam")
             self.opt.step(zero_grad=True, grad_buffers=self.grad_map)
-            self._mark("adam", ev)
-        _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
+            self._mark("adam", e0)
+            _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st2), "mne_loss_finalize")
         self.iteration += 1
+        if prefetch and not host_batch and side is not None:
+            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st2)
+            self._prefetched = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
+        self._after(main, ev[3], side)                            # whatever the caller enqueues next sees both streams
 
     def _mark(self, name, start=None):
         """HIP events on the launch stream around one launch (bench.py's live kernel timing)."""

@@ -172,12 +172,15 @@ class RenderFunction(torch.autograd.Function):
         row = lib.mne_tape_row_floats(C.byref(sc))
         tape = torch.empty(R * S, row, **opts)
         tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        ws_bytes = lib.mne_render_workspace_bytes(R, S)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         _lib.check(lib.mne_render_backward(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d),
                                            _lib.ptr(tgt_rgb) if coef is not None else None,
                                            _lib.ptr(tgt_d), _lib.ptr(z_vals), _lib.ptr(packed), _lib.ptr(raw),
                                            _lib.ptr(coef), _lib.ptr(_f32c(g_rgb, "g_rgb")),
                                            _lib.ptr(_f32c(g_depth, "g_depth")), _lib.ptr(tape), R * S,
-                                           _lib.ptr(tape_rows), _lib.ptr(d_o), _lib.ptr(d_d), st), "mne_render_backward")
+                                           _lib.ptr(tape_rows), _lib.ptr(d_o), _lib.ptr(d_d), _lib.ptr(ws), ws_bytes, st),
+                   "mne_render_backward")
         nparam = lib.mne_decoder_param_floats(C.byref(sc))
         partials = torch.empty(lib.mne_wgrad_partial_floats(C.byref(sc)), **opts)
         dgrad = torch.empty(nparam, **opts)

@@ -117,13 +117,14 @@ class Mapper():
         cur = current_rays.to(self.device, torch.float32).contiguous()
         poses = poses.to(self.device, torch.float32).contiguous()
         n_pix = self.slam.dataset.H * self.slam.dataset.W
-        for _ in range(self.config["mapping"]["iters"]):
+        n_it = self.config["mapping"]["iters"]
+        for it in range(n_it):
             idx_g = idx_c = None
             if self.sampler == "host":                               # same draws, same order as the reference
                 idx_g = torch.tensor(random.sample(range(n_kf * kf.num_rays_to_save), n)).to(self.device)
                 idx_c = torch.tensor(random.sample(range(0, n_pix), n_cur)).to(self.device)
             fs.step(kf_rays, n_kf * kf.num_rays_to_save, kf.num_rays_to_save, cur, poses, n, n_cur,
-                    idx_global=idx_g, idx_cur=idx_c, u=self._jitter(fs))
+                    idx_global=idx_g, idx_cur=idx_c, u=self._jitter(fs), prefetch=it + 1 < n_it)
         self.last_losses = fs.loss_dict()
 
     def _first_frame_fused(self, batch, c2w, n_iters):
@@ -132,11 +133,11 @@ class Mapper():
         cur = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
         cur = cur.reshape(-1, 7).to(self.device, torch.float32).contiguous()
         poses = c2w.reshape(1, 4, 4).to(torch.float32).contiguous()
-        for _ in range(n_iters):
+        for it in range(n_iters):
             idx_c = None
             if self.sampler == "host":
                 ind = self.slam.select_samples(H, W, n)
                 # the reference indexes [H,W] images with (ind % H, ind // H)  (mp_slam/mapper.py:76-77)
                 idx_c = ((ind % H) * W + torch.div(ind, H, rounding_mode="trunc")).to(self.device)
-            fs.step(None, 0, 1, cur, poses, 0, n, idx_cur=idx_c, u=self._jitter(fs))
+            fs.step(None, 0, 1, cur, poses, 0, n, idx_cur=idx_c, u=self._jitter(fs), prefetch=it + 1 < n_iters)
         self.last_losses = fs.loss_dict()
