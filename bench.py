@@ -88,7 +88,8 @@ class Agent:
         self.fused = None
         if path == "fused":
             self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device,
-                                   scatter=scatter, shared_decoder=share_decoder)
+                                   scatter=scatter, shared_decoder=share_decoder,
+                                   overlap=os.environ.get("MNE_NO_OVERLAP", "0") != "1")
             self.fused.seed = seed
 
     def sample_rays(self):

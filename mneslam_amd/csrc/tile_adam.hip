@@ -29,24 +29,43 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
 // NW corner relative to the tile (+1, so 0 means "one cell before the tile") and the four bilinear
 // weights (0 for corners outside the plane).  The tile kernel therefore does no coordinate math.
 //
-// LDS fp32 atomics (ds_add_f32) measured ~0.25 op/clk/CU here (profiles/r01_ablation_tile_adam.txt), so
-// the accumulation avoids them: per pass of PASS_ENTRIES list entries the workgroup first copies the
-// entries into LDS and files each into the queues of the (at most two) tile rows it touches (integer
-// LDS counters only); then every half-wave owns one tile row (or half of one), lane = channel, and
-// applies its row queue with plain read-add-write: single owner, DS operations of a wave complete in
-// order.  The gradient-row loads of QB queue items are issued together.
+// Accumulation (per pass of PASS_ENTRIES list entries).  Heavy tiles are the critical path of the launch,
+// and their entries are concentrated: a wall or the floor projects onto a LINE of cells of the planes
+// it is perpendicular to, so a whole pass may hit one or two cell rows.  Work is therefore split by
+// CONTRIBUTION, not by position:
+//   A  every entry is copied to LDS and its (up to) four corner contributions are ranked per cell with
+//      integer LDS counters (counting sort by cell, 256 keys);
+//   B  one wave turns the counts into start offsets;  C  the contributions are written in cell order;
+//   (meanwhile every entry's gradient row -- 32 floats of this plane level -- is fetched from the tape
+//   into LDS exactly once, all loads of the pass in flight together: corner-level work would otherwise
+//   read each row four times, and these reads compete with the Adam stream for HBM/Infinity-Cache)
+//   D  the sorted array is cut into TILE_HW equal ranges, one per half-wave (lane = channel): each
+//      walks its range reading rows from LDS, sums runs of equal cells in a register and
+//      adds a finished run to the LDS tile -- with a plain read-add-write when the run lies strictly
+//      inside the range (nobody else touches that cell in this pass), with ds_add_f32 for the first and
+//      last run of a range, which may continue in the neighbouring ranges.
+// Every half-wave thus handles the same number of contributions whatever their spatial distribution.
 #ifndef TILE_THREADS
 #define TILE_THREADS 512
 #endif
 #ifndef PASS_ENTRIES
 #define PASS_ENTRIES 256
 #endif
-#ifndef QB
-#define QB 8
+// -DTILE_PROFILE (experiments only, profiles/tile_phase_times.py): thread 0 of the first 4096 workgroups
+// stamps the constant 100 MHz clock at the phase boundaries into the unused tail of the spill area.
+#ifdef TILE_PROFILE
+#define TILE_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096) \
+    ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 8192) * MNE_SPILL_WORDS))[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TILE_STAMP(k) do { } while (0)
 #endif
-#define TILE_HW (TILE_THREADS / 32)           // half-waves: 16 rows x TILE_SIDES
-#define TILE_SIDES (TILE_HW / MNE_TILE)
-#define SIDE_CELLS (MNE_TILE / TILE_SIDES)
+#ifndef DB
+#define DB 8
+#endif
+#define TILE_HW (TILE_THREADS / 32)           // half-waves
+#define TILE_CELLS (MNE_TILE * MNE_TILE)
+static_assert(PASS_ENTRIES <= TILE_THREADS && PASS_ENTRIES <= 1024 && PASS_ENTRIES % TILE_HW == 0, "one staged entry per thread; item index must fit 10 bits");
+static_assert(TILE_CELLS == 256, "the prefix step assumes 4 cells per lane of one wave");
 
 // Processing order: tiles bucketed by floor(log2(list length + 1)), heaviest bucket first, so the few
 // very long lists (every ray of a keyframe passes through the tile holding its camera centre) start
@@ -67,11 +86,15 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
 }
 
 __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a) {
-    __shared__ __attribute__((aligned(16))) float g[MNE_TILE * MNE_TILE * MNE_C];     // 32 KiB gradient tile
-    __shared__ unsigned short rowq[MNE_TILE][PASS_ENTRIES];                           // row queues of this pass
+    MNE_DYN_LDS(lds_raw);
+    float* g = (float*)lds_raw;                                   // [16][16][32] gradient tile, 32 KiB
+    float* stage = g + TILE_CELLS * MNE_C;                        // [PASS_ENTRIES][32] gradient rows of this pass
     __shared__ unsigned ents[PASS_ENTRIES][MNE_ENTRY_WORDS];                          // entries of this pass
-    __shared__ int rowq_n[MNE_TILE];
+    __shared__ unsigned short sorted[PASS_ENTRIES * 4];                               // contributions in cell order
+    __shared__ int hist[TILE_CELLS];                                                  // counts, then start offsets
+    __shared__ int n_contrib;
     const int tid = threadIdx.x;
+    TILE_STAMP(0);
     const int tile = a.bins.order[blockIdx.x];
     int pidx = 0;
     while (pidx + 1 < a.n_planes && tile >= a.bins.tile_base[pidx + 1]) ++pidx;
@@ -79,7 +102,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     const mne_plane_t& pl = a.sc.plane[set][(pidx % 6) / 2][lvl];
     const int local = tile - a.bins.tile_base[pidx];
     const int tx0 = local % a.bins.ntx[pidx], ty0 = local / a.bins.ntx[pidx];
-    for (int i = tid; i < MNE_TILE * MNE_TILE * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int cnt = a.bins.counts[tile];
     const int n_list = (a.dbg & 32) ? 0 : (cnt < a.bins.cap ? cnt : a.bins.cap);
     int n_spill = 0;
@@ -89,60 +112,122 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     }
     const unsigned* lst = a.bins.lists + (size_t)tile * a.bins.cap * MNE_ENTRY_WORDS;
     const int c = tid & 31, hw = tid >> 5;
-    const int my_row = hw / TILE_SIDES, my_lo = (hw % TILE_SIDES) * SIDE_CELLS;   // cells [my_lo, my_lo+SIDE_CELLS) of my_row
-    // passes over the list, then over the spill area (spill entries of other tiles are skipped when filing)
+    const float* dfeat = a.tape + a.t_dfeat + set * MNE_FEAT + lvl * MNE_C + c;
+    // passes over the list, then over the spill area (spill entries of other tiles contribute nothing)
     const int n_total = n_list + n_spill;
+    TILE_STAMP(1);
     for (int p0 = 0; p0 < n_total; p0 += PASS_ENTRIES) {
-        if (tid < MNE_TILE) rowq_n[tid] = 0;
+        for (int i = tid; i < TILE_CELLS; i += TILE_THREADS) hist[i] = 0;
         __syncthreads();
-        const int p1 = p0 + PASS_ENTRIES < n_total ? p0 + PASS_ENTRIES : n_total;
-        for (int e = p0 + tid; e < p1; e += TILE_THREADS) {
-            const unsigned* ent;
+        if (p0 == 0) TILE_STAMP(2);
+        // ---- A: stage this thread's entry, rank its contributions per cell
+        int cellk[4] = {-1, -1, -1, -1}, rank[4] = {0, 0, 0, 0};
+        const int e = p0 + tid;
+        if (tid < PASS_ENTRIES) ents[tid][0] = 0xffffffffu;                  // "no entry staged in this slot"
+        if (tid < PASS_ENTRIES && e < n_total) {
+            const unsigned* ent = nullptr;
             if (e < n_list) ent = lst + (size_t)e * MNE_ENTRY_WORDS;
             else {
                 const unsigned* sp = a.bins.spill + (size_t)(e - n_list) * MNE_SPILL_WORDS;
-                if (sp[0] != (unsigned)tile) continue;
-                ent = sp + 1;
+                if (sp[0] == (unsigned)tile) ent = sp + 1;
             }
-            const unsigned short item = (unsigned short)(e - p0);
+            if (ent) {
+                unsigned wds[MNE_ENTRY_WORDS];
 #pragma unroll
-            for (int w = 0; w < MNE_ENTRY_WORDS; ++w) ents[item][w] = ent[w];
-            const int ly = (int)((ent[1] >> 8) & 0xff) - 1;
-            if (ly >= 0) rowq[ly][atomicAdd(&rowq_n[ly], 1)] = item;
-            if (ly + 1 < MNE_TILE) rowq[ly + 1][atomicAdd(&rowq_n[ly + 1], 1)] = item;
-        }
-        __syncthreads();
-        const int nq = rowq_n[my_row];
-        float* grow = g + my_row * MNE_TILE * MNE_C + c;
-        for (int q0 = 0; q0 < nq; q0 += QB) {
-            unsigned hdr[QB];
-            float w0[QB], w1[QB], gc[QB];
+                for (int w = 0; w < MNE_ENTRY_WORDS; ++w) { wds[w] = ent[w]; ents[tid][w] = wds[w]; }
+                const int lx = (int)(wds[1] & 0xff) - 1, ly = (int)((wds[1] >> 8) & 0xff) - 1;
 #pragma unroll
-            for (int j = 0; j < QB; ++j) {
-                const unsigned* ent = ents[rowq[my_row][q0 + j < nq ? q0 + j : q0]];
-                hdr[j] = ent[1];
-                const bool bottom = ((int)((hdr[j] >> 8) & 0xff) - 1) != my_row;     // this row is the footprint's lower row
-                w0[j] = __uint_as_float(ent[bottom ? 4 : 2]);
-                w1[j] = __uint_as_float(ent[bottom ? 5 : 3]);
-                gc[j] = (a.dbg & 256) ? 1.0f : a.tape[(size_t)ent[0] * a.row_stride + a.t_dfeat + set * MNE_FEAT + lvl * MNE_C + c];
-            }
-#pragma unroll
-            for (int j = 0; j < QB; ++j) {
-                if (q0 + j < nq) {
-                    const int lx = (int)(hdr[j] & 0xff) - 1;
-                    if (lx >= my_lo && lx < my_lo + SIDE_CELLS && w0[j] != 0.0f) grow[lx * MNE_C] += gc[j] * w0[j];
-                    if (lx + 1 >= my_lo && lx + 1 < my_lo + SIDE_CELLS && w1[j] != 0.0f) grow[(lx + 1) * MNE_C] += gc[j] * w1[j];
+                for (int q = 0; q < 4; ++q) {
+                    const int x = lx + (q & 1), y = ly + (q >> 1);
+                    if (x >= 0 && x < MNE_TILE && y >= 0 && y < MNE_TILE && __uint_as_float(wds[2 + q]) != 0.0f) {
+                        cellk[q] = y * MNE_TILE + x;
+                        rank[q] = atomicAdd(&hist[cellk[q]], 1);
+                    }
                 }
             }
         }
         __syncthreads();
+        if (p0 == 0) TILE_STAMP(3);
+        // ---- every entry's gradient row (this plane level: 32 floats) is fetched ONCE per pass, by the
+        // half-waves round-robin, all loads in flight together; its (up to four) corner contributions
+        // then read it from LDS.  The loads overlap steps B and C.
+        float grow[PASS_ENTRIES / TILE_HW];
+#pragma unroll
+        for (int j = 0; j < PASS_ENTRIES / TILE_HW; ++j) {
+            const unsigned row = ents[j * TILE_HW + hw][0];
+            grow[j] = (row != 0xffffffffu && !(a.dbg & 256)) ? dfeat[(size_t)row * a.row_stride] : 1.0f;
+        }
+        // ---- B: counts -> exclusive start offsets (one wave, 4 cells per lane)
+        if (tid < MNE_WAVE) {
+            const int v0 = hist[4 * tid], v1 = hist[4 * tid + 1], v2 = hist[4 * tid + 2], v3 = hist[4 * tid + 3];
+            const int sum = v0 + v1 + v2 + v3;
+            int inc = sum;
+#pragma unroll
+            for (int d = 1; d < MNE_WAVE; d <<= 1) {
+                const int up = __shfl_up(inc, d);
+                if (tid >= d) inc += up;
+            }
+            const int ex = inc - sum;
+            hist[4 * tid] = ex; hist[4 * tid + 1] = ex + v0; hist[4 * tid + 2] = ex + v0 + v1; hist[4 * tid + 3] = ex + v0 + v1 + v2;
+            if (tid == MNE_WAVE - 1) n_contrib = inc;
+        }
+        __syncthreads();
+        // ---- C: contributions in cell order: item | corner << 10
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (cellk[q] >= 0) sorted[hist[cellk[q]] + rank[q]] = (unsigned short)(tid | (q << 10));
+#pragma unroll
+        for (int j = 0; j < PASS_ENTRIES / TILE_HW; ++j) stage[(j * TILE_HW + hw) * MNE_C + c] = grow[j];
+        __syncthreads();
+        if (p0 == 0) TILE_STAMP(4);
+        // ---- D: equal ranges of the sorted contributions, one per half-wave
+        const int nC = n_contrib;
+        const int chunk = (nC + TILE_HW - 1) / TILE_HW;
+        const int b0 = hw * chunk, b1 = b0 + chunk < nC ? b0 + chunk : nC;
+        int cur = -1, runs_done = 0;
+        float acc = 0.0f;
+        for (int q0 = b0; q0 < b1; q0 += DB) {
+            // the three dependent LDS reads (key -> entry -> row) of DB contributions are issued as three
+            // independent groups, then the run logic consumes them in order
+            unsigned key[DB], hdr[DB];
+            float wt[DB], gv[DB];
+#pragma unroll
+            for (int j = 0; j < DB; ++j) key[j] = sorted[q0 + j < b1 ? q0 + j : b1 - 1];
+#pragma unroll
+            for (int j = 0; j < DB; ++j) {
+                const unsigned* ent = ents[key[j] & 1023u];
+                hdr[j] = ent[1];
+                wt[j] = __uint_as_float(ent[2 + (key[j] >> 10)]);
+                gv[j] = stage[(key[j] & 1023u) * MNE_C + c];
+            }
+#pragma unroll
+            for (int j = 0; j < DB; ++j) {
+                if (q0 + j < b1) {
+                    const int cn = (int)(key[j] >> 10);
+                    const int cell = ((int)((hdr[j] >> 8) & 0xff) - 1 + (cn >> 1)) * MNE_TILE + (int)(hdr[j] & 0xff) - 1 + (cn & 1);
+                    if (cell != cur) {
+                        if (cur >= 0) {                                   // a finished run
+                            if (runs_done == 0) atomicAdd(&g[cur * MNE_C + c], acc);       // may have begun in the previous range
+                            else g[cur * MNE_C + c] += acc;
+                            ++runs_done;
+                        }
+                        cur = cell;
+                        acc = 0.0f;
+                    }
+                    acc = fmaf(gv[j], wt[j], acc);
+                }
+            }
+        }
+        if (cur >= 0) atomicAdd(&g[cur * MNE_C + c], acc);                 // may continue in the next range
+        __syncthreads();
     }
     __syncthreads();
+    TILE_STAMP(5);
     // ---- Adam on the tile: 16 rows x (16 cells x 32 ch) = 2048 float4
     const PlaneOpt& o = a.opt[pidx];
     float* P = (float*)pl.data;
 #pragma unroll
-    for (int it = 0; it < (MNE_TILE * MNE_TILE * MNE_C / 4) / TILE_THREADS; ++it) {
+    for (int it = 0; it < (TILE_CELLS * MNE_C / 4) / TILE_THREADS; ++it) {
         if (a.dbg & 64) break;
         const int i4 = it * TILE_THREADS + tid;
         const int y = i4 / (MNE_TILE * MNE_C / 4), x4 = i4 % (MNE_TILE * MNE_C / 4);
@@ -157,6 +242,11 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
             *(float4*)(P + off) = p; *(float4*)(o.m + off) = m; *(float4*)(o.v + off) = v;
         }
     }
+    TILE_STAMP(6);
+#ifdef TILE_PROFILE
+    if (tid == 0 && blockIdx.x < 4096)
+        ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 8192) * MNE_SPILL_WORDS))[blockIdx.x * 8 + 7] = (unsigned long long)cnt;
+#endif
     if (tid == 0) a.bins.counts[tile] = 0;                                     // ready for the next iteration
 }
 
@@ -179,6 +269,8 @@ int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st) {
     const int n_tiles = a.bins.tile_base[a.n_planes];
     if (n_tiles <= 0) return 0;
     MNE_LAUNCH(tile_order_kernel, 1, 1024, 0, st, a, n_tiles);
-    MNE_LAUNCH(tile_adam_kernel, n_tiles, TILE_THREADS, 0, st, a);
+    const size_t lds = (size_t)(TILE_CELLS + PASS_ENTRIES) * MNE_C * sizeof(float);
+    if (lds > 32 * 1024) MNE_SET_MAX_LDS(tile_adam_kernel, lds);        // static LDS (entries, keys, counters) comes on top
+    MNE_LAUNCH(tile_adam_kernel, n_tiles, TILE_THREADS, lds, st, a);
     return 0;
 }
