@@ -211,18 +211,24 @@ def main():
         S = cfg["training"]["n_range_d"] + cfg["training"]["n_samples_d"]
         R = cfg["mapping"]["sample"] + agent.n_cur
         n_par = agent.n_plane_params + agent.n_dec_params
-        # algorithmic bytes per launch (stated in DESIGN.md):
-        #   adam   : 32 B/param = read p,g,m,v + write p,m,v + zero g
-        #   render : gather + scatter of every sample, G = 6 planes x 4 corners x 32 ch x 4 B per set
+        # algorithmic bytes per launch = SURVEY.md section 8d's per-unit figures x the units the launch processes
+        # (both stated in DESIGN.md):  G = planes x 4 corners x 32 ch x 4 B per point per gather or scatter pass,
+        # 32 B per parameter per optimiser sweep (the reference's read p,g,m,v + write p,m,v + zero g).
+        #   tile_adam_kernel      : scatter of the P' contributing samples (tape rows, read back live) + the sweep
+        #   mne_render_fused call : forward gather of all R*S samples (decode_kernel) + the backward's re-gather of P'
+        #   atomics variant       : adam_kernel = the sweep; the render call also scatters (atomics)
         G = 3072.0 * (1 if cfg["grid"]["oneGrid"] else 2)
         binned = agent.fused is not None and agent.fused.bins is not None
-        if binned:      # gather in the render kernel; scatter + Adam (no gradient buffer) in tile_adam_kernel
-            alg = {"adam": R * S * G + 32.0 * n_par, "render": 1.0 * R * S * G}
-            kern = {"adam": "tile_adam_kernel (binned scatter + Adam)", "render": "render_kernel<pass1,bwd> (fused forward+backward)"}
+        p_contrib = float(agent.fused.tape_rows.item()) if agent.fused is not None else float(R * S)
+        if binned:
+            alg = {"adam": p_contrib * G + 32.0 * n_par, "render": (R * S + p_contrib) * G}
+            kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)",
+                    "render": "decode_kernel + composite_kernel + scan_kernel + backward_kernel (one mne_render_fused call)"}
         else:
-            alg = {"adam": 32.0 * n_par, "render": 2.0 * R * S * G}
-            kern = {"adam": "adam_kernel", "render": "render_kernel<pass1,bwd> (fused forward+backward)"}
-        dom = max(avg_ms, key=avg_ms.get) if avg_ms else "adam"
+            alg = {"adam": 32.0 * n_par, "render": (R * S + 2.0 * p_contrib) * G}
+            kern = {"adam": "adam_kernel (planes + decoder, one launch)",
+                    "render": "decode_kernel + composite_kernel + scan_kernel + backward_kernel (one mne_render_fused call, atomic scatter)"}
+        dom = "adam" if "adam" in avg_ms else (max(avg_ms, key=avg_ms.get) if avg_ms else "adam")
         dom_ms = avg_ms.get(dom, 0.0)
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM traffic of the same kernel from committed PMC passes (rocprofv3 cannot run inside the timed loop)
@@ -249,6 +255,8 @@ def main():
             "roofline": {"kernel": kern[dom], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms,
+                         "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms > 0) else None,
+                         "contributing_samples_last_iter": p_contrib,
                          "other_kernels_avg_ms": {kern[k]: v for k, v in avg_ms.items() if k != dom},
                          "other_kernels_algorithmic_bytes": {kern[k]: alg[k] for k in alg if k != dom},
                          "iteration_algorithmic_bytes": alg["adam"] + alg["render"],

@@ -224,6 +224,9 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
  * (mneslam_mp.py:459-469) with no gradient buffer and no global atomics.  opt[] has 6*n_sets entries.
  * *tape_rows is written by mne_render_fused itself in every mode. */
 size_t mne_tile_count(const mne_scene_t* scene);
+/* Processing order of the tiles for the next mne_tile_adam call (bins->order): longest lists first, so the
+ * few very long lists do not form the tail of the launch.  Call after mne_render_fused, before mne_tile_adam. */
+int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* stream);
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
                   const mne_tile_bins_t* bins, void* stream);
 

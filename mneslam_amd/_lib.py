@@ -82,6 +82,7 @@ _PROTOS = {
     "mne_render_fused": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 12
                          + [C.c_int64, C.c_void_p, C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
+    "mne_tile_order": (C.c_int, [C.POINTER(Scene), C.POINTER(TileBins), C.c_void_p]),
     "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.c_void_p]),
     "mne_sample_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 6),

@@ -230,6 +230,18 @@ size_t mne_tile_count(const mne_scene_t* scene) {
     return (size_t)b.tile_base[scene->n_sets * 6];
 }
 
+int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* stream) {
+    if (int rc = check_scene(scene, false)) return rc;
+    if (!bins || !bins->counts || !bins->order) return fail(-1, "mne_tile_order: NULL argument");
+    TileAdamArgs a = {};
+    a.sc = *scene;
+    a.n_planes = scene->n_sets * 6;
+    a.bins.counts = bins->counts; a.bins.order = bins->order;
+    mne_tile_geometry(*scene, a.bins);
+    mne_launch_tile_order(a, (hipStream_t)stream);
+    return check_launch("tile_order");
+}
+
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
                   const mne_tile_bins_t* bins, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;

@@ -149,6 +149,7 @@ int mne_launch_loss_coef(const LossArgs& a, hipStream_t st);
 int mne_launch_wgrad(const mne_scene_t& sc, WgradArgs a, int impl, hipStream_t st);
 int mne_launch_adam(const AdamArgs& a, hipStream_t st);
 int mne_launch_grid(const GridArgs& a, int bwd, hipStream_t st);
+int mne_launch_tile_order(const TileAdamArgs& a, hipStream_t st);
 int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st);
 void mne_tile_geometry(const mne_scene_t& sc, TileBins& b);
 int mne_launch_sample_rays(SampleRaysArgs a, unsigned long long seed, unsigned long long iteration, hipStream_t st);

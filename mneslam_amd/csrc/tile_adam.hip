@@ -39,12 +39,12 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
 //   (meanwhile every entry's gradient row -- 32 floats of this plane level -- is fetched from the tape
 //   into LDS exactly once, all loads of the pass in flight together: corner-level work would otherwise
 //   read each row four times, and these reads compete with the Adam stream for HBM/Infinity-Cache)
-//   D  the sorted array is cut into TILE_HW equal ranges, one per half-wave (lane = channel): each
-//      walks its range reading rows from LDS, sums runs of equal cells in a register and
-//      adds a finished run to the LDS tile -- with a plain read-add-write when the run lies strictly
-//      inside the range (nobody else touches that cell in this pass), with ds_add_f32 for the first and
-//      last run of a range, which may continue in the neighbouring ranges.
-// Every half-wave thus handles the same number of contributions whatever their spatial distribution.
+//   D  the sorted array is cut into TILE_GROUPS equal ranges, one per 8-lane group (float4 per lane = the
+//      32 channels of a row; the walk is VALU-issue-bound, so 8 contributions per wave instruction
+//      instead of 2): each walks its range reading rows from LDS, sums runs of equal cells in registers and
+//      adds a finished run to the LDS tile with a plain read-add-write: a run belongs to the group in
+//      whose range it starts, so every cell has a single writer per pass and no LDS atomics are needed.
+// Every group thus handles the same number of contributions whatever their spatial distribution.
 #ifndef TILE_THREADS
 #define TILE_THREADS 512
 #endif
@@ -62,9 +62,9 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
 #ifndef DB
 #define DB 8
 #endif
-#define TILE_HW (TILE_THREADS / 32)           // half-waves
+#define TILE_GROUPS (TILE_THREADS / 8)        // 8-lane groups (float4 per lane = one 32-channel row)
 #define TILE_CELLS (MNE_TILE * MNE_TILE)
-static_assert(PASS_ENTRIES <= TILE_THREADS && PASS_ENTRIES <= 1024 && PASS_ENTRIES % TILE_HW == 0, "one staged entry per thread; item index must fit 10 bits");
+static_assert(PASS_ENTRIES <= TILE_THREADS && PASS_ENTRIES <= 256 && PASS_ENTRIES % TILE_GROUPS == 0, "one staged entry per thread; item index must fit 8 bits");
 static_assert(TILE_CELLS == 256, "the prefix step assumes 4 cells per lane of one wave");
 
 // Processing order: tiles bucketed by floor(log2(list length + 1)), heaviest bucket first, so the few
@@ -89,9 +89,10 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     MNE_DYN_LDS(lds_raw);
     float* g = (float*)lds_raw;                                   // [16][16][32] gradient tile, 32 KiB
     float* stage = g + TILE_CELLS * MNE_C;                        // [PASS_ENTRIES][32] gradient rows of this pass
-    __shared__ unsigned ents[PASS_ENTRIES][MNE_ENTRY_WORDS];                          // entries of this pass
-    __shared__ unsigned short sorted[PASS_ENTRIES * 4];                               // contributions in cell order
-    __shared__ int hist[TILE_CELLS];                                                  // counts, then start offsets
+    __shared__ unsigned erow[PASS_ENTRIES];                       // tape row of each staged entry (~0u: slot unused)
+    __shared__ unsigned short skey[PASS_ENTRIES * 4];             // contributions in cell order: cell << 8 | item
+    __shared__ float swt[PASS_ENTRIES * 4];                       //   ... and their bilinear weights
+    __shared__ int hist[TILE_CELLS];                              // per-cell counts, then start offsets
     __shared__ int n_contrib;
     const int tid = threadIdx.x;
     TILE_STAMP(0);
@@ -111,8 +112,9 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
         n_spill = ns < a.bins.spill_cap ? ns : a.bins.spill_cap;
     }
     const unsigned* lst = a.bins.lists + (size_t)tile * a.bins.cap * MNE_ENTRY_WORDS;
-    const int c = tid & 31, hw = tid >> 5;
-    const float* dfeat = a.tape + a.t_dfeat + set * MNE_FEAT + lvl * MNE_C + c;
+    // lane layout of the row work: 8 lanes x float4 = the 32 channels of one gradient row
+    const int sub = tid & 7, grp = tid >> 3;
+    const float* dfeat = a.tape + a.t_dfeat + set * MNE_FEAT + lvl * MNE_C + sub * 4;
     // passes over the list, then over the spill area (spill entries of other tiles contribute nothing)
     const int n_total = n_list + n_spill;
     TILE_STAMP(1);
@@ -120,42 +122,47 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
         for (int i = tid; i < TILE_CELLS; i += TILE_THREADS) hist[i] = 0;
         __syncthreads();
         if (p0 == 0) TILE_STAMP(2);
-        // ---- A: stage this thread's entry, rank its contributions per cell
+        // ---- A: this thread's entry (kept in registers), its contributions ranked per cell
         int cellk[4] = {-1, -1, -1, -1}, rank[4] = {0, 0, 0, 0};
+        float wq[4] = {0.f, 0.f, 0.f, 0.f};
         const int e = p0 + tid;
-        if (tid < PASS_ENTRIES) ents[tid][0] = 0xffffffffu;                  // "no entry staged in this slot"
-        if (tid < PASS_ENTRIES && e < n_total) {
+        if (tid < PASS_ENTRIES) {
+            unsigned row = 0xffffffffu;
             const unsigned* ent = nullptr;
             if (e < n_list) ent = lst + (size_t)e * MNE_ENTRY_WORDS;
-            else {
+            else if (e < n_total) {
                 const unsigned* sp = a.bins.spill + (size_t)(e - n_list) * MNE_SPILL_WORDS;
                 if (sp[0] == (unsigned)tile) ent = sp + 1;
             }
             if (ent) {
                 unsigned wds[MNE_ENTRY_WORDS];
 #pragma unroll
-                for (int w = 0; w < MNE_ENTRY_WORDS; ++w) { wds[w] = ent[w]; ents[tid][w] = wds[w]; }
+                for (int w = 0; w < MNE_ENTRY_WORDS; ++w) wds[w] = ent[w];
+                row = wds[0];
                 const int lx = (int)(wds[1] & 0xff) - 1, ly = (int)((wds[1] >> 8) & 0xff) - 1;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int x = lx + (q & 1), y = ly + (q >> 1);
-                    if (x >= 0 && x < MNE_TILE && y >= 0 && y < MNE_TILE && __uint_as_float(wds[2 + q]) != 0.0f) {
+                    wq[q] = __uint_as_float(wds[2 + q]);
+                    if (x >= 0 && x < MNE_TILE && y >= 0 && y < MNE_TILE && wq[q] != 0.0f) {
                         cellk[q] = y * MNE_TILE + x;
                         rank[q] = atomicAdd(&hist[cellk[q]], 1);
                     }
                 }
             }
+            erow[tid] = row;
         }
         __syncthreads();
         if (p0 == 0) TILE_STAMP(3);
         // ---- every entry's gradient row (this plane level: 32 floats) is fetched ONCE per pass, by the
-        // half-waves round-robin, all loads in flight together; its (up to four) corner contributions
+        // 8-lane groups round-robin, all loads in flight together; its (up to four) corner contributions
         // then read it from LDS.  The loads overlap steps B and C.
-        float grow[PASS_ENTRIES / TILE_HW];
+        float4 grow[PASS_ENTRIES / TILE_GROUPS];
 #pragma unroll
-        for (int j = 0; j < PASS_ENTRIES / TILE_HW; ++j) {
-            const unsigned row = ents[j * TILE_HW + hw][0];
-            grow[j] = (row != 0xffffffffu && !(a.dbg & 256)) ? dfeat[(size_t)row * a.row_stride] : 1.0f;
+        for (int j = 0; j < PASS_ENTRIES / TILE_GROUPS; ++j) {
+            const unsigned row = erow[j * TILE_GROUPS + grp];
+            grow[j] = (row != 0xffffffffu && !(a.dbg & 256)) ? *(const float4*)(dfeat + (size_t)row * a.row_stride)
+                                                             : make_float4(1.f, 1.f, 1.f, 1.f);
         }
         // ---- B: counts -> exclusive start offsets (one wave, 4 cells per lane)
         if (tid < MNE_WAVE) {
@@ -172,53 +179,72 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
             if (tid == MNE_WAVE - 1) n_contrib = inc;
         }
         __syncthreads();
-        // ---- C: contributions in cell order: item | corner << 10
+        // ---- C: contribution records in cell order
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (cellk[q] >= 0) sorted[hist[cellk[q]] + rank[q]] = (unsigned short)(tid | (q << 10));
-#pragma unroll
-        for (int j = 0; j < PASS_ENTRIES / TILE_HW; ++j) stage[(j * TILE_HW + hw) * MNE_C + c] = grow[j];
-        __syncthreads();
-        if (p0 == 0) TILE_STAMP(4);
-        // ---- D: equal ranges of the sorted contributions, one per half-wave
-        const int nC = n_contrib;
-        const int chunk = (nC + TILE_HW - 1) / TILE_HW;
-        const int b0 = hw * chunk, b1 = b0 + chunk < nC ? b0 + chunk : nC;
-        int cur = -1, runs_done = 0;
-        float acc = 0.0f;
-        for (int q0 = b0; q0 < b1; q0 += DB) {
-            // the three dependent LDS reads (key -> entry -> row) of DB contributions are issued as three
-            // independent groups, then the run logic consumes them in order
-            unsigned key[DB], hdr[DB];
-            float wt[DB], gv[DB];
-#pragma unroll
-            for (int j = 0; j < DB; ++j) key[j] = sorted[q0 + j < b1 ? q0 + j : b1 - 1];
-#pragma unroll
-            for (int j = 0; j < DB; ++j) {
-                const unsigned* ent = ents[key[j] & 1023u];
-                hdr[j] = ent[1];
-                wt[j] = __uint_as_float(ent[2 + (key[j] >> 10)]);
-                gv[j] = stage[(key[j] & 1023u) * MNE_C + c];
+            if (cellk[q] >= 0) {
+                const int pos = hist[cellk[q]] + rank[q];
+                skey[pos] = (unsigned short)((cellk[q] << 8) | tid);
+                swt[pos] = wq[q];
             }
 #pragma unroll
+        for (int j = 0; j < PASS_ENTRIES / TILE_GROUPS; ++j) *(float4*)(stage + (j * TILE_GROUPS + grp) * MNE_C + sub * 4) = grow[j];
+        __syncthreads();
+        if (p0 == 0) TILE_STAMP(4);
+        // ---- D: equal ranges of the sorted contributions, one per 8-lane group; a run of equal cells is
+        // summed by the group in whose range it STARTS (that group reads on past its range end, the next
+        // one skips to the end of the run using the start offsets), so the LDS tile is only ever
+        // updated with plain read-add-write by a single owner.  (ds_add_f32 is very slow here: with
+        // atomic boundary runs this step took 3x longer -- profiles/r01_tile_adam_phases.txt.)
+        const int nC = n_contrib;
+        const int chunk = (nC + TILE_GROUPS - 1) / TILE_GROUPS;
+        const int b0 = grp * chunk, b1 = b0 + chunk < nC ? b0 + chunk : nC;
+        int q0 = b0;
+        if (b0 > 0 && b0 < nC) {
+            const int pc = (int)(skey[b0 - 1] >> 8);
+            q0 = pc == TILE_CELLS - 1 ? nC : hist[pc + 1];
+        }
+        bool done = q0 >= b1;
+        int cur = -1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (; !done; q0 += DB) {
+            unsigned key[DB];
+            float wt[DB];
+            float4 gv[DB];
+#pragma unroll
             for (int j = 0; j < DB; ++j) {
-                if (q0 + j < b1) {
-                    const int cn = (int)(key[j] >> 10);
-                    const int cell = ((int)((hdr[j] >> 8) & 0xff) - 1 + (cn >> 1)) * MNE_TILE + (int)(hdr[j] & 0xff) - 1 + (cn & 1);
+                const int q = q0 + j < nC ? q0 + j : nC - 1;
+                key[j] = skey[q];
+                wt[j] = swt[q];
+            }
+#pragma unroll
+            for (int j = 0; j < DB; ++j) gv[j] = *(const float4*)(stage + (key[j] & 255u) * MNE_C + sub * 4);
+#pragma unroll
+            for (int j = 0; j < DB; ++j) {
+                const int cell = (int)(key[j] >> 8);
+                if (!done && (q0 + j >= nC || (q0 + j >= b1 && cell != cur))) done = true;
+                if (!done) {
                     if (cell != cur) {
                         if (cur >= 0) {                                   // a finished run
-                            if (runs_done == 0) atomicAdd(&g[cur * MNE_C + c], acc);       // may have begun in the previous range
-                            else g[cur * MNE_C + c] += acc;
-                            ++runs_done;
+                            float* gp = g + cur * MNE_C + sub * 4;
+                            float4 t = *(float4*)gp;
+                            t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+                            *(float4*)gp = t;
                         }
                         cur = cell;
-                        acc = 0.0f;
+                        acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                    acc = fmaf(gv[j], wt[j], acc);
+                    acc.x = fmaf(gv[j].x, wt[j], acc.x); acc.y = fmaf(gv[j].y, wt[j], acc.y);
+                    acc.z = fmaf(gv[j].z, wt[j], acc.z); acc.w = fmaf(gv[j].w, wt[j], acc.w);
                 }
             }
         }
-        if (cur >= 0) atomicAdd(&g[cur * MNE_C + c], acc);                 // may continue in the next range
+        if (cur >= 0) {
+            float* gp = g + cur * MNE_C + sub * 4;
+            float4 t = *(float4*)gp;
+            t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+            *(float4*)gp = t;
+        }
         __syncthreads();
     }
     __syncthreads();
@@ -265,12 +291,17 @@ void mne_tile_geometry(const mne_scene_t& sc, TileBins& b) {
     b.tile_base[sc.n_sets * 6] = base;
 }
 
+int mne_launch_tile_order(const TileAdamArgs& a, hipStream_t st) {
+    const int n_tiles = a.bins.tile_base[a.n_planes];
+    if (n_tiles > 0) MNE_LAUNCH(tile_order_kernel, 1, 1024, 0, st, a, n_tiles);
+    return 0;
+}
+
 int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st) {
     const int n_tiles = a.bins.tile_base[a.n_planes];
     if (n_tiles <= 0) return 0;
-    MNE_LAUNCH(tile_order_kernel, 1, 1024, 0, st, a, n_tiles);
     const size_t lds = (size_t)(TILE_CELLS + PASS_ENTRIES) * MNE_C * sizeof(float);
-    if (lds > 32 * 1024) MNE_SET_MAX_LDS(tile_adam_kernel, lds);        // static LDS (entries, keys, counters) comes on top
+    if (lds > 32 * 1024) MNE_SET_MAX_LDS(tile_adam_kernel, lds);        // static LDS (keys, weights, counters) comes on top
     MNE_LAUNCH(tile_adam_kernel, n_tiles, TILE_THREADS, lds, st, a);
     return 0;
 }

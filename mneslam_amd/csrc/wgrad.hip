@@ -78,29 +78,37 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, GemmDesc g
 // All four GEMMs in ONE pass over the tape (HID = HIDC = 32): every wave reads each of its tape rows once --
 // A operands dh(32) | dout(16) | dhc(32) | dc(4), B operands x(112) | h(32) | cin(CINP) | hc(32) -- and
 // keeps the 8 (or 10) 32x32 accumulator tiles of dW1, dW2, dV1, dV2 in registers.
+// The pass is latency-bound (a wave issues one batch of row loads, waits, multiplies), so the tape is cut
+// finely: 4 waves per workgroup, each with its own slice, 2*WG_KS rows per batch; the four waves'
+// accumulators are then summed tile by tile through 12 KiB of LDS (plain stores/loads, fixed order) and
+// the workgroup writes ONE partial result, so the second-stage reduction stays small.
+#ifndef WG_KS
+#define WG_KS 4
+#endif
+#ifndef WG_FUSED_BLOCKS
+#define WG_FUSED_BLOCKS 256          // x 4 waves; measured best next to the concurrent tile_adam_kernel (profiles/r01_wgrad_variants.txt)
+#endif
 template <int HID, int HIDC, bool CP>
 __global__ __launch_bounds__(256) void wgrad_fused_kernel(WgradArgs a) {
     typedef DecDims<HID, HIDC, CP> D;
     static_assert(HID == 32 && HIDC == 32, "fused weight-gradient kernel is built for the 2x32 decoders");
     constexpr int TNC = D::CINP / 32;
-    constexpr int KS = 2;
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int nw = gridDim.x * (blockDim.x >> 6);
+    constexpr int KS = WG_KS;
+    constexpr int NTILE = 4 + 1 + TNC + 1;
+    __shared__ float red[3][64 * 16];                            // one 32x32 tile of waves 1..3
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wv;
+    const int nw = gridDim.x * 4;
     const int n = *a.tape_rows;
     int per = (n + nw - 1) / nw;
     per = (per + 2 * KS - 1) / (2 * KS) * (2 * KS);
-    const int t0 = gw * per;
+    const int t0 = gw * per < n ? gw * per : n;
     const int t1 = (t0 + per < n) ? t0 + per : n;
-    f32x16 w1[4], w2, v1[TNC], v2;
+    f32x16 acc[NTILE];                                           // w1[0..3] | w2 | v1[0..TNC) | v2
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        w2[e] = 0.f; v2[e] = 0.f;
+    for (int q = 0; q < NTILE; ++q)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w1[q][e] = 0.f;
-#pragma unroll
-        for (int q = 0; q < TNC; ++q) v1[q][e] = 0.f;
-    }
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
     const int col = lane & 31, kk = lane >> 5;
     for (int t = t0; t < t1; t += 2 * KS) {
         float adh[KS], ado[KS], adc[KS], adq[KS], bx[KS][4], bh[KS], bc[KS][TNC], bhc[KS];
@@ -123,27 +131,44 @@ __global__ __launch_bounds__(256) void wgrad_fused_kernel(WgradArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w1[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adh[ks], bx[ks][q], w1[q], 0, 0, 0);
-            w2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ado[ks], bh[ks], w2, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adh[ks], bx[ks][q], acc[q], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(ado[ks], bh[ks], acc[4], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < TNC; ++q) v1[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adc[ks], bc[ks][q], v1[q], 0, 0, 0);
-            v2 = __builtin_amdgcn_mfma_f32_32x32x2f32(adq[ks], bhc[ks], v2, 0, 0, 0);
+            for (int q = 0; q < TNC; ++q) acc[5 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adc[ks], bc[ks][q], acc[5 + q], 0, 0, 0);
+            acc[5 + TNC] = __builtin_amdgcn_mfma_f32_32x32x2f32(adq[ks], bhc[ks], acc[5 + TNC], 0, 0, 0);
         }
     }
-    float* out = a.partials + (size_t)gw * D::NPARAM;
+    // ---- sum of the four waves, tile by tile, in wave order
+#pragma unroll
+    for (int q = 0; q < NTILE; ++q) {
+        if (wv > 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wv - 1][e * 64 + lane] = acc[q][e];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[q][e] += red[w][e * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wv != 0) return;
+    float* out = a.partials + (size_t)blockIdx.x * D::NPARAM;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int o = (e & 3) + 8 * (e >> 2) + 4 * kk;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (32 * q + col < MNE_IN1) out[D::P_SDF0 + o * MNE_IN1 + 32 * q + col] = w1[q][e];
-        if (o < MNE_OUT1) out[D::P_SDF1 + o * HID + col] = w2[e];
+            if (32 * q + col < MNE_IN1) out[D::P_SDF0 + o * MNE_IN1 + 32 * q + col] = acc[q][e];
+        if (o < MNE_OUT1) out[D::P_SDF1 + o * HID + col] = acc[4][e];
 #pragma unroll
         for (int q = 0; q < TNC; ++q) {
             const int i = 32 * q + col;                      // tape column of the colour-net input
-            if (i != D::CINB) out[D::P_COL0 + o * D::CIN + (i > D::CINB ? i - 1 : i)] = v1[q][e];
+            if (i != D::CINB) out[D::P_COL0 + o * D::CIN + (i > D::CINB ? i - 1 : i)] = acc[5 + q][e];
         }
-        if (o < 3) out[D::P_COL1 + o * HIDC + col] = v2[e];
+        if (o < 3) out[D::P_COL1 + o * HIDC + col] = acc[5 + TNC][e];
     }
 }
 
@@ -198,16 +223,20 @@ static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
             MNE_LAUNCH(wgrad_scalar_kernel, (gs[k].OUT * gs[k].ld + 255) / 256, 256, 0, st, a, gs[k], D::ROW);
         return 0;
     }
-    int blocks = (a.n_waves + 3) / 4;                    // caller's bound on the tape length
-    blocks = blocks < 1 ? 1 : (blocks > MNE_WGRAD_BLOCKS ? MNE_WGRAD_BLOCKS : blocks);
-    a.n_waves = blocks * 4;
     if constexpr (HID == 32 && HIDC == 32) {
         if (impl == 0) {
+            // one partial per WORKGROUP: as many workgroups as there are partial slots, fewer for short tapes
+            int blocks = a.n_waves * (64 / (2 * WG_KS * 4));      // n_waves = 64-row chunks of the caller's bound: >= 2*WG_KS rows per wave
+            blocks = blocks < 1 ? 1 : (blocks > WG_FUSED_BLOCKS ? WG_FUSED_BLOCKS : blocks);
+            a.n_waves = blocks;
             MNE_LAUNCH((wgrad_fused_kernel<HID, HIDC, CP>), blocks, 256, 0, st, a);
             MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
             return 0;
         }
     }
+    int blocks = (a.n_waves + 3) / 4;                    // caller's bound on the tape length
+    blocks = blocks < 1 ? 1 : (blocks > MNE_WGRAD_BLOCKS ? MNE_WGRAD_BLOCKS : blocks);
+    a.n_waves = blocks * 4;
     MNE_LAUNCH((wgrad_mfma_kernel<HID / 32, 4>), blocks, 256, 0, st, a, g1, D::ROW, D::NPARAM);
     MNE_LAUNCH((wgrad_mfma_kernel<1, HID / 32>), blocks, 256, 0, st, a, g2, D::ROW, D::NPARAM);
     MNE_LAUNCH((wgrad_mfma_kernel<HIDC / 32, D::CINP / 32>), blocks, 256, 0, st, a, g3, D::ROW, D::NPARAM);

@@ -204,6 +204,7 @@ class FusedStep:
                 stt = self.opt._state(p)
                 stt["step"] += 1
                 self.plane_opt[k].step = stt["step"]
+            _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st), "mne_tile_order")
             e0 = self._mark("adam")
             _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), st),
                        "mne_tile_adam")
