@@ -217,7 +217,6 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
         a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
         a.bins.spill_count = bins->spill_count; a.bins.order = bins->order; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
         mne_tile_geometry(*scene, a.bins);
-        if (hipMemsetAsync(bins->spill_count, 0, sizeof(int32_t), st) != hipSuccess) return fail(-10, "memset(spill_count) failed");
     }
     if (int rc = mne_launch_render(a, 1, 1, workspace, st)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_fused");

@@ -221,15 +221,10 @@ __global__ __launch_bounds__(64 * MAX_WPB) void decode_kernel(RenderArgs a) {
     }
 }
 
-// One wave per ray, 4 rays per workgroup.  LDS per wave: raws[Spad][4].
+// One wave per ray.  LDS per wave: raws[Spad][4].
 template <bool BWD>
-__global__ __launch_bounds__(256) void composite_kernel(RenderArgs a) {
-    MNE_DYN_LDS(lds_raw);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wv;
-    if (r >= a.R) return;
+__device__ __forceinline__ void composite_ray(const RenderArgs& a, int r, int lane, float* raws) {
     const int S = a.S, Spad = (S + 3) & ~3;
-    float* raws = (float*)lds_raw + (size_t)wv * Spad * 4;
     const bool has_t = a.target_d != nullptr;
     const float td = has_t ? a.target_d[r] : 0.0f;
     const float* zr = a.z_vals + (size_t)r * S;
@@ -358,17 +353,18 @@ __global__ __launch_bounds__(256) void composite_kernel(RenderArgs a) {
     }
 }
 
-// exclusive prefix sum of ccount[R] -> coffset[R+1]; total -> tape_rows (single workgroup)
-__global__ __launch_bounds__(1024) void scan_kernel(RenderArgs a) {
-    __shared__ int part[1024];
+// exclusive prefix sum of ccount[R] -> coffset[R+1], total -> tape_rows, first ray of every 32-row tile of
+// the compacted list -> tile_ray; executed by ONE workgroup of NT threads (part = NT ints of LDS)
+template <int NT>
+__device__ __forceinline__ void scan_counts(const RenderArgs& a, int* part) {
     const int tid = threadIdx.x;
-    const int per = (a.R + 1023) / 1024;
-    const int b0 = tid * per, b1 = (b0 + per < a.R) ? b0 + per : a.R;
+    const int per = (a.R + NT - 1) / NT;
+    const int b0 = tid * per < a.R ? tid * per : a.R, b1 = (b0 + per < a.R) ? b0 + per : a.R;
     int s = 0;
     for (int i = b0; i < b1; ++i) s += a.ccount[i];
     part[tid] = s;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
+    for (int off = 1; off < NT; off <<= 1) {
         const int v = tid >= off ? part[tid - off] : 0;
         __syncthreads();
         part[tid] += v;
@@ -382,7 +378,24 @@ __global__ __launch_bounds__(1024) void scan_kernel(RenderArgs a) {
         for (int t = (c0 + TILE - 1) / TILE; t * TILE < c1; ++t) a.tile_ray[t] = i;
         run = c1;
     }
-    if (tid == 1023) { a.coffset[a.R] = part[1023]; *a.tape_rows = part[1023]; }
+    if (tid == NT - 1) { a.coffset[a.R] = part[NT - 1]; *a.tape_rows = part[NT - 1]; }
+}
+
+// 4 rays per workgroup.  (Folding the prefix sum into the last workgroup to finish -- ticket counter plus
+// agent-scope fences -- was measured: every workgroup's release fence writes its XCD's L2 back and the
+// kernel went from 10 us to 54 us, so the scan stays a separate 5 us launch.)
+template <bool BWD>
+__global__ __launch_bounds__(256) void composite_kernel(RenderArgs a) {
+    MNE_DYN_LDS(lds_raw);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (BWD && blockIdx.x == 0 && threadIdx.x == 0 && a.bins.spill_count) *a.bins.spill_count = 0;   // before any append of this call
+    if (r < a.R) composite_ray<BWD>(a, r, lane, (float*)lds_raw + (size_t)wv * ((a.S + 3) & ~3) * 4);
+}
+
+__global__ __launch_bounds__(1024) void scan_kernel(RenderArgs a) {
+    __shared__ int part[1024];
+    scan_counts<1024>(a, part);
 }
 
 #ifndef MAX_WPB_BWD
