@@ -1,7 +1,9 @@
 """Mapper -- the mapping-thread methods that drive the hot path (reference: mp_slam/mapper.py):
 ``first_frame_mapping`` (:52-89, the training loop only), ``mapping_optimize`` (:118-162) and its
-alias ``optimize_map`` (the name BASELINE.json uses).  Keyframe bookkeeping, image/mesh dumps, loop
-closure and fusion around these calls stay with the host application.
+alias ``optimize_map`` (the name BASELINE.json uses), plus the two training loops of loop closure that
+run on the same kernels: the pose alignment of ``handle_loop_closure`` (:362-412) and ``distillation``
+(:594-644).  Keyframe bookkeeping, image/mesh dumps, file exchange and fusion policy around these calls
+stay with the host application.
 
 ``SLAM`` is the reference's MNESLAM-like object; the fields read here are the ones the reference's
 Mapper reads for these methods: ``model``, ``map_optimizer``, ``device``, ``dataset.H/.W``,
@@ -94,6 +96,80 @@ class Mapper():
             self.map_optimizer.zero_grad()
 
     optimize_map = mapping_optimize
+
+    # ------------------------------------------------------------------ N2: loop-closure loops on R13
+    def optimize_relative_pose(self, base_c2w, target_c2w_initial, model_for_base, model_for_target, n_iters=None,
+                               rays_d_cam_batch=None):
+        """Pose alignment loop of ``handle_loop_closure`` (reference: mp_slam/mapper.py:362-412): render
+        ``mapping.sample`` random camera rays from ``base_c2w`` with the base model (teacher, no grad),
+        then ``loop_iters`` Adam steps on the 6 pose parameters of the target so that the target model
+        renders the same rgb/depth: ``render_rays`` (R13: gradients reach the rays) -> MSE losses weighted by
+        ``training.rgb_weight / depth_weight`` -> backward -> ``pose_optimizer.step()``.  Pose
+        parametrisation and optimizer are the host's (``SLAM.get_pose_param_optim``, ``SLAM.matrix_from_tensor``,
+        mneslam_mp.py:577-584).  Returns (relative_transform = base_c2w @ inv(best target pose), best loss)."""
+        cfg, dev = self.config, self.device
+        n = cfg["mapping"]["sample"]
+        n_iters = cfg["mapping"]["loop_iters"] if n_iters is None else n_iters
+        base_c2w, target_c2w_initial = base_c2w.to(dev), target_c2w_initial.to(dev)
+        target_rot, target_trans, pose_optimizer = self.slam.get_pose_param_optim(target_c2w_initial[None, ...], mapping=False)
+        with torch.no_grad():
+            if rays_d_cam_batch is None:
+                rays_d_cam = self.dataset.rays_d.reshape(-1, 3)
+                sample_indices = torch.randint(0, len(rays_d_cam), (n,))
+                rays_d_cam_batch = rays_d_cam[sample_indices]
+            rays_d_cam_batch = rays_d_cam_batch.to(dev)
+            n = rays_d_cam_batch.shape[0]
+            rays_o_base = base_c2w[:3, 3].unsqueeze(0).repeat(n, 1)
+            rays_d_base = torch.sum(rays_d_cam_batch[..., None, :] * base_c2w[:3, :3], dim=-1)
+            base_ret = model_for_base.render_rays(rays_o_base, rays_d_base, target_d=None)
+            target_rgb, target_depth = base_ret["rgb"].detach(), base_ret["depth"].detach()
+        best_loss, best_c2w = float("inf"), target_c2w_initial.clone()
+        for _ in range(n_iters):
+            pose_optimizer.zero_grad()
+            c2w_est = self.slam.matrix_from_tensor(target_rot, target_trans).squeeze(0)
+            rays_o = c2w_est[:3, 3].unsqueeze(0).repeat(n, 1)
+            rays_d = torch.sum(rays_d_cam_batch[..., None, :] * c2w_est[:3, :3], dim=-1)
+            ret = model_for_target.render_rays(rays_o, rays_d, target_d=None)
+            loss_c = torch.nn.functional.mse_loss(ret["rgb"], target_rgb)
+            loss_d = torch.nn.functional.mse_loss(ret["depth"], target_depth)
+            loss = cfg["training"]["rgb_weight"] * loss_c + cfg["training"]["depth_weight"] * loss_d
+            if loss.item() < best_loss:
+                best_loss, best_c2w = loss.item(), c2w_est.detach().clone()
+            loss.backward()
+            pose_optimizer.step()
+        return base_c2w @ torch.inverse(best_c2w), best_loss
+
+    def distillation(self, other_rank, expanded_foreign_kfs_for_distill, num_expanded_kfs):
+        """Joint distillation of a foreign agent's map (``model_shared``, the teacher) into ``model``
+        (reference: mp_slam/mapper.py:594-644, the training loop; the mesh dump after it stays with the
+        host): per iteration, ``sample_per_match`` random camera rays per foreign keyframe pose, teacher
+        ``render_rays`` without depth guidance, student ``forward`` on the teacher's rgb/depth, the usual
+        weighted loss, backward, Adam."""
+        cfg = self.config
+        for _ in range(cfg["mapping"]["distill_iters"]):
+            all_o, all_d, all_rgb, all_depth = [], [], [], []
+            per = max(cfg["mapping"]["sample"] // num_expanded_kfs, cfg["mapping"]["min_pixels_cur"]) \
+                if num_expanded_kfs > 0 else cfg["mapping"]["sample"]
+            for kf_data in expanded_foreign_kfs_for_distill:
+                pose = kf_data["pose"].to(self.device)
+                rays_d_cam = self.dataset.rays_d.reshape(-1, 3)
+                idx = torch.randint(0, len(rays_d_cam), (per,))
+                rays_d_cam_batch = rays_d_cam[idx].to(self.device)
+                rays_o = pose[:3, 3].unsqueeze(0).repeat(per, 1)
+                rays_d = torch.sum(rays_d_cam_batch[..., None, :] * pose[:3, :3], dim=-1)
+                all_o.append(rays_o)
+                all_d.append(rays_d)
+                with torch.no_grad():
+                    teacher = self.model_shared.render_rays(rays_o, rays_d, target_d=None)
+                    all_rgb.append(teacher["rgb"].detach())
+                    all_depth.append(teacher["depth"].detach().unsqueeze(-1))
+            if not all_o:
+                continue
+            self.map_optimizer.zero_grad()
+            ret = self.model.forward(torch.cat(all_o, 0), torch.cat(all_d, 0), torch.cat(all_rgb, 0), torch.cat(all_depth, 0))
+            loss = self.slam.get_loss_from_ret(ret, is_co_sdf=cfg["is_co_sdf"])
+            loss.backward()
+            self.map_optimizer.step()
 
     # ------------------------------------------------------------------ fused path
     def _fused_step(self, n_rays):

@@ -407,3 +407,139 @@ def check_oracle_random_scene(device, hidden=32, one_grid=True, n_rays=24, S_d=2
         for k, w in zip(DEC_KEYS, sc.col_w + sc.sdf_w):
             r = w.grad.numpy()
             assert_close(got[k].grad.cpu(), r, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(r).max()), what=f"dec grad {k} co={co}")
+
+
+# ---------------------------------------------------------------- N2: loop-closure loops
+def _rodrigues(rot):
+    """axis-angle [B,3] -> rotation matrices [B,3,3] (differentiable; test stand-in for the host's pose code)."""
+    th = torch.sqrt((rot * rot).sum(-1) + 1e-12)[:, None, None]
+    k = rot / th[:, :, 0]
+    K = torch.zeros(rot.shape[0], 3, 3, dtype=rot.dtype, device=rot.device)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0] = -k[:, 2], k[:, 1], k[:, 2]
+    K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -k[:, 0], -k[:, 1], k[:, 0]
+    eye = torch.eye(3, dtype=rot.dtype, device=rot.device)[None]
+    return eye + torch.sin(th) * K + (1.0 - torch.cos(th)) * (K @ K)
+
+
+class _PoseSLAM:
+    """The two MNESLAM methods the alignment loop calls (mneslam_mp.py:577-584), axis-angle about the
+    initial rotation so that no matrix logarithm is needed in the test."""
+
+    def __init__(self, lr_rot=1e-3, lr_trans=1e-3):
+        self.lr_rot, self.lr_trans, self.R0 = lr_rot, lr_trans, None
+
+    def get_pose_param_optim(self, poses, mapping=True):
+        self.R0 = poses[:, :3, :3].detach().clone()
+        cur_trans = torch.nn.Parameter(poses[:, :3, 3].detach().clone())
+        cur_rot = torch.nn.Parameter(torch.zeros(poses.shape[0], 3, dtype=poses.dtype, device=poses.device))
+        opt = torch.optim.Adam([{"params": cur_rot, "lr": self.lr_rot}, {"params": cur_trans, "lr": self.lr_trans}])
+        return cur_rot, cur_trans, opt
+
+    def matrix_from_tensor(self, rot, trans):
+        T = torch.eye(4, dtype=rot.dtype, device=rot.device)[None].repeat(rot.shape[0], 1, 1)
+        T[:, :3, :3] = _rodrigues(rot) @ self.R0
+        T[:, :3, 3] = trans
+        return T
+
+
+class _OracleModel:
+    """render_rays of the CPU oracle behind the JointEncoding call signature."""
+
+    def __init__(self, scene):
+        self.scene = scene
+
+    def render_rays(self, rays_o, rays_d, target_d=None):
+        return self.scene.render_rays(rays_o, rays_d, target_d=target_d)
+
+
+def _alignment_setup(g, device):
+    rays_o, rays_d, *_ = fixture_inputs(g)
+    cam_dirs = rays_d[:48].clone()                                   # any fixed bundle of camera-frame directions
+    base = torch.eye(4)
+    base[:3, 3] = rays_o[0]
+    target0 = base.clone()
+    target0[:3, :3] = _rodrigues(torch.tensor([[0.02, -0.015, 0.01]]))[0]
+    target0[:3, 3] += torch.tensor([0.03, -0.02, 0.025])
+    return cam_dirs, base, target0
+
+
+def check_pose_alignment(device):
+    """Mapper.optimize_relative_pose (reference loop: mp_slam/mapper.py:362-412) on the HIP path vs the same loop
+    driven by the CPU oracle's autograd: same seeds -> same jitter draws -> same pose trajectory."""
+    g = load_golden("render_nodepth")
+    cfg = configs.small_test_config()
+    cfg["mapping"]["loop_iters"] = 4
+    cam_dirs, base, target0 = _alignment_setup(g, device)
+    results = []
+    for kind in ("hip", "oracle"):
+        if kind == "hip":
+            model, dev = model_from_golden(g, cfg, device).eval(), device
+        else:
+            model, dev = _OracleModel(oracle_scene_from_golden(g, cfg)), "cpu"
+        slam = types.SimpleNamespace(model=model, model_shared=model, map_optimizer=None, device=torch.device(dev),
+                                     dataset=None, video=None, get_pose_param_optim=None, matrix_from_tensor=None)
+        pose = _PoseSLAM()
+        slam.get_pose_param_optim, slam.matrix_from_tensor = pose.get_pose_param_optim, pose.matrix_from_tensor
+        mp = Mapper(cfg, slam)
+        torch.manual_seed(11)
+        rel, best = mp.optimize_relative_pose(base.clone(), target0.clone(), model, model, rays_d_cam_batch=cam_dirs.clone())
+        results.append((rel.detach().cpu(), best))
+    (rel_h, best_h), (rel_o, best_o) = results
+    assert best_h == best_h and abs(best_h - best_o) <= 1e-3 * abs(best_o) + 1e-7, (best_h, best_o)
+    assert_close(rel_h, rel_o, rtol=1e-4, atol=2e-5, what="relative transform")
+    assert not torch.allclose(rel_h, base @ torch.inverse(target0))     # the pose moved
+
+
+def check_distillation(device):
+    """Mapper.distillation (reference loop: mp_slam/mapper.py:598-640): teacher = model_shared, student = model; three
+    iterations on the HIP path vs the same loop on the CPU oracle (oracle forward/backward + OracleAdam)."""
+    g = load_golden("mapping3_onegrid_esdf")
+    cfg = configs.small_test_config(one_grid=True, is_co_sdf=False)
+    cfg["mapping"].update(sample=64, min_pixels_cur=10, distill_iters=3)
+    H, W = int(g["H"]), int(g["W"])
+    direction = torch.from_numpy(g["direction"])
+    kfs = [{"pose": torch.from_numpy(g[f"frame{k}.c2w"]).clone()} for k in (0, 2)]
+    dataset = types.SimpleNamespace(H=H, W=W, rays_d=direction)
+    # HIP: teacher holds the fixture's initial map, the student starts from a perturbed copy
+    teacher = model_from_golden(g, cfg, device, prefix="init.").eval()
+    student = model_from_golden(g, cfg, device, prefix="init.").train()
+    for lst in student.all_planes:
+        for l in range(2):
+            lst[l] = (lst[l] * 0.5).contiguous(memory_format=torch.channels_last)
+    opt = slam_glue.create_optimizer(student, cfg)
+    slam = types.SimpleNamespace(model=student, model_shared=teacher, map_optimizer=opt, device=torch.device(device),
+                                 dataset=dataset, video=None,
+                                 get_loss_from_ret=lambda ret, is_co_sdf=True: slam_glue.get_loss_from_ret(cfg, ret, is_co_sdf=is_co_sdf))
+    mp = Mapper(cfg, slam)
+    torch.manual_seed(5)
+    mp.distillation(1, kfs, len(kfs))
+    # oracle: the same loop with the CPU restatement
+    t_sc = oracle_scene_from_golden(g, cfg, prefix="init.")
+    s_sc = oracle_scene_from_golden(g, cfg, prefix="init.")
+    s_sc.all_planes = tuple([(p * 0.5).clone() for p in lst] for lst in s_sc.all_planes)
+    s_sc.requires_grad_(True)
+    o_opt = omap.OracleAdam(s_sc, cfg)
+    torch.manual_seed(5)
+    per = max(cfg["mapping"]["sample"] // len(kfs), cfg["mapping"]["min_pixels_cur"])
+    for _ in range(cfg["mapping"]["distill_iters"]):
+        ro, rd, tr, td = [], [], [], []
+        for kf in kfs:
+            pose = kf["pose"]
+            idx = torch.randint(0, H * W, (per,))
+            dcam = direction.reshape(-1, 3)[idx]
+            o = pose[:3, 3].unsqueeze(0).repeat(per, 1)
+            d = torch.sum(dcam[..., None, :] * pose[:3, :3], dim=-1)
+            with torch.no_grad():
+                t = t_sc.render_rays(o, d, target_d=None)
+            ro.append(o); rd.append(d); tr.append(t["rgb"]); td.append(t["depth"].unsqueeze(-1))
+        o_opt.zero_grad()
+        ret = s_sc.forward(torch.cat(ro), torch.cat(rd), torch.cat(tr), torch.cat(td))
+        omap.loss_from_ret(cfg, ret, is_co_sdf=False).backward()
+        o_opt.step()
+    k = 0
+    for s, lst in enumerate(student.all_planes):
+        for l in range(2):
+            assert_close(lst[l].detach().cpu(), s_sc.all_planes[s][l].detach(), rtol=1e-3, atol=1e-4, what=f"plane {s}/{l}")
+            k += 1
+    for (n, p), q in zip(student.decoder.named_parameters(), [s_sc.col_w[0], s_sc.col_w[1], s_sc.sdf_w[0], s_sc.sdf_w[1]]):
+        assert_close(p.detach().cpu(), q.detach(), rtol=1e-3, atol=1e-4, what=n)

@@ -98,6 +98,14 @@ def test_random_scene_vs_oracle(hidden, one_grid):
     pc.check_oracle_random_scene(DEV, hidden=hidden, one_grid=one_grid, n_rays=96, S_d=96, S_r=32)
 
 
+def test_loop_closure_pose_alignment():
+    pc.check_pose_alignment(DEV)
+
+
+def test_loop_closure_distillation():
+    pc.check_distillation(DEV)
+
+
 def test_full_size_paths_agree_and_learn():
     """BASELINE-size workload (office0 planes 38.4 M params, 2150 rays x 128 samples): the fused path with
     binned scatter, the fused path with global atomics and the drop-in autograd path, driven with the

@@ -122,3 +122,13 @@ def test_render_nodepth_pose_gradients():
 @pytest.mark.parametrize("kind", ["hash", "dense"])
 def test_grid_encoding(kind):
     pc.check_grid_encoding(DEV, kind)
+
+
+@full
+def test_loop_closure_pose_alignment():
+    pc.check_pose_alignment(DEV)
+
+
+@full
+def test_loop_closure_distillation():
+    pc.check_distillation(DEV)
