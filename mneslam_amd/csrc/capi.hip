@@ -43,9 +43,19 @@ static int check_scene(const mne_scene_t* sc, bool need_grad) {
     return 0;
 }
 
-static void fill_render_consts(RenderArgs& a, const mne_render_cfg_t* cfg) {
+// Timing-ablation switches (profiles/ablate_*.sh): only a -DMNE_ABLATION build reads them; the shipped
+// library always runs with dbg = 0.
+static int ablation_flags() {
+#ifdef MNE_ABLATION
     const char* dbg = getenv("MNE_DBG_FLAGS");
-    a.dbg = dbg ? atoi(dbg) : 0;
+    return dbg ? atoi(dbg) : 0;
+#else
+    return 0;
+#endif
+}
+
+static void fill_render_consts(RenderArgs& a, const mne_render_cfg_t* cfg) {
+    a.dbg = ablation_flags();
     a.trunc_f = (float)cfg->trunc;
     a.win_f = (float)(cfg->sc_factor * cfg->trunc);       // python: sc_factor * trunc, then fp32
     a.e_T = (float)cfg->truncation;
@@ -266,7 +276,7 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
     a.row_stride = (int)mne_dims_tape_row(*scene);
     a.t_dfeat = (int)mne_dims_tape_dfeat(*scene);
     a.t_pn = (int)mne_dims_tape_pn(*scene);
-    { const char* dbg = getenv("MNE_DBG_FLAGS"); a.dbg = dbg ? atoi(dbg) : 0; }
+    a.dbg = ablation_flags();
     mne_launch_tile_adam(a, (hipStream_t)stream);
     return check_launch("tile_adam");
 }

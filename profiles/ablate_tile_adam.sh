@@ -1,3 +1,4 @@
+# needs an ablation build as the in-tree library: bash profiles/build_variants.sh capi.hip "abl:-DMNE_ABLATION" && cp profiles/_variants/lib_abl.so mneslam_amd/libmneslam_hip.so
 mkdir -p gpurun_out; rm -f gpurun_out/ablate_tile.log
 for f in 0 32 64; do
   echo "FLAGS=$f" >> gpurun_out/ablate_tile.log

@@ -1,3 +1,4 @@
+# needs an ablation build as the in-tree library: bash profiles/build_variants.sh capi.hip "abl:-DMNE_ABLATION" && cp profiles/_variants/lib_abl.so mneslam_amd/libmneslam_hip.so
 # per-kernel times of the fused iteration under timing-ablation flags (results are wrong when flags != 0)
 mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
 out=gpurun_out/ablate_tilepar.txt; : > $out
