@@ -15,6 +15,22 @@
 // compiler use scalar (SMEM) loads, so the tiny-MLP FMAs take their weight operand from SGPRs.
 typedef const __attribute__((address_space(4))) float* mne_cptr;
 #define MNE_CPTR(p) ((mne_cptr)(unsigned long long)(p))
+// Broadcast of lane k (0..7, compile-time) inside every aligned group of 8 lanes: ds_swizzle in bit-mask mode,
+// new_lane = (lane & 0x18) | k within each half-wave; goes through the LDS crossbar, touches no LDS memory.
+#define MNE_SWZ8(k) (0x18 | ((k) << 5))
+static __device__ __forceinline__ int mne_bcast8(int v, int k) {
+    switch (k) {      // the pattern must be an immediate
+        case 0: return __builtin_amdgcn_ds_swizzle(v, MNE_SWZ8(0));
+        case 1: return __builtin_amdgcn_ds_swizzle(v, MNE_SWZ8(1));
+        case 2: return __builtin_amdgcn_ds_swizzle(v, MNE_SWZ8(2));
+        case 3: return __builtin_amdgcn_ds_swizzle(v, MNE_SWZ8(3));
+        case 4: return __builtin_amdgcn_ds_swizzle(v, MNE_SWZ8(4));
+        case 5: return __builtin_amdgcn_ds_swizzle(v, MNE_SWZ8(5));
+        case 6: return __builtin_amdgcn_ds_swizzle(v, MNE_SWZ8(6));
+        default: return __builtin_amdgcn_ds_swizzle(v, MNE_SWZ8(7));
+    }
+}
+static __device__ __forceinline__ float mne_bcast8(float v, int k) { return __int_as_float(mne_bcast8(__float_as_int(v), k)); }
 // LDS hand-off between the lanes of ONE wave (each wave owns a private LDS region): DS operations of
 // a wave complete in issue order, so draining lgkmcnt and pinning the compiler's order is enough --
 // no s_barrier, the four waves of a workgroup never wait for each other.

@@ -140,6 +140,7 @@ typedef const float* mne_cptr;
 inline void __syncthreads() { hipemu::g_ctx->block_bar->arrive_and_wait(); }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 template <class T> inline T __shfl(T v, int src, int = 64) { return hipemu::shfl_idx(v, src); }
+template <class T> inline T mne_bcast8(T v, int k) { return __shfl(v, (int)((threadIdx.x & 63u) & ~7u) | k); }
 template <class T> inline T __shfl_xor(T v, int m, int = 64) { return hipemu::shfl_idx(v, hipemu::lane() ^ m); }
 template <class T> inline T __shfl_down(T v, unsigned d, int = 64) {
     int s = hipemu::lane() + (int)d;
