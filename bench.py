@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--scatter", default="binned", choices=["binned", "atomics"],
                     help="fused path: tile-binned LDS scatter fused with Adam (default) or global atomics + streaming Adam")
+    ap.add_argument("--event-every", type=int, default=8, help="bracket the dominant launches with HIP events on every N-th timed step")
     ap.add_argument("--share-decoder", action="store_true",
                     help="EXTENSION: all-reduce (mean) the decoder gradient over agents each iteration (RCCL)")
     ap.add_argument("--small", action="store_true", help="tiny planes/frames (functional check, not a benchmark)")
@@ -201,7 +202,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):        # every timed iteration draws its own batch inside the timed region:
-        agent.step(timers, prefetch=i + 1 < args.steps)      # step i+1's batch is drawn while step i's planes update
+        # step i+1's batch is drawn while step i's planes update.  HIP events bracket the two dominant launches on
+        # every `event_every`-th step only: each record is a barrier packet on the stream (~6 us of idle time).
+        agent.step(timers if i % args.event_every == 0 else None, prefetch=i + 1 < args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = mdist.max_over_ranks(elapsed, device)

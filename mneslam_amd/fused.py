@@ -1,8 +1,8 @@
-"""The fused mapping iteration: sample rays -> z -> forward+backward in one kernel -> decoder
-weight-gradient GEMM -> one Adam launch over planes + decoder (gradients zeroed in the same pass).
-No autograd graph, no per-iteration allocation, no host synchronisation: every buffer is allocated
-once per ``FusedStep`` and the ~9 C-ABI calls of an iteration are asynchronous launches on the
-caller's stream.
+"""The fused mapping iteration: sample rays -> z -> decode / composite / backward -> decoder
+weight-gradient pass + decoder Adam, and -- concurrently on a second HIP stream -- the per-tile plane
+scatter fused with Adam.  No autograd graph, no per-iteration allocation, no host synchronisation: every
+buffer is allocated once per ``FusedStep`` and the ~10 C-ABI calls of an iteration are asynchronous
+launches on the caller's stream and one private side stream (joined with events, see ``step``).
 
 Semantically one ``step`` equals the reference's
 ``forward -> get_loss_from_ret -> backward -> map_optimizer.step() -> zero_grad()``
@@ -115,16 +115,16 @@ class FusedStep:
                 o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
         self.events = None          # set to {} to record HIP events around the two dominant launches
         self.overlap = overlap
-        self._side, self._ev, self._prefetched = None, None, None
+        self._side, self._ev, self._prefetched, self._planes_pending = None, None, None, False
         self.iteration = 0
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
 
     # ---------------------------------------------------------------- stream plumbing
     def _streams(self):
-        """(main, side) as (torch stream, raw handle) pairs.  The plane update (tile_adam_kernel, HBM-bound)
-        and the decoder chain (weight-gradient MFMA pass -> reduce -> decoder Adam -> loss scalars ->
-        next batch's sampling) are independent after the backward kernel, so they run on two HIP
-        streams; with scatter="atomics", or on the host emulator, everything stays on one stream."""
+        """(main, side) as (torch stream, raw handle) pairs: the caller's current stream, and a private stream
+        for the plane update (tile_adam_kernel, HBM-bound), which is independent of the decoder chain (weight
+        gradients -> decoder Adam -> loss scalars -> next batch) once the backward kernel is done.  With
+        scatter="atomics", or on the host emulator, everything stays on one stream."""
         main_h = _lib.stream_for(self.rays_o)
         if not self.rays_o.is_cuda or self.bins is None or not self.overlap:
             return (None, main_h), (None, main_h)
@@ -162,9 +162,10 @@ class FusedStep:
         """One mapping iteration.  kf_rays [*,7] / cur_rays [H*W,7] / poses [N,4,4] live on the device;
         idx_global / idx_cur (int64 device tensors) and u [R,S] reproduce a host-RNG batch.
         prefetch=True promises that the NEXT call has the same ray sources and poses (the iterations of
-        one keyframe, mp_slam/mapper.py:133): its batch is then drawn on the side stream while this
-        iteration's plane update runs (device sampler only; the batch buffers rays_o/tgt_*/z_vals then
-        already hold the next batch when this call returns -- losses, rgb and depth are this iteration's)."""
+        one keyframe, mp_slam/mapper.py:133): its batch is then drawn while this iteration's plane update
+        still runs on the side stream (device sampler only; the batch buffers rays_o/tgt_*/z_vals then already
+        hold the next batch when this call returns, and the plane update is only joined by the next step or by
+        ``synchronize()``; a step with prefetch=False, as Mapper's last one, leaves everything joined)."""
         lib, P = self.lib, _lib.ptr
         R, S = self.R, self.S
         if n_global + n_cur != R:
@@ -173,13 +174,21 @@ class FusedStep:
         ev = self._ev if side is not None else [None] * 4
         host_batch = idx_global is not None or idx_cur is not None or u is not None
         key = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
+        # Stream roles.  The caller's stream carries the whole dependency chain of the decoder:
+        #   [batch] -> pack -> render (decode .. backward) -> wgrad -> decoder Adam -> loss scalars -> [next batch]
+        # and the plane update (tile_order + tile_adam, HBM-bound, the longest kernel) runs on the side stream
+        # between two events: "backward done" (recorded on the caller's stream) and "planes updated" (waited for
+        # by the caller's stream right before the next decode, or at the end of a step without prefetch).  The
+        # caller's stream has long parked on that wait when the plane update finishes, so the next decode starts
+        # ~2 us later; joining the other way round (the decoder chain on the side stream) put an event wait
+        # BEHIND the long kernel on the same queue and cost 18-20 us per iteration (profiles/r01_gap_analysis.txt).
         if host_batch or self._prefetched != key:
-            self._after(side, ev[0], main)                        # the caller's inputs were produced on `main`
-            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st2)
+            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st)
         self._prefetched = None
-        # side stream so far: ... decoder Adam of the previous iteration -> this batch -> pack
-        _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st2), "mne_pack_decoder")
-        self._after(main, ev[1], side)
+        _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
+        if self._planes_pending:                                  # previous step's plane update (side stream)
+            main.wait_event(ev[1])
+            self._planes_pending = False
         e0 = self._mark("render")
         _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
                                         P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals), P(self.packed), P(self.coef),
@@ -188,47 +197,59 @@ class FusedStep:
                                         P(self.ws), self.ws_bytes, st),
                    "mne_render_fused")
         self._mark("render", e0)
-        self._after(side, ev[2], main)
-        # ---- decoder chain (side stream)
-        _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), R * S, P(self.partials),
-                                         P(self.dec_grad), self.model.wgrad_impl, st2), "mne_decoder_wgrad")
         if self.bins is not None:
-            with (torch.cuda.stream(side) if side is not None else _null_ctx()):
-                if self.shared_decoder:
-                    from . import dist as mdist
-                    mdist.allreduce_mean_(self.dec_grad)
-                self.opt.step(zero_grad=False, grad_buffers=self.grad_map)      # decoder tensors
-            _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st2), "mne_loss_finalize")
-            # ---- plane update (main stream), concurrent with the chain above
+            # ---- plane update on the side stream
+            self._after(side, ev[0], main)
             for k, p in enumerate(self.planes):
                 stt = self.opt._state(p)
                 stt["step"] += 1
                 self.plane_opt[k].step = stt["step"]
-            _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st), "mne_tile_order")
-            e0 = self._mark("adam")
-            _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), st),
+            _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
+            e0 = self._mark("adam", stream=side)
+            _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), st2),
                        "mne_tile_adam")
-            self._mark("adam", e0)
+            self._mark("adam", e0, stream=side)
+            if side is not None:
+                ev[1].record(side)
+                self._planes_pending = True
+            # ---- decoder chain on the caller's stream, concurrent with the plane update
+            _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), R * S, P(self.partials),
+                                             P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
+            if self.shared_decoder:
+                from . import dist as mdist
+                mdist.allreduce_mean_(self.dec_grad)
+            self.opt.step(zero_grad=False, grad_buffers=self.grad_map)      # decoder tensors
         else:
+            _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), R * S, P(self.partials),
+                                             P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
             if self.shared_decoder:
                 from . import dist as mdist
                 mdist.allreduce_mean_(self.dec_grad)
             e0 = self._mark("adam")
             self.opt.step(zero_grad=True, grad_buffers=self.grad_map)
             self._mark("adam", e0)
-            _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st2), "mne_loss_finalize")
+        _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
         self.iteration += 1
         if prefetch and not host_batch and side is not None:
-            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st2)
+            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st)
             self._prefetched = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
-        self._after(main, ev[3], side)                            # whatever the caller enqueues next sees both streams
+        elif self._planes_pending:                                # whatever the caller enqueues next sees the updated planes
+            main.wait_event(ev[1])
+            self._planes_pending = False
 
-    def _mark(self, name, start=None):
+    def synchronize(self):
+        """Make the caller's current stream wait for a plane update still running on the side stream (only needed
+        after a step with prefetch=True if planes are read before the next step)."""
+        if self._planes_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._ev[1])
+            self._planes_pending = False
+
+    def _mark(self, name, start=None, stream=None):
         """HIP events on the launch stream around one launch (bench.py's live kernel timing)."""
         if self.events is None or not self.rays_o.is_cuda:
             return None
         e = torch.cuda.Event(enable_timing=True)
-        e.record()
+        e.record(stream) if stream is not None else e.record()
         if start is not None:
             self.events.setdefault(name, []).append((start, e))
         return e
