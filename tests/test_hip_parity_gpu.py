@@ -117,11 +117,13 @@ def test_full_size_paths_agree_and_learn():
     cfg = configs.bench_office0()
     dev = torch.device("cuda")
     finals, losses = {}, {}
-    for mode in ("binned", "atomics"):
-        ag = bench.Agent(cfg, dev, seed=3, n_keyframes=4, path="fused", scatter=mode)
+    for mode in ("binned", "atomics", "binned+prefetch"):
+        ag = bench.Agent(cfg, dev, seed=3, n_keyframes=4, path="fused", scatter=mode.split("+")[0])
         hist = []
-        for _ in range(6):
-            ag.step()
+        for it in range(6):
+            # "+prefetch": the two HIP streams swap roles every iteration and the next batch is drawn early
+            ag.step(prefetch=mode.endswith("prefetch") and it < 5)
+            ag.fused.synchronize()
             hist.append(float(ag.fused.losses[0] + ag.fused.losses[1]))
         finals[mode] = [p.detach().clone() for lst in ag.model.all_planes for p in lst] + \
                        [p.detach().clone() for p in ag.model.decoder.parameters()]
@@ -136,7 +138,10 @@ def test_full_size_paths_agree_and_learn():
         d = (a - b).abs()
         assert float(d.mean()) < 1e-7, "binned and atomic scatter disagree"
         assert float((d > 1e-4).float().mean()) < 1e-5 and float(d.max()) < 0.05
-    for x, y in zip(losses["binned"], losses["atomics"]):
-        assert x == x and abs(x - y) <= 1e-3 * abs(y), "loss histories of the two schedules diverge"
+    for a, b in zip(finals["binned"], finals["binned+prefetch"]):
+        d = (a - b).abs()
+        assert float(d.mean()) < 1e-7 and float((d > 1e-4).float().mean()) < 1e-5, "prefetching / stream alternation changes the result"
+    for x, y, z in zip(losses["binned"], losses["atomics"], losses["binned+prefetch"]):
+        assert x == x and abs(x - y) <= 1e-3 * abs(y) and abs(x - z) <= 1e-3 * abs(x), "loss histories of the schedules diverge"
     # the mean absolute update is non-trivial (dense Adam moved the touched cells)
     assert float((finals["binned"][1] != 0).float().mean()) > 0.5
