@@ -65,3 +65,62 @@ def test_two_agents_gloo(tmp_path):
     ret = str(tmp_path / "r")
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert os.path.exists(ret + ".ok0") and os.path.exists(ret + ".ok1")
+
+
+def _shared_decoder_worker(rank, world, port, ret):
+    """Two agents, each with its own planes and ray batch, ONE decoder (EXTENSION, BASELINE multi-GPU configs):
+    FusedStep(shared_decoder=True) averages the decoder gradient over the agents before the decoder's Adam step,
+    so decoders that start equal stay bit-equal while the planes diverge.  Kernels run through the host emulator."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import build_emu
+    from mneslam_amd import _lib, configs, dist as mdist, slam_glue
+    from mneslam_amd.fused import FusedStep
+    import parity_cases as pc
+    from helpers import load_golden
+    _lib.unload()
+    _lib.load(build_emu.build())
+    mdist.init_agents(backend="gloo")
+    g = load_golden("mapping3_onegrid_esdf")
+    cfg = configs.small_test_config(one_grid=True, is_co_sdf=False)
+    n_rays = 48
+    model = pc.model_from_golden(g, cfg, "cpu", prefix="init.").train()           # same decoder on both ranks
+    for lst in model.all_planes:                                                  # different maps
+        for l in range(2):
+            lst[l] = (lst[l] * (1.0 + 0.25 * rank)).contiguous(memory_format=torch.channels_last)
+    opt = slam_glue.create_optimizer(model, cfg)
+    fs = FusedStep(model, opt, cfg, n_rays, "cpu", shared_decoder=True)
+    H, W = int(g["H"]), int(g["W"])
+    k = 1 + rank                                                                  # different frame per agent
+    cur = torch.cat([torch.from_numpy(g["direction"]), torch.from_numpy(g[f"frame{k}.rgb"]),
+                     torch.from_numpy(g[f"frame{k}.depth"])[..., None]], -1).reshape(-1, 7).contiguous()
+    poses = torch.from_numpy(g[f"frame{k}.c2w"]).reshape(1, 4, 4).contiguous()
+    gen = torch.Generator().manual_seed(7 + rank)
+    for it in range(2):
+        idx = torch.randperm(H * W, generator=gen)[:n_rays]
+        fs.step(None, 0, 1, cur, poses, 0, n_rays, idx_cur=idx, u=torch.rand(n_rays, fs.S, generator=gen))
+    dec = torch.cat([p.detach().reshape(-1) for p in model.decoder.parameters()])
+    gathered = [torch.zeros_like(dec) for _ in range(world)]
+    dist.all_gather(gathered, dec)
+    assert torch.equal(gathered[0], gathered[1]), "shared decoder diverged between the agents"
+    init = torch.cat([torch.from_numpy(g[f"init.dec.{kk}"]).reshape(-1) for kk in pc.DEC_KEYS])
+    assert torch.isfinite(dec).all() and not torch.equal(dec.sort().values, init.sort().values), "decoder did not train"
+    pl = torch.cat([p.detach().reshape(-1)[:4096] for lst in model.all_planes for p in lst])
+    gp = [torch.zeros_like(pl) for _ in range(world)]
+    dist.all_gather(gp, pl)
+    assert not torch.equal(gp[0], gp[1])                                          # planes stay per-agent
+    dist.destroy_process_group()
+    open(ret + f".ok{rank}", "w").write("ok")
+
+
+def test_two_agents_shared_decoder_fused_step(tmp_path):
+    port = 29900 + (os.getpid() % 90)
+    ret = str(tmp_path / "s")
+    sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
+    import build_emu
+    build_emu.build()                           # once, before the workers race for it
+    mp.spawn(_shared_decoder_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert os.path.exists(ret + ".ok0") and os.path.exists(ret + ".ok1")
