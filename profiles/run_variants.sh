@@ -12,7 +12,7 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  ms/step %.4f  it/s %.1f psnr %.2f' % (d['ms_per_step'], d['value'], d['psnr_last_iter']))
 " >> $out
   rm -rf /tmp/pv; timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pv -o t -- python bench.py --steps 60 --warmup 10 --cpu-iters 0 > /dev/null 2>&1
-  python profiles/summarize_rocprof_db.py $(find /tmp/pv -name '*.db' | head -1) 2>&1 | grep -E "backward_kernel|decode_kernel|tile_adam_kernel|wgrad_fused|wgrad_reduce" | cut -c1-130 >> $out
+  python profiles/summarize_rocprof_db.py $(find /tmp/pv -name '*.db' | head -1) 2>&1 | grep -E "backward_kernel|decode_kernel|tile_adam_kernel|wgrad_fused" | cut -c1-130 >> $out
 done
 cp /tmp/lib_orig.so mneslam_amd/libmneslam_hip.so
 cat $out
