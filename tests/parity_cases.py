@@ -289,6 +289,12 @@ def check_oneblob(device):
     x = torch.cat([torch.rand(200, 3), torch.tensor([[0.0, 1.0, 0.5], [-0.3, 1.7, 0.03125], [0.999, 0.001, 0.0625]])])
     got = enc(x.double().to(device)).cpu()          # double input is cast to fp32 like tinycudann
     assert_close(got, oneblob(x, 16), rtol=0, atol=0, what="OneBlob (bit-exact vs spec)")
+    # inputs strictly inside the unit interval, including the bin edges next to its ends
+    xi = torch.rand(256, 3) * (254.0 / 256.0) + 1.0 / 256.0
+    xi = xi.clamp(1.0 / 256.0, 255.0 / 256.0)
+    xi[:4] = torch.tensor([[1 / 256, 255 / 256, 0.5], [255 / 256, 1 / 256, 15 / 16], [1 / 16, 0.9375 + 1e-4, 0.06], [0.004, 0.996, 0.9]])
+    got = enc(xi.double().to(device)).cpu()
+    assert_close(got, oneblob(xi, 16), rtol=0, atol=0, what="OneBlob inside the box (bit-exact vs spec)")
 
 
 def check_grid_encoding(device, kind="hash"):
