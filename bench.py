@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--scatter", default="binned", choices=["binned", "atomics"],
                     help="fused path: tile-binned LDS scatter fused with Adam (default) or global atomics + streaming Adam")
+    ap.add_argument("--no-overlap", action="store_true", help="run the plane update and the decoder chain on ONE stream (ablation)")
     ap.add_argument("--event-every", type=int, default=8, help="bracket the dominant launches with HIP events on every N-th timed step")
     ap.add_argument("--share-decoder", action="store_true",
                     help="EXTENSION: all-reduce (mean) the decoder gradient over agents each iteration (RCCL)")
@@ -58,7 +59,8 @@ def parse_args():
 class Agent:
     """One mapping agent: scene model + optimizer + device-resident keyframe rays."""
 
-    def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused", scatter="binned", share_decoder=False):
+    def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused", scatter="binned", share_decoder=False,
+                 overlap=True):
         self.cfg, self.device, self.path = cfg, device, path
         cam = dict(synthetic.REPLICA_CAM)
         if small:
@@ -90,7 +92,7 @@ class Agent:
         if path == "fused":
             self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device,
                                    scatter=scatter, shared_decoder=share_decoder,
-                                   overlap=os.environ.get("MNE_NO_OVERLAP", "0") != "1")
+                                   overlap=overlap and os.environ.get("MNE_NO_OVERLAP", "0") != "1")
             self.fused.seed = seed
 
     def sample_rays(self):
@@ -189,7 +191,7 @@ def main():
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
     agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter,
-                  share_decoder=args.share_decoder)
+                  share_decoder=args.share_decoder, overlap=not args.no_overlap)
 
     def barrier():
         if world > 1:
