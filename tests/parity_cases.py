@@ -359,7 +359,7 @@ def check_queries(device):
     assert_close(m.query_color(pts.to(device)).cpu(), torch.sigmoid(ref[..., :3]), rtol=1e-4, atol=1e-5, what="query_color")
 
 
-def check_oracle_random_scene(device, hidden=32, one_grid=True, n_rays=24, S_d=20, S_r=9, seed=5):
+def check_oracle_random_scene(device, hidden=32, one_grid=True, n_rays=24, S_d=20, S_r=9, seed=5, invalid_every=5):
     """Seeded random scene at a configuration without fixture (e.g. hidden 64): HIP vs oracle,
     forward and gradients."""
     cfg = configs.small_test_config(one_grid=one_grid, n_samples_d=S_d, n_range_d=S_r)
@@ -384,7 +384,8 @@ def check_oracle_random_scene(device, hidden=32, one_grid=True, n_rays=24, S_d=2
     rays_d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=-1) * 0.7
     rgb = torch.rand(n_rays, 3, generator=gen)
     d = torch.rand(n_rays, 1, generator=gen) * 2.0 + 0.2
-    d[::5] = 0.0
+    if invalid_every:
+        d[::invalid_every] = 0.0
     U = torch.rand(n_rays, S_d + S_r, generator=gen)
     ref = sc.forward(rays_o, rays_d, rgb, d, u=U)
     out = m._render(*to_dev([rays_o, rays_d, rgb, d], device), u=U.to(device))

@@ -98,6 +98,11 @@ def test_random_scene_vs_oracle(hidden, one_grid):
     pc.check_oracle_random_scene(DEV, hidden=hidden, one_grid=one_grid, n_rays=96, S_d=96, S_r=32)
 
 
+@pytest.mark.parametrize("n_rays,S_d,S_r", [(1, 4, 3), (5, 20, 13), (3, 1, 1), (257, 43, 21)])
+def test_ragged_sizes_vs_oracle(n_rays, S_d, S_r):
+    pc.check_oracle_random_scene(DEV, n_rays=n_rays, S_d=S_d, S_r=S_r, invalid_every=0 if n_rays < 10 else 5)
+
+
 def test_loop_closure_pose_alignment():
     pc.check_pose_alignment(DEV)
 
@@ -145,3 +150,45 @@ def test_full_size_paths_agree_and_learn():
         assert x == x and abs(x - y) <= 1e-3 * abs(y) and abs(x - z) <= 1e-3 * abs(x), "loss histories of the schedules diverge"
     # the mean absolute update is non-trivial (dense Adam moved the touched cells)
     assert float((finals["binned"][1] != 0).float().mean()) > 0.5
+
+
+def test_full_size_properties():
+    """BASELINE-size batch (2150 rays x 128 samples, office0 planes), size-independent properties of the path:
+    the forward is deterministic bit for bit; sampled z are sorted inside [near, far]; rendered weights sum to <= 1,
+    depth lies inside the sampled interval; the backward's tape holds exactly the samples that the reference's
+    masks select (render window, Co-SLAM / ESLAM truncation masks), recomputed here with torch from raw and z."""
+    import bench
+    from mneslam_amd import configs
+    cfg = configs.bench_office0()
+    dev = torch.device("cuda")
+    ag = bench.Agent(cfg, dev, seed=5, n_keyframes=4, path="fused", scatter="binned")
+    for _ in range(3):
+        ag.step()                                         # a few updates so that the SDF has sign changes
+    fs, m = ag.fused, ag.model
+    torch.cuda.synchronize()
+    rays_o, rays_d, tgt_d = fs.rays_o.clone(), fs.rays_d.clone(), fs.tgt_d.clone()
+    U = torch.rand(fs.R, fs.S, device=dev)
+    outs = [m._render(rays_o, rays_d, None, tgt_d[:, None], u=U) for _ in range(2)]
+    for a, b in zip(outs[0][:7], outs[1][:7]):
+        assert torch.equal(a, b), "forward is not deterministic"
+    rgb, depth, _, acc, var, z, raw = [t.detach() for t in outs[0][:7]]
+    near, far = cfg["cam"]["near"], cfg["cam"]["far"]
+    assert torch.all(z[:, 1:] >= z[:, :-1]) and float(z.min()) >= min(near, float((tgt_d - cfg["training"]["range_d"]).min())) - 1e-6
+    assert float(acc.max()) <= 1.0 + 1e-5 and float(acc.min()) >= 0.0
+    assert torch.all(depth >= z[:, 0] * acc - 1e-4) and torch.all(depth <= z[:, -1] * acc + 1e-4)
+    assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0 + 1e-5 and float(var.min()) >= -1e-6
+    # contributing samples of the LAST fused step vs the masks of the reference, from that step's own raw / z
+    ag.step()
+    torch.cuda.synchronize()
+    z, sdf, td = fs.z_vals, fs.raw[..., 3], fs.tgt_d[:, None]
+    tr, T = cfg["training"]["trunc"], cfg["model"]["truncation"]
+    win = cfg["data"]["sc_factor"] * tr
+    sign = (sdf[:, 1:] * sdf[:, :-1]) < 0
+    first = torch.where(sign.any(1), sign.float().argmax(1), torch.zeros(fs.R, dtype=torch.long, device=dev))
+    z_lim = z.gather(1, first[:, None]) + win
+    has_d = td > 0
+    front, back = z < (td - T), z > (td + T)
+    center = (z > (td - 0.4 * T)) & (z < (td + 0.4 * T))
+    eslam = has_d & (front | center | (~front & ~back & ~center))          # = every sample not behind the surface band
+    expected = int(((z < z_lim) | eslam).sum())
+    assert int(fs.tape_rows.item()) == expected, (int(fs.tape_rows.item()), expected)

@@ -132,3 +132,9 @@ def test_loop_closure_pose_alignment():
 @full
 def test_loop_closure_distillation():
     pc.check_distillation(DEV)
+
+
+@pytest.mark.parametrize("n_rays,S_d,S_r", [(1, 4, 3), (5, 20, 13), (3, 1, 1)])
+def test_ragged_sizes_vs_oracle(n_rays, S_d, S_r):
+    """a single ray; S = 33 (one sample past a 32-sample tile); S = 2 -- forward and gradients vs the oracle"""
+    pc.check_oracle_random_scene(DEV, n_rays=n_rays, S_d=S_d, S_r=S_r, invalid_every=0)
