@@ -132,6 +132,7 @@ class Agent:
     def quality(self):
         if self.fused is not None:
             f = self.fused
+            f.check()                                   # no list entry was dropped during the run
             ret, tgt_rgb, tgt_d = f.loss_dict(), f.tgt_rgb, f.tgt_d[:, None]
         else:
             ret, tgt_rgb, tgt_d = self.last

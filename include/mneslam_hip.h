@@ -91,6 +91,9 @@ typedef struct mne_tile_bins {
     int32_t* spill_count;  /* [1] */
     int32_t* order;        /* [mne_tile_count()] scratch: tile processing order (heaviest first) */
     int32_t cap, spill_cap;
+    int32_t* dropped;      /* [1] sticky: entries that fit neither their list nor the spill area (their gradient is
+                            * LOST); never reset by the library.  A spill area of n_rays*n_samples*6*n_sets*4 entries
+                            * cannot overflow.  Must be zero-initialised by the caller; check it after a run. */
 } mne_tile_bins_t;
 
 /* Adam state and hyper-parameters of one plane, in JointEncoding.all_planes order
@@ -117,6 +120,8 @@ const char* mne_last_error(void);
 size_t mne_sizeof_scene(void);
 size_t mne_sizeof_render_cfg(void);
 size_t mne_sizeof_adam_seg(void);
+size_t mne_sizeof_tile_bins(void);
+size_t mne_sizeof_plane_opt(void);
 
 /* Number of samples per ray: n_range_d + n_samples_d with depth guidance, n_samples without
  * (model/scene_rep.py:362-374). */

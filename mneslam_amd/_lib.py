@@ -45,7 +45,7 @@ class AdamSeg(C.Structure):
 
 class TileBins(C.Structure):
     _fields_ = [("lists", C.c_void_p), ("counts", C.c_void_p), ("spill", C.c_void_p), ("spill_count", C.c_void_p),
-                ("order", C.c_void_p), ("cap", C.c_int32), ("spill_cap", C.c_int32)]
+                ("order", C.c_void_p), ("cap", C.c_int32), ("spill_cap", C.c_int32), ("dropped", C.c_void_p)]
 
 
 class PlaneOpt(C.Structure):
@@ -67,6 +67,8 @@ _PROTOS = {
     "mne_sizeof_scene": (C.c_size_t, []),
     "mne_sizeof_render_cfg": (C.c_size_t, []),
     "mne_sizeof_adam_seg": (C.c_size_t, []),
+    "mne_sizeof_tile_bins": (C.c_size_t, []),
+    "mne_sizeof_plane_opt": (C.c_size_t, []),
     "mne_num_samples": (C.c_int, [C.POINTER(RenderCfg), C.c_int]),
     "mne_sample_z": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -123,7 +125,8 @@ def load(path=None):
         if lib.mne_abi_version() != 1:
             raise RuntimeError("libmneslam_hip ABI version mismatch")
         for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
-                       (lib.mne_sizeof_adam_seg, AdamSeg)):
+                       (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),
+                       (lib.mne_sizeof_plane_opt, PlaneOpt)):
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"struct layout mismatch for {st.__name__}: C {fn()} vs ctypes {C.sizeof(st)}")
         _lib = lib

@@ -71,6 +71,8 @@ const char* mne_last_error(void) { return g_err.c_str(); }
 size_t mne_sizeof_scene(void) { return sizeof(mne_scene_t); }
 size_t mne_sizeof_render_cfg(void) { return sizeof(mne_render_cfg_t); }
 size_t mne_sizeof_adam_seg(void) { return sizeof(mne_adam_seg_t); }
+size_t mne_sizeof_tile_bins(void) { return sizeof(mne_tile_bins_t); }
+size_t mne_sizeof_plane_opt(void) { return sizeof(mne_plane_opt_t); }
 
 int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d) {
     if (!cfg) return fail(-1, "cfg is NULL");
@@ -205,7 +207,7 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
                      float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
                      const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_scene(scene, bins == nullptr)) return rc;
-    if (bins && (!bins->lists || !bins->counts || !bins->spill || !bins->spill_count || !bins->order || bins->cap < 1 || bins->spill_cap < 1))
+    if (bins && (!bins->lists || !bins->counts || !bins->spill || !bins->spill_count || !bins->order || !bins->dropped || bins->cap < 1 || bins->spill_cap < 1))
         return fail(-1, "mne_render_fused: incomplete tile bins");
     if (!cfg || !rays_o || !rays_d || !target_rgb || !target_d || !z_vals || !packed_decoder || !coef || !raw ||
         !tape || !tape_rows || !workspace)
@@ -226,6 +228,7 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
     if (bins) {
         a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
         a.bins.spill_count = bins->spill_count; a.bins.order = bins->order; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
+        a.bins.dropped = bins->dropped;
         mne_tile_geometry(*scene, a.bins);
     }
     if (int rc = mne_launch_render(a, 1, 1, workspace, st)) return fail(rc, "unsupported scene configuration");

@@ -678,6 +678,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
                             else {
                                 const int sp = atomicAdd(a.bins.spill_count, 1);
                                 if (sp < a.bins.spill_cap) { dst = a.bins.spill + (size_t)sp * MNE_SPILL_WORDS; *dst++ = (unsigned)want[e]; }
+                                else atomicAdd(a.bins.dropped, 1);          // caller-sized spill area too small: reported, never silent
                             }
                             if (dst) {
                                 dst[0] = trow;

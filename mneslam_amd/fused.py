@@ -27,7 +27,7 @@ class _null_ctx:
 
 class FusedStep:
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
-                 tile_capacity=4096, spill_capacity=1 << 18, shared_decoder=False, overlap=True):
+                 tile_capacity=None, spill_capacity=None, shared_decoder=False, overlap=True):
         """scatter="binned": plane gradients are accumulated per 16x16-cell tile in LDS and Adam is applied
         in the same kernel (csrc/tile_adam.hip; no gradient buffers).  scatter="atomics": global
         atomic adds into persistent gradient buffers + the streaming Adam kernel."""
@@ -95,16 +95,28 @@ class FusedStep:
             self.grad_map.update({p: g for p, g in zip(self.planes, self.grads)})
         else:
             n_tiles = self.lib.mne_tile_count(C.byref(self.scene))
+            if tile_capacity is None:
+                # 4x the mean list length of the plane with the fewest tiles if every sample contributed (a sample
+                # touches ~1.3 tiles of a plane); office0: 5,020 entries (longest list observed: 2,840).  Overflow is
+                # still correct (spill area), only slower.
+                tiles_min = min(((p.shape[2] + 15) // 16) * ((p.shape[3] + 15) // 16) for p in self.planes)
+                tile_capacity = int(min(max(4096, 4 * 1.3 * R * S / tiles_min), 1 << 20))
             self.tile_lists = torch.zeros(n_tiles, tile_capacity, 6, device=dev, dtype=torch.int32)
             self.tile_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
+            if spill_capacity is None:
+                # worst case: every sample appends to 4 tiles of every plane and every entry overflows its list --
+                # then nothing can ever be dropped (small scenes put >4096 samples into most tiles; office0 none)
+                spill_capacity = R * S * len(self.planes) * 4
             self.spill = torch.zeros(spill_capacity, 8, device=dev, dtype=torch.int32)
             self.spill_count = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.dropped = torch.zeros(1, device=dev, dtype=torch.int32)
             b = _lib.TileBins()
             b.lists, b.counts = self.tile_lists.data_ptr(), self.tile_counts.data_ptr()
             b.spill, b.spill_count = self.spill.data_ptr(), self.spill_count.data_ptr()
             self.tile_order = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
             b.order = self.tile_order.data_ptr()
             b.cap, b.spill_cap = tile_capacity, spill_capacity
+            b.dropped = self.dropped.data_ptr()
             self.bins = b
             self.plane_opt = (_lib.PlaneOpt * len(self.planes))()
             for k, p in enumerate(self.planes):
@@ -157,6 +169,29 @@ class FusedStep:
         _lib.check(lib.mne_loss_coef(C.byref(self.rc), R, S, P(self.counts), P(self.loss_w), P(self.coef), st),
                    "mne_loss_coef")
 
+    def _refresh_pointers(self):
+        """Planes, decoder weights and Adam moments are ordinary tensors owned by Python: their storage may be
+        re-bound between calls (``p.data = ...``, ``optimizer.load_state_dict``), so no device pointer survives
+        from one step to the next (ownership)."""
+        n = 0
+        for s in range(self.scene.n_sets):
+            for o in range(3):
+                for l in range(2):
+                    p = self.planes[n]
+                    if not (p.is_contiguous(memory_format=torch.channels_last) and p.stride(1) == 1):
+                        raise ValueError("fused step needs channels_last planes (a plane was re-bound with another layout)")
+                    pl = self.scene.plane[s][o][l]
+                    pl.data = p.data_ptr()
+                    if self.grads is not None:
+                        pl.grad = self.grads[n].data_ptr()
+                    if self.bins is not None:
+                        st = self.opt._state(p)
+                        self.plane_opt[n].m, self.plane_opt[n].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                    n += 1
+        w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
+        self.scene.w_sdf0, self.scene.w_sdf1 = w_sdf0.data_ptr(), w_sdf1.data_ptr()
+        self.scene.w_col0, self.scene.w_col1 = w_col0.data_ptr(), w_col1.data_ptr()
+
     def step(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global=None, idx_cur=None, u=None,
              prefetch=False):
         """One mapping iteration.  kf_rays [*,7] / cur_rays [H*W,7] / poses [N,4,4] live on the device;
@@ -170,6 +205,7 @@ class FusedStep:
         R, S = self.R, self.S
         if n_global + n_cur != R:
             raise ValueError(f"this FusedStep was built for {R} rays, got {n_global}+{n_cur}")
+        self._refresh_pointers()
         (main, st), (side, st2) = self._streams()
         ev = self._ev if side is not None else [None] * 4
         host_batch = idx_global is not None or idx_cur is not None or u is not None
@@ -236,6 +272,13 @@ class FusedStep:
         elif self._planes_pending:                                # whatever the caller enqueues next sees the updated planes
             main.wait_event(ev[1])
             self._planes_pending = False
+
+    def check(self):
+        """Host-synchronising sanity check (call once per mapping_optimize, not per step): raises if list entries
+        were lost because a caller-chosen spill_capacity was too small."""
+        self.synchronize()
+        if self.bins is not None and int(self.dropped.item()) != 0:
+            raise RuntimeError(f"binned scatter lost {int(self.dropped.item())} list entries: spill_capacity too small")
 
     def synchronize(self):
         """Make the caller's current stream wait for a plane update still running on the side stream (only needed

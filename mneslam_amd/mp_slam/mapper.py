@@ -201,6 +201,7 @@ class Mapper():
                 idx_c = torch.tensor(random.sample(range(0, n_pix), n_cur)).to(self.device)
             fs.step(kf_rays, n_kf * kf.num_rays_to_save, kf.num_rays_to_save, cur, poses, n, n_cur,
                     idx_global=idx_g, idx_cur=idx_c, u=self._jitter(fs), prefetch=it + 1 < n_it)
+        fs.check()
         self.last_losses = fs.loss_dict()
 
     def _first_frame_fused(self, batch, c2w, n_iters):
@@ -216,4 +217,5 @@ class Mapper():
                 # the reference indexes [H,W] images with (ind % H, ind // H)  (mp_slam/mapper.py:76-77)
                 idx_c = ((ind % H) * W + torch.div(ind, H, rounding_mode="trunc")).to(self.device)
             fs.step(None, 0, 1, cur, poses, 0, n, idx_cur=idx_c, u=self._jitter(fs), prefetch=it + 1 < n_iters)
+        fs.check()
         self.last_losses = fs.loss_dict()

@@ -192,3 +192,31 @@ def test_full_size_properties():
     eslam = has_d & (front | center | (~front & ~back & ~center))          # = every sample not behind the surface band
     expected = int(((z < z_lim) | eslam).sum())
     assert int(fs.tape_rows.item()) == expected, (int(fs.tape_rows.item()), expected)
+
+
+def test_rebinding_tensors_between_fused_steps():
+    """Planes / Adam moments are ordinary tensors that the host may re-bind between calls ("never cache
+    data_ptr()"): a run in which every plane and moment is moved to fresh storage half-way must equal an undisturbed run."""
+    import bench
+    from mneslam_amd import configs
+    cfg = configs.bench_office0()
+    cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
+    finals = []
+    for rebind in (False, True):
+        ag = bench.Agent(cfg, torch.device("cuda"), seed=9, n_keyframes=8, small=True, path="fused", scatter="binned")
+        for it in range(4):
+            if rebind and it == 2:
+                torch.cuda.synchronize()
+                for lst in ag.model.all_planes:
+                    for p in lst:
+                        p.data = p.data.clone(memory_format=torch.preserve_format)
+                        st = ag.opt._state(p)
+                        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+            ag.step()
+        torch.cuda.synchronize()
+        finals.append([p.detach().clone() for lst in ag.model.all_planes for p in lst] +
+                      [p.detach().clone() for p in ag.model.decoder.parameters()])
+    for a, b in zip(*finals):
+        d = (a - b).abs()
+        assert torch.isfinite(a).all() and float(d.mean()) < 1e-7 and float((d > 1e-4).float().mean()) < 1e-4
