@@ -550,3 +550,48 @@ def check_distillation(device):
             k += 1
     for (n, p), q in zip(student.decoder.named_parameters(), [s_sc.col_w[0], s_sc.col_w[1], s_sc.sdf_w[0], s_sc.sdf_w[1]]):
         assert_close(p.detach().cpu(), q.detach(), rtol=1e-3, atol=1e-4, what=n)
+
+
+def check_fused_vs_autograd(device, hidden=64, one_grid=False, co=True, seed=31, iters=3):
+    """Decoder shapes without golden fixtures (2x64, the class defaults BASELINE.json quotes): the fused step must
+    reach the parameters of the drop-in autograd path (itself pinned against the oracle by
+    check_oracle_random_scene) from the same state with the same host-drawn batches."""
+    g = load_golden("mapping3_colorplanes_cosdf" if not one_grid else "mapping3_onegrid_esdf")
+    H, W, n_save = int(g["H"]), int(g["W"]), int(g["n_save"])
+    direction = torch.from_numpy(g["direction"])
+    frames = [dict(frame_id=k, c2w=torch.from_numpy(g[f"frame{k}.c2w"]), rgb=torch.from_numpy(g[f"frame{k}.rgb"]),
+                   depth=torch.from_numpy(g[f"frame{k}.depth"]), direction=direction) for k in range(4)]
+    finals = []
+    for compute in ("autograd", "fused"):
+        cfg = configs.small_test_config(one_grid=one_grid, is_co_sdf=co)
+        cfg["decoder"]["hidden_dim"] = cfg["decoder"]["hidden_dim_color"] = hidden
+        cfg["mapping"].update(sample=64, min_pixels_cur=10, iters=iters, n_pixels=0.25)
+        torch.manual_seed(seed)
+        m = JointEncoding(cfg, torch.from_numpy(g["bounding_box"]).to(device))
+        m.device = torch.device(device)
+        m = m.to(device).train()
+        for lst in m.all_planes:
+            for l in range(2):
+                lst[l] = (lst[l] * 20.0).contiguous(memory_format=torch.channels_last)
+        opt = slam_glue.create_optimizer(m, cfg)
+        random.seed(seed)
+        torch.manual_seed(seed)
+        kfdb = KeyFrameDatabase(cfg, H, W, 8, n_save, device)
+        for k in range(3):
+            kfdb.add_keyframe(frames[k], k + 1)
+        slam = types.SimpleNamespace(
+            config=cfg, model=m, map_optimizer=opt, device=torch.device(device),
+            dataset=types.SimpleNamespace(H=H, W=W), video=types.SimpleNamespace(keyframe=kfdb),
+            get_loss_from_ret=lambda ret, cfg=cfg, **kw: slam_glue.get_loss_from_ret(cfg, ret, **kw),
+            select_samples=slam_glue.select_samples)
+        mapper = Mapper(cfg, slam, compute=compute, sampler="host")
+        poses = torch.stack([f["c2w"] for f in frames]).to(device)
+        random.seed(seed + 1)
+        torch.manual_seed(seed + 1)
+        mapper.optimize_map(frames[3], poses)
+        finals.append([p.detach().cpu().clone() for lst in m.all_planes for p in lst] +
+                      [p.detach().cpu().clone() for p in m.decoder.parameters()])
+    for k, (a, b) in enumerate(zip(*finals)):
+        assert torch.isfinite(a).all()
+        assert_close(b, a, rtol=1e-3, atol=1e-4, what=f"tensor {k}: fused vs autograd path")
+    assert not torch.equal(finals[0][-1], torch.zeros_like(finals[0][-1]))

@@ -103,6 +103,11 @@ def test_ragged_sizes_vs_oracle(n_rays, S_d, S_r):
     pc.check_oracle_random_scene(DEV, n_rays=n_rays, S_d=S_d, S_r=S_r, invalid_every=0 if n_rays < 10 else 5)
 
 
+@pytest.mark.parametrize("hidden,one_grid,co", [(64, False, True), (64, True, False), (32, False, False)])
+def test_fused_step_matches_autograd_path(hidden, one_grid, co):
+    pc.check_fused_vs_autograd(DEV, hidden=hidden, one_grid=one_grid, co=co)
+
+
 def test_loop_closure_pose_alignment():
     pc.check_pose_alignment(DEV)
 

@@ -138,3 +138,8 @@ def test_loop_closure_distillation():
 def test_ragged_sizes_vs_oracle(n_rays, S_d, S_r):
     """a single ray; S = 33 (one sample past a 32-sample tile); S = 2 -- forward and gradients vs the oracle"""
     pc.check_oracle_random_scene(DEV, n_rays=n_rays, S_d=S_d, S_r=S_r, invalid_every=0)
+
+
+@full
+def test_fused_step_matches_autograd_path_2x64_colorplanes():
+    pc.check_fused_vs_autograd(DEV, hidden=64, one_grid=False, co=True, iters=2)
