@@ -225,3 +225,28 @@ def test_rebinding_tensors_between_fused_steps():
     for a, b in zip(*finals):
         d = (a - b).abs()
         assert torch.isfinite(a).all() and float(d.mean()) < 1e-7 and float((d > 1e-4).float().mean()) < 1e-4
+
+
+@pytest.mark.parametrize("sample,n_samples_d,n_range_d", [(8192, 96, 32), (2048, 200, 56), (333, 5, 2)])
+def test_batch_shapes_binned_vs_atomics(sample, n_samples_d, n_range_d):
+    """Other batch shapes on the office0 planes (4x the rays; 256 samples per ray; 333+ rays x 7 samples), prefetching
+    steps: the binned scatter (lists, counting sort, tile Adam) and the atomic scatter + streaming Adam are two
+    schedules of the same sums and must agree; no list entry may be dropped."""
+    import bench
+    from mneslam_amd import configs
+    cfg = configs.bench_office0()
+    cfg["mapping"]["sample"] = sample
+    cfg["training"]["n_samples_d"], cfg["training"]["n_range_d"] = n_samples_d, n_range_d
+    finals = {}
+    for mode in ("binned", "atomics"):
+        ag = bench.Agent(cfg, torch.device("cuda"), seed=4, n_keyframes=6, path="fused", scatter=mode)
+        for it in range(4):
+            ag.step(prefetch=it < 3)
+        ag.fused.check()
+        torch.cuda.synchronize()
+        finals[mode] = torch.cat([p.detach().reshape(-1) for lst in ag.model.all_planes for p in lst])
+        assert torch.isfinite(ag.fused.losses[:2]).all()
+        del ag
+        torch.cuda.empty_cache()
+    d = (finals["binned"] - finals["atomics"]).abs()
+    assert float(d.mean()) < 1e-7 and float((d > 1e-4).float().mean()) < 1e-5
