@@ -172,6 +172,97 @@ __global__ __launch_bounds__(256) void wgrad_fused_kernel(WgradArgs a) {
     }
 }
 
+// The same single pass for the 2x64 decoders: the 64 hidden rows of dW1 / dV1 need 8 + 2*TNC accumulator tiles,
+// too many for one wave, so a pair of waves shares a tape slice -- wave parity hh takes hidden rows [32 hh, 32 hh + 32) of
+// dW1 and dV1; the even wave also accumulates dW2 (16 x 64), the odd one dV2 (3 x 64).  Waves 2,3 of the workgroup
+// work on a second slice and are summed into waves 0,1 through LDS; one partial per workgroup.
+template <bool CP>
+__global__ __launch_bounds__(256) void wgrad_fused64_kernel(WgradArgs a) {
+    typedef DecDims<64, 64, CP> D;
+    constexpr int TNC = D::CINP / 32;
+    constexpr int KS = 2;
+    constexpr int NTILE = 4 + TNC + 2;
+    __shared__ float red[2][64 * 16];                            // one 32x32 tile of waves 2 and 3
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int hh = wv & 1;                                       // hidden-row half of this wave
+    const int slice = blockIdx.x * 2 + (wv >> 1);
+    const int nslice = gridDim.x * 2;
+    const int n = *a.tape_rows;
+    int per = (n + nslice - 1) / nslice;
+    per = (per + 2 * KS - 1) / (2 * KS) * (2 * KS);
+    const int t0 = slice * per < n ? slice * per : n;
+    const int t1 = (t0 + per < n) ? t0 + per : n;
+    f32x16 acc[NTILE];                                           // w1[0..3] | v1[0..TNC) | (w2 or v2)[0..1]
+#pragma unroll
+    for (int q = 0; q < NTILE; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    const int col = lane & 31, kk = lane >> 5;
+    // the small GEMM of this wave: even = dout (16 rows) x h (64), odd = dc (3 rows) x hc (64)
+    const int offA2 = hh ? D::T_DC : D::T_DOUT, rowsA2 = hh ? 3 : MNE_OUT1, offB2 = hh ? D::T_HC : D::T_H;
+    for (int t = t0; t < t1; t += 2 * KS) {
+        float adh[KS], adc[KS], a2[KS], bx[KS][4], bc[KS][TNC], b2[KS][2];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int tt = t + 2 * ks + kk;
+            const bool ok = tt < t1;
+            const float* row = a.tape + (size_t)(ok ? tt : t0) * D::ROW;
+            adh[ks] = ok ? row[D::T_DH + 32 * hh + col] : 0.f;
+            adc[ks] = ok ? row[D::T_DHC + 32 * hh + col] : 0.f;
+            a2[ks] = (ok && col < rowsA2) ? row[offA2 + col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bx[ks][q] = (ok && 32 * q + col < MNE_IN1) ? row[D::T_X + 32 * q + col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < TNC; ++q) bc[ks][q] = ok ? row[D::T_CIN + 32 * q + col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) b2[ks][q] = ok ? row[offB2 + 32 * q + col] : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adh[ks], bx[ks][q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TNC; ++q) acc[4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adc[ks], bc[ks][q], acc[4 + q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[4 + TNC + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ks], b2[ks][q], acc[4 + TNC + q], 0, 0, 0);
+        }
+    }
+    // ---- waves 2,3 -> waves 0,1 (same hh), tile by tile
+#pragma unroll
+    for (int q = 0; q < NTILE; ++q) {
+        if (wv >= 2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wv - 2][e * 64 + lane] = acc[q][e];
+        }
+        __syncthreads();
+        if (wv < 2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][e] += red[wv][e * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wv >= 2) return;
+    float* out = a.partials + (size_t)blockIdx.x * D::NPARAM;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int lo = (e & 3) + 8 * (e >> 2) + 4 * kk;          // row inside the 32-row tile
+        const int o = 32 * hh + lo;                              // hidden unit
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (32 * q + col < MNE_IN1) out[D::P_SDF0 + o * MNE_IN1 + 32 * q + col] = acc[q][e];
+#pragma unroll
+        for (int q = 0; q < TNC; ++q) {
+            const int i = 32 * q + col;                          // tape column of the colour-net input
+            if (i != D::CINB) out[D::P_COL0 + o * D::CIN + (i > D::CINB ? i - 1 : i)] = acc[4 + q][e];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (hh == 0) { if (lo < MNE_OUT1) out[D::P_SDF1 + lo * 64 + 32 * q + col] = acc[4 + TNC + q][e]; }
+            else if (lo < 3) out[D::P_COL1 + lo * 64 + 32 * q + col] = acc[4 + TNC + q][e];
+        }
+    }
+}
+
 // 32 parameters per block, 8 groups of partials per parameter, fixed summation order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int nparam) {
     __shared__ float part[8][32];
@@ -230,6 +321,16 @@ static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
             blocks = blocks < 1 ? 1 : (blocks > WG_FUSED_BLOCKS ? WG_FUSED_BLOCKS : blocks);
             a.n_waves = blocks;
             MNE_LAUNCH((wgrad_fused_kernel<HID, HIDC, CP>), blocks, 256, 0, st, a);
+            MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
+            return 0;
+        }
+    }
+    if constexpr (HID == 64 && HIDC == 64) {
+        if (impl == 0) {
+            int blocks = a.n_waves * (64 / (2 * 2 * 2));          // >= 4 rows per slice; two slices per workgroup
+            blocks = blocks < 1 ? 1 : (blocks > WG_FUSED_BLOCKS ? WG_FUSED_BLOCKS : blocks);
+            a.n_waves = blocks;
+            MNE_LAUNCH((wgrad_fused64_kernel<CP>), blocks, 256, 0, st, a);
             MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
             return 0;
         }

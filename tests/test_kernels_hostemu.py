@@ -143,3 +143,10 @@ def test_ragged_sizes_vs_oracle(n_rays, S_d, S_r):
 @full
 def test_fused_step_matches_autograd_path_2x64_colorplanes():
     pc.check_fused_vs_autograd(DEV, hidden=64, one_grid=False, co=True, iters=2)
+
+
+@full
+@pytest.mark.parametrize("one_grid", [True, False])
+def test_random_scene_2x64_vs_oracle(one_grid):
+    """2x64 decoders (ALDS / global A tables, fused 2x64 weight-gradient kernel) against the oracle's autograd"""
+    pc.check_oracle_random_scene(DEV, hidden=64, one_grid=one_grid, n_rays=12, S_d=20, S_r=9)
