@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MNE_ABI_VERSION 1
+#define MNE_ABI_VERSION 2
 
 /* orientation index of a plane triple, as in JointEncoding.all_planes (scene_rep.py:117) */
 enum { MNE_XY = 0, MNE_XZ = 1, MNE_YZ = 2 };
@@ -255,11 +255,16 @@ int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* st
 
 /* ---- point queries (forward only) -------------------------------------------------------- */
 /* Replaces JointEncoding.query_color_sdf / query_sdf / run_network_flat (scene_rep.py:232-331):
- * raw [N][4] for arbitrary points [N][3]; geo (optional) [N][geo_feat_dim]. */
-#define MNE_QUERY_PTS_NORMALISED 1   /* pts are already in [-1,1] plane coordinates (feat only) */
+ * raw [N][4] for arbitrary points [N][3]; geo (optional) [N][geo_feat_dim]; feat (optional)
+ * [N][2*c_dim] = sample_plane_feature of the geometry planes (scene_rep.py:28-53).
+ * corner_idx (optional) [N][3*n_sets][2][2] int32 receives the integer NW corner (ix0, iy0) of the
+ * bilinear footprint of every point in every plane, in [set*3 + orientation][level] order -- the
+ * "bit-exact integer indices" of the tri-plane lookup (ATen grid_sampler_2d, align_corners=True,
+ * padding_mode='border'; scene_rep.py:43-47).  They are the values the gather itself uses. */
+#define MNE_QUERY_PTS_NORMALISED 1   /* pts are already in [-1,1] plane coordinates (feat / corner_idx only) */
 int mne_query_points(const mne_scene_t* scene, int64_t n_pts, const float* pts,
-                     const float* packed_decoder, float* raw, float* geo, float* feat, int flags,
-                     void* stream);
+                     const float* packed_decoder, float* raw, float* geo, float* feat,
+                     int32_t* corner_idx, int flags, void* stream);
 
 /* ---- R7: OneBlob encoding as a stand-alone op -------------------------------------------- */
 /* Replaces tcnn.Encoding(otype="OneBlob", n_bins=16) (model/encodings.py:61-71):

@@ -12,6 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmneslam_hip.so")
 
+ABI_VERSION = 2
 N_LOSS = 8
 N_COUNT = 8
 L_RGB, L_DEPTH, L_CO_SDF, L_CO_FS, L_E_FS, L_E_CENTER, L_E_TAIL, L_PSNR = range(8)
@@ -92,7 +93,7 @@ _PROTOS = {
     "mne_wgrad_partial_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_decoder_wgrad": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.c_void_p]),
-    "mne_query_points": (C.c_int, [C.POINTER(Scene), C.c_int64] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
+    "mne_query_points": (C.c_int, [C.POINTER(Scene), C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "mne_grid_level_table": (C.c_int, [C.POINTER(GridCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_grid_param_count": (C.c_size_t, [C.POINTER(GridCfg)]),
     "mne_grid_encode": (C.c_int, [C.POINTER(GridCfg), C.c_int64] + [C.c_void_p] * 5),
@@ -122,7 +123,7 @@ def load(path=None):
         for name, (res, args) in _PROTOS.items():
             fn = getattr(lib, name)          # AttributeError = the library does not export the ABI
             fn.restype, fn.argtypes = res, args
-        if lib.mne_abi_version() != 1:
+        if lib.mne_abi_version() != ABI_VERSION:
             raise RuntimeError("libmneslam_hip ABI version mismatch")
         for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
                        (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),

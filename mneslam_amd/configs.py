@@ -57,6 +57,93 @@ def bench_office0(n_range_d=32, n_samples_d=96, hidden=32):
     return cfg
 
 
+def _overlay(base, over):
+    for k, v in over.items():
+        if isinstance(v, dict) and isinstance(base.get(k), dict):
+            _overlay(base[k], v)
+        else:
+            base[k] = copy.deepcopy(v)
+    return base
+
+
+# configs/Replica/apart1_agent{1,2}.yaml:3-4 (inherit replica.yaml; only the bounds differ)
+_APART1_BOUNDS = {1: [[-2.8, 8.2], [-1.1, 7.2], [-2, 1.3]], 2: [[-2.8, 7.0], [1.0, 9.0], [-2.5, 1.3]]}
+
+
+def apartment_agent(agent=1):
+    """Replica Apart-1 split into two agents (BASELINE configs[2]): replica.yaml + the agent's bound
+    (configs/Replica/apart1_agent1.yaml, apart1_agent2.yaml); agent 1: 62.4 M plane parameters."""
+    cfg = replica_office0()
+    b = _APART1_BOUNDS[agent]
+    cfg["mapping"]["bound"] = copy.deepcopy(b)
+    cfg["mapping"]["marching_cubes_bound"] = copy.deepcopy(b)
+    cfg["enable_loop_detect"] = True
+    return cfg
+
+
+# configs/ScanNet/scannet.yaml (values that differ from replica.yaml) + configs/ScanNet/scene0000.yaml
+_SCANNET = {
+    "dataset": "scannet",
+    "mapping": {"min_pixels_cur": 20, "w_sdf_tail": 10,
+                "bound": [[-0.1, 8.6], [-0.1, 8.9], [-0.3, 3.3]],
+                "marching_cubes_bound": [[-0.1, 8.6], [-0.1, 8.9], [-0.3, 3.3]]},
+    "grid": {"hash_size": 19, "voxel_sdf": 0.04, "oneGrid": False},
+    "cam": {"H": 480, "W": 640, "fx": 577.590698, "fy": 578.729797, "cx": 318.905426, "cy": 242.683609,
+            "crop_edge": 10, "near": 0, "far": 8, "depth_trunc": 100.0},
+    "training": {"sdf_weight": 1000, "smooth_weight": 0.001, "n_samples_d": 96, "range_d": 0.25, "n_range_d": 21},
+}
+
+
+def scannet_scene0000(hidden=32):
+    """ScanNet scene0000_00 (BASELINE configs[3]): colour planes (oneGrid False), 21 + 96 = 117 samples,
+    480x640 frames cropped to 460x620, no ``training.n_samples`` key (configs/ScanNet/scannet.yaml:115)."""
+    cfg = _overlay(replica_office0(), _SCANNET)
+    del cfg["training"]["n_samples"]
+    cfg["decoder"]["hidden_dim"] = cfg["decoder"]["hidden_dim_color"] = hidden
+    return cfg
+
+
+# configs/Indoor/indoor.yaml + indoor_agent{0..3}.yaml (bounds = loop_bound.bound_k, indoor.yaml:169-173)
+_INDOOR_BOUNDS = {0: [[-6.2, 20], [-15.8, 0], [-1.0, 4.5]], 1: [[-6.2, 56.4], [-15.8, -7.0], [-1.0, 4.5]],
+                  2: [[25.0, 56.4], [-13.5, -2.0], [-2.0, 4.5]], 3: [[-6.2, 50.0], [-6.5, -2.2], [-2.0, 4.5]]}
+_INDOOR = {
+    "dataset": "indoor",
+    "mapping": {"iters": 100, "lr_embed": 0.01, "lr_embed_color": 0.01, "w_sdf_fs": 10, "w_sdf_tail": 50},
+    "cam": {"H": 720, "W": 1280, "fx": 637.147, "fy": 636.668, "cx": 637.003, "cy": 363.032,
+            "crop_edge": 0, "near": 0, "far": 60.0, "depth_trunc": 100.0},
+    "training": {"sdf_weight": 1000, "smooth_weight": 0.001, "n_samples": 512, "n_samples_d": 1024,
+                 "range_d": 0.2, "n_range_d": 21},
+    "planes_res": {"coarse": 0.24, "fine": 0.06, "bound_dividable": 0.24},
+    "c_planes_res": {"coarse": 0.24, "fine": 0.06},
+    "loop_bound": {f"bound_{k}": v for k, v in _INDOOR_BOUNDS.items()},
+}
+
+
+def indoor_agent(agent=0):
+    """INS Indoor agent ``agent`` (BASELINE configs[4]): 21 + 1024 = 1045 samples per ray, far 60 m,
+    planes 0.24 / 0.06 m on the agent's bound (configs/Indoor/indoor.yaml:21-23,135-139,169-173;
+    configs/Indoor/indoor_agent0.yaml)."""
+    cfg = _overlay(replica_office0(), _INDOOR)
+    b = _INDOOR_BOUNDS[agent]
+    cfg["mapping"]["bound"] = copy.deepcopy(b)
+    cfg["mapping"]["marching_cubes_bound"] = copy.deepcopy(b)
+    cfg["enable_loop_detect"] = True
+    return cfg
+
+
+WORKLOADS = {
+    # name -> (config factory, workload label used in bench.py's config.workload)
+    "office0": (lambda hidden=32: bench_office0(hidden=hidden), "replica_office0_triplane_asWired_2048x128"),
+    "office0_asShipped": (lambda hidden=32: _overlay(replica_office0(), {"decoder": {"hidden_dim": hidden, "hidden_dim_color": hidden}}),
+                          "replica_office0_triplane_asShipped_2048x43"),
+    "apartment": (lambda hidden=32: _overlay(apartment_agent(1), {"decoder": {"hidden_dim": hidden, "hidden_dim_color": hidden}}),
+                  "replica_apart1_agent1_triplane_2048x43"),
+    "scannet": (lambda hidden=32: scannet_scene0000(hidden), "scannet_scene0000_colorplanes_2048x117"),
+    "indoor": (lambda hidden=32: _overlay(indoor_agent(0), {"decoder": {"hidden_dim": hidden, "hidden_dim_color": hidden}}),
+               "ins_indoor_agent0_triplane_2048x1045"),
+}
+
+
 def small_test_config(one_grid=True, is_co_sdf=False, n_samples_d=32, n_range_d=11, depth_trunc=100.0):
     """The reduced configuration of the golden fixtures (tests/golden/make_golden.py::small_config)."""
     cfg = replica_office0()

@@ -179,7 +179,8 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
                         float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
                         float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
                         void* stream) {
-    if (int rc = check_scene(scene, true)) return rc;
+    // plane gradients are optional as a whole: all plane[].grad NULL = ray / decoder gradients only
+    if (int rc = check_scene(scene, scene && scene->plane[0][0][0].grad != nullptr)) return rc;
     if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows || !workspace)
         return fail(-1, "mne_render_backward: NULL argument");
     if (n_rays <= 0) return 0;
@@ -345,12 +346,12 @@ int mne_encode_oneblob(int64_t n_pts, int dims, const float* x, float* out, void
 }
 
 int mne_query_points(const mne_scene_t* scene, int64_t n_pts, const float* pts, const float* packed_decoder,
-                     float* raw, float* geo, float* feat, int flags, void* stream) {
+                     float* raw, float* geo, float* feat, int32_t* corner_idx, int flags, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
     if (!pts || ((raw || geo) && !packed_decoder)) return fail(-1, "mne_query_points: NULL argument");
     if (n_pts <= 0) return 0;
     QueryArgs a = {};
-    a.sc = *scene; a.n = n_pts; a.pts = pts; a.packed = packed_decoder; a.raw = raw; a.geo = geo; a.feat_out = feat; a.flags = flags;
+    a.sc = *scene; a.n = n_pts; a.pts = pts; a.packed = packed_decoder; a.raw = raw; a.geo = geo; a.feat_out = feat; a.corner_idx = corner_idx; a.flags = flags;
     if ((flags & MNE_QUERY_PTS_NORMALISED) && (raw || geo)) return fail(-1, "normalised points only support the feature output");
     if (int rc = mne_launch_query(a, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("query_points");

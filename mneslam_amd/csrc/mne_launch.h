@@ -75,6 +75,7 @@ struct QueryArgs {
     const float* pts;
     const float* packed;
     float *raw, *geo, *feat_out;
+    int* corner_idx;     // optional [n][3*n_sets][2][2]: (ix0, iy0) per plane
     int flags;
 };
 

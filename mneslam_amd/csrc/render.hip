@@ -690,7 +690,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
                     }
                 }
             }
-        } else {
+        } else if (a.sc.plane[0][0][0].grad) {                    // NULL: the caller wants no plane gradients (pose-only loops)
             scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane, a.dbg);
         }
     }
@@ -772,6 +772,23 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a) {
     if (a.flags & MNE_QUERY_PTS_NORMALISED) { pnv[0] = p[0]; pnv[1] = p[1]; pnv[2] = p[2]; }
     if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
     MNE_WAVE_SYNC();
+    if (a.corner_idx && valid) {
+        // integer NW corners of every plane: the same bilin_setup on the same staged fp32 coordinates as the
+        // gather below (lane half = plane level)
+        const float qx = pn[pt * 4 + 0], qy = pn[pt * 4 + 1], qz = pn[pt * 4 + 2];
+#pragma unroll
+        for (int set = 0; set < NSETS; ++set)
+#pragma unroll
+            for (int ori = 0; ori < 3; ++ori) {
+                const mne_plane_t& pl = a.sc.plane[set][ori][hf];
+                float gx, gy;
+                orient_coords(ori, qx, qy, qz, gx, gy);
+                Bilin b;
+                bilin_setup(gx, gy, pl.h, pl.w, b);
+                int* dst = a.corner_idx + ((i * (3 * NSETS) + set * 3 + ori) * 2 + hf) * 2;
+                dst[0] = b.ix0; dst[1] = b.iy0;
+            }
+    }
     gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
     MNE_WAVE_SYNC();
     if (a.feat_out && valid) {

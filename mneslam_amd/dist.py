@@ -36,13 +36,16 @@ def init_agents(backend=None):
 
 
 def _meta_tensor(model):
-    """[n_planes, then (C,H,W) per plane, then 6 bound + 6 bounding-box values] as float64."""
+    """[n_planes, then (C,H,W) per plane, then 6 bound + 6 bounding-box values, then 1.0 if the bounding box is
+    float64 (it is in the live system, mneslam_mp.py:223) else 0.0] as float64."""
     planes = [p for lst in model.all_planes for p in lst]
     vals = [float(len(planes))]
     for p in planes:
         vals += [float(p.shape[1]), float(p.shape[2]), float(p.shape[3])]
     vals += [float(v) for v in model.bound.reshape(-1)]
-    vals += [float(v) for v in torch.as_tensor(model.bounding_box).detach().cpu().reshape(-1)]
+    bb = torch.as_tensor(model.bounding_box).detach().cpu()
+    vals += [float(v) for v in bb.reshape(-1)]
+    vals.append(1.0 if bb.dtype == torch.float64 else 0.0)
     return torch.tensor(vals, dtype=torch.float64)
 
 
@@ -74,6 +77,8 @@ def recv_model_into(model_shared, src, device=None):
     shapes = meta[1:1 + 3 * n_planes].reshape(n_planes, 3).to(torch.int64).tolist()
     bound = meta[1 + 3 * n_planes:7 + 3 * n_planes].reshape(3, 2)
     bbox = meta[7 + 3 * n_planes:13 + 3 * n_planes].reshape(3, 2)
+    if float(meta[13 + 3 * n_planes]) == 0.0:        # the sender's box was fp32: keep its dtype (torch.load would)
+        bbox = bbox.float()
     planes = []
     for c, h, w in shapes:
         buf = torch.empty(1, c, h, w, device=device)

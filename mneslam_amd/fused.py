@@ -158,7 +158,7 @@ class FusedStep:
 
     def _sample_batch(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st):
         """R1-R3 for iteration `self.iteration`: ray batch, z samples (+ mask counts), loss coefficients."""
-        lib, P, R, S = self.lib, _lib.ptr, self.R, self.S
+        lib, P, R, S = self.lib, _lib.ptr, int(n_global + n_cur), self.S
         _lib.check(lib.mne_sample_rays(P(kf_rays), int(n_kf_rays), int(n_save), None, P(cur_rays), cur_rays.shape[0],
                                        P(poses), poses.shape[0], n_global, n_cur, P(idx_global), P(idx_cur),
                                        self.seed, self.iteration, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb),
@@ -202,9 +202,10 @@ class FusedStep:
         hold the next batch when this call returns, and the plane update is only joined by the next step or by
         ``synchronize()``; a step with prefetch=False, as Mapper's last one, leaves everything joined)."""
         lib, P = self.lib, _lib.ptr
-        R, S = self.R, self.S
-        if n_global + n_cur != R:
-            raise ValueError(f"this FusedStep was built for {R} rays, got {n_global}+{n_cur}")
+        R, S = int(n_global + n_cur), self.S
+        if R > self.R or R < 1:
+            raise ValueError(f"this FusedStep was built for at most {self.R} rays, got {n_global}+{n_cur}")
+        self.n_active = R            # every buffer is [ray][...]: a smaller batch uses the leading rows
         self._refresh_pointers()
         (main, st), (side, st2) = self._streams()
         ev = self._ev if side is not None else [None] * 4
@@ -299,6 +300,7 @@ class FusedStep:
 
     def loss_dict(self):
         L = self.losses
-        return {"rgb": self.rgb, "depth": self.depth, "rgb_loss": L[_lib.L_RGB], "depth_loss": L[_lib.L_DEPTH],
+        n = getattr(self, "n_active", self.R)
+        return {"rgb": self.rgb[:n], "depth": self.depth[:n], "rgb_loss": L[_lib.L_RGB], "depth_loss": L[_lib.L_DEPTH],
                 "co_sdf_loss": L[_lib.L_CO_SDF], "co_fs_loss": L[_lib.L_CO_FS], "e_fs_loss": L[_lib.L_E_FS],
                 "e_center_loss": L[_lib.L_E_CENTER], "e_tail_loss": L[_lib.L_E_TAIL], "psnr": L[_lib.L_PSNR:_lib.L_PSNR + 1]}

@@ -162,7 +162,11 @@ class RenderFunction(torch.autograd.Function):
         want_ray = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         d_o = torch.zeros(R, 3, **opts) if want_ray else None
         d_d = torch.zeros(R, 3, **opts) if want_ray else None
-        grads = [torch.zeros_like(p) for p in planes]          # channels_last preserved
+        # plane gradients only when some plane asks for one (the pose-alignment loop differentiates w.r.t. rays only:
+        # no zero-fill of 150-300 MB, no scatter)
+        first_plane = 8
+        want_planes = any(ctx.needs_input_grad[first_plane:first_plane + n_planes])
+        grads = [torch.zeros_like(p) for p in planes] if want_planes else None     # channels_last preserved
         sc = scene_struct(info, list(planes), list(dec_w), grads)
         coef = None
         if ctx.want_losses and g_losses is not None:
@@ -193,11 +197,14 @@ class RenderFunction(torch.autograd.Function):
         g_sdf0 = dgrad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0)
         g_sdf1 = dgrad[n0 + n1 + n2:].view_as(w_sdf1)
         return (None, None, d_o if ctx.needs_input_grad[2] else None, d_d if ctx.needs_input_grad[3] else None,
-                None, None, None, None, *grads, g_sdf0, g_sdf1, g_col0, g_col1)
+                None, None, None, None, *(grads if grads is not None else [None] * n_planes),
+                g_sdf0, g_sdf1, g_col0, g_col1)
 
 
-def query_points(info, planes, dec_w, pts, want_raw=True, want_geo=False, want_feat=False, normalised=False):
-    """Forward-only point query (no autograd): raw [N,4], geo [N,15], feat [N,64]."""
+def query_points(info, planes, dec_w, pts, want_raw=True, want_geo=False, want_feat=False, normalised=False,
+                 want_corner_idx=False):
+    """Forward-only point query (no autograd): raw [N,4], geo [N,15], feat [N,64]
+    (+ corner_idx [N, n_planes/2, 2, 2] int32 = (ix0, iy0) per plane when asked for)."""
     lib = _lib.load()
     flat = _f32c(pts.reshape(-1, 3).detach(), "pts")
     n = flat.shape[0]
@@ -210,6 +217,9 @@ def query_points(info, planes, dec_w, pts, want_raw=True, want_geo=False, want_f
     raw = torch.empty(n, 4, **opts) if want_raw else None
     geo = torch.empty(n, info["geo_feat_dim"], **opts) if want_geo else None
     feat = torch.empty(n, 2 * info["c_dim"], **opts) if want_feat else None
+    cidx = torch.empty(n, len(planes_cl) // 2, 2, 2, device=flat.device, dtype=torch.int32) if want_corner_idx else None
     _lib.check(lib.mne_query_points(C.byref(sc), n, _lib.ptr(flat), _lib.ptr(packed), _lib.ptr(raw), _lib.ptr(geo),
-                                    _lib.ptr(feat), 1 if normalised else 0, st), "mne_query_points")
+                                    _lib.ptr(feat), _lib.ptr(cidx), 1 if normalised else 0, st), "mne_query_points")
+    if want_corner_idx:
+        return raw, geo, feat, cidx
     return raw, geo, feat

@@ -173,15 +173,23 @@ class Mapper():
 
     # ------------------------------------------------------------------ fused path
     def _fused_step(self, n_rays):
-        key = (n_rays, id(self.map_optimizer))
-        if key not in self._fused:
-            self._fused[key] = FusedStep(self.model, self.map_optimizer, self.config, n_rays, self.device,
-                                         scatter=self.scatter, **self.fused_kwargs)
-        return self._fused[key]
+        """ONE FusedStep per (model, optimizer), sized for the largest batch the mapping loop can ask for --
+        ``sample`` global rays + max(sample // 1, min_pixels_cur) current-frame rays -- and reused for every
+        smaller batch (n_cur shrinks as keyframes accumulate): its scratch (tape, tile lists, spill area) is
+        allocated once, not once per distinct ray count."""
+        n = self.config["mapping"]["sample"]
+        cap = max(n_rays, n + max(n, self.config["mapping"]["min_pixels_cur"]))
+        key = (id(self.model), id(self.map_optimizer))
+        fs = self._fused.get(key)
+        if fs is None or fs.R < n_rays:
+            self._fused.clear()                      # drop the previous scratch before allocating the new one
+            fs = self._fused[key] = FusedStep(self.model, self.map_optimizer, self.config, cap, self.device,
+                                              scatter=self.scatter, **self.fused_kwargs)
+        return fs
 
     def _jitter(self, fs):
         if self.sampler == "host" and self.config["training"]["perturb"] > 0.0:
-            return torch.rand(fs.R, fs.S).to(self.device)        # the reference's CPU draw (scene_rep.py:381)
+            return torch.rand(self._n_batch, fs.S).to(self.device)   # the reference's CPU draw (scene_rep.py:381)
         return None
 
     def _mapping_optimize_fused(self, current_rays, poses):
@@ -189,6 +197,7 @@ class Mapper():
         n, n_kf = self.config["mapping"]["sample"], len(kf.frame_ids)
         n_cur = max(n // n_kf, self.config["mapping"]["min_pixels_cur"])
         fs = self._fused_step(n + n_cur)
+        self._n_batch = n + n_cur
         kf_rays = kf.device_rays(self.device)
         cur = current_rays.to(self.device, torch.float32).contiguous()
         poses = poses.to(self.device, torch.float32).contiguous()
@@ -207,6 +216,7 @@ class Mapper():
     def _first_frame_fused(self, batch, c2w, n_iters):
         H, W, n = self.slam.dataset.H, self.slam.dataset.W, self.config["mapping"]["sample"]
         fs = self._fused_step(n)
+        self._n_batch = n
         cur = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
         cur = cur.reshape(-1, 7).to(self.device, torch.float32).contiguous()
         poses = c2w.reshape(1, 4, 4).to(torch.float32).contiguous()

@@ -95,3 +95,21 @@ def make_frames(n_frames: int, H: int, W: int, fx: float, fy: float, cx: float, 
 REPLICA_CAM = dict(H=680, W=1200, fx=600.0, fy=600.0, cx=599.0, cy=339.0)
 OFFICE0_ROOM = [[-2.2, 2.6], [-3.4, 2.1], [-1.4, 2.0]]       # configs/Replica/office0.yaml:4
 OFFICE0_BOUND = [[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]]      # configs/Replica/office0.yaml:3
+
+
+def camera_from_config(cfg):
+    """Mapping-side camera of a reference config, restating datasets/dataset.py:38-44 (H, W, fx, fy, cx, cy
+    floor-divided by ``data.downsample`` -- also for the float intrinsics: cx 599.5 -> 599.0) and :174-178
+    (``cam.crop_edge`` removes a border and shifts the principal point)."""
+    cam, ds = cfg["cam"], cfg["data"]["downsample"]
+    H, W = cam["H"] // ds, cam["W"] // ds
+    fx, fy, cx, cy = cam["fx"] // ds, cam["fy"] // ds, cam["cx"] // ds, cam["cy"] // ds
+    edge = cam.get("crop_edge", 0)
+    if edge > 0:
+        H, W, cx, cy = H - 2 * edge, W - 2 * edge, cx - edge, cy - edge
+    return dict(H=int(H), W=int(W), fx=float(fx), fy=float(fy), cx=float(cx), cy=float(cy))
+
+
+def room_from_config(cfg, shrink=0.0):
+    """The synthetic room of a config = its ``mapping.marching_cubes_bound`` (the region the scene fills)."""
+    return [[lo + shrink, hi - shrink] for lo, hi in cfg["mapping"]["marching_cubes_bound"]]

@@ -330,11 +330,13 @@ class OracleScene:
             rgb_map = rgb_map + (1.0 - acc[..., None])
         return dict(rgb=rgb_map, depth=depth, disp_map=disp, acc_map=acc, depth_var=depth_var, weights=w)
 
-    def render_rays(self, rays_o, rays_d, target_d=None, u=None, impl="explicit"):
-        """model/scene_rep.py:351-419 (n_importance == 0 in every shipped config)."""
+    def render_rays(self, rays_o, rays_d, target_d=None, u=None, impl="explicit", z_vals=None):
+        """model/scene_rep.py:351-419 (n_importance == 0 in every shipped config).
+        ``z_vals`` (checker convenience, not reference API): use these samples instead of drawing them,
+        so that a batch whose jitter came from another generator can be re-evaluated."""
         assert self.pc.n_importance == 0, "importance sampling is dead code in the reference configs"
         n = rays_o.shape[0]
-        z = self.sample_z(n, target_d, u).to(rays_o)
+        z = (self.sample_z(n, target_d, u) if z_vals is None else z_vals).to(rays_o)
         pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]
         raw = self.query_color_sdf(pts, impl=impl).reshape(n, z.shape[1], 4)
         out = self.composite(raw, z)
@@ -372,9 +374,9 @@ class OracleScene:
         sd = F.mse_loss((z + sdf * t) * sdf_m, target_d * sdf_m) * sdf_w
         return fs, sd
 
-    def forward(self, rays_o, rays_d, target_rgb, target_d, u=None, impl="explicit"):
+    def forward(self, rays_o, rays_d, target_rgb, target_d, u=None, impl="explicit", z_vals=None):
         """Training-mode JointEncoding.forward.  model/scene_rep.py:549-611."""
-        rd = self.render_rays(rays_o, rays_d, target_d, u, impl)
+        rd = self.render_rays(rays_o, rays_d, target_d, u, impl, z_vals=z_vals)
         td = target_d.squeeze()
         valid = (td > 0.0) & (td < self.pc.depth_trunc)
         rgb_loss = F.mse_loss(rd["rgb"], target_rgb)

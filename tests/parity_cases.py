@@ -359,6 +359,53 @@ def check_queries(device):
     assert_close(m.query_color(pts.to(device)).cpu(), torch.sigmoid(ref[..., :3]), rtol=1e-4, atol=1e-5, what="query_color")
 
 
+def check_corner_indices(device, name="fwd_colorplanes"):
+    """R6 headline: the integer NW corner (ix0, iy0) of every bilinear footprint, exported by the HIP gather
+    itself (mne_query_points corner_idx), must EQUAL oracle.scene_rep.bilinear_corners for every plane and
+    level -- on the reference's own normalised points (golden mid.p_nor) and on adversarial points sitting
+    exactly on, and one ulp either side of, every cell edge of every plane, plus border / out-of-range values."""
+    from oracle.scene_rep import bilinear_corners
+    g = load_golden(name)
+    cfg = configs.small_test_config(**FWD_CASES[name])
+    m = model_from_golden(g, cfg, device).eval()
+    planes = [p for lst in m.all_planes for p in lst]
+    p_nor = [torch.from_numpy(g["mid.p_nor"])]
+    # cell edges: g = 2 k / (size - 1) - 1 and its fp32 neighbours, for every distinct plane extent
+    sizes = sorted({int(s) for p in planes for s in p.shape[2:]})
+    edge = []
+    for n in sizes:
+        k = torch.arange(0, n, dtype=torch.float32)
+        e = (k * 2.0) / float(n - 1) - 1.0
+        edge += [e, torch.nextafter(e, torch.full_like(e, 2.0)), torch.nextafter(e, torch.full_like(e, -2.0))]
+    edge = torch.cat(edge + [torch.tensor([-1.5, -1.0, 1.0, 1.5, 0.0, -0.0, 1.0000001, -1.0000001, 0.99999994])])
+    gen = torch.Generator().manual_seed(11)
+    for _ in range(3):      # every edge value on every axis, paired with shuffled edge values on the other two
+        cols = [edge[torch.randperm(edge.numel(), generator=gen)] for _ in range(3)]
+        p_nor.append(torch.stack(cols, -1))
+    p_nor = torch.cat(p_nor, 0).contiguous()
+    info = m._info()
+    out = __import__("mneslam_amd.hip_path", fromlist=["x"]).query_points(
+        info, [p.to(device) for p in planes], m.decoder.hip_weights(), p_nor.to(device), want_raw=False,
+        want_feat=True, normalised=True, want_corner_idx=True)
+    cidx = out[3].cpu()
+    n_sets = len(planes) // 6
+    assert cidx.shape == (p_nor.shape[0], 3 * n_sets, 2, 2) and cidx.dtype == torch.int32
+    axes = [(0, 1), (0, 2), (1, 2)]
+    checked = 0
+    for s in range(n_sets):
+        for ori in range(3):
+            for lvl in range(2):
+                pl = m.all_planes[s * 3 + ori][lvl]
+                h, w = pl.shape[2], pl.shape[3]
+                a, b = axes[ori]
+                ix0, iy0, _ = bilinear_corners(p_nor[:, a], p_nor[:, b], h, w)
+                assert torch.equal(cidx[:, s * 3 + ori, lvl, 0].long(), ix0), f"ix0 differs: set {s} ori {ori} lvl {lvl}"
+                assert torch.equal(cidx[:, s * 3 + ori, lvl, 1].long(), iy0), f"iy0 differs: set {s} ori {ori} lvl {lvl}"
+                checked += ix0.numel() * 2
+    assert checked > 0
+    return checked
+
+
 def check_oracle_random_scene(device, hidden=32, one_grid=True, n_rays=24, S_d=20, S_r=9, seed=5, invalid_every=5):
     """Seeded random scene at a configuration without fixture (e.g. hidden 64): HIP vs oracle,
     forward and gradients."""
@@ -595,3 +642,115 @@ def check_fused_vs_autograd(device, hidden=64, one_grid=False, co=True, seed=31,
         assert torch.isfinite(a).all()
         assert_close(b, a, rtol=1e-3, atol=1e-4, what=f"tensor {k}: fused vs autograd path")
     assert not torch.equal(finals[0][-1], torch.zeros_like(finals[0][-1]))
+
+
+def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0, small=False, impl="grid_sample",
+                               scatter="binned"):
+    """The BENCH path -- bench.Agent: device Feistel ray sampler, Philox jitter, FusedStep on two streams --
+    against ONE oracle iteration on the SAME device-drawn batch: the batch (ray indices, rays, targets, z samples)
+    is copied back from the device, the oracle (CPU autograd) evaluates forward, the seven losses, backward and
+    Adam from the same parameters, and everything the iteration produces is compared:
+      rays / targets   bit-exact re-assembly from the indices the device sampler drew
+      z samples        inside the stratified intervals [lower, upper] the oracle computes from target depth
+      rgb / depth      mean L1 < 1e-4 (north-star bar), elementwise rtol 1e-4
+      7 losses + psnr  rtol 1e-4
+      decoder grads    rtol 2e-3        plane grads (= exp_avg / (1 - beta1) after the first step) rtol 2e-3
+      post-Adam parameters and moments.
+    Works at any size (full office0: 38.4 M parameters, 2150 x 128 samples; ~2 s of oracle time)."""
+    import bench
+    dev = torch.device(device)
+    ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, small=small, path="fused", scatter=scatter)
+    fs, m = ag.fused, ag.model
+    for _ in range(warm_steps):
+        ag.step()
+    fs.synchronize()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    cpu = lambda t: t.detach().to("cpu", copy=True)
+    planes0 = [[cpu(p).contiguous() for p in lst] for lst in m.all_planes]
+    dec0 = {k: cpu(v) for k, v in m.decoder.state_dict().items()}
+    opt_state0 = [{k: (cpu(v).contiguous() if torch.is_tensor(v) else v) for k, v in ag.opt._state(p).items()}
+                  for lst in m.all_planes for p in lst]
+    dec_params = list(m.decoder.parameters())
+    dec_state0 = [{k: (cpu(v) if torch.is_tensor(v) else v) for k, v in ag.opt._state(p).items()} for p in dec_params]
+    ag.step()                                            # the iteration under test
+    fs.synchronize()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    fs.check()
+    R, S = fs.R, fs.S
+    rays_o, rays_d, tgt_rgb, tgt_d = cpu(fs.rays_o), cpu(fs.rays_d), cpu(fs.tgt_rgb), cpu(fs.tgt_d)
+    z = cpu(fs.z_vals)
+    # ---- the batch: indices drawn on the device -> the reference's own assembly on the CPU
+    idx = cpu(fs.idx)
+    n = cfg["mapping"]["sample"]
+    kf, cur, poses = cpu(ag.kf_rays), cpu(ag.cur_rays), cpu(ag.poses)
+    ig, ic = idx[:n], idx[n:]
+    assert ig.unique().numel() == n and ic.unique().numel() == ic.numel(), "sampling without replacement violated"
+    rays7 = torch.cat([kf[ig], cur[ic]], 0)
+    ids = torch.cat([torch.div(ig, ag.n_save, rounding_mode="trunc"), -torch.ones(ic.numel(), dtype=torch.int64)])
+    ref_o, ref_d, ref_rgb, ref_dep = omap.assemble_rays(rays7, ids, poses)
+    assert_close(rays_o, ref_o, rtol=0, atol=0, what="rays_o (bit-exact)")
+    assert_close(rays_d, ref_d, rtol=0, atol=0, what="rays_d (bit-exact)")
+    assert_close(tgt_rgb, ref_rgb, rtol=0, atol=0, what="target rgb")
+    assert_close(tgt_d, ref_dep[:, 0], rtol=0, atol=0, what="target depth")
+    # ---- oracle scene with the pre-step parameters
+    sc = OracleScene(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64), build=False)
+    sc.all_planes = tuple([p.contiguous() for p in lst] for lst in planes0)
+    sc.col_w = [dec0["color_net.model.0.weight"], dec0["color_net.model.2.weight"]]
+    sc.sdf_w = [dec0["sdf_net.model.0.weight"], dec0["sdf_net.model.2.weight"]]
+    sc.requires_grad_(True)
+    lo = sc.sample_z(R, tgt_d[:, None], u=torch.zeros(R, S))
+    hi = sc.sample_z(R, tgt_d[:, None], u=torch.ones(R, S))
+    assert bool(((z >= lo) & (z <= hi)).all()), "device z samples leave their stratified intervals"
+    assert float((z - lo).abs().max()) > 0, "no jitter was applied"
+    opt = omap.OracleAdam(sc, cfg)
+    for g_, states in zip(opt.groups, [dec_state0, opt_state0[:6], opt_state0[6:]]):
+        if states and states[0].get("step", 0):
+            g_.t = int(states[0]["step"])
+            g_.m = [st["exp_avg"].clone() for st in states]
+            g_.v = [st["exp_avg_sq"].clone() for st in states]
+    ret = sc.forward(rays_o, rays_d, tgt_rgb, tgt_d[:, None], impl=impl, z_vals=z)
+    loss = omap.loss_from_ret(cfg, ret, is_co_sdf=cfg["is_co_sdf"])
+    loss.backward()
+    # ---- forward
+    rgb, depth = cpu(fs.rgb), cpu(fs.depth)
+    assert float((rgb - ret["rgb"].detach()).abs().mean()) < 1e-4 and float((depth - ret["depth"].detach()).abs().mean()) < 1e-4
+    assert_close(rgb, ret["rgb"].detach(), rtol=1e-4, atol=2e-5, what="rgb")
+    assert_close(depth, ret["depth"].detach(), rtol=1e-4, atol=2e-5, what="depth")
+    assert_close(cpu(fs.raw), ret["raw"].detach(), rtol=1e-4, atol=2e-5, what="raw")
+    L = cpu(fs.losses)
+    for k, key in enumerate(LOSS_KEYS):
+        assert_close(L[k], ret[key].detach().reshape(()), rtol=1e-4, atol=1e-7, what=key)
+    # ---- gradients
+    n0, n1, n2 = [w.numel() for w in (sc.col_w[0], sc.col_w[1], sc.sdf_w[0])]
+    dg = cpu(fs.dec_grad)
+    got = [dg[:n0], dg[n0:n0 + n1], dg[n0 + n1:n0 + n1 + n2], dg[n0 + n1 + n2:]]
+    for gk, w, nm in zip(got, sc.decoder_list(), DEC_KEYS):
+        ref = w.grad
+        assert_close(gk.reshape(ref.shape), ref, rtol=2e-3, atol=2e-5 * max(1.0, float(ref.abs().max())), what=f"decoder grad {nm}")
+    flat_planes = [p for lst in m.all_planes for p in lst]
+    first_step = not (opt_state0[0].get("step", 0))
+    if first_step:
+        b1 = ag.opt.param_groups[1]["betas"][0]
+        for k, (p, ref_p) in enumerate(zip(flat_planes, sc.plane_list())):
+            g_hip = cpu(ag.opt._state(p)["exp_avg"]) / (1.0 - b1)           # m1 = (1 - b1) g  after the first step
+            ref = ref_p.grad
+            assert_close(g_hip, ref, rtol=2e-3, atol=2e-5 * max(1e-6, float(ref.abs().max())), what=f"plane grad {k}")
+    # ---- Adam
+    opt.step()
+    for k, (p, ref_p, g_m) in enumerate(zip(flat_planes, sc.plane_list(), opt.groups[1].m + (opt.groups[2].m if len(opt.groups) > 2 else []))):
+        st = ag.opt._state(p)
+        assert_close(cpu(st["exp_avg"]), g_m, rtol=2e-3, atol=2e-6 * max(1e-6, float(g_m.abs().max())), what=f"exp_avg {k}")
+        d = (cpu(p) - ref_p.detach()).abs()
+        # eps = 1e-15 makes Adam scale-free: where the gradient is fp32 noise the step is +-lr whatever its size,
+        # so a few cells may differ by O(lr); all others agree to rounding
+        lr = ag.opt.param_groups[1]["lr"]
+        assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 2e-3, \
+            f"plane {k} after Adam: mean {float(d.mean()):.3e}, outliers {float((d > 0.05 * lr).float().mean()):.3e}"
+    for w_hip, w_ref, nm in zip(dec_params, sc.decoder_list(), DEC_KEYS):
+        d = (cpu(w_hip) - w_ref.detach()).abs()
+        lr = ag.opt.param_groups[0]["lr"]
+        assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 5e-3, f"decoder {nm} after Adam"
+    return {"R": R, "S": S, "contributing": int(fs.tape_rows.item()),
+            "rgb_l1": float((rgb - ret["rgb"].detach()).abs().mean()), "depth_l1": float((depth - ret["depth"].detach()).abs().mean())}

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 def test_struct_layouts_and_version(lib_path):
     _lib.unload()
     lib = _lib.load(lib_path)       # checks ABI version and sizeof(struct) against ctypes
-    assert lib.mne_abi_version() == 1
+    assert lib.mne_abi_version() == _lib.ABI_VERSION
     _lib.unload()
 
 

@@ -31,7 +31,7 @@ def emulator_library():
 
 
 def test_abi_structs_match():
-    assert _lib.load().mne_abi_version() == 1
+    assert _lib.load().mne_abi_version() == _lib.ABI_VERSION
 
 
 def test_oneblob():
@@ -78,6 +78,10 @@ def test_render_nodepth():
 @full
 def test_queries():
     pc.check_queries(DEV)
+
+
+def test_corner_indices_bit_exact():
+    pc.check_corner_indices(DEV, "fwd_onegrid")
 
 
 @full
@@ -150,3 +154,21 @@ def test_fused_step_matches_autograd_path_2x64_colorplanes():
 def test_random_scene_2x64_vs_oracle(one_grid):
     """2x64 decoders (ALDS / global A tables, fused 2x64 weight-gradient kernel) against the oracle's autograd"""
     pc.check_oracle_random_scene(DEV, hidden=64, one_grid=one_grid, n_rays=12, S_d=20, S_r=9)
+
+
+def _tiny_bench_cfg(one_grid=True, hidden=32):
+    from mneslam_amd import configs
+    cfg = configs.bench_office0(n_range_d=9, n_samples_d=20, hidden=hidden)
+    cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["planes_res"] = {"coarse": 0.2, "fine": 0.1, "bound_dividable": 0.2}
+    cfg["c_planes_res"] = {"coarse": 0.4, "fine": 0.2}
+    cfg["grid"]["oneGrid"] = one_grid
+    cfg["mapping"]["sample"], cfg["mapping"]["min_pixels_cur"] = 40, 8
+    cfg["cam"]["far"] = 4.0
+    return cfg
+
+
+def test_bench_path_step_vs_oracle():
+    """The bench path (device sampler + Philox jitter + FusedStep) vs one oracle iteration on the same batch."""
+    out = pc.check_fused_step_vs_oracle(DEV, _tiny_bench_cfg(), n_keyframes=3, seed=2, small=True, impl="explicit")
+    assert out["contributing"] > 0
