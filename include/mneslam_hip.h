@@ -91,6 +91,11 @@ typedef struct mne_tile_bins {
     int32_t* spill_count;  /* [1] */
     int32_t* order;        /* [mne_tile_count()] scratch: tile processing order (heaviest first) */
     int32_t cap, spill_cap;
+    int32_t* last_counts;  /* optional [mne_tile_count()]: mne_tile_adam saves every list length here before resetting
+                            * `counts`, and mne_tile_order then sorts by THESE lengths -- i.e. the order of the next
+                            * iteration can be computed off the critical path, after mne_tile_adam, from the previous
+                            * iteration's lengths (the order is a scheduling hint only; results do not depend on it).
+                            * `order` must then hold a valid permutation before the first mne_tile_adam (e.g. 0..n-1). */
     int32_t* dropped;      /* [1] sticky: entries that fit neither their list nor the spill area (their gradient is
                             * LOST); never reset by the library.  A spill area of n_rays*n_samples*6*n_sets*4 entries
                             * cannot overflow.  Must be zero-initialised by the caller; check it after a run. */

@@ -46,7 +46,8 @@ class AdamSeg(C.Structure):
 
 class TileBins(C.Structure):
     _fields_ = [("lists", C.c_void_p), ("counts", C.c_void_p), ("spill", C.c_void_p), ("spill_count", C.c_void_p),
-                ("order", C.c_void_p), ("cap", C.c_int32), ("spill_cap", C.c_int32), ("dropped", C.c_void_p)]
+                ("order", C.c_void_p), ("cap", C.c_int32), ("spill_cap", C.c_int32), ("last_counts", C.c_void_p),
+                ("dropped", C.c_void_p)]
 
 
 class PlaneOpt(C.Structure):

@@ -249,7 +249,7 @@ int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* 
     TileAdamArgs a = {};
     a.sc = *scene;
     a.n_planes = scene->n_sets * 6;
-    a.bins.counts = bins->counts; a.bins.order = bins->order;
+    a.bins.counts = bins->last_counts ? bins->last_counts : bins->counts; a.bins.order = bins->order;
     mne_tile_geometry(*scene, a.bins);
     mne_launch_tile_order(a, (hipStream_t)stream);
     return check_launch("tile_order");
@@ -265,6 +265,7 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
     a.n_planes = scene->n_sets * 6;
     a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
     a.bins.spill_count = bins->spill_count; a.bins.order = bins->order; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
+    a.bins.last_counts = bins->last_counts;
     mne_tile_geometry(*scene, a.bins);
     for (int k = 0; k < a.n_planes; ++k) {
         const mne_plane_opt_t& g = opt[k];

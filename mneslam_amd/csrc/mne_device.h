@@ -155,7 +155,7 @@ __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float*
                     b.o10 = mne_bcast8(bm.o10, lvl * 3 + ori); b.o11 = mne_bcast8(bm.o11, lvl * 3 + ori);
                     b.w00 = mne_bcast8(bm.w00, lvl * 3 + ori); b.w01 = mne_bcast8(bm.w01, lvl * 3 + ori);
                     b.w10 = mne_bcast8(bm.w10, lvl * 3 + ori); b.w11 = mne_bcast8(bm.w11, lvl * 3 + ori);
-                    if (dbg & 4) { b.o00 = b.o01 = b.o10 = b.o11 = 0; }      // ablation: every load hits one line
+                    if MNE_ABL(dbg, 4) { b.o00 = b.o01 = b.o10 = b.o11 = 0; }      // ablation: every load hits one line
                     const float* base = pl.data + cg * 4;
                     const float4 v00 = *(const float4*)(base + b.o00);
                     const float4 v01 = *(const float4*)(base + b.o01);
@@ -241,7 +241,7 @@ template <int NSETS, int NPTS>
 __device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float* pn, const float* dfeat,
                                               int n_valid, int lane, int dbg = 0) {
     const int c = lane & 31, half = lane >> 5;
-    if (dbg & 1) return;
+    if MNE_ABL(dbg, 1) return;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 2; ++it) {
         const int slot = it * 2 + half;

@@ -29,6 +29,7 @@ struct TileBins {
     int* spill_count;
     int* order;               // [n_tiles] processing order of tile_adam_kernel (heaviest lists first)
     int cap, spill_cap;
+    int* last_counts;         // optional: list lengths of the previous tile_adam launch (source of tile_order)
     int* dropped;             // sticky count of entries lost to a full spill area
     int tile_base[MNE_MAX_PLANES + 1];   // first tile id of each plane ([set][orient][level] order)
     int ntx[MNE_MAX_PLANES];             // tiles per plane row

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * MAX_WPB) void decode_kernel(RenderArgs a) {
         float pos[24];
         oneblob_half(u, hf, pos);
         MlpState<HID, HIDC> st;
-        if (!(a.dbg & 8)) mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, atab, lane, st);
+        if (!MNE_ABL(a.dbg, 8)) mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, atab, lane, st);
         else { st.rgb[0] = st.rgb[1] = st.rgb[2] = pos[0]; st.out[0] = pos[1]; }
         if (valid && hf == 0)                                  // rows 0..3 live in the lower half
             *(float4*)(a.raw + ((size_t)r * S + i) * 4) = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);
@@ -345,7 +345,7 @@ __device__ __forceinline__ void composite_ray(const RenderArgs& a, int r, int la
             n_contrib += __popcll(m);
         }
         if (lane == 0) {
-            a.ccount[r] = (a.dbg & 16) ? 0 : n_contrib;
+            a.ccount[r] = MNE_ABL(a.dbg, 16) ? 0 : n_contrib;
             float* rc = a.ray_ctx + (size_t)r * RC_N;
             rc[RC_DENOM] = denom; rc[RC_ZLIM] = z_lim; rc[RC_AQ] = Aq;
             rc[RC_GR] = g_rgb[0]; rc[RC_GG] = g_rgb[1]; rc[RC_GB] = g_rgb[2]; rc[RC_GDEP] = g_dep;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
         // following offsets are fetched with one coalesced load and scanned with wave-uniform reads
         // (a tile of 32 rows rarely spans more than two or three rays).
         int lo = a.tile_ray[tile];
-        if (!(a.dbg & 1024)) {
+        if (!MNE_ABL(a.dbg, 1024)) {
             const int r0 = lo;
             const int cnext = a.coffset[(r0 + 1 + lane < a.R) ? r0 + 1 + lane : a.R];     // coffset[R] = total > kk
             const int k_last = (int)(tile * TILE) + TILE - 1;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
             }
         }
         const int r = lo;
-        const int i = (a.dbg & 1024) ? kk % S : a.clist[(size_t)r * Spad + (kk - a.coffset[r])];
+        const int i = MNE_ABL(a.dbg, 1024) ? kk % S : a.clist[(size_t)r * Spad + (kk - a.coffset[r])];
         const float z = a.z_vals[(size_t)r * S + i];
         const float td = has_t ? a.target_d[r] : 0.0f;
         const float* rc = a.ray_ctx + (size_t)r * RC_N;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
         float pos[24];
         oneblob_half(u, hf, pos);
         MlpState<HID, HIDC> st;
-        if (!(a.dbg & 512)) mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, atab, lane, st);
+        if (!MNE_ABL(a.dbg, 512)) mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, atab, lane, st);
         else {
             st.out = f32x16_zero(); st.rgb = f32x16_zero(); st.rgb[0] = pos[0];
             for (int t = 0; t < NT; ++t) st.h[t] = f32x16_zero();
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
         }
         // ---- tape: forward activations of this point (each lane writes the part it holds)
         float* row = a.tape + (size_t)kk * D::ROW;
-        const bool tape_on = valid && !(a.dbg & 2);
+        const bool tape_on = valid && !MNE_ABL(a.dbg, 2);
         if (tape_on) {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
         }
         // ---- MFMA backward chain; d(feature) rows overwrite this point's LDS feature rows
         f32x16 dh[NT], dout, dhc[NTC];
-        if (!(a.dbg & 4096)) mlp_backward_mfma<HID, HIDC, CP>(st, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
+        if (!MNE_ABL(a.dbg, 4096)) mlp_backward_mfma<HID, HIDC, CP>(st, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
         else {
             dout = f32x16_zero();
             for (int t = 0; t < NT; ++t) dh[t] = f32x16_zero();
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
                             *(const float4*)(feat + set * TILE * MNE_FS + pt * MNE_FS + hf * 32 + 4 * q);
                 if (hf == 0) *(float4*)(row + D::T_PN) = *(const float4*)(pn + pt * 4);
             }
-            if (!(a.dbg & 1)) {
+            if (!MNE_ABL(a.dbg, 1)) {
                 // One returning atomic per DISTINCT tile list per wave: lanes that append to the same
                 // list are grouped with ballots and the group leader reserves the whole run of slots.
                 // Three phases so that all reservations of a tile are in flight together: (A) grouping,

@@ -62,6 +62,9 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
 #ifndef DB
 #define DB 8
 #endif
+#ifndef TILE_PREFETCH
+#define TILE_PREFETCH 0
+#endif
 #define TILE_GROUPS (TILE_THREADS / 8)        // 8-lane groups (float4 per lane = one 32-channel row)
 #define TILE_CELLS (MNE_TILE * MNE_TILE)
 static_assert(PASS_ENTRIES <= TILE_THREADS && PASS_ENTRIES <= 256 && PASS_ENTRIES % TILE_GROUPS == 0, "one staged entry per thread; item index must fit 8 bits");
@@ -105,13 +108,34 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     const int tx0 = local % a.bins.ntx[pidx], ty0 = local / a.bins.ntx[pidx];
     for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int cnt = a.bins.counts[tile];
-    const int n_list = (a.dbg & 32) ? 0 : (cnt < a.bins.cap ? cnt : a.bins.cap);
+    const int n_list = MNE_ABL(a.dbg, 32) ? 0 : (cnt < a.bins.cap ? cnt : a.bins.cap);
     int n_spill = 0;
     if (cnt > a.bins.cap) {                     // only a tile whose list overflowed has entries in the spill area
         const int ns = *a.bins.spill_count;
         n_spill = ns < a.bins.spill_cap ? ns : a.bins.spill_cap;
     }
     const unsigned* lst = a.bins.lists + (size_t)tile * a.bins.cap * MNE_ENTRY_WORDS;
+    // Adam operands of this thread's elements, requested BEFORE the list passes so that the HBM stream of the
+    // sweep (24 B/param) overlaps the LDS accumulation instead of following it (TILE_PREFETCH: 0 none, 1 p+m, 2 p+m+v)
+    constexpr int NIT = (TILE_CELLS * MNE_C / 4) / TILE_THREADS;
+    const PlaneOpt& o = a.opt[pidx];
+    float* P = (float*)pl.data;
+    float4 pre_p[NIT], pre_m[NIT], pre_v[NIT];
+#if TILE_PREFETCH
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i4 = it * TILE_THREADS + tid;
+        const int y = i4 / (MNE_TILE * MNE_C / 4), x4 = i4 % (MNE_TILE * MNE_C / 4);
+        const int gy = ty0 * MNE_TILE + y, gx = tx0 * MNE_TILE + x4 / (MNE_C / 4);
+        if (gy < pl.h && gx < pl.w) {
+            const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + (x4 % (MNE_C / 4)) * 4;
+            pre_p[it] = *(const float4*)(P + off); pre_m[it] = *(const float4*)(o.m + off);
+#if TILE_PREFETCH >= 2
+            pre_v[it] = *(const float4*)(o.v + off);
+#endif
+        }
+    }
+#endif
     // lane layout of the row work: 8 lanes x float4 = the 32 channels of one gradient row
     const int sub = tid & 7, grp = tid >> 3;
     const float* dfeat = a.tape + a.t_dfeat + set * MNE_FEAT + lvl * MNE_C + sub * 4;
@@ -161,7 +185,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
 #pragma unroll
         for (int j = 0; j < PASS_ENTRIES / TILE_GROUPS; ++j) {
             const unsigned row = erow[j * TILE_GROUPS + grp];
-            grow[j] = (row != 0xffffffffu && !(a.dbg & 256)) ? *(const float4*)(dfeat + (size_t)row * a.row_stride)
+            grow[j] = (row != 0xffffffffu && !MNE_ABL(a.dbg, 256)) ? *(const float4*)(dfeat + (size_t)row * a.row_stride)
                                                              : make_float4(1.f, 1.f, 1.f, 1.f);
         }
         // ---- B: counts -> exclusive start offsets (one wave, 4 cells per lane)
@@ -250,18 +274,22 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     __syncthreads();
     TILE_STAMP(5);
     // ---- Adam on the tile: 16 rows x (16 cells x 32 ch) = 2048 float4
-    const PlaneOpt& o = a.opt[pidx];
-    float* P = (float*)pl.data;
 #pragma unroll
-    for (int it = 0; it < (TILE_CELLS * MNE_C / 4) / TILE_THREADS; ++it) {
-        if (a.dbg & 64) break;
+    for (int it = 0; it < NIT; ++it) {
+        if MNE_ABL(a.dbg, 64) break;
         const int i4 = it * TILE_THREADS + tid;
         const int y = i4 / (MNE_TILE * MNE_C / 4), x4 = i4 % (MNE_TILE * MNE_C / 4);
         const int cell = x4 / (MNE_C / 4), ch4 = x4 % (MNE_C / 4);
         const int gy = ty0 * MNE_TILE + y, gx = tx0 * MNE_TILE + cell;
         if (gy < pl.h && gx < pl.w) {
             const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + ch4 * 4;
+#if TILE_PREFETCH >= 2
+            float4 p = pre_p[it], m = pre_m[it], v = pre_v[it];
+#elif TILE_PREFETCH == 1
+            float4 p = pre_p[it], m = pre_m[it], v = *(float4*)(o.v + off);
+#else
             float4 p = *(float4*)(P + off), m = *(float4*)(o.m + off), v = *(float4*)(o.v + off);
+#endif
             const float4 gg = ((const float4*)g)[i4];
             adam_elem(p.x, gg.x, m.x, v.x, o); adam_elem(p.y, gg.y, m.y, v.y, o);
             adam_elem(p.z, gg.z, m.z, v.z, o); adam_elem(p.w, gg.w, m.w, v.w, o);
@@ -273,7 +301,10 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     if (tid == 0 && blockIdx.x < 4096)
         ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 8192) * MNE_SPILL_WORDS))[blockIdx.x * 8 + 7] = (unsigned long long)cnt;
 #endif
-    if (tid == 0) a.bins.counts[tile] = 0;                                     // ready for the next iteration
+    if (tid == 0) {
+        if (a.bins.last_counts) a.bins.last_counts[tile] = cnt;                // source of the next tile_order
+        a.bins.counts[tile] = 0;                                               // ready for the next iteration
+    }
 }
 
 void mne_tile_geometry(const mne_scene_t& sc, TileBins& b) {

@@ -103,27 +103,28 @@ class JointEncoding(nn.Module):
         if cfg["model"]["c_dim"] != 32 or cfg["pos"]["n_bins"] != 16 or cfg["decoder"]["geo_feat_dim"] != 15:
             raise NotImplementedError("the HIP path is built for c_dim=32, n_bins=16, geo_feat_dim=15 "
                                       "(every shipped config)")
-        bb_cpu = self._host_bounding_box()
+        bb_cpu = self._host_copy("bounding_box")
+        bound = self._host_copy("bound")          # a peer's checkpoint puts it on the device (mp_slam/mapper.py:721)
         return {
             "n_planes": 6 * (1 if cfg["grid"]["oneGrid"] else 2),
             "c_dim": cfg["model"]["c_dim"], "hidden": cfg["decoder"]["hidden_dim"],
             "hidden_color": cfg["decoder"]["hidden_dim_color"], "geo_feat_dim": cfg["decoder"]["geo_feat_dim"],
             "n_bins": cfg["pos"]["n_bins"], "bb_is_f64": bb_cpu.dtype == torch.float64,
-            "bound_lo": [float(v) for v in self.bound[:, 0]], "bound_hi": [float(v) for v in self.bound[:, 1]],
+            "bound_lo": [float(v) for v in bound[:, 0]], "bound_hi": [float(v) for v in bound[:, 1]],
             "bb_lo": [float(v) for v in bb_cpu[:, 0]], "bb_hi": [float(v) for v in bb_cpu[:, 1]],
             "render_cfg": hip_path.render_cfg_struct(cfg), "wgrad_impl": self.wgrad_impl,
         }
 
-    def _host_bounding_box(self):
-        """Host copy of ``bounding_box`` (it lives on the device in the live system): fetched once per distinct
+    def _host_copy(self, attr):
+        """Host copy of ``bounding_box`` / ``bound`` (device tensors in the live system): fetched once per distinct
         tensor / in-place version instead of one device synchronisation per render call."""
-        bb = self.bounding_box
-        key = (id(bb), getattr(bb, "_version", None), getattr(bb, "dtype", None))
-        cache = getattr(self, "_bb_cache", None)
-        if cache is None or cache[0] != key:
-            cache = (key, torch.as_tensor(bb).detach().cpu())
-            self._bb_cache = cache
-        return cache[1]
+        t = getattr(self, attr)
+        key = (id(t), getattr(t, "_version", None), getattr(t, "dtype", None))
+        caches = self.__dict__.setdefault("_host_cache", {})
+        hit = caches.get(attr)
+        if hit is None or hit[0] != key:
+            hit = caches[attr] = (key, torch.as_tensor(t).detach().cpu())
+        return hit[1]
 
     def _flat_planes(self):
         planes = [p for lst in self.all_planes for p in lst]

@@ -1,13 +1,24 @@
-"""Mapper -- the mapping-thread methods that drive the hot path (reference: mp_slam/mapper.py):
-``first_frame_mapping`` (:52-89, the training loop only), ``mapping_optimize`` (:118-162) and its
-alias ``optimize_map`` (the name BASELINE.json uses), plus the two training loops of loop closure that
-run on the same kernels: the pose alignment of ``handle_loop_closure`` (:362-412) and ``distillation``
-(:594-644).  Keyframe bookkeeping, image/mesh dumps, file exchange and fusion policy around these calls
-stay with the host application.
+"""Mapping-thread entry points of the hot path.
 
-``SLAM`` is the reference's MNESLAM-like object; the fields read here are the ones the reference's
-Mapper reads for these methods: ``model``, ``map_optimizer``, ``device``, ``dataset.H/.W``,
-``video.keyframe`` (KeyFrameDatabase), ``get_loss_from_ret``, ``select_samples``.
+What a host application needs depends on the integration level:
+
+1. **Drop-in scene model only.**  The host keeps its own ``mp_slam.mapper.Mapper`` untouched and constructs
+   ``mneslam_amd.model.scene_rep.JointEncoding`` (+ ``mneslam_amd.optim.FusedAdam``) instead of its own classes: the
+   host's loops call ``model.forward -> get_loss_from_ret -> loss.backward() -> map_optimizer.step()`` and every one of
+   those lands in the HIP kernels.  ``tests/test_dropin_reference.py`` runs the reference's unmodified Mapper that way.
+
+2. **Fused iteration.**  ``FusedMappingMixin`` goes in FRONT of the host's Mapper class,
+
+       from mp_slam.mapper import Mapper as HostMapper
+       Mapper = mneslam_amd.mp_slam.mapper.bind(HostMapper, sampler="host")
+
+   and replaces exactly two methods: ``mapping_optimize`` (reference mp_slam/mapper.py:118-162 -- nothing but the
+   iteration loop) and the training loop of ``first_frame_mapping`` (:72-89) -- the host's own method is then called
+   with ``n_iters=0`` so that ITS bookkeeping (first keyframe, descriptor, checkpoint, image / mesh dumps, :91-116) runs
+   unchanged.  ``run()``, ``final_run()``, loop closure and fusion policy stay the host's.
+
+``Mapper`` below is the stand-alone composition used by this repository's tests and bench (no host application here):
+the mixin over a minimal base that owns the reference's field names and the plain autograd iteration.
 """
 import random
 
@@ -16,216 +27,250 @@ import torch
 from ..fused import FusedStep
 
 
-class Mapper():
-    """``compute``: "autograd" = the reference's own sequence (model.forward -> get_loss_from_ret ->
-    backward -> map_optimizer.step/zero_grad) through the autograd node; "fused" = FusedStep (same
-    math, one forward+backward kernel, no graph).  ``sampler``: "host" = python ``random`` draws in
-    the reference's order (seed-for-seed identical batches); "device" = keyed permutation on the GPU
-    (no host work per iteration).  Defaults reproduce the reference exactly."""
+def frame_ray_table(batch):
+    """[H*W, 7] = dir3 | rgb3 | depth1 of one frame dict, row-major over (h, w)."""
+    return torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1).reshape(-1, 7)
+
+
+def world_rays(rays7, c2w_of_row):
+    """Camera-frame rows -> (rays_o, rays_d, target_rgb, target_d[:,None]) with one c2w per row ([N,4,4]):
+    rays_d = R dir, rays_o = t  (mp_slam/mapper.py:151-153)."""
+    rot, trans = c2w_of_row[:, :3, :3], c2w_of_row[:, :3, 3]
+    rays_d = torch.sum(rays7[:, None, :3] * rot, -1)          # elementwise product + sum: the reference's rounding
+    return trans, rays_d, rays7[:, 3:6], rays7[:, 6:7]
+
+
+class FusedMappingMixin:
+    """Fused replacements of the two training loops; see the module docstring.  Reads the host Mapper's fields
+    ``config, slam, model, map_optimizer, device, video`` (mp_slam/mapper.py:12-24).  Options are class attributes so
+    that ``bind`` can set them without touching the host's constructor."""
+    compute = "fused"          # "autograd": leave the host's loops alone
+    sampler = "host"           # "host": python-random draws in the reference's order;  "device": keyed permutation
+    scatter = "binned"
+    fused_kwargs = {}
+
+    # ---------------------------------------------------------------- plumbing
+    def _fused_step(self, n_rays):
+        """ONE FusedStep per (model, optimizer), sized for the largest batch the mapping loop can ask for --
+        ``sample`` global rays + max(sample, min_pixels_cur) current-frame rays -- and reused for every smaller batch
+        (n_cur shrinks as keyframes accumulate): tape, tile lists and spill area are allocated once."""
+        n = self.config["mapping"]["sample"]
+        cap = max(n_rays, n + max(n, self.config["mapping"]["min_pixels_cur"]))
+        cache = self.__dict__.setdefault("_fused", {})
+        key = (id(self.model), id(self.map_optimizer))
+        fs = cache.get(key)
+        if fs is None or fs.R < n_rays:
+            cache.clear()                            # release the previous scratch before allocating the new one
+            fs = cache[key] = FusedStep(self.model, self.map_optimizer, self.config, cap, self.device,
+                                        scatter=self.scatter, **self.fused_kwargs)
+        return fs
+
+    def _device_ray_db(self, store):
+        """Device copy of the keyframe ray store.  This repository's KeyFrameDatabase keeps its own mirror with dirty
+        tracking; a HOST database (the reference's class, which only has the CPU tensor ``rays``) is mirrored here: a new
+        tensor object (``del_keyframe`` re-creates it) is uploaded whole, in-place growth uploads the slots from the last
+        previously live one onwards (``add_keyframe`` rewrites only slot counter-1)."""
+        if hasattr(store, "device_rays"):
+            return store.device_rays(self.device)
+        live = len(store.frame_ids)
+        tag = (id(store.rays), store.rays._version)
+        st = self.__dict__.setdefault("_kf_mirror", {"tag": None, "live": 0, "dev": None})
+        if st["dev"] is None or st["tag"] is None or st["tag"][0] != tag[0] or st["dev"].shape != store.rays.shape:
+            st["dev"] = store.rays.to(self.device)
+        elif st["tag"][1] != tag[1] or st["live"] != live:
+            lo = max(min(st["live"], live) - 1, 0)
+            st["dev"][lo:live] = store.rays[lo:live].to(self.device)
+        st["tag"], st["live"] = tag, live
+        return st["dev"]
+
+    def _host_jitter(self, n_rays, fs):
+        if self.sampler == "host" and self.config["training"]["perturb"] > 0.0:
+            return torch.rand(n_rays, fs.S).to(self.device)           # the reference's CPU draw (scene_rep.py:381)
+        return None
+
+    # ---------------------------------------------------------------- the two replaced loops
+    def mapping_optimize(self, batch, poses):
+        """``mapping.iters`` iterations over `sample` global keyframe rays + the current frame's share
+        (reference: mp_slam/mapper.py:118-162); ``poses`` [N,4,4] c2w, the current frame's pose last."""
+        if self.compute != "fused":
+            return super().mapping_optimize(batch, poses)
+        cfg, store = self.config["mapping"], self.video.keyframe
+        self.map_optimizer.zero_grad()
+        n_kf, per_kf = len(store.frame_ids), store.num_rays_to_save
+        n_glob, n_cur = cfg["sample"], max(cfg["sample"] // n_kf, cfg["min_pixels_cur"])
+        fs = self._fused_step(n_glob + n_cur)
+        db = self._device_ray_db(store)
+        cur = frame_ray_table(batch).to(self.device, torch.float32).contiguous()
+        poses = poses.to(self.device, torch.float32).contiguous()
+        n_pix = self.slam.dataset.H * self.slam.dataset.W
+        for it in range(cfg["iters"]):
+            picks = (None, None)
+            if self.sampler == "host":                # same two draws, same order as the reference's iteration
+                picks = (torch.tensor(random.sample(range(n_kf * per_kf), n_glob)).to(self.device),
+                         torch.tensor(random.sample(range(0, n_pix), n_cur)).to(self.device))
+            fs.step(db, n_kf * per_kf, per_kf, cur, poses, n_glob, n_cur, idx_global=picks[0], idx_cur=picks[1],
+                    u=self._host_jitter(n_glob + n_cur, fs), prefetch=it + 1 < cfg["iters"])
+        fs.check()
+        self.last_losses = fs.loss_dict()
+
+    def first_frame_mapping(self, batch, n_iters=100):
+        """Fused training on the first frame, then the host's own method with zero iterations for its bookkeeping."""
+        if self.compute != "fused":
+            return super().first_frame_mapping(batch, n_iters)
+        if batch["frame_id"] != 0:
+            raise ValueError("First frame mapping must be the first frame!")
+        self.model.train()
+        H, W, n = self.slam.dataset.H, self.slam.dataset.W, self.config["mapping"]["sample"]
+        fs = self._fused_step(n)
+        cur = frame_ray_table(batch).to(self.device, torch.float32).contiguous()
+        pose = batch["c2w"].to(self.device).reshape(1, 4, 4).to(torch.float32).contiguous()
+        for it in range(n_iters):
+            pick = None
+            if self.sampler == "host":
+                flat = self.slam.select_samples(H, W, n)
+                # the reference turns a flat draw into (h, w) = (flat % H, flat // H)  (mp_slam/mapper.py:76-77)
+                pick = ((flat % H) * W + torch.div(flat, H, rounding_mode="trunc")).to(self.device)
+            fs.step(None, 0, 1, cur, pose, 0, n, idx_cur=pick, u=self._host_jitter(n, fs), prefetch=it + 1 < n_iters)
+        fs.check()
+        self.last_losses = fs.loss_dict()
+        return super().first_frame_mapping(batch, 0)
+
+    # ---------------------------------------------------------------- N2: loop-closure loops on the same kernels
+    def optimize_relative_pose(self, base_c2w, target_c2w_initial, model_for_base, model_for_target, n_iters=None,
+                               rays_d_cam_batch=None):
+        """Pose alignment of loop closure (the loop inside ``handle_loop_closure``, mp_slam/mapper.py:362-412): the base
+        model renders ``mapping.sample`` camera rays from ``base_c2w`` (teacher, 256 uniform samples, no gradient); the
+        6 pose parameters of the target are then fitted so that the target model renders the same rgb / depth --
+        ``render_rays`` with ray gradients (R13; planes get no gradient buffers), weighted MSE, the host's pose
+        optimizer (``SLAM.get_pose_param_optim`` / ``SLAM.matrix_from_tensor``, mneslam_mp.py:577-584).
+        The best pose is tracked on the device: no host synchronisation inside the loop.
+        Returns (base_c2w @ inv(best target pose), best loss)."""
+        cfg, dev = self.config, self.device
+        w_rgb, w_depth = cfg["training"]["rgb_weight"], cfg["training"]["depth_weight"]
+        steps = cfg["mapping"]["loop_iters"] if n_iters is None else n_iters
+        base_c2w, start = base_c2w.to(dev), target_c2w_initial.to(dev)
+        rot, trans, pose_opt = self.slam.get_pose_param_optim(start[None, ...], mapping=False)
+        with torch.no_grad():
+            if rays_d_cam_batch is None:
+                pool = self.dataset.rays_d.reshape(-1, 3)
+                rays_d_cam_batch = pool[torch.randint(0, len(pool), (cfg["mapping"]["sample"],))]
+            dirs = rays_d_cam_batch.to(dev)
+            n = dirs.shape[0]
+            o_t, d_t, _, _ = world_rays(torch.cat([dirs, dirs.new_zeros(n, 4)], -1), base_c2w.expand(n, 4, 4))
+            teacher = model_for_base.render_rays(o_t, d_t, target_d=None)
+            want_rgb, want_depth = teacher["rgb"].detach(), teacher["depth"].detach()
+        best = torch.full((), float("inf"), device=dev)
+        best_pose = start.clone()
+        for _ in range(steps):
+            pose_opt.zero_grad()
+            c2w = self.slam.matrix_from_tensor(rot, trans).squeeze(0)
+            rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], dim=-1)
+            out = model_for_target.render_rays(c2w[:3, 3].unsqueeze(0).repeat(n, 1), rays_d, target_d=None)
+            loss = w_rgb * torch.nn.functional.mse_loss(out["rgb"], want_rgb) \
+                + w_depth * torch.nn.functional.mse_loss(out["depth"], want_depth)
+            with torch.no_grad():
+                better = loss.detach() < best
+                best = torch.where(better, loss.detach(), best)
+                best_pose = torch.where(better, c2w.detach(), best_pose)
+            loss.backward()
+            pose_opt.step()
+        return base_c2w @ torch.inverse(best_pose), float(best)
+
+    def distillation(self, other_rank, expanded_foreign_kfs_for_distill, num_expanded_kfs):
+        """Distil a foreign agent's map (``model_shared`` = teacher) into ``model`` (the training loop of
+        mp_slam/mapper.py:594-644): every iteration draws camera rays at each foreign keyframe pose, the teacher renders
+        them without depth guidance (no gradient), the student trains on the teacher's rgb / depth with the usual loss."""
+        cfg = self.config
+        n, floor = cfg["mapping"]["sample"], cfg["mapping"]["min_pixels_cur"]
+        per_kf = max(n // num_expanded_kfs, floor) if num_expanded_kfs > 0 else n
+        pool = self.dataset.rays_d.reshape(-1, 3)
+        for _ in range(cfg["mapping"]["distill_iters"]):
+            pieces = []
+            for kf in expanded_foreign_kfs_for_distill:
+                pose = kf["pose"].to(self.device)
+                dirs = pool[torch.randint(0, len(pool), (per_kf,))].to(self.device)
+                rays_o = pose[:3, 3].unsqueeze(0).repeat(per_kf, 1)
+                rays_d = torch.sum(dirs[..., None, :] * pose[:3, :3], dim=-1)
+                with torch.no_grad():
+                    t = self.model_shared.render_rays(rays_o, rays_d, target_d=None)
+                pieces.append((rays_o, rays_d, t["rgb"].detach(), t["depth"].detach().unsqueeze(-1)))
+            if not pieces:
+                continue
+            self.map_optimizer.zero_grad()
+            ret = self.model.forward(*[torch.cat(col, 0) for col in zip(*pieces)])
+            self.slam.get_loss_from_ret(ret, is_co_sdf=cfg["is_co_sdf"]).backward()
+            self.map_optimizer.step()
+
+
+def bind(host_mapper_cls, compute="fused", sampler="host", scatter="binned", **fused_kwargs):
+    """``class Mapper(FusedMappingMixin, host_mapper_cls)`` with the given options: the host's Mapper with its two
+    training loops replaced by the fused iteration (everything else inherited unchanged)."""
+    if compute not in ("autograd", "fused") or sampler not in ("host", "device"):
+        raise ValueError("compute must be autograd|fused and sampler host|device")
+    if sampler == "device" and compute != "fused":
+        raise ValueError("the device sampler is part of the fused path")
+    return type("Mapper", (FusedMappingMixin, host_mapper_cls),
+                dict(compute=compute, sampler=sampler, scatter=scatter, fused_kwargs=dict(fused_kwargs),
+                     optimize_map=FusedMappingMixin.mapping_optimize))
+
+
+class _PlainMapper:
+    """Minimal stand-in for a host Mapper (this repository has no host application): the reference's field names
+    (mp_slam/mapper.py:12-50) and the plain iteration -- ``forward -> get_loss_from_ret -> backward -> step`` on the
+    drop-in model -- for both loops, written around two small helpers."""
+
+    def __init__(self, config, SLAM) -> None:
+        self.config, self.slam = config, SLAM
+        self.model, self.model_shared = SLAM.model, getattr(SLAM, "model_shared", None)
+        self.map_optimizer = SLAM.map_optimizer
+        self.device, self.dataset, self.video = SLAM.device, SLAM.dataset, SLAM.video
+        self.rank, self.world_size = getattr(SLAM, "rank", 0), getattr(SLAM, "world_size", 1)
+
+    def _train_on(self, rays_o, rays_d, target_rgb, target_d):
+        ret = self.model.forward(rays_o, rays_d, target_rgb, target_d)
+        self.slam.get_loss_from_ret(ret, is_co_sdf=self.config["is_co_sdf"]).backward()
+        self.map_optimizer.step()
+        return ret
+
+    def first_frame_mapping(self, batch, n_iters=100):
+        if batch["frame_id"] != 0:
+            raise ValueError("First frame mapping must be the first frame!")
+        self.model.train()
+        H, W, n = self.slam.dataset.H, self.slam.dataset.W, self.config["mapping"]["sample"]
+        c2w = batch["c2w"].to(self.device)
+        table = frame_ray_table(batch)
+        for _ in range(n_iters):
+            self.map_optimizer.zero_grad()
+            flat = self.slam.select_samples(H, W, n)
+            rows = (flat % H) * W + torch.div(flat, H, rounding_mode="trunc")     # (h, w) = (flat % H, flat // H), :76-77
+            self._train_on(*world_rays(table[rows].to(self.device), c2w.expand(n, 4, 4)))
+        self.video.keyframe.add_keyframe(batch, 1, filter_depth=self.config["mapping"]["filter_depth"])   # :92
+
+    def mapping_optimize(self, batch, poses):
+        cfg, store = self.config["mapping"], self.video.keyframe
+        self.map_optimizer.zero_grad()
+        table = frame_ray_table(batch)
+        n_pix = self.slam.dataset.H * self.slam.dataset.W
+        for _ in range(cfg["iters"]):
+            glob, owner = store.sample_global_rays(cfg["sample"])
+            cur_rows = random.sample(range(0, n_pix), max(cfg["sample"] // len(store.frame_ids), cfg["min_pixels_cur"]))
+            rays7 = torch.cat([glob, table[cur_rows]], 0).to(self.device)
+            pose_row = torch.cat([owner.to(torch.int64), torch.full((len(cur_rows),), -1, dtype=torch.int64)])
+            self._train_on(*world_rays(rays7, poses[pose_row.to(poses.device)]))     # id -1 = the current frame's pose
+            self.map_optimizer.zero_grad()
+
+
+class Mapper(FusedMappingMixin, _PlainMapper):
+    """Stand-alone mapper of this repository: ``compute`` "autograd" (the plain iteration) or "fused";
+    ``sampler`` "host" (seed-for-seed the reference's batches) or "device"."""
 
     def __init__(self, config, SLAM, compute="autograd", sampler="host", scatter="binned") -> None:
         if compute not in ("autograd", "fused") or sampler not in ("host", "device"):
             raise ValueError("compute must be autograd|fused and sampler host|device")
         if sampler == "device" and compute != "fused":
             raise ValueError("the device sampler is part of the fused path")
+        super().__init__(config, SLAM)
         self.compute, self.sampler, self.scatter = compute, sampler, scatter
-        self._fused = {}
-        self.fused_kwargs = {}          # extra FusedStep options (e.g. tile_capacity)
-        self.config = config
-        self.slam = SLAM
-        self.model = SLAM.model
-        self.model_shared = getattr(SLAM, "model_shared", None)
-        self.map_optimizer = SLAM.map_optimizer
-        self.device = SLAM.device
-        self.dataset = SLAM.dataset
-        self.video = SLAM.video
-        self.rank = getattr(SLAM, "rank", 0)
-        self.world_size = getattr(SLAM, "world_size", 1)
+        self.fused_kwargs = {}
 
-    def first_frame_mapping(self, batch, n_iters=100):
-        """Training loop of the first frame (reference: mp_slam/mapper.py:65-89): ``n_iters`` x
-        {zero_grad, python-random pixel selection, forward, loss, backward, Adam step}."""
-        if batch["frame_id"] != 0:
-            raise ValueError("First frame mapping must be the first frame!")
-        c2w = batch["c2w"].to(self.device)
-        self.model.train()
-        H, n = self.slam.dataset.H, self.config["mapping"]["sample"]
-        if self.compute == "fused":
-            return self._first_frame_fused(batch, c2w, n_iters)
-        for _ in range(n_iters):
-            self.map_optimizer.zero_grad()
-            indice = self.slam.select_samples(self.slam.dataset.H, self.slam.dataset.W, n)
-            indice_h = indice % H
-            indice_w = torch.div(indice, H, rounding_mode="trunc")
-            rays_d_cam = batch["direction"][indice_h, indice_w, :].to(self.device)
-            target_s = batch["rgb"][indice_h, indice_w, :].to(self.device)
-            target_d = batch["depth"][indice_h, indice_w].to(self.device).unsqueeze(-1)
-            rays_o = c2w[None, :3, -1].repeat(n, 1)
-            rays_d = torch.sum(rays_d_cam[..., None, :] * c2w[:3, :3], -1)
-            ret = self.model.forward(rays_o, rays_d, target_s, target_d)
-            loss = self.slam.get_loss_from_ret(ret, is_co_sdf=self.config["is_co_sdf"])
-            loss.backward()
-            self.map_optimizer.step()
-
-    def mapping_optimize(self, batch, poses):
-        """Global bundle adjustment over all keyframes + the current frame (reference:
-        mp_slam/mapper.py:118-162).  ``poses`` [N,4,4] c2w; rows sampled from the current frame use
-        ``poses[-1]`` (id -1)."""
-        self.map_optimizer.zero_grad()
-        current_rays = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
-        current_rays = current_rays.reshape(-1, current_rays.shape[-1])
-        n = self.config["mapping"]["sample"]
-        if self.compute == "fused":
-            return self._mapping_optimize_fused(current_rays, poses)
-        for _ in range(self.config["mapping"]["iters"]):
-            rays, ids = self.video.keyframe.sample_global_rays(n)
-            idx_cur = random.sample(range(0, self.slam.dataset.H * self.slam.dataset.W),
-                                    max(n // len(self.video.keyframe.frame_ids), self.config["mapping"]["min_pixels_cur"]))
-            rays = torch.cat([rays, current_rays[idx_cur, :]], dim=0)
-            ids_all = torch.cat([ids, -torch.ones((len(idx_cur)))]).to(torch.int64)
-            rays_d_cam = rays[..., :3].to(self.device)
-            target_s = rays[..., 3:6].to(self.device)
-            target_d = rays[..., 6:7].to(self.device)
-            rot = poses[ids_all.to(poses.device), :3, :3]
-            rays_d = torch.sum(rays_d_cam[:, None, :] * rot, -1)
-            rays_o = poses[ids_all.to(poses.device), :3, -1]
-            ret = self.model.forward(rays_o, rays_d, target_s, target_d)
-            loss = self.slam.get_loss_from_ret(ret, is_co_sdf=self.config["is_co_sdf"])
-            loss.backward()
-            self.map_optimizer.step()
-            self.map_optimizer.zero_grad()
-
-    optimize_map = mapping_optimize
-
-    # ------------------------------------------------------------------ N2: loop-closure loops on R13
-    def optimize_relative_pose(self, base_c2w, target_c2w_initial, model_for_base, model_for_target, n_iters=None,
-                               rays_d_cam_batch=None):
-        """Pose alignment loop of ``handle_loop_closure`` (reference: mp_slam/mapper.py:362-412): render
-        ``mapping.sample`` random camera rays from ``base_c2w`` with the base model (teacher, no grad),
-        then ``loop_iters`` Adam steps on the 6 pose parameters of the target so that the target model
-        renders the same rgb/depth: ``render_rays`` (R13: gradients reach the rays) -> MSE losses weighted by
-        ``training.rgb_weight / depth_weight`` -> backward -> ``pose_optimizer.step()``.  Pose
-        parametrisation and optimizer are the host's (``SLAM.get_pose_param_optim``, ``SLAM.matrix_from_tensor``,
-        mneslam_mp.py:577-584).  Returns (relative_transform = base_c2w @ inv(best target pose), best loss)."""
-        cfg, dev = self.config, self.device
-        n = cfg["mapping"]["sample"]
-        n_iters = cfg["mapping"]["loop_iters"] if n_iters is None else n_iters
-        base_c2w, target_c2w_initial = base_c2w.to(dev), target_c2w_initial.to(dev)
-        target_rot, target_trans, pose_optimizer = self.slam.get_pose_param_optim(target_c2w_initial[None, ...], mapping=False)
-        with torch.no_grad():
-            if rays_d_cam_batch is None:
-                rays_d_cam = self.dataset.rays_d.reshape(-1, 3)
-                sample_indices = torch.randint(0, len(rays_d_cam), (n,))
-                rays_d_cam_batch = rays_d_cam[sample_indices]
-            rays_d_cam_batch = rays_d_cam_batch.to(dev)
-            n = rays_d_cam_batch.shape[0]
-            rays_o_base = base_c2w[:3, 3].unsqueeze(0).repeat(n, 1)
-            rays_d_base = torch.sum(rays_d_cam_batch[..., None, :] * base_c2w[:3, :3], dim=-1)
-            base_ret = model_for_base.render_rays(rays_o_base, rays_d_base, target_d=None)
-            target_rgb, target_depth = base_ret["rgb"].detach(), base_ret["depth"].detach()
-        best_loss, best_c2w = float("inf"), target_c2w_initial.clone()
-        for _ in range(n_iters):
-            pose_optimizer.zero_grad()
-            c2w_est = self.slam.matrix_from_tensor(target_rot, target_trans).squeeze(0)
-            rays_o = c2w_est[:3, 3].unsqueeze(0).repeat(n, 1)
-            rays_d = torch.sum(rays_d_cam_batch[..., None, :] * c2w_est[:3, :3], dim=-1)
-            ret = model_for_target.render_rays(rays_o, rays_d, target_d=None)
-            loss_c = torch.nn.functional.mse_loss(ret["rgb"], target_rgb)
-            loss_d = torch.nn.functional.mse_loss(ret["depth"], target_depth)
-            loss = cfg["training"]["rgb_weight"] * loss_c + cfg["training"]["depth_weight"] * loss_d
-            if loss.item() < best_loss:
-                best_loss, best_c2w = loss.item(), c2w_est.detach().clone()
-            loss.backward()
-            pose_optimizer.step()
-        return base_c2w @ torch.inverse(best_c2w), best_loss
-
-    def distillation(self, other_rank, expanded_foreign_kfs_for_distill, num_expanded_kfs):
-        """Joint distillation of a foreign agent's map (``model_shared``, the teacher) into ``model``
-        (reference: mp_slam/mapper.py:594-644, the training loop; the mesh dump after it stays with the
-        host): per iteration, ``sample_per_match`` random camera rays per foreign keyframe pose, teacher
-        ``render_rays`` without depth guidance, student ``forward`` on the teacher's rgb/depth, the usual
-        weighted loss, backward, Adam."""
-        cfg = self.config
-        for _ in range(cfg["mapping"]["distill_iters"]):
-            all_o, all_d, all_rgb, all_depth = [], [], [], []
-            per = max(cfg["mapping"]["sample"] // num_expanded_kfs, cfg["mapping"]["min_pixels_cur"]) \
-                if num_expanded_kfs > 0 else cfg["mapping"]["sample"]
-            for kf_data in expanded_foreign_kfs_for_distill:
-                pose = kf_data["pose"].to(self.device)
-                rays_d_cam = self.dataset.rays_d.reshape(-1, 3)
-                idx = torch.randint(0, len(rays_d_cam), (per,))
-                rays_d_cam_batch = rays_d_cam[idx].to(self.device)
-                rays_o = pose[:3, 3].unsqueeze(0).repeat(per, 1)
-                rays_d = torch.sum(rays_d_cam_batch[..., None, :] * pose[:3, :3], dim=-1)
-                all_o.append(rays_o)
-                all_d.append(rays_d)
-                with torch.no_grad():
-                    teacher = self.model_shared.render_rays(rays_o, rays_d, target_d=None)
-                    all_rgb.append(teacher["rgb"].detach())
-                    all_depth.append(teacher["depth"].detach().unsqueeze(-1))
-            if not all_o:
-                continue
-            self.map_optimizer.zero_grad()
-            ret = self.model.forward(torch.cat(all_o, 0), torch.cat(all_d, 0), torch.cat(all_rgb, 0), torch.cat(all_depth, 0))
-            loss = self.slam.get_loss_from_ret(ret, is_co_sdf=cfg["is_co_sdf"])
-            loss.backward()
-            self.map_optimizer.step()
-
-    # ------------------------------------------------------------------ fused path
-    def _fused_step(self, n_rays):
-        """ONE FusedStep per (model, optimizer), sized for the largest batch the mapping loop can ask for --
-        ``sample`` global rays + max(sample // 1, min_pixels_cur) current-frame rays -- and reused for every
-        smaller batch (n_cur shrinks as keyframes accumulate): its scratch (tape, tile lists, spill area) is
-        allocated once, not once per distinct ray count."""
-        n = self.config["mapping"]["sample"]
-        cap = max(n_rays, n + max(n, self.config["mapping"]["min_pixels_cur"]))
-        key = (id(self.model), id(self.map_optimizer))
-        fs = self._fused.get(key)
-        if fs is None or fs.R < n_rays:
-            self._fused.clear()                      # drop the previous scratch before allocating the new one
-            fs = self._fused[key] = FusedStep(self.model, self.map_optimizer, self.config, cap, self.device,
-                                              scatter=self.scatter, **self.fused_kwargs)
-        return fs
-
-    def _jitter(self, fs):
-        if self.sampler == "host" and self.config["training"]["perturb"] > 0.0:
-            return torch.rand(self._n_batch, fs.S).to(self.device)   # the reference's CPU draw (scene_rep.py:381)
-        return None
-
-    def _mapping_optimize_fused(self, current_rays, poses):
-        kf = self.video.keyframe
-        n, n_kf = self.config["mapping"]["sample"], len(kf.frame_ids)
-        n_cur = max(n // n_kf, self.config["mapping"]["min_pixels_cur"])
-        fs = self._fused_step(n + n_cur)
-        self._n_batch = n + n_cur
-        kf_rays = kf.device_rays(self.device)
-        cur = current_rays.to(self.device, torch.float32).contiguous()
-        poses = poses.to(self.device, torch.float32).contiguous()
-        n_pix = self.slam.dataset.H * self.slam.dataset.W
-        n_it = self.config["mapping"]["iters"]
-        for it in range(n_it):
-            idx_g = idx_c = None
-            if self.sampler == "host":                               # same draws, same order as the reference
-                idx_g = torch.tensor(random.sample(range(n_kf * kf.num_rays_to_save), n)).to(self.device)
-                idx_c = torch.tensor(random.sample(range(0, n_pix), n_cur)).to(self.device)
-            fs.step(kf_rays, n_kf * kf.num_rays_to_save, kf.num_rays_to_save, cur, poses, n, n_cur,
-                    idx_global=idx_g, idx_cur=idx_c, u=self._jitter(fs), prefetch=it + 1 < n_it)
-        fs.check()
-        self.last_losses = fs.loss_dict()
-
-    def _first_frame_fused(self, batch, c2w, n_iters):
-        H, W, n = self.slam.dataset.H, self.slam.dataset.W, self.config["mapping"]["sample"]
-        fs = self._fused_step(n)
-        self._n_batch = n
-        cur = torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1)
-        cur = cur.reshape(-1, 7).to(self.device, torch.float32).contiguous()
-        poses = c2w.reshape(1, 4, 4).to(torch.float32).contiguous()
-        for it in range(n_iters):
-            idx_c = None
-            if self.sampler == "host":
-                ind = self.slam.select_samples(H, W, n)
-                # the reference indexes [H,W] images with (ind % H, ind // H)  (mp_slam/mapper.py:76-77)
-                idx_c = ((ind % H) * W + torch.div(ind, H, rounding_mode="trunc")).to(self.device)
-            fs.step(None, 0, 1, cur, poses, 0, n, idx_cur=idx_c, u=self._jitter(fs), prefetch=it + 1 < n_iters)
-        fs.check()
-        self.last_losses = fs.loss_dict()
+    optimize_map = FusedMappingMixin.mapping_optimize          # the name BASELINE.json uses

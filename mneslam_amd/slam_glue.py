@@ -5,11 +5,20 @@ taking the SLAM object / config, with the reference's names and argument meaning
   get_loss_from_ret   mneslam_mp.py:350-372
   create_optimizer    mneslam_mp.py:431-469
 
+plus the FILE formats through which agents hand maps and keyframe poses to each other (row N4 of SURVEY.md 8f;
+the xGMI form of the same hand-off is mneslam_amd/dist.py):
+
+  save_latest_checkpoint   mneslam_mp.py:294-315      agent_<rank>/latest_checkpoint.pt
+  load_foreign_model       mp_slam/mapper.py:708-726  (reader of the above)
+  save_keyframe_poses / load_keyframe_poses   mp_slam/mapper.py:565-592, :344-356   key_est_poses.npy, key_timestamps.npy
+
 The rest of mneslam_mp.py (dataset, DROID tracker, threads, checkpoints, image dumps) is
 orchestration that stays with the host application.
 """
+import os
 import random
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -82,3 +91,68 @@ def create_optimizer(model, config, optimizer_cls=FusedAdam):
     if not one_grid:
         groups.append({"params": c_planes_para, "eps": 1e-15, "lr": config["mapping"]["lr_embed_color"]})
     return optimizer_cls(groups, betas=(0.9, 0.99))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# inter-agent files (N4)
+# --------------------------------------------------------------------------------------------------------------
+def agent_dir(config, rank):
+    """<data.output>/<data.exp_name>/agent_<rank>: where an agent publishes its state for its peers."""
+    return os.path.join(config["data"]["output"], config["data"]["exp_name"], f"agent_{rank}")
+
+
+def _publish(path, writer):
+    """Write next to ``path`` and rename: a peer polling the file never sees a partial one."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    tmp = path + ".tmp"
+    writer(tmp)
+    os.replace(tmp, path)
+
+
+def save_latest_checkpoint(model, config, rank):
+    """``latest_checkpoint.pt`` in the reference's layout: ``{'model': state_dict, 'all_planes': tuple of lists of
+    [1,C,H,W] tensors, 'bound', 'bounding_box'}`` (host copies of the two boxes).  Planes are pickled as they are --
+    torch.save keeps their channels_last strides, and any consumer (ATen grid_sample included) reads them through the
+    logical NCHW shape."""
+    path = os.path.join(agent_dir(config, rank), "latest_checkpoint.pt")
+    payload = {"model": model.state_dict(), "all_planes": model.all_planes,
+               "bound": torch.as_tensor(model.bound).cpu(), "bounding_box": torch.as_tensor(model.bounding_box).cpu()}
+    _publish(path, lambda tmp: torch.save(payload, tmp))
+    return path
+
+
+def load_foreign_model(model_shared, config, other_rank, device):
+    """Read a peer's ``latest_checkpoint.pt`` into ``model_shared`` (decoder weights, planes, both boxes) and put it
+    in eval mode.  Planes written by a reference agent are NCHW-contiguous: they are re-laid channels_last HERE, once,
+    so that rendering never converts per call."""
+    path = os.path.join(agent_dir(config, other_rank), "latest_checkpoint.pt")
+    ckpt = torch.load(path, map_location=device, weights_only=False)
+    model_shared.load_state_dict(ckpt["model"])
+    if "all_planes" in ckpt:
+        model_shared.all_planes = tuple([p.detach().to(device).contiguous(memory_format=torch.channels_last) for p in lst]
+                                        for lst in ckpt["all_planes"])
+    if "bound" in ckpt:
+        model_shared.bound = ckpt["bound"].to(device)
+    if "bounding_box" in ckpt:
+        model_shared.bounding_box = ckpt["bounding_box"].to(device)
+    model_shared.eval()
+    return ckpt
+
+
+def save_keyframe_poses(config, rank, poses_c2w, timestamps):
+    """``key_est_poses.npy`` [K,4,4] and ``key_timestamps.npy`` [K] of this agent, each published atomically."""
+    d = agent_dir(config, rank)
+    # np.save appends ".npy" to names without it: keep the temporary name's suffix
+    for name, arr in (("key_est_poses", poses_c2w), ("key_timestamps", timestamps)):
+        final = os.path.join(d, name + ".npy")
+        os.makedirs(d, exist_ok=True)
+        tmp = os.path.join(d, name + "_tmp.npy")
+        np.save(tmp, torch.as_tensor(arr).detach().cpu().numpy())
+        os.replace(tmp, final)
+    return d
+
+
+def load_keyframe_poses(config, other_rank):
+    """(poses [K,4,4], timestamps [K]) published by agent ``other_rank``."""
+    d = agent_dir(config, other_rank)
+    return np.load(os.path.join(d, "key_est_poses.npy")), np.load(os.path.join(d, "key_timestamps.npy"))
