@@ -10,6 +10,7 @@ Semantically one ``step`` equals the reference's
 golden parameters.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -113,13 +114,11 @@ class FusedStep:
             b = _lib.TileBins()
             b.lists, b.counts = self.tile_lists.data_ptr(), self.tile_counts.data_ptr()
             b.spill, b.spill_count = self.spill.data_ptr(), self.spill_count.data_ptr()
-            # processing order of the tiles (heaviest lists first): a scheduling hint, computed AFTER each plane
-            # update from that iteration's list lengths (last_counts) and used by the next one -- the 16 us single-
-            # workgroup sort is then off the critical path (ray batches of consecutive iterations load the tiles alike)
+            # processing order of the tiles (heaviest lists first), recomputed every iteration from that iteration's list
+            # lengths.  (Sorting by the PREVIOUS iteration's lengths after the plane update, off the critical path, was
+            # measured: tile_adam_kernel 244 us instead of 225 us, iteration 557 us instead of 544 us -- profiles/r02_order_ab.txt.)
             self.tile_order = torch.arange(n_tiles, device=dev, dtype=torch.int32)
-            self.tile_last_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
             b.order = self.tile_order.data_ptr()
-            b.last_counts = self.tile_last_counts.data_ptr()
             b.cap, b.spill_cap = tile_capacity, spill_capacity
             b.dropped = self.dropped.data_ptr()
             self.bins = b
@@ -246,6 +245,7 @@ class FusedStep:
                 stt = self.opt._state(p)
                 stt["step"] += 1
                 self.plane_opt[k].step = stt["step"]
+            _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             e0 = self._mark("adam", stream=side)
             _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), st2),
                        "mne_tile_adam")
@@ -253,7 +253,6 @@ class FusedStep:
             if side is not None:
                 ev[1].record(side)                      # "planes updated": what the next decode waits for
                 self._planes_pending = True
-            _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             # ---- decoder chain on the caller's stream, concurrent with the plane update
             _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), R * S, P(self.partials),
                                              P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
