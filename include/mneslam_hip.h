@@ -37,7 +37,9 @@ enum { MNE_L_RGB = 0, MNE_L_DEPTH = 1, MNE_L_CO_SDF = 2, MNE_L_CO_FS = 3, MNE_L_
        MNE_L_E_CENTER = 5, MNE_L_E_TAIL = 6, MNE_L_PSNR = 7, MNE_N_LOSS = 8 };
 /* mask-count slots produced by mne_sample_z */
 enum { MNE_C_VALID = 0, MNE_C_E_FRONT = 1, MNE_C_E_CENTER = 2, MNE_C_E_TAIL = 3, MNE_C_CO_FS = 4,
-       MNE_C_CO_SDF = 5, MNE_N_COUNT = 8 };
+       MNE_C_CO_SDF = 5,
+       MNE_C_NEED = 6,   /* per-ray only: leading samples that can carry a loss term (z <= target depth + truncation) */
+       MNE_N_COUNT = 8 };
 
 typedef struct mne_plane {
     const float* data;   /* [h][w][c_dim] */
@@ -91,11 +93,6 @@ typedef struct mne_tile_bins {
     int32_t* spill_count;  /* [1] */
     int32_t* order;        /* [mne_tile_count()] scratch: tile processing order (heaviest first) */
     int32_t cap, spill_cap;
-    int32_t* last_counts;  /* optional [mne_tile_count()]: mne_tile_adam saves every list length here before resetting
-                            * `counts`, and mne_tile_order then sorts by THESE lengths -- i.e. the order of the next
-                            * iteration can be computed off the critical path, after mne_tile_adam, from the previous
-                            * iteration's lengths (the order is a scheduling hint only; results do not depend on it).
-                            * `order` must then hold a valid permutation before the first mne_tile_adam (e.g. 0..n-1). */
     int32_t* dropped;      /* [1] sticky: entries that fit neither their list nor the spill area (their gradient is
                             * LOST); never reset by the library.  A spill area of n_rays*n_samples*6*n_sets*4 entries
                             * cannot overflow.  Must be zero-initialised by the caller; check it after a run. */
@@ -174,12 +171,18 @@ int mne_pack_decoder(const mne_scene_t* scene, float* packed, void* stream);
  * OneBlob model/encodings.py:61-71, decoder model/decoder.py:143-175) -> raw2outputs/sdf2weights
  * (:183-230).  Outputs (any may be NULL except raw): rgb [R][3], depth/disp/acc/depth_var [R],
  * raw [R][S][4].  When target_rgb/target_d are given, ray_sums [R][MNE_N_LOSS] receives each ray's
- * partial sums of the seven losses of JointEncoding.forward (:570-590). */
+ * partial sums of the seven losses of JointEncoding.forward (:570-590).
+ * flags & MNE_RENDER_EARLY_TERMINATION: exact early ray termination -- a ray's samples are decoded only up to the
+ * last one that can influence its maps or losses (first SDF sign change + truncation window, loss masks); the maps
+ * and ray_sums are the same, but `raw` is then scratch: entries behind a ray's last needed sample are undefined.
+ * ray_counts (optional, with target_d) = the per-ray counts of mne_sample_z: lets the decode of the samples that are
+ * needed whatever the decoder says run tile-parallel instead of on demand. */
+#define MNE_RENDER_EARLY_TERMINATION 1
 int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                        const float* rays_o, const float* rays_d, const float* target_rgb,
                        const float* target_d, const float* z_vals, const float* packed_decoder,
                        float* rgb, float* depth, float* disp, float* acc, float* depth_var,
-                       float* raw, float* ray_sums, void* stream);
+                       float* raw, float* ray_sums, const int32_t* ray_counts, int flags, void* stream);
 
 /* ---- R10: loss scalars ------------------------------------------------------------------- */
 /* losses[MNE_N_LOSS] = rgb, depth, co_sdf, co_fs, e_fs, e_center, e_tail, psnr with the reference's
@@ -194,36 +197,40 @@ int mne_loss_coef(const mne_render_cfg_t* cfg, int n_rays, int n_samples, const 
                   const float* grad_losses, float* coef, void* stream);
 
 /* ---- backward of R4-R10 (+R13) ----------------------------------------------------------- */
-/* Rows of the decoder-gradient tape (per contributing sample). */
+/* Floats per tape row (one row per SAMPLE: row = ray * n_samples + sample). */
 size_t mne_tape_row_floats(const mne_scene_t* scene);
 /* Replaces loss.backward() through the graph built by JointEncoding.forward
  * (mp_slam/mapper.py:159): accumulates plane gradients into scene->plane[..].grad (atomic adds,
- * buffers must be zeroed by the caller / the fused Adam), writes one tape row per contributing
- * sample for mne_decoder_wgrad, and optionally d/d rays_o, d/d rays_d [R][3] (R13: pose
- * optimisation in loop closure, mp_slam/mapper.py:388-408).  `coef` from mne_loss_coef (NULL = no
- * loss terms); g_rgb [R][3] / g_depth [R] are optional extra upstream gradients of the rendered
- * maps (callers that build their own loss on render_rays outputs).  `raw` is the forward's output
- * for the same inputs.  *tape_rows (int32, device) receives the number of tape rows written; rows are
- * in (ray, sample) order, so the result does not depend on scheduling.  `workspace` is caller-owned
- * device scratch of at least mne_render_workspace_bytes(n_rays, n_samples) bytes (per-ray gradient
- * constants and the compacted lists of contributing samples; contents are meaningless afterwards). */
+ * buffers must be zeroed by the caller / the fused Adam; ALL grad pointers NULL = no plane gradients
+ * wanted, e.g. the pose-only loop of loop closure, mp_slam/mapper.py:388-408), fills the tape rows of every
+ * sample that can receive gradient (and of the rest of their 32-sample tiles) for mne_decoder_wgrad, and optionally
+ * writes d/d rays_o, d/d rays_d [R][3] (R13: pose optimisation in loop closure, mp_slam/mapper.py:388-408).
+ * `coef` from mne_loss_coef (NULL = no loss terms); g_rgb [R][3] / g_depth [R] are optional extra upstream gradients
+ * of the rendered maps (callers that build their own loss on render_rays outputs).  `raw` is the forward's output
+ * for the same inputs (complete: produced without MNE_RENDER_EARLY_TERMINATION).  ray_counts: as for
+ * mne_render_forward (NULL without target_d).  Outputs: *tape_rows (int32, device) = number of samples that received
+ * gradient; ray_tiles [R] (int32, device) = per ray, the number of leading 32-sample tiles whose tape rows are
+ * complete (input of mne_decoder_wgrad).  `workspace` is caller-owned device scratch of at least
+ * mne_render_workspace_bytes(n_rays, n_samples) bytes (ReLU bit masks of the decoded samples). */
 size_t mne_render_workspace_bytes(int n_rays, int n_samples);
 int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                         const float* rays_o, const float* rays_d, const float* target_rgb,
-                        const float* target_d, const float* z_vals, const float* packed_decoder,
-                        const float* raw, const float* coef, const float* g_rgb, const float* g_depth,
-                        float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                        float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
+                        const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                        const float* packed_decoder, const float* raw, const float* coef, const float* g_rgb,
+                        const float* g_depth, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                        int32_t* ray_tiles, float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
                         void* stream);
 
-/* Fused training form of the two calls above (what Mapper.mapping_optimize runs per iteration):
- * decodes all samples (writes raw, rgb, depth, ray_sums like mne_render_forward) and back-propagates
- * with the loss coefficients `coef` (mne_loss_coef) in one call, sharing the compositing pass. */
+/* Fused training form of the two calls above (what Mapper.mapping_optimize runs per iteration), with early ray
+ * termination: decodes every ray up to the last sample it needs (tile-parallel for the samples ray_counts marks,
+ * on demand for the rest), composites (rgb, depth, ray_sums like mne_render_forward) and back-propagates with the
+ * loss coefficients `coef` (mne_loss_coef) from the ReLU masks saved by the decode -- no forward recompute.
+ * `raw` is scratch (see MNE_RENDER_EARLY_TERMINATION).  ray_counts NULL = decode everything up front. */
 int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                      const float* rays_o, const float* rays_d, const float* target_rgb,
-                     const float* target_d, const float* z_vals, const float* packed_decoder,
-                     const float* coef, float* rgb, float* depth, float* raw, float* ray_sums,
-                     float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                     const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                     const float* packed_decoder, const float* coef, float* rgb, float* depth, float* raw,
+                     float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, int32_t* ray_tiles,
                      const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Binned scatter + Adam for the planes (see csrc/tile_adam.hip): with `bins` given, mne_render_fused
@@ -232,7 +239,7 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
  * weights in LDS and applies torch.optim.Adam's update to the tile -- i.e. it replaces
  * grid_sampler_2d_backward + Adam.step() + zero_grad() for the plane groups
  * (mneslam_mp.py:459-469) with no gradient buffer and no global atomics.  opt[] has 6*n_sets entries.
- * *tape_rows is written by mne_render_fused itself in every mode. */
+ * Entries reference tape rows (ray * n_samples + sample). */
 size_t mne_tile_count(const mne_scene_t* scene);
 /* Processing order of the tiles for the next mne_tile_adam call (bins->order): longest lists first, so the
  * few very long lists do not form the tail of the launch.  Call after mne_render_fused, before mne_tile_adam. */
@@ -242,14 +249,14 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
 
 /* Decoder weight gradients from the tape: dW = sum_rows outer(d_out, in) for the four matrices,
  * written as [w_col0 | w_col1 | w_sdf0 | w_sdf1] (the order of decoder.parameters(),
- * model/decoder.py:150-159) into grad_out.  `partials` is scratch of
- * mne_wgrad_partial_floats() floats; max_rows = host-known upper bound of *tape_rows (sizes the
- * launch).  impl: 0 = MFMA (v_mfma_f32_32x32x2_f32; one fused pass over the tape for the 2x32 decoders),
+ * model/decoder.py:150-159) into grad_out.  Rows = for every ray r, the first ray_tiles[r] * 32 samples (as left by
+ * mne_render_backward / mne_render_fused); summed ray by ray in a fixed order.  `partials` is scratch of
+ * mne_wgrad_partial_floats() floats.  impl: 0 = MFMA (v_mfma_f32_32x32x2_f32), one fused pass over the tape,
  * 1 = scalar check, 2 = MFMA with one launch per matrix. */
 size_t mne_decoder_param_floats(const mne_scene_t* scene);
 size_t mne_wgrad_partial_floats(const mne_scene_t* scene);
-int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* tape_rows,
-                      int64_t max_rows, float* partials, float* grad_out, int impl, void* stream);
+int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* ray_tiles, int n_rays, int n_samples,
+                      float* partials, float* grad_out, int impl, void* stream);
 
 /* ---- R12: fused dense Adam --------------------------------------------------------------- */
 /* Replaces torch.optim.Adam.step() + zero_grad() over the groups of MNESLAM.create_optimizer

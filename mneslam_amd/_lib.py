@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libmneslam_hip.so")
 ABI_VERSION = 2
 N_LOSS = 8
 N_COUNT = 8
+C_NEED = 6
+RENDER_EARLY_TERMINATION = 1
 L_RGB, L_DEPTH, L_CO_SDF, L_CO_FS, L_E_FS, L_E_CENTER, L_E_TAIL, L_PSNR = range(8)
 
 
@@ -46,8 +48,7 @@ class AdamSeg(C.Structure):
 
 class TileBins(C.Structure):
     _fields_ = [("lists", C.c_void_p), ("counts", C.c_void_p), ("spill", C.c_void_p), ("spill_count", C.c_void_p),
-                ("order", C.c_void_p), ("cap", C.c_int32), ("spill_cap", C.c_int32), ("last_counts", C.c_void_p),
-                ("dropped", C.c_void_p)]
+                ("order", C.c_void_p), ("cap", C.c_int32), ("spill_cap", C.c_int32), ("dropped", C.c_void_p)]
 
 
 class PlaneOpt(C.Structure):
@@ -76,15 +77,16 @@ _PROTOS = {
                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_packed_decoder_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_pack_decoder": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p]),
-    "mne_render_forward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 14),
+    "mne_render_forward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 14
+                           + [C.c_int, C.c_void_p]),
     "mne_loss_finalize": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_loss_coef": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_tape_row_floats": (C.c_size_t, [C.POINTER(Scene)]),
-    "mne_render_backward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 11
-                            + [C.c_int64] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]),
+    "mne_render_backward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 12
+                            + [C.c_int64] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
     "mne_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "mne_render_fused": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 12
-                         + [C.c_int64, C.c_void_p, C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mne_render_fused": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 13
+                         + [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_tile_order": (C.c_int, [C.POINTER(Scene), C.POINTER(TileBins), C.c_void_p]),
     "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.c_void_p]),
@@ -92,7 +94,8 @@ _PROTOS = {
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 6),
     "mne_decoder_param_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_wgrad_partial_floats": (C.c_size_t, [C.POINTER(Scene)]),
-    "mne_decoder_wgrad": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mne_decoder_wgrad": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p]),
     "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.c_void_p]),
     "mne_query_points": (C.c_int, [C.POINTER(Scene), C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "mne_grid_level_table": (C.c_int, [C.POINTER(GridCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -43,19 +43,7 @@ static int check_scene(const mne_scene_t* sc, bool need_grad) {
     return 0;
 }
 
-// Timing-ablation switches (profiles/ablate_*.sh): only a -DMNE_ABLATION build reads them; the shipped
-// library always runs with dbg = 0.
-static int ablation_flags() {
-#ifdef MNE_ABLATION
-    const char* dbg = getenv("MNE_DBG_FLAGS");
-    return dbg ? atoi(dbg) : 0;
-#else
-    return 0;
-#endif
-}
-
 static void fill_render_consts(RenderArgs& a, const mne_render_cfg_t* cfg) {
-    a.dbg = ablation_flags();
     a.trunc_f = (float)cfg->trunc;
     a.win_f = (float)(cfg->sc_factor * cfg->trunc);       // python: sc_factor * trunc, then fp32
     a.e_T = (float)cfg->truncation;
@@ -128,13 +116,14 @@ int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, in
                        const float* rays_o, const float* rays_d, const float* target_rgb,
                        const float* target_d, const float* z_vals, const float* packed_decoder,
                        float* rgb, float* depth, float* disp, float* acc, float* depth_var,
-                       float* raw, float* ray_sums, void* stream) {
+                       float* raw, float* ray_sums, const int32_t* ray_counts, int flags, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
     if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw) return fail(-1, "mne_render_forward: NULL argument");
     if (n_rays <= 0) return 0;
     if (n_samples < 1 || n_samples > 16384) return fail(-1, "samples per ray out of range");
     if (mne_render_lds_bytes(*scene, n_samples, 0) > 160 * 1024) return fail(-1, "samples per ray too large for the LDS staging");
     if (ray_sums && (!target_rgb || !target_d)) return fail(-1, "ray_sums needs target_rgb and target_d");
+    if (ray_counts && !target_d) return fail(-1, "ray_counts belongs to a depth-guided batch (target_d)");
     RenderArgs a = {};
     a.sc = *scene;
     a.R = n_rays; a.S = n_samples;
@@ -143,7 +132,10 @@ int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, in
     a.z_vals = z_vals; a.packed = packed_decoder;
     a.rgb = rgb; a.depth = depth; a.disp = disp; a.acc = acc; a.depth_var = depth_var; a.raw = raw;
     a.ray_sums = ray_sums;
-    if (int rc = mne_launch_render(a, 1, 0, nullptr, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    const bool early = (flags & MNE_RENDER_EARLY_TERMINATION) != 0;
+    a.ray_counts = early ? ray_counts : nullptr;
+    a.prefix_default = early ? 1 : (1 << 30);
+    if (int rc = mne_launch_render(a, early ? 1 : 0, nullptr, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_forward");
 }
 
@@ -172,46 +164,58 @@ size_t mne_render_workspace_bytes(int n_rays, int n_samples) {
     return mne_render_workspace(n_rays, n_samples);
 }
 
+static int fill_bins(const mne_scene_t* scene, const mne_tile_bins_t* bins, TileBins& out) {
+    if (!bins->lists || !bins->counts || !bins->spill || !bins->spill_count || !bins->order || !bins->dropped || bins->cap < 1 ||
+        bins->spill_cap < 1)
+        return fail(-1, "incomplete tile bins");
+    out.lists = bins->lists; out.counts = bins->counts; out.spill = bins->spill;
+    out.spill_count = bins->spill_count; out.order = bins->order; out.cap = bins->cap; out.spill_cap = bins->spill_cap;
+    out.dropped = bins->dropped;
+    mne_tile_geometry(*scene, out);
+    return 0;
+}
+
 int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                         const float* rays_o, const float* rays_d, const float* target_rgb,
-                        const float* target_d, const float* z_vals, const float* packed_decoder,
-                        const float* raw, const float* coef, const float* g_rgb, const float* g_depth,
-                        float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                        float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
+                        const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                        const float* packed_decoder, const float* raw, const float* coef, const float* g_rgb,
+                        const float* g_depth, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                        int32_t* ray_tiles, float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
                         void* stream) {
     // plane gradients are optional as a whole: all plane[].grad NULL = ray / decoder gradients only
     if (int rc = check_scene(scene, scene && scene->plane[0][0][0].grad != nullptr)) return rc;
-    if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows || !workspace)
+    if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows || !ray_tiles || !workspace)
         return fail(-1, "mne_render_backward: NULL argument");
     if (n_rays <= 0) return 0;
     if (workspace_bytes < mne_render_workspace(n_rays, n_samples)) return fail(-1, "mne_render_backward: workspace too small");
     if (n_samples < 1 || mne_render_lds_bytes(*scene, n_samples, 1) > 160 * 1024) return fail(-1, "samples per ray out of range");
     if (tape_capacity_rows < (int64_t)n_rays * n_samples) return fail(-1, "tape must hold n_rays*n_samples rows");
     if (coef && (!target_rgb || !target_d)) return fail(-1, "loss coefficients need target_rgb and target_d");
+    if (ray_counts && !target_d) return fail(-1, "ray_counts belongs to a depth-guided batch (target_d)");
     RenderArgs a = {};
     a.sc = *scene;
     a.R = n_rays; a.S = n_samples;
     fill_render_consts(a, cfg);
     a.rays_o = rays_o; a.rays_d = rays_d; a.target_rgb = target_rgb; a.target_d = target_d;
     a.z_vals = z_vals; a.packed = packed_decoder; a.raw_in = raw;
+    a.ray_counts = ray_counts;
+    a.prefix_default = ray_counts ? 0 : 1;          // without depth guidance the forward half of the tape is made on demand
     a.coef = coef; a.g_rgb = g_rgb; a.g_depth = g_depth;
-    a.tape = tape; a.tape_cap = tape_capacity_rows; a.tape_rows = tape_rows;
+    a.tape = tape; a.tape_rows = tape_rows; a.ray_tiles = ray_tiles;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d;
-    if (int rc = mne_launch_render(a, 0, 1, workspace, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    if (int rc = mne_launch_render(a, 3, workspace, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_backward");
 }
 
 int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                      const float* rays_o, const float* rays_d, const float* target_rgb,
-                     const float* target_d, const float* z_vals, const float* packed_decoder,
-                     const float* coef, float* rgb, float* depth, float* raw, float* ray_sums,
-                     float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                     const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                     const float* packed_decoder, const float* coef, float* rgb, float* depth, float* raw,
+                     float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, int32_t* ray_tiles,
                      const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_scene(scene, bins == nullptr)) return rc;
-    if (bins && (!bins->lists || !bins->counts || !bins->spill || !bins->spill_count || !bins->order || !bins->dropped || bins->cap < 1 || bins->spill_cap < 1))
-        return fail(-1, "mne_render_fused: incomplete tile bins");
     if (!cfg || !rays_o || !rays_d || !target_rgb || !target_d || !z_vals || !packed_decoder || !coef || !raw ||
-        !tape || !tape_rows || !workspace)
+        !tape || !tape_rows || !ray_tiles || !workspace)
         return fail(-1, "mne_render_fused: NULL argument");
     if (n_rays <= 0) return 0;
     if (workspace_bytes < mne_render_workspace(n_rays, n_samples)) return fail(-1, "mne_render_fused: workspace too small");
@@ -223,16 +227,13 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
     fill_render_consts(a, cfg);
     a.rays_o = rays_o; a.rays_d = rays_d; a.target_rgb = target_rgb; a.target_d = target_d;
     a.z_vals = z_vals; a.packed = packed_decoder; a.coef = coef;
+    a.ray_counts = ray_counts;
+    a.prefix_default = 1 << 30;                     // no counts: decode every sample up front
     a.rgb = rgb; a.depth = depth; a.raw = raw; a.ray_sums = ray_sums;
-    a.tape = tape; a.tape_cap = tape_capacity_rows; a.tape_rows = tape_rows;
-    hipStream_t st = (hipStream_t)stream;
-    if (bins) {
-        a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
-        a.bins.spill_count = bins->spill_count; a.bins.order = bins->order; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
-        a.bins.dropped = bins->dropped;
-        mne_tile_geometry(*scene, a.bins);
-    }
-    if (int rc = mne_launch_render(a, 1, 1, workspace, st)) return fail(rc, "unsupported scene configuration");
+    a.tape = tape; a.tape_rows = tape_rows; a.ray_tiles = ray_tiles;
+    if (bins)
+        if (int rc = fill_bins(scene, bins, a.bins)) return rc;
+    if (int rc = mne_launch_render(a, 2, workspace, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_fused");
 }
 
@@ -249,7 +250,7 @@ int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* 
     TileAdamArgs a = {};
     a.sc = *scene;
     a.n_planes = scene->n_sets * 6;
-    a.bins.counts = bins->last_counts ? bins->last_counts : bins->counts; a.bins.order = bins->order;
+    a.bins.counts = bins->counts; a.bins.order = bins->order;
     mne_tile_geometry(*scene, a.bins);
     mne_launch_tile_order(a, (hipStream_t)stream);
     return check_launch("tile_order");
@@ -258,15 +259,11 @@ int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* 
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
                   const mne_tile_bins_t* bins, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
-    if (!opt || !tape || !bins || !bins->lists || !bins->counts || !bins->spill || !bins->spill_count || !bins->order)
-        return fail(-1, "mne_tile_adam: NULL argument");
+    if (!opt || !tape || !bins) return fail(-1, "mne_tile_adam: NULL argument");
     TileAdamArgs a = {};
     a.sc = *scene;
     a.n_planes = scene->n_sets * 6;
-    a.bins.lists = bins->lists; a.bins.counts = bins->counts; a.bins.spill = bins->spill;
-    a.bins.spill_count = bins->spill_count; a.bins.order = bins->order; a.bins.cap = bins->cap; a.bins.spill_cap = bins->spill_cap;
-    a.bins.last_counts = bins->last_counts;
-    mne_tile_geometry(*scene, a.bins);
+    if (int rc = fill_bins(scene, bins, a.bins)) return rc;
     for (int k = 0; k < a.n_planes; ++k) {
         const mne_plane_opt_t& g = opt[k];
         if (!g.m || !g.v || g.step < 1) return fail(-1, "mne_tile_adam: bad plane optimizer state");
@@ -281,7 +278,6 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
     a.row_stride = (int)mne_dims_tape_row(*scene);
     a.t_dfeat = (int)mne_dims_tape_dfeat(*scene);
     a.t_pn = (int)mne_dims_tape_pn(*scene);
-    a.dbg = ablation_flags();
     mne_launch_tile_adam(a, (hipStream_t)stream);
     return check_launch("tile_adam");
 }
@@ -306,13 +302,13 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
     return check_launch("sample_rays");
 }
 
-int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* tape_rows, int64_t max_rows,
+int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* ray_tiles, int n_rays, int n_samples,
                       float* partials, float* grad_out, int impl, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
-    if (!tape || !tape_rows || !grad_out || (impl == 0 && !partials)) return fail(-1, "mne_decoder_wgrad: NULL argument");
+    if (!tape || !ray_tiles || !grad_out || (impl != 1 && !partials)) return fail(-1, "mne_decoder_wgrad: NULL argument");
+    if (n_rays < 1 || n_samples < 1) return fail(-1, "mne_decoder_wgrad: empty batch");
     WgradArgs a = {};
-    a.tape = tape; a.tape_rows = tape_rows; a.partials = partials; a.grad_out = grad_out;
-    a.n_waves = (int)(max_rows > 0 ? (max_rows + 63) / 64 : 1);      // >= 64 rows per wave when the tape is full
+    a.tape = tape; a.ray_tiles = ray_tiles; a.R = n_rays; a.S = n_samples; a.partials = partials; a.grad_out = grad_out;
     if (int rc = mne_launch_wgrad(*scene, a, impl, (hipStream_t)stream)) return fail(rc, "unsupported decoder shape");
     return check_launch("decoder_wgrad");
 }

@@ -213,11 +213,26 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float*
     }
 }
 
+// ReLU pattern of this lane's hidden rows: bit (16 t + e) = (S.h[t][e] > 0), same for hc.  Saved by the forward
+// (8 bytes per lane) so that the backward chain needs no activations.
+template <int HID, int HIDC>
+__device__ __forceinline__ void relu_masks(const MlpState<HID, HIDC>& S, unsigned& mh, unsigned& mhc) {
+    mh = 0u; mhc = 0u;
+#pragma unroll
+    for (int t = 0; t < HID / 32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mh |= (S.h[t][e] > 0.0f ? 1u : 0u) << (16 * t + e);
+#pragma unroll
+    for (int t = 0; t < HIDC / 32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mhc |= (S.hc[t][e] > 0.0f ? 1u : 0u) << (16 * t + e);
+}
+
 // Backward data path.  ds/dc: d(total)/d(sdf), d(total)/d(raw rgb) of this lane's point (identical on
-// both lanes of the pair).  Outputs: dh, dout, dhc (tape) and d(feature) rows written to LDS
-// (dfrow / dcfrow = the point's rows; each lane writes the rows it holds).
+// both lanes of the pair); mh / mhc: relu_masks of the forward.  Outputs: dh, dout, dhc (tape) and d(feature)
+// rows written to LDS (dfrow / dcfrow = the point's rows; each lane writes the rows it holds).
 template <int HID, int HIDC, bool CP>
-__device__ __forceinline__ void mlp_backward_mfma(const MlpState<HID, HIDC>& S, float ds, const float (&dc)[3],
+__device__ __forceinline__ void mlp_backward_mfma(unsigned mh, unsigned mhc, float ds, const float (&dc)[3],
                                                   const float* atab, int lane, f32x16 (&dh)[HID / 32],
                                                   f32x16& dout, f32x16 (&dhc)[HIDC / 32], float* dfrow, float* dcfrow) {
     typedef ATab<HID, HIDC, CP> T;
@@ -231,7 +246,7 @@ __device__ __forceinline__ void mlp_backward_mfma(const MlpState<HID, HIDC>& S, 
         acc = MNE_MFMA(A[(T::OFF_B1 + 2 * t + 0) * 64], h ? dc[1] : dc[0], acc);
         acc = MNE_MFMA(A[(T::OFF_B1 + 2 * t + 1) * 64], h ? 0.0f : dc[2], acc);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = S.hc[t][e] > 0.0f ? acc[e] : 0.0f;
+        for (int e = 0; e < 16; ++e) acc[e] = ((mhc >> (16 * t + e)) & 1u) ? acc[e] : 0.0f;
         dhc[t] = acc;
     }
     {
@@ -265,7 +280,7 @@ __device__ __forceinline__ void mlp_backward_mfma(const MlpState<HID, HIDC>& S, 
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc = MNE_MFMA(A[(T::OFF_B3 + 8 * t + s) * 64], dout[s], acc);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = S.h[t][e] > 0.0f ? acc[e] : 0.0f;
+        for (int e = 0; e < 16; ++e) acc[e] = ((mh >> (16 * t + e)) & 1u) ? acc[e] : 0.0f;
         dh[t] = acc;
     }
 #pragma unroll

@@ -123,11 +123,19 @@ __device__ __forceinline__ void oneblob16(float x, float* out /*16*/, bool inter
 // (level, orientation) planes of the set (lanes 6, 7 recompute planes 0, 1), and the eight values of plane k
 // are then broadcast inside the 8-lane group (ds_swizzle, no LDS memory).  Same fp32 operations on the same
 // inputs as a per-lane set-up, so indices and weights are bit-identical; 6x fewer set-up instructions.
+// Load scheduling is explicit: per pass and plane set, (1) the 48 broadcasts, (2) all corner-row loads of a group of
+// planes back to back (MNE_GATHER_INFLIGHT = 12: one level, or 24: both levels -> that many float4 in flight per lane),
+// (3) the blends.  Left to the compiler, every load queued behind its own ds_swizzle and the kernel ran 40 % slower
+// (profiles/r02_order_ab.txt); the scheduling barriers pin the three phases.
+#ifndef MNE_GATHER_INFLIGHT
+#define MNE_GATHER_INFLIGHT 12
+#endif
 template <int NSETS, int NPTS>
-__device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane, int dbg = 0) {
+__device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane) {
     const int cg = lane & 7;
     const int kmine = cg < 6 ? cg : cg - 6;                        // this lane's plane: k = lvl * 3 + ori
     const int lvl_m = kmine >= 3 ? 1 : 0, ori_m = kmine - 3 * lvl_m;
+    constexpr int NLV = MNE_GATHER_INFLIGHT / 12;                   // levels loaded together
 #pragma unroll 1
     for (int it = 0; it < NPTS / 8; ++it) {
         const int slot = it * 8 + (lane >> 3);
@@ -145,33 +153,44 @@ __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float*
             Bilin bm;
             bilin_setup(gx, gy, Hm, Wm, bm);
 #pragma unroll
-            for (int lvl = 0; lvl < 2; ++lvl) {
-                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int l0 = 0; l0 < 2; l0 += NLV) {
+                int off[3 * NLV][4];
+                float wgt[3 * NLV][4];
 #pragma unroll
-                for (int ori = 0; ori < 3; ++ori) {
-                    const mne_plane_t& pl = sc.plane[set][ori][lvl];
-                    Bilin b;
-                    b.o00 = mne_bcast8(bm.o00, lvl * 3 + ori); b.o01 = mne_bcast8(bm.o01, lvl * 3 + ori);
-                    b.o10 = mne_bcast8(bm.o10, lvl * 3 + ori); b.o11 = mne_bcast8(bm.o11, lvl * 3 + ori);
-                    b.w00 = mne_bcast8(bm.w00, lvl * 3 + ori); b.w01 = mne_bcast8(bm.w01, lvl * 3 + ori);
-                    b.w10 = mne_bcast8(bm.w10, lvl * 3 + ori); b.w11 = mne_bcast8(bm.w11, lvl * 3 + ori);
-                    if MNE_ABL(dbg, 4) { b.o00 = b.o01 = b.o10 = b.o11 = 0; }      // ablation: every load hits one line
-                    const float* base = pl.data + cg * 4;
-                    const float4 v00 = *(const float4*)(base + b.o00);
-                    const float4 v01 = *(const float4*)(base + b.o01);
-                    const float4 v10 = *(const float4*)(base + b.o10);
-                    const float4 v11 = *(const float4*)(base + b.o11);
-                    float4 acc;
-                    acc.x = v00.x * b.w00; acc.y = v00.y * b.w00; acc.z = v00.z * b.w00; acc.w = v00.w * b.w00;
-                    acc.x = fmaf(v01.x, b.w01, acc.x); acc.y = fmaf(v01.y, b.w01, acc.y);
-                    acc.z = fmaf(v01.z, b.w01, acc.z); acc.w = fmaf(v01.w, b.w01, acc.w);
-                    acc.x = fmaf(v10.x, b.w10, acc.x); acc.y = fmaf(v10.y, b.w10, acc.y);
-                    acc.z = fmaf(v10.z, b.w10, acc.z); acc.w = fmaf(v10.w, b.w10, acc.w);
-                    acc.x = fmaf(v11.x, b.w11, acc.x); acc.y = fmaf(v11.y, b.w11, acc.y);
-                    acc.z = fmaf(v11.z, b.w11, acc.z); acc.w = fmaf(v11.w, b.w11, acc.w);
-                    sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;   // xy + xz + yz
+                for (int j = 0; j < 3 * NLV; ++j) {
+                    const int k = l0 * 3 + j;                               // k = lvl * 3 + ori
+                    off[j][0] = mne_bcast8(bm.o00, k); off[j][1] = mne_bcast8(bm.o01, k);
+                    off[j][2] = mne_bcast8(bm.o10, k); off[j][3] = mne_bcast8(bm.o11, k);
+                    wgt[j][0] = mne_bcast8(bm.w00, k); wgt[j][1] = mne_bcast8(bm.w01, k);
+                    wgt[j][2] = mne_bcast8(bm.w10, k); wgt[j][3] = mne_bcast8(bm.w11, k);
                 }
-                *(float4*)(feat + set * NPTS * MNE_FS + slot * MNE_FS + lvl * MNE_C + cg * 4) = sum;
+                MNE_SCHED_BARRIER();
+                float4 v[3 * NLV][4];
+#pragma unroll
+                for (int j = 0; j < 3 * NLV; ++j) {
+                    const int k = l0 * 3 + j;
+                    const float* base = sc.plane[set][k % 3][k / 3].data + cg * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[j][q] = *(const float4*)(base + off[j][q]);
+                }
+                MNE_SCHED_BARRIER();
+#pragma unroll
+                for (int lv = 0; lv < NLV; ++lv) {
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int ori = 0; ori < 3; ++ori) {
+                        const int j = lv * 3 + ori;
+                        float4 acc;
+                        acc.x = v[j][0].x * wgt[j][0]; acc.y = v[j][0].y * wgt[j][0]; acc.z = v[j][0].z * wgt[j][0]; acc.w = v[j][0].w * wgt[j][0];
+#pragma unroll
+                        for (int q = 1; q < 4; ++q) {
+                            acc.x = fmaf(v[j][q].x, wgt[j][q], acc.x); acc.y = fmaf(v[j][q].y, wgt[j][q], acc.y);
+                            acc.z = fmaf(v[j][q].z, wgt[j][q], acc.z); acc.w = fmaf(v[j][q].w, wgt[j][q], acc.w);
+                        }
+                        sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;       // xy + xz + yz
+                    }
+                    *(float4*)(feat + set * NPTS * MNE_FS + slot * MNE_FS + (l0 + lv) * MNE_C + cg * 4) = sum;
+                }
             }
         }
     }
@@ -237,15 +256,15 @@ __device__ __forceinline__ void gather_coord_grad(const mne_scene_t& sc, const f
 
 // ---- scatter: d(feature) rows in LDS -> atomic adds into the plane gradients -------------------
 // Lane layout: 32 lanes = the 32 channels of one corner row (one 128-B line per half-wave).
+// `live`: bit s set = slot s holds a sample that receives gradient (the others have an all-zero row).
 template <int NSETS, int NPTS>
 __device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float* pn, const float* dfeat,
-                                              int n_valid, int lane, int dbg = 0) {
+                                              unsigned long long live, int lane) {
     const int c = lane & 31, half = lane >> 5;
-    if MNE_ABL(dbg, 1) return;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 2; ++it) {
         const int slot = it * 2 + half;
-        if (slot < n_valid) {
+        if ((live >> slot) & 1ull) {
             const float px = pn[slot * 4 + 0], py = pn[slot * 4 + 1], pz = pn[slot * 4 + 2];
 #pragma unroll
             for (int set = 0; set < NSETS; ++set) {
@@ -271,26 +290,37 @@ __device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float
     }
 }
 
-// ---- decoder dimensions --------------------------------------------------------------------------
+// ---- decoder dimensions and the tape row --------------------------------------------------------------
+// One tape row per SAMPLE (row index = ray * S + sample; only rows of decoded tiles are ever touched):
+//   forward part, written by whoever decodes the sample (decode_kernel, or ray_kernel's on-demand decode):
+//     X[112] = plane features (64) | OneBlob (48)      H[HID] = relu(W1 x)      OUT[16] = (sdf, geo15)
+//     HC[HIDC] = relu(V1 [pos,(cf),geo])               CF[64] = colour-plane features (colour planes only)
+//   backward part, written by ray_kernel:
+//     DH[HID] | DOUT[16] | DHC[HIDC] | DC[4] = d(total)/d(pre-activations) -- the dY operands of the decoder
+//     weight-gradient GEMMs (wgrad.hip) -- then DFEAT[64 per plane set] = d(total)/d(plane features) and PN[4] =
+//     the normalised point, read by the binned plane update (tile_adam.hip).
 template <int HID, int HIDC, bool CP>
 struct DecDims {
     static constexpr int CINB = CP ? (MNE_POS + MNE_FEAT) : MNE_POS;   // where geo starts in the colour input
     static constexpr int CIN = CINB + MNE_GEO;                           // 63 or 127
-    static constexpr int CINP = CINB + MNE_OUT1;                         // tape: [pos | (colour feat) | out16]
-    // tape row: X[112] | H[HID] | DH[HID] | DOUT[16] | CIN[CINP] | HC[HIDC] | DHC[HIDC] | DC[4] | DFEAT | PN[4]
-    // (CIN holds the whole out16 = (sdf, geo15); the sdf slot is skipped by the weight-gradient GEMM)
+    static constexpr int CINP = CINB + MNE_OUT1;                         // GEMM view of the colour input: [pos | (cf) | out16]
     static constexpr int T_X = 0;
     static constexpr int T_H = T_X + MNE_IN1;
-    static constexpr int T_DH = T_H + HID;
+    static constexpr int T_OUT = T_H + HID;
+    static constexpr int T_HC = T_OUT + MNE_OUT1;
+    static constexpr int T_CF = T_HC + HIDC;
+    static constexpr int T_FWD_END = T_CF + (CP ? MNE_FEAT : 0);
+    static constexpr int T_DH = T_FWD_END;
     static constexpr int T_DOUT = T_DH + HID;
-    static constexpr int T_CIN = T_DOUT + MNE_OUT1;
-    static constexpr int T_HC = T_CIN + CINP;
-    static constexpr int T_DHC = T_HC + HIDC;
+    static constexpr int T_DHC = T_DOUT + MNE_OUT1;
     static constexpr int T_DC = T_DHC + HIDC;
-    // binned scatter (tile_adam.hip): d(feature) rows [set][64] and the normalised point
     static constexpr int T_DFEAT = T_DC + 4;
     static constexpr int T_PN = T_DFEAT + (CP ? 2 : 1) * MNE_FEAT;
     static constexpr int ROW = T_PN + 4;
+    // tape column of element c (0 <= c < CINP) of the colour-net input [pos48 | (cf64) | out16]
+    __host__ __device__ static constexpr int cin_col(int c) {
+        return c < MNE_POS ? T_X + MNE_FEAT + c : (CP && c < MNE_POS + MNE_FEAT) ? T_CF + (c - MNE_POS) : T_OUT + (c - CINB);
+    }
     // decoder parameter buffer (order of decoder.parameters()): col0 | col1 | sdf0 | sdf1
     static constexpr int P_COL0 = 0;
     static constexpr int P_COL1 = P_COL0 + HIDC * CIN;

@@ -29,7 +29,6 @@ struct TileBins {
     int* spill_count;
     int* order;               // [n_tiles] processing order of tile_adam_kernel (heaviest lists first)
     int cap, spill_cap;
-    int* last_counts;         // optional: list lengths of the previous tile_adam launch (source of tile_order)
     int* dropped;             // sticky count of entries lost to a full spill area
     int tile_base[MNE_MAX_PLANES + 1];   // first tile id of each plane ([set][orient][level] order)
     int ntx[MNE_MAX_PLANES];             // tiles per plane row
@@ -44,20 +43,16 @@ struct RenderArgs {
     float depth_trunc;
     const float *rays_o, *rays_d, *target_rgb, *target_d, *z_vals, *packed;
     float *rgb, *depth, *disp, *acc, *depth_var, *raw, *ray_sums;
-    const float* raw_in;
+    const float* raw_in;        // backward-only call: raw of ALL samples from the forward call (NULL otherwise)
+    const int* ray_counts;      // [R][MNE_N_COUNT] from sample_z (slot MNE_C_NEED = a-priori sample count)
+    int prefix_default;         // ray_counts == NULL: a-priori tiles of every ray (ntile = decode everything, 1 = on demand only)
     const float *coef, *g_rgb, *g_depth;
-    float* tape;
-    long long tape_cap;
-    int* tape_rows;
+    float* tape;                // [R*S][ROW]; NULL = forward only
+    int* tape_rows;             // total number of samples that received gradient
+    unsigned* relu_mask;        // [R*S][4]: per lane half (h mask, hc mask)
+    int* ray_tiles;             // [R] number of leading 32-sample tiles of each ray whose tape rows are complete
     float *d_rays_o, *d_rays_d;
-    TileBins bins;        // bins.lists != NULL: binned scatter instead of atomics into plane[].grad
-    // backward workspace (mne_render_workspace_bytes): per-ray gradient constants, per-ray compacted
-    // list of contributing samples, its length and the exclusive prefix of the lengths
-    float* ray_ctx;
-    unsigned short* clist;
-    int *ccount, *coffset;
-    int* tile_ray;        // first ray of every 32-row tile of the compacted list
-    int dbg;              // MNE_DBG_FLAGS (timing ablations only; results are wrong when non-zero)
+    TileBins bins;              // bins.lists != NULL: binned scatter instead of atomics into plane[].grad
 };
 
 struct LossArgs {
@@ -113,11 +108,12 @@ struct GridArgs {
 };
 
 struct WgradArgs {
-    const float* tape;
-    const int* tape_rows;
-    float* partials;      // [n_waves][NPARAM]
-    float* grad_out;      // [NPARAM]
-    int n_waves;
+    const float* tape;        // [R*S][ROW]
+    const int* ray_tiles;     // [R] leading tiles of each ray with complete tape rows (ray_kernel)
+    int R, S;
+    float* partials;          // [n_partials][NPARAM]
+    float* grad_out;          // [NPARAM]
+    int n_waves;              // number of partial results
 };
 
 struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, bc2_sqrt; };
@@ -129,7 +125,6 @@ struct TileAdamArgs {
     const float* tape;
     int row_stride, t_dfeat, t_pn;
     int n_planes;
-    int dbg;
 };
 
 struct AdamArgs {
@@ -143,7 +138,9 @@ struct AdamArgs {
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st);
 int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
-int mne_launch_render(const RenderArgs& a, int pass1, int bwd, void* workspace, hipStream_t st);
+// mode: 0 = forward, every sample decoded (raw complete);  1 = forward with early ray termination (maps only);
+//       2 = training iteration (decode + backward);  3 = backward of an earlier forward call (raw_in given)
+int mne_launch_render(const RenderArgs& a, int mode, void* workspace, hipStream_t st);
 size_t mne_render_workspace(int R, int S);
 int mne_launch_query(const QueryArgs& a, hipStream_t st);
 int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStream_t st);

@@ -41,6 +41,8 @@ static __device__ __forceinline__ float mne_bcast8(float v, int k) { return __in
 // LDS hand-off between the lanes of ONE wave (each wave owns a private LDS region): DS operations of
 // a wave complete in issue order, so draining lgkmcnt and pinning the compiler's order is enough --
 // no s_barrier, the four waves of a workgroup never wait for each other.
+// pin the instruction scheduler at this point (nothing moves across it)
+#define MNE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define MNE_WAVE_SYNC()                                         \
     do {                                                        \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \

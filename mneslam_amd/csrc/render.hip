@@ -1,19 +1,22 @@
 // render.hip -- z sampling, fused tri-plane gather -> OneBlob -> MFMA tiny-MLP -> SDF compositing
-// (forward) and its backward (loss gradients -> MFMA MLP backward -> plane-gradient scatter +
+// (forward) and its backward (loss gradients -> MFMA MLP backward -> plane-gradient scatter/append +
 // decoder tape) for the MNE-SLAM mapping iteration on gfx950.
 //
-// Work decomposition: ONE WAVE PER RAY, four independent waves per 256-thread workgroup (they never
-// barrier with each other; each owns a private LDS region and hands data between its own lanes
-// with MNE_WAVE_SYNC).  Samples are processed in tiles of 32 points, two lanes per point:
-//   pass 1  all S samples: coalesced gather (8 lanes x 16 B per 128-B corner row, 12 rows in flight
-//           per lane) -> per-point feature rows in LDS -> OneBlob in registers -> MFMA chain
-//           (mlp_mfma.h) -> raw (r,g,b,sdf) to global and to LDS.
-//   pass 2  per-ray reductions with shuffles/ballot (lane per sample): first SDF sign change,
-//           truncated sigmoid-product weights, rgb/depth/acc/var maps, loss partial sums.
-//   pass 3  (backward) ballot/prefix-sum compaction of the samples that can receive gradient
-//           (render window or loss masks), forward recompute on the compacted tiles, loss and
-//           compositing gradients, MFMA backward chain, one tape row per sample for the decoder
-//           weight-gradient GEMM, half-wave-per-row atomic scatter into the plane gradients.
+// Work decomposition of one training iteration (mne_render_fused):
+//   decode_kernel  one wave per (ray, 32-sample tile), two lanes per point, persistent grid: coalesced gather
+//                  (8 lanes x 16 B per 128-B corner row) -> feature rows in LDS -> OneBlob in registers -> MFMA
+//                  chain (mlp_mfma.h) -> raw (r,g,b,sdf), the ReLU bit masks and the forward half of the tape row.
+//                  EARLY RAY TERMINATION: only the tiles a ray needs a priori are decoded -- those holding a sample
+//                  with a loss mask (z <= target depth + truncation; known from z and the target depth alone,
+//                  counted by sample_z_kernel) and at least the first tile.
+//   ray_kernel     one wave per ray: finds the first SDF sign change among the decoded samples; if the render
+//                  window (z < z_first + trunc) or the search itself runs past the decoded prefix, the wave decodes
+//                  further tiles ON DEMAND (same code as decode_kernel) until the ray is resolved -- so the result is
+//                  exactly the reference's, whatever the scene looks like.  Then compositing (weights, maps, loss
+//                  partial sums; shuffles/ballot) and, for training, the backward of the ray's own tiles: loss /
+//                  compositing gradients -> MFMA backward chain from the saved ReLU masks (no forward recompute, no
+//                  re-gather) -> backward half of the tape row -> plane-gradient appends (binned) or atomics.
+// Samples beyond the last one a ray needs are never touched: they have zero weight and no loss term in the reference.
 //
 // Reference semantics: model/scene_rep.py:28-53,183-230,351-419,475-611; model/decoder.py:110-175;
 // model/utils.py:27-41,117-185 (include/mneslam_hip.h maps each entry point).
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
         for (int e = lane; e < S; e += MNE_WAVE) vals[e] = tab[e];
     }
     MNE_WAVE_SYNC();
-    int n_front = 0, n_center = 0, n_tail = 0, n_cofs = 0, n_cosdf = 0;
+    int n_front = 0, n_center = 0, n_tail = 0, n_cofs = 0, n_cosdf = 0, n_need = 0;
     for (int i = lane; i < S; i += MNE_WAVE) {
         float z = vals[i];
         if (a.perturb > 0.0f) {                                     // scene_rep.py:377-381
@@ -92,18 +95,21 @@ __global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
             const bool cf = z < (d - a.co_T), cb = z > (d + a.co_T);   // Co-SLAM masks, model/utils.py:131-137
             n_cofs += cf;
             n_cosdf += (!cf && !cb && d > 0.0f);
+            // samples that can carry a loss term whatever the decoder says: not behind either truncation band
+            // (z sorted: a prefix of the ray).  The render kernels decode at least these (early ray termination).
+            n_need += (d > 0.0f) && (!(z > (d + a.e_T)) || !cb);
         }
     }
     if (a.has_d) {
-        int sums[5] = {n_front, n_center, n_tail, n_cofs, n_cosdf};
+        int sums[6] = {n_front, n_center, n_tail, n_cofs, n_cosdf, n_need};
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
+        for (int k = 0; k < 6; ++k)
             for (int m = 32; m >= 1; m >>= 1) sums[k] += __shfl_xor(sums[k], m);
         if (lane == 0) {                 // per-ray counts; summed by counts_reduce_kernel (no same-address atomics)
             int* rc = a.ray_counts + (size_t)r * MNE_N_COUNT;
             rc[MNE_C_VALID] = (d > 0.0f && d < a.depth_trunc) ? 1 : 0;          // scene_rep.py:570
             rc[MNE_C_E_FRONT] = sums[0]; rc[MNE_C_E_CENTER] = sums[1]; rc[MNE_C_E_TAIL] = sums[2];
-            rc[MNE_C_CO_FS] = sums[3]; rc[MNE_C_CO_SDF] = sums[4]; rc[6] = 0; rc[7] = 0;
+            rc[MNE_C_CO_FS] = sums[3]; rc[MNE_C_CO_SDF] = sums[4]; rc[MNE_C_NEED] = sums[5]; rc[7] = 0;
         }
     }
 }
@@ -135,15 +141,7 @@ __global__ __launch_bounds__(256) void pack_decoder_kernel(mne_scene_t sc, float
 }
 
 // -----------------------------------------------------------------------------------------------
-// render kernels (tile-parallel):
-//   decode_kernel     one wave per 32-sample tile of a ray: gather -> OneBlob -> MFMA forward -> raw
-//   composite_kernel  one wave per ray: SDF compositing, maps, loss partial sums; for the backward also
-//                     the per-ray constants of the gradient and the compacted list of samples that can
-//                     receive gradient (ballot + prefix popcount)
-//   scan_kernel       exclusive prefix of the per-ray counts (deterministic tape order, no atomics)
-//   backward_kernel   one wave per 32 contributing samples, packed ACROSS rays (full tiles): forward
-//                     recompute, loss/compositing gradients, MFMA backward, tape row, scatter/append
-// A ray is therefore never a serial chain of tiles: the batch exposes R*S/32 + P'/32 independent wave tasks.
+// render kernels
 // -----------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x16 f32x16_zero() { f32x16 v; for (int q = 0; q < 16; ++q) v[q] = 0.0f; return v; }
 
@@ -163,15 +161,91 @@ __device__ __forceinline__ SampleMasks sample_masks(float z, float d, bool has_t
     return m;
 }
 
-// per-wave LDS of the tile kernels: pn[32][4] | feat[NSETS][32][FS]  (+ ray-gradient variant: dpos[32][64] | dpn[32][4])
+// per-wave LDS of the tile code: pn[32][4] | feat[NSETS][32][FS]  (+ ray-gradient variant: dpos[32][64] | dpn[32][4])
 __host__ __device__ inline size_t tile_wave_lds_bytes(int nsets, bool raygrad = false) {
     size_t b = (size_t)(TILE * 4 + nsets * TILE * MNE_FS) * sizeof(float);
     if (raygrad) b += (size_t)(TILE * 64 + TILE * 4) * sizeof(float);
     return b;
 }
 
-// ray_ctx[r][16]: constants of one ray's gradient, written by composite_kernel
-enum { RC_DENOM = 0, RC_ZLIM = 1, RC_AQ = 2, RC_GR = 3, RC_GG = 4, RC_GB = 5, RC_GDEP = 6, RC_N = 16 };
+// number of leading tiles of ray r that are decoded a priori (see the file header)
+__device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntile) {
+    if (!a.ray_counts) return a.prefix_default < ntile ? a.prefix_default : ntile;
+    const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
+    const int t = (need + TILE - 1) / TILE;
+    return t < 1 ? 1 : (t > ntile ? ntile : t);
+}
+
+// Decode tile c of ray r with the calling wave: raw -> a.raw (when given), ReLU masks -> a.relu_mask, forward half of
+// the tape rows -> a.tape.  Returns (r,g,b,sdf) of this lane's point (valid lanes); pnv/u are its coordinates.
+template <int HID, int HIDC, bool CP>
+__device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c, int lane, float* pn, float* feat,
+                                              const float* atab, float (&pnv)[3], float (&u)[3], uint2& relu) {
+    typedef DecDims<HID, HIDC, CP> D;
+    constexpr int NSETS = CP ? 2 : 1;
+    constexpr int NT = HID / 32, NTC = HIDC / 32;
+    const int S = a.S, pt = lane & 31, hf = lane >> 5;
+    const int i = c * TILE + pt;
+    const bool valid = i < S;
+    const float z = a.z_vals[(size_t)r * S + (valid ? i : S - 1)];
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = a.rays_o[r * 3 + k] + a.rays_d[r * 3 + k] * z;      // scene_rep.py:384
+    point_coords(a.sc, p, pnv, u);
+    MNE_WAVE_SYNC();                                       // earlier LDS reads of this wave are done
+    if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+    MNE_WAVE_SYNC();
+    gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+    MNE_WAVE_SYNC();
+    const float* frow = feat + pt * MNE_FS;
+    const float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
+    float pos[24];
+    oneblob_half(u, hf, pos);
+    MlpState<HID, HIDC> st;
+    mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, atab, lane, st);
+    const float4 rw = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);      // rows 0..3 live in the lower half
+    relu = make_uint2(0u, 0u);
+    if (a.relu_mask) relu_masks<HID, HIDC>(st, relu.x, relu.y);
+    if (valid) {
+        const size_t e = (size_t)r * S + i;
+        if (a.raw && hf == 0) *(float4*)(a.raw + e * 4) = rw;
+        if (a.relu_mask) *(uint2*)(a.relu_mask + e * 4 + hf * 2) = relu;
+#ifdef ABL_NO_FWD_TAPE
+        if (false) {
+#else
+        if (a.tape) {                                      // forward half of the tape row (each lane: the part it holds)
+#endif
+            float* row = a.tape + e * D::ROW;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *(float4*)(row + D::T_X + hf * 32 + 4 * q) = *(const float4*)(frow + hf * 32 + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                *(float4*)(row + D::T_X + MNE_FEAT + hf * 24 + 4 * q) = make_float4(pos[4 * q], pos[4 * q + 1], pos[4 * q + 2], pos[4 * q + 3]);
+            if (CP) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    *(float4*)(row + D::T_CF + hf * 32 + 4 * q) = *(const float4*)(cfrow + hf * 32 + 4 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                *(float4*)(row + D::T_OUT + 8 * q + 4 * hf) = make_float4(st.out[4 * q], st.out[4 * q + 1], st.out[4 * q + 2], st.out[4 * q + 3]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4*)(row + D::T_H + 32 * t + 8 * q + 4 * hf) =
+                        make_float4(st.h[t][4 * q], st.h[t][4 * q + 1], st.h[t][4 * q + 2], st.h[t][4 * q + 3]);
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4*)(row + D::T_HC + 32 * t + 8 * q + 4 * hf) =
+                        make_float4(st.hc[t][4 * q], st.hc[t][4 * q + 1], st.hc[t][4 * q + 2], st.hc[t][4 * q + 3]);
+        }
+    }
+    return rw;
+}
 
 #ifndef MAX_WPB
 #define MAX_WPB 12
@@ -183,6 +257,10 @@ __global__ __launch_bounds__(64 * MAX_WPB) void decode_kernel(RenderArgs a) {
     constexpr int TAB_FLOATS = ALDS ? T::FWD_STEPS * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     const int wpb = blockDim.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {             // counters of this call, reset before any consumer runs
+        if (a.tape_rows) *a.tape_rows = 0;
+        if (a.bins.spill_count) *a.bins.spill_count = 0;
+    }
     if (ALDS) {                                            // stage the A tables: the only block-wide step
         float4* dst = (float4*)lds_raw;
         const float4* src = (const float4*)a.packed;
@@ -191,63 +269,48 @@ __global__ __launch_bounds__(64 * MAX_WPB) void decode_kernel(RenderArgs a) {
     }
     const float* atab = ALDS ? (const float*)lds_raw : a.packed;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int S = a.S, ntile = (S + TILE - 1) / TILE;
+    const int ntile = (a.S + TILE - 1) / TILE;
     const long long ntask = (long long)a.R * ntile;
     float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(NSETS));
     float* feat = pn + TILE * 4;
-    const int pt = lane & 31, hf = lane >> 5;
-    // persistent waves: a wave strides over the (ray, tile) tasks; nothing below is block-wide
+    // persistent waves over the (tile, ray) tasks, TILE-major: the a-priori tiles of all rays come first, so the
+    // skipped tasks (tiles beyond a ray's prefix) cluster at the end and the real ones spread evenly over the waves
     for (long long task = (long long)blockIdx.x * wpb + wv; task < ntask; task += (long long)gridDim.x * wpb) {
-        const int r = (int)(task / ntile), c = (int)(task % ntile);
-        const int i = c * TILE + pt;
-        const bool valid = i < S;
-        const float z = a.z_vals[(size_t)r * S + (valid ? i : S - 1)];
-        float p[3], pnv[3], u[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = a.rays_o[r * 3 + k] + a.rays_d[r * 3 + k] * z;      // scene_rep.py:384
-        point_coords(a.sc, p, pnv, u);
-        MNE_WAVE_SYNC();                                       // previous task's LDS reads are done
-        if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
-        MNE_WAVE_SYNC();
-        gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane, a.dbg);
-        MNE_WAVE_SYNC();
-        float pos[24];
-        oneblob_half(u, hf, pos);
-        MlpState<HID, HIDC> st;
-        if (!MNE_ABL(a.dbg, 8)) mlp_forward_mfma<HID, HIDC, CP>(feat + pt * MNE_FS, feat + TILE * MNE_FS + pt * MNE_FS, pos, atab, lane, st);
-        else { st.rgb[0] = st.rgb[1] = st.rgb[2] = pos[0]; st.out[0] = pos[1]; }
-        if (valid && hf == 0)                                  // rows 0..3 live in the lower half
-            *(float4*)(a.raw + ((size_t)r * S + i) * 4) = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);
+        const int c = (int)(task / a.R), r = (int)(task % a.R);
+        if (c >= prefix_tiles(a, r, ntile)) continue;
+        float pnv[3], u[3];
+        uint2 relu;
+        decode_tile<HID, HIDC, CP>(a, r, c, lane, pn, feat, atab, pnv, u, relu);
     }
 }
 
-// One wave per ray.  LDS per wave: raws[Spad][4].
-template <bool BWD>
-__device__ __forceinline__ void composite_ray(const RenderArgs& a, int r, int lane, float* raws) {
-    const int S = a.S, Spad = (S + 3) & ~3;
+// -----------------------------------------------------------------------------------------------
+// compositing of one ray (wave-wide): raws[i] = (r,g,b,sdf) of the first D samples in LDS
+// -----------------------------------------------------------------------------------------------
+struct RayGrad { float denom, z_lim, Aq, g_rgb[3], g_dep; };
+
+// first adjacent sign change among samples [from, D) (pairs (i, i+1), both < D); -1 when none
+__device__ __forceinline__ int first_crossing(const float* raws, int from, int D, int lane) {
+    for (int base = from; base < D - 1; base += MNE_WAVE) {
+        const int i = base + lane;
+        const bool cr = (i < D - 1) && (raws[4 * (i + 1) + 3] * raws[4 * i + 3] < 0.0f);
+        const unsigned long long m = __ballot(cr);
+        if (m) return base + __ffsll(m) - 1;
+    }
+    return -1;
+}
+
+// Maps, loss partial sums and (WITH_GRAD) the per-ray constants of the gradient.  `first` = index of the first sign
+// change (0 when the whole ray has none, scene_rep.py:195-199); all samples with z < z_lim are among the first D.
+template <bool WITH_GRAD>
+__device__ __forceinline__ void composite_ray(const RenderArgs& a, int r, int lane, const float* raws, int D, int first, RayGrad& G) {
+    const int S = a.S;
     const bool has_t = a.target_d != nullptr;
     const float td = has_t ? a.target_d[r] : 0.0f;
     const float* zr = a.z_vals + (size_t)r * S;
-    {
-        const float4* src = (const float4*)(a.raw_in + (size_t)r * S * 4);
-        for (int i = lane; i < S; i += MNE_WAVE) *(float4*)(raws + 4 * i) = src[i];
-    }
-    MNE_WAVE_SYNC();
-    // first adjacent sign change (argmax of a 0/1 mask = first occurrence, 0 when none), scene_rep.py:195-199
-    int first = 0;
-    {
-        const int nchunk = (S + MNE_WAVE - 1) / MNE_WAVE;
-        for (int c = 0; c < nchunk; ++c) {
-            const int i = c * MNE_WAVE + lane;
-            const bool cr = (i < S - 1) && (raws[4 * (i + 1) + 3] * raws[4 * i + 3] < 0.0f);
-            const unsigned long long m = __ballot(cr);
-            if (m) { first = c * MNE_WAVE + __ffsll(m) - 1; break; }
-        }
-    }
-    const float z_min = zr[first];
-    const float z_lim = z_min + a.win_f;                                   // scene_rep.py:200
+    const float z_lim = zr[first] + a.win_f;                                // scene_rep.py:200
     float wsum = 0.0f;
-    for (int i = lane; i < S; i += MNE_WAVE) {
+    for (int i = lane; i < D; i += MNE_WAVE) {
         const float s = raws[4 * i + 3];
         const float wt = sigmoidf_(s / a.trunc_f) * sigmoidf_(-s / a.trunc_f);
         wsum += (zr[i] < z_lim) ? wt : 0.0f;
@@ -256,7 +319,7 @@ __device__ __forceinline__ void composite_ray(const RenderArgs& a, int r, int la
     const float denom = wsum + 1e-8f;                                       // scene_rep.py:203
     float m_rgb[3] = {0.f, 0.f, 0.f}, m_depth = 0.f, m_acc = 0.f;
     float l_efs = 0.f, l_ec = 0.f, l_et = 0.f, l_cofs = 0.f, l_cosdf = 0.f;
-    for (int i = lane; i < S; i += MNE_WAVE) {
+    for (int i = lane; i < D; i += MNE_WAVE) {
         const float4 rw = *(const float4*)(raws + 4 * i);
         const float s = rw.w, z = zr[i];
         const float wt = sigmoidf_(s / a.trunc_f) * sigmoidf_(-s / a.trunc_f);
@@ -280,7 +343,7 @@ __device__ __forceinline__ void composite_ray(const RenderArgs& a, int r, int la
     m_acc = wave_sum(m_acc);
     if (a.depth_var || a.disp) {
         float var = 0.f;
-        for (int i = lane; i < S; i += MNE_WAVE) {
+        for (int i = lane; i < D; i += MNE_WAVE) {
             const float s = raws[4 * i + 3], z = zr[i];
             const float wt = sigmoidf_(s / a.trunc_f) * sigmoidf_(-s / a.trunc_f);
             const float w = ((z < z_lim) ? wt : 0.0f) / denom;
@@ -315,103 +378,54 @@ __device__ __forceinline__ void composite_ray(const RenderArgs& a, int r, int la
             rs[MNE_L_PSNR] = 0.0f;
         }
     }
-    if (BWD) {
-        float cf[MNE_N_LOSS];
-#pragma unroll
-        for (int k = 0; k < MNE_N_LOSS; ++k) cf[k] = a.coef ? a.coef[k] : 0.0f;
-        float g_rgb[3], g_dep;
+    if (WITH_GRAD) {
+        float cf_rgb = a.coef ? a.coef[MNE_L_RGB] : 0.0f, cf_dep = a.coef ? a.coef[MNE_L_DEPTH] : 0.0f;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            g_rgb[k] = (a.target_rgb ? cf[MNE_L_RGB] * (m_rgb[k] - trgb[k]) : 0.0f) + (a.g_rgb ? a.g_rgb[r * 3 + k] : 0.0f);
-        g_dep = (valid_ray ? cf[MNE_L_DEPTH] * (m_depth - td) : 0.0f) + (a.g_depth ? a.g_depth[r] : 0.0f);
-        const float Aq = g_rgb[0] * m_rgb[0] + g_rgb[1] * m_rgb[1] + g_rgb[2] * m_rgb[2] + g_dep * m_depth;
-        const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
-        const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
-        // compaction of the samples that can receive a non-zero gradient (wave ballot + prefix popcount)
-        unsigned short* list = a.clist + (size_t)r * Spad;
-        int n_contrib = 0;
-        const int nchunk = (S + MNE_WAVE - 1) / MNE_WAVE;
-        for (int c = 0; c < nchunk; ++c) {
-            const int i = c * MNE_WAVE + lane;
-            bool f = false;
-            if (i < S) {
-                const float z = zr[i];
-                const SampleMasks mk = sample_masks(z, td, has_t, a);
-                f = (z < z_lim) || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) ||
-                    (use_co && (mk.co_fs || mk.co_sdf));
-            }
-            const unsigned long long m = __ballot(f);
-            if (f) list[n_contrib + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
-            n_contrib += __popcll(m);
-        }
-        if (lane == 0) {
-            a.ccount[r] = MNE_ABL(a.dbg, 16) ? 0 : n_contrib;
-            float* rc = a.ray_ctx + (size_t)r * RC_N;
-            rc[RC_DENOM] = denom; rc[RC_ZLIM] = z_lim; rc[RC_AQ] = Aq;
-            rc[RC_GR] = g_rgb[0]; rc[RC_GG] = g_rgb[1]; rc[RC_GB] = g_rgb[2]; rc[RC_GDEP] = g_dep;
-        }
+            G.g_rgb[k] = (a.target_rgb ? cf_rgb * (m_rgb[k] - trgb[k]) : 0.0f) + (a.g_rgb ? a.g_rgb[r * 3 + k] : 0.0f);
+        G.g_dep = (valid_ray ? cf_dep * (m_depth - td) : 0.0f) + (a.g_depth ? a.g_depth[r] : 0.0f);
+        G.Aq = G.g_rgb[0] * m_rgb[0] + G.g_rgb[1] * m_rgb[1] + G.g_rgb[2] * m_rgb[2] + G.g_dep * m_depth;
+        G.denom = denom; G.z_lim = z_lim;
     }
 }
 
-// exclusive prefix sum of ccount[R] -> coffset[R+1], total -> tape_rows, first ray of every 32-row tile of
-// the compacted list -> tile_ray; executed by ONE workgroup of NT threads (part = NT ints of LDS)
-template <int NT>
-__device__ __forceinline__ void scan_counts(const RenderArgs& a, int* part) {
-    const int tid = threadIdx.x;
-    const int per = (a.R + NT - 1) / NT;
-    const int b0 = tid * per < a.R ? tid * per : a.R, b1 = (b0 + per < a.R) ? b0 + per : a.R;
-    int s = 0;
-    for (int i = b0; i < b1; ++i) s += a.ccount[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < NT; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = part[tid] - s;                        // exclusive prefix of this thread's chunk
-    for (int i = b0; i < b1; ++i) {
-        const int c0 = run, c1 = run + a.ccount[i];
-        a.coffset[i] = c0;
-        // ray i owns the 32-row tiles whose first row lies in [c0, c1): backward_kernel starts its search there
-        for (int t = (c0 + TILE - 1) / TILE; t * TILE < c1; ++t) a.tile_ray[t] = i;
-        run = c1;
-    }
-    if (tid == NT - 1) { a.coffset[a.R] = part[NT - 1]; *a.tape_rows = part[NT - 1]; }
-}
-
-// 4 rays per workgroup.  (Folding the prefix sum into the last workgroup to finish -- ticket counter plus
-// agent-scope fences -- was measured: every workgroup's release fence writes its XCD's L2 back and the
-// kernel went from 10 us to 54 us, so the scan stays a separate 5 us launch.)
-template <bool BWD>
+// all samples decoded: 4 rays per workgroup, raws staged in LDS (forward calls that must return raw)
 __global__ __launch_bounds__(256) void composite_kernel(RenderArgs a) {
     MNE_DYN_LDS(lds_raw);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wv;
-    if (BWD && blockIdx.x == 0 && threadIdx.x == 0 && a.bins.spill_count) *a.bins.spill_count = 0;   // before any append of this call
-    if (r < a.R) composite_ray<BWD>(a, r, lane, (float*)lds_raw + (size_t)wv * ((a.S + 3) & ~3) * 4);
+    if (r >= a.R) return;
+    const int S = a.S;
+    float* raws = (float*)lds_raw + (size_t)wv * ((S + 3) & ~3) * 4;
+    const float4* src = (const float4*)(a.raw_in + (size_t)r * S * 4);
+    for (int i = lane; i < S; i += MNE_WAVE) *(float4*)(raws + 4 * i) = src[i];
+    MNE_WAVE_SYNC();
+    const int f = first_crossing(raws, 0, S, lane);
+    RayGrad G;
+    composite_ray<false>(a, r, lane, raws, S, f < 0 ? 0 : f, G);
 }
 
-__global__ __launch_bounds__(1024) void scan_kernel(RenderArgs a) {
-    __shared__ int part[1024];
-    scan_counts<1024>(a, part);
-}
-
-#ifndef MAX_WPB_BWD
-#define MAX_WPB_BWD 8
+// -----------------------------------------------------------------------------------------------
+// ray_kernel: resolve (on-demand decode) -> composite -> backward of the ray's own tiles
+//   MODE 0: forward only (maps; early ray termination)
+//        1: training iteration (raw / masks / tape of every tile it touches exist: written by decode_kernel or by its own
+//           resolve step)
+//        2: backward of an EARLIER forward call (raw_in complete; forward tape rows of tiles beyond the a-priori prefix
+//           are produced on demand inside the backward loop)        3: = 2 with ray gradients (R13)
+// -----------------------------------------------------------------------------------------------
+#ifndef MAX_WPB_RAY
+#define MAX_WPB_RAY 8
 #endif
-template <int HID, int HIDC, bool CP, bool ALDS, bool RAYGRAD>
-__global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a) {
+template <int HID, int HIDC, bool CP, bool ALDS, int MODE>
+__global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
     typedef DecDims<HID, HIDC, CP> D;
     typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
     constexpr int NT = HID / 32, NTC = HIDC / 32;
-    constexpr int TAB_FLOATS = ALDS ? (RAYGRAD ? T::TOTAL_RAYGRAD : T::TOTAL) * 64 : 0;
+    constexpr bool BWD = MODE >= 1, RAYGRAD = MODE == 3, LATE_DECODE = MODE >= 2;
+    constexpr int TAB_FLOATS = ALDS ? (RAYGRAD ? T::TOTAL_RAYGRAD : BWD ? T::TOTAL : T::FWD_STEPS) * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     const int wpb = blockDim.x >> 6;
-    const int total = a.coffset[a.R];
-    if ((long long)blockIdx.x * wpb * TILE >= total) return;      // whole workgroup beyond the compacted list
     if (ALDS) {
         float4* dst = (float4*)lds_raw;
         const float4* src = (const float4*)a.packed;
@@ -420,199 +434,197 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
     }
     const float* atab = ALDS ? (const float*)lds_raw : a.packed;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(NSETS, RAYGRAD);
-    float* pn = (float*)my;
+    const int S = a.S, Spad = (S + 3) & ~3, ntile = (S + TILE - 1) / TILE;
+    const size_t wave_bytes = (size_t)Spad * 4 * sizeof(float) + tile_wave_lds_bytes(NSETS, RAYGRAD);
+    unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * wave_bytes;
+    float* raws = (float*)my;                                     // [Spad][4]
+    float* pn = raws + (size_t)Spad * 4;
     float* feat = pn + TILE * 4;
     float* dposL = feat + NSETS * TILE * MNE_FS;                  // RAYGRAD: [32][64] d OneBlob rows
     float* dpnL = dposL + TILE * 64;                              // RAYGRAD: [32][4]  d normalised point
     const int pt = lane & 31, hf = lane >> 5;
-    const int S = a.S, Spad = (S + 3) & ~3;
     const bool has_t = a.target_d != nullptr;
     float cf[MNE_N_LOSS];
 #pragma unroll
-    for (int q = 0; q < MNE_N_LOSS; ++q) cf[q] = a.coef ? a.coef[q] : 0.0f;
-    const long long ntile = ((long long)total + TILE - 1) / TILE;
-    // persistent waves over the tiles of the compacted list; nothing below is block-wide
-    for (long long tile = (long long)blockIdx.x * wpb + wv; tile < ntile; tile += (long long)gridDim.x * wpb) {
-        const int k = (int)(tile * TILE) + pt;                    // position in the compacted list = tape row
-        const bool valid = k < total;
-        const int kk = valid ? k : total - 1;
-        // owning ray = last r with coffset[r] <= kk.  The tile's first row belongs to tile_ray[tile]; the
-        // following offsets are fetched with one coalesced load and scanned with wave-uniform reads
-        // (a tile of 32 rows rarely spans more than two or three rays).
-        int lo = a.tile_ray[tile];
-        if (!MNE_ABL(a.dbg, 1024)) {
-            const int r0 = lo;
-            const int cnext = a.coffset[(r0 + 1 + lane < a.R) ? r0 + 1 + lane : a.R];     // coffset[R] = total > kk
-            const int k_last = (int)(tile * TILE) + TILE - 1;
-            bool open_end = true;
-            for (int j = 0; j < MNE_WAVE; ++j) {
-                const int v = __shfl(cnext, j);
-                if (v > k_last) { open_end = false; break; }
-                lo += (v <= kk) ? 1 : 0;
-            }
-            if (open_end) {                                       // > 64 rays (mostly empty ones) inside this tile
-                int hi = a.R;
-                if (lo < r0 + MNE_WAVE) hi = lo + 1;              // this lane's ray was already found
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (a.coffset[mid] <= kk) lo = mid; else hi = mid;
-                }
-            }
-        }
-        const int r = lo;
-        const int i = MNE_ABL(a.dbg, 1024) ? kk % S : a.clist[(size_t)r * Spad + (kk - a.coffset[r])];
-        const float z = a.z_vals[(size_t)r * S + i];
+    for (int q = 0; q < MNE_N_LOSS; ++q) cf[q] = (BWD && a.coef) ? a.coef[q] : 0.0f;
+    const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
+    const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
+    for (int r = blockIdx.x * wpb + wv; r < a.R; r += gridDim.x * wpb) {
+        const float* zr = a.z_vals + (size_t)r * S;
         const float td = has_t ? a.target_d[r] : 0.0f;
-        const float* rc = a.ray_ctx + (size_t)r * RC_N;
-        const float denom = rc[RC_DENOM], z_lim = rc[RC_ZLIM], Aq = rc[RC_AQ], g_dep = rc[RC_GDEP];
-        const float g_rgb[3] = {rc[RC_GR], rc[RC_GG], rc[RC_GB]};
-        float p[3], pnv[3], u[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) p[q] = a.rays_o[r * 3 + q] + a.rays_d[r * 3 + q] * z;
-        point_coords(a.sc, p, pnv, u);
-        MNE_WAVE_SYNC();                                          // previous tile's LDS reads are done
-        if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+        MNE_WAVE_SYNC();                                          // previous ray's LDS reads are done
+        // ---- samples whose raw is known: everything (backward of an earlier forward) or the decoded prefix
+        int t_dec = prefix_tiles(a, r, ntile);                    // tiles with raw / masks / tape rows written
+        int Dn = a.raw_in ? S : (t_dec * TILE < S ? t_dec * TILE : S);
+        {
+            const float4* src = (const float4*)((a.raw_in ? a.raw_in : a.raw) + (size_t)r * S * 4);
+            for (int i = lane; i < Dn; i += MNE_WAVE) *(float4*)(raws + 4 * i) = src[i];
+        }
         MNE_WAVE_SYNC();
-        gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane, a.dbg);
-        MNE_WAVE_SYNC();
-        float* frow = feat + pt * MNE_FS;
-        float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
-        float pos[24];
-        oneblob_half(u, hf, pos);
-        MlpState<HID, HIDC> st;
-        if (!MNE_ABL(a.dbg, 512)) mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, atab, lane, st);
-        else {
-            st.out = f32x16_zero(); st.rgb = f32x16_zero(); st.rgb[0] = pos[0];
-            for (int t = 0; t < NT; ++t) st.h[t] = f32x16_zero();
-            for (int t = 0; t < NTC; ++t) st.hc[t] = f32x16_zero();
+        // ---- resolve: first sign change + every sample inside the render window must be known
+        int first = -1, from = 0;
+        while (true) {
+            if (first < 0) first = first_crossing(raws, from, Dn, lane);
+            if (Dn >= S) break;
+            if (first >= 0 && !(zr[Dn] < zr[first] + a.win_f)) break;       // z sorted: the window ends before sample Dn
+            // decode the next tile on demand (Dn is a multiple of TILE here)
+            float pnv[3], u[3];
+            uint2 relu;
+            const float4 rw = decode_tile<HID, HIDC, CP>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu);
+            const int i = t_dec * TILE + pt;
+            if (i < S && hf == 0) *(float4*)(raws + 4 * i) = rw;
+            MNE_WAVE_SYNC();
+            from = Dn > 0 ? Dn - 1 : 0;
+            ++t_dec;
+            Dn = t_dec * TILE < S ? t_dec * TILE : S;
         }
-        // ---- d(total)/d(raw) of this point (both lanes of the pair compute the same values)
-        const float4 rw = *(const float4*)(a.raw_in + ((size_t)r * S + i) * 4);
-        const float s = rw.w;
-        float ds = 0.0f, dc[3] = {0.f, 0.f, 0.f};
-        if (valid) {
-            if (z < z_lim) {
-                const float pp = sigmoidf_(s / a.trunc_f), qq = sigmoidf_(-s / a.trunc_f);
-                const float wt = pp * qq;
-                const float w = wt / denom;
-                const float sg[3] = {sigmoidf_(rw.x), sigmoidf_(rw.y), sigmoidf_(rw.z)};
-                const float dLdw = g_rgb[0] * sg[0] + g_rgb[1] * sg[1] + g_rgb[2] * sg[2] + g_dep * z;
-                ds += ((dLdw - Aq) / denom) * (wt * (qq - pp) / a.trunc_f);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) dc[q] = g_rgb[q] * w * (sg[q] * (1.0f - sg[q]));
+        RayGrad G;
+        composite_ray<BWD>(a, r, lane, raws, Dn, first < 0 ? 0 : first, G);
+        if (!BWD) continue;
+        // ---- samples that can receive gradient: render window or an active loss mask (exact)
+        int last = -1, n_contrib = 0;
+        for (int base = 0; base < Dn; base += MNE_WAVE) {
+            const int i = base + lane;
+            bool f = false;
+            if (i < Dn) {
+                const float z = zr[i];
+                const SampleMasks mk = sample_masks(z, td, has_t, a);
+                f = (z < G.z_lim) || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) || (use_co && (mk.co_fs || mk.co_sdf));
             }
-            const SampleMasks mk = sample_masks(z, td, has_t, a);
-            const float e_res = (z + s * a.e_T) - td, c_res = (z + s * a.win_f) - td;
-            if (mk.e_front) ds += cf[MNE_L_E_FS] * (s - 1.0f);
-            if (mk.e_center) ds += cf[MNE_L_E_CENTER] * e_res;
-            if (mk.e_tail) ds += cf[MNE_L_E_TAIL] * e_res;
-            if (mk.co_fs) ds += cf[MNE_L_CO_FS] * (s - 1.0f);
-            if (mk.co_sdf) ds += cf[MNE_L_CO_SDF] * c_res;
+            const unsigned long long m = __ballot(f);
+            if (m) last = base + 63 - __clzll(m);
+            n_contrib += __popcll(m);
         }
-        // ---- tape: forward activations of this point (each lane writes the part it holds)
-        float* row = a.tape + (size_t)kk * D::ROW;
-        const bool tape_on = valid && !MNE_ABL(a.dbg, 2);
-        if (tape_on) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                *(float4*)(row + D::T_X + hf * 32 + 4 * q) = *(const float4*)(frow + hf * 32 + 4 * q);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const float4 pv = make_float4(pos[4 * q], pos[4 * q + 1], pos[4 * q + 2], pos[4 * q + 3]);
-                *(float4*)(row + D::T_X + MNE_FEAT + hf * 24 + 4 * q) = pv;
-                *(float4*)(row + D::T_CIN + hf * 24 + 4 * q) = pv;
-            }
-            if (CP) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    *(float4*)(row + D::T_CIN + MNE_POS + hf * 32 + 4 * q) = *(const float4*)(cfrow + hf * 32 + 4 * q);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                *(float4*)(row + D::T_CIN + D::CINB + 8 * q + 4 * hf) =
-                    make_float4(st.out[4 * q], st.out[4 * q + 1], st.out[4 * q + 2], st.out[4 * q + 3]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(float4*)(row + D::T_H + 32 * t + 8 * q + 4 * hf) =
-                        make_float4(st.h[t][4 * q], st.h[t][4 * q + 1], st.h[t][4 * q + 2], st.h[t][4 * q + 3]);
-#pragma unroll
-            for (int t = 0; t < NTC; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(float4*)(row + D::T_HC + 32 * t + 8 * q + 4 * hf) =
-                        make_float4(st.hc[t][4 * q], st.hc[t][4 * q + 1], st.hc[t][4 * q + 2], st.hc[t][4 * q + 3]);
-            if (hf == 0) *(float4*)(row + D::T_DC) = make_float4(dc[0], dc[1], dc[2], 0.0f);
+        const int nb = last < 0 ? 0 : last / TILE + 1;
+        if (lane == 0) {
+            if (a.ray_tiles) a.ray_tiles[r] = nb;
+            if (a.tape_rows && n_contrib) atomicAdd(a.tape_rows, n_contrib);
         }
-        // ---- MFMA backward chain; d(feature) rows overwrite this point's LDS feature rows
-        f32x16 dh[NT], dout, dhc[NTC];
-        if (!MNE_ABL(a.dbg, 4096)) mlp_backward_mfma<HID, HIDC, CP>(st, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
-        else {
-            dout = f32x16_zero();
+        float ray_do[3] = {0.f, 0.f, 0.f}, ray_dd[3] = {0.f, 0.f, 0.f};
+        for (int c = 0; c < nb; ++c) {
+            const int i = c * TILE + pt;
+            const bool valid = i < Dn;
+            const int ii = valid ? i : Dn - 1;
+            const float z = zr[ii];
+            float p[3], pnv[3], u[3];
+            const size_t e = (size_t)r * S + ii;
+            uint2 mk2;
+            if (LATE_DECODE && c >= t_dec) {                      // backward-only call: tape rows of this tile are missing
+                decode_tile<HID, HIDC, CP>(a, r, c, lane, pn, feat, atab, pnv, u, mk2);
+                t_dec = c + 1;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) p[q] = a.rays_o[r * 3 + q] + a.rays_d[r * 3 + q] * z;
+                point_coords(a.sc, p, pnv, u);
+                mk2 = *(const uint2*)(a.relu_mask + e * 4 + hf * 2);
+            }
+            // ---- d(total)/d(raw) of this point (both lanes of the pair compute the same values)
+            const float4 rw = *(const float4*)(raws + 4 * ii);
+            const float s = rw.w;
+            float ds = 0.0f, dc[3] = {0.f, 0.f, 0.f};
+            bool contrib = false;
+            if (valid) {
+                if (z < G.z_lim) {
+                    const float pp = sigmoidf_(s / a.trunc_f), qq = sigmoidf_(-s / a.trunc_f);
+                    const float wt = pp * qq;
+                    const float w = wt / G.denom;
+                    const float sg[3] = {sigmoidf_(rw.x), sigmoidf_(rw.y), sigmoidf_(rw.z)};
+                    const float dLdw = G.g_rgb[0] * sg[0] + G.g_rgb[1] * sg[1] + G.g_rgb[2] * sg[2] + G.g_dep * z;
+                    ds += ((dLdw - G.Aq) / G.denom) * (wt * (qq - pp) / a.trunc_f);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) dc[q] = G.g_rgb[q] * w * (sg[q] * (1.0f - sg[q]));
+                    contrib = true;
+                }
+                const SampleMasks mk = sample_masks(z, td, has_t, a);
+                const float e_res = (z + s * a.e_T) - td, c_res = (z + s * a.win_f) - td;
+                if (mk.e_front) ds += cf[MNE_L_E_FS] * (s - 1.0f);
+                if (mk.e_center) ds += cf[MNE_L_E_CENTER] * e_res;
+                if (mk.e_tail) ds += cf[MNE_L_E_TAIL] * e_res;
+                if (mk.co_fs) ds += cf[MNE_L_CO_FS] * (s - 1.0f);
+                if (mk.co_sdf) ds += cf[MNE_L_CO_SDF] * c_res;
+                contrib = contrib || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) || (use_co && (mk.co_fs || mk.co_sdf));
+            }
+            MNE_WAVE_SYNC();                                      // feat rows are about to be overwritten
+            // ---- MFMA backward chain from the saved ReLU masks; d(feature) rows land in this point's LDS rows.
+            // A sample without gradient has ds = dc = 0 and therefore an all-zero backward row.
+            float* frow = feat + pt * MNE_FS;
+            float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
+            f32x16 dh[NT], dout, dhc[NTC];
+#ifdef ABL_NO_BWD_MFMA
+            dout = f32x16_zero(); dout[0] = ds + dc[0];
             for (int t = 0; t < NT; ++t) dh[t] = f32x16_zero();
             for (int t = 0; t < NTC; ++t) dhc[t] = f32x16_zero();
-        }
-        if (tape_on) {
+#else
+            mlp_backward_mfma<HID, HIDC, CP>(mk2.x, mk2.y, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
+#endif
+            float* row = a.tape + e * D::ROW;
+#ifdef ABL_NO_BWD_TAPE
+            if (false) {
+#else
+            if (valid) {
+#endif
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                *(float4*)(row + D::T_DOUT + 8 * q + 4 * hf) = make_float4(dout[4 * q], dout[4 * q + 1], dout[4 * q + 2], dout[4 * q + 3]);
+                for (int q = 0; q < 2; ++q)
+                    *(float4*)(row + D::T_DOUT + 8 * q + 4 * hf) = make_float4(dout[4 * q], dout[4 * q + 1], dout[4 * q + 2], dout[4 * q + 3]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(float4*)(row + D::T_DH + 32 * t + 8 * q + 4 * hf) =
-                        make_float4(dh[t][4 * q], dh[t][4 * q + 1], dh[t][4 * q + 2], dh[t][4 * q + 3]);
+                    for (int q = 0; q < 4; ++q)
+                        *(float4*)(row + D::T_DH + 32 * t + 8 * q + 4 * hf) =
+                            make_float4(dh[t][4 * q], dh[t][4 * q + 1], dh[t][4 * q + 2], dh[t][4 * q + 3]);
 #pragma unroll
-            for (int t = 0; t < NTC; ++t)
+                for (int t = 0; t < NTC; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(float4*)(row + D::T_DHC + 32 * t + 8 * q + 4 * hf) =
-                        make_float4(dhc[t][4 * q], dhc[t][4 * q + 1], dhc[t][4 * q + 2], dhc[t][4 * q + 3]);
-        }
-        if (RAYGRAD) {
-            // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates;
-            // the rays of a tile differ, so each point adds its share to its ray with atomics ([R][3])
-            float* dprow = dposL + pt * 64;
-            mlp_backward_dpos<HID, HIDC, CP>(dh, dhc, atab, lane, dprow);
-            MNE_WAVE_SYNC();
-            gather_coord_grad<NSETS, TILE>(a.sc, pn, feat, dpnL, lane);
-            MNE_WAVE_SYNC();
-            float du[3];
-            oneblob_half_backward(u, hf, dprow, du);
+                    for (int q = 0; q < 4; ++q)
+                        *(float4*)(row + D::T_DHC + 32 * t + 8 * q + 4 * hf) =
+                            make_float4(dhc[t][4 * q], dhc[t][4 * q + 1], dhc[t][4 * q + 2], dhc[t][4 * q + 3]);
+                if (hf == 0) *(float4*)(row + D::T_DC) = make_float4(dc[0], dc[1], dc[2], 0.0f);
+            }
+            if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+            if (RAYGRAD) {
+                // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates; every
+                // point of the tile belongs to this ray: summed over the wave, stored once at the end
+                float* dprow = dposL + pt * 64;
+                mlp_backward_dpos<HID, HIDC, CP>(dh, dhc, atab, lane, dprow);
+                MNE_WAVE_SYNC();
+                gather_coord_grad<NSETS, TILE>(a.sc, pn, feat, dpnL, lane);
+                MNE_WAVE_SYNC();
+                float du[3];
+                oneblob_half_backward(u, hf, dprow, du);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) du[q] += __shfl_xor(du[q], 32);
-            if (valid && hf == 0) {
+                for (int q = 0; q < 3; ++q) du[q] += __shfl_xor(du[q], 32);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const float inv_bb = a.sc.bb_is_f64 ? (float)(1.0 / (a.sc.bb_hi[q] - a.sc.bb_lo[q]))
                                                         : 1.0f / ((float)a.sc.bb_hi[q] - (float)a.sc.bb_lo[q]);
-                    const float dp = dpnL[pt * 4 + q] * (2.0f / (a.sc.bound_hi[q] - a.sc.bound_lo[q])) + du[q] * inv_bb;
-                    if (a.d_rays_o) unsafeAtomicAdd(a.d_rays_o + r * 3 + q, dp);
-                    if (a.d_rays_d) unsafeAtomicAdd(a.d_rays_d + r * 3 + q, z * dp);
+                    const float dp = (valid && contrib && hf == 0)
+                        ? dpnL[pt * 4 + q] * (2.0f / (a.sc.bound_hi[q] - a.sc.bound_lo[q])) + du[q] * inv_bb : 0.0f;
+                    ray_do[q] += dp;
+                    ray_dd[q] += z * dp;
                 }
             }
-        }
-        MNE_WAVE_SYNC();
-        const int n_here = total - (int)(tile * TILE);
-        if (a.bins.lists) {
-            // binned scatter: d(feature) + normalised point go to the tape row, and the sample is
-            // appended to the list of every plane tile its 2x2 footprint touches (tile_adam.hip)
-            if (tape_on) {
+            MNE_WAVE_SYNC();
+#ifdef ABL_NO_APPEND
+            const bool live = false;
+#else
+            const bool live = valid && contrib;
+#endif
+            if (a.bins.lists) {
+                // binned scatter: d(feature) + normalised point go to the tape row, and the sample is appended to
+                // the list of every plane tile its 2x2 footprints touch (tile_adam.hip)
+                if (live) {
 #pragma unroll
-                for (int set = 0; set < NSETS; ++set)
+                    for (int set = 0; set < NSETS; ++set)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        *(float4*)(row + D::T_DFEAT + set * MNE_FEAT + hf * 32 + 4 * q) =
-                            *(const float4*)(feat + set * TILE * MNE_FS + pt * MNE_FS + hf * 32 + 4 * q);
-                if (hf == 0) *(float4*)(row + D::T_PN) = *(const float4*)(pn + pt * 4);
-            }
-            if (!MNE_ABL(a.dbg, 1)) {
-                // One returning atomic per DISTINCT tile list per wave: lanes that append to the same
-                // list are grouped with ballots and the group leader reserves the whole run of slots.
-                // Three phases so that all reservations of a tile are in flight together: (A) grouping,
-                // registers only; (B) the leaders' atomics, back to back; (C) slots and entry writes.
+                        for (int q = 0; q < 8; ++q)
+                            *(float4*)(row + D::T_DFEAT + set * MNE_FEAT + hf * 32 + 4 * q) =
+                                *(const float4*)(feat + set * TILE * MNE_FS + pt * MNE_FS + hf * 32 + 4 * q);
+                    if (hf == 0) *(float4*)(row + D::T_PN) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+                }
+                // One returning atomic per DISTINCT tile list per wave: lanes that append to the same list are
+                // grouped with ballots and the group leader reserves the whole run of slots.  Three phases so
+                // that all reservations of a tile are in flight together: (A) grouping, registers only; (B) the
+                // leaders' atomics, back to back; (C) slots and entry writes.
                 constexpr int NQ = NSETS * 3 * 4;
                 int want[NQ];
                 unsigned meta[NQ];                                 // leader lane | rank << 8 | group size << 16
@@ -632,7 +644,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
                     for (int q = 0; q < 4; ++q) {
                         const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
                         const bool dup = ((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0);   // same tile again
-                        const int w_ = (valid && !dup) ? base + ty * ntx + tx : -1;
+                        const int w_ = (live && !dup) ? base + ty * ntx + tx : -1;
                         unsigned long long todo = __ballot(w_ >= 0);
                         unsigned m_ = 0;
                         while (todo) {
@@ -648,13 +660,13 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
                         meta[j * 4 + q] = m_;
                     }
                 }
-                int first[NQ];
+                int first_slot[NQ];
 #pragma unroll
-                for (int e = 0; e < NQ; ++e) {
-                    first[e] = 0;
-                    if (want[e] >= 0 && (int)(meta[e] & 255u) == lane) first[e] = atomicAdd(a.bins.counts + want[e], (int)(meta[e] >> 16));
+                for (int q = 0; q < NQ; ++q) {
+                    first_slot[q] = 0;
+                    if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q], (int)(meta[q] >> 16));
                 }
-                const unsigned trow = (unsigned)kk;
+                const unsigned trow = (unsigned)e;
 #pragma unroll
                 for (int j = 0; j < NSETS * 3; ++j) {
                     const int pidx = 2 * j + hf;
@@ -668,16 +680,16 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
                     const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int e = j * 4 + q;
+                        const int eq = j * 4 + q;
                         const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
-                        const int f0 = __shfl(first[e], (int)(meta[e] & 255u));
-                        if (want[e] >= 0) {
-                            const int slot = f0 + (int)((meta[e] >> 8) & 255u);
+                        const int f0 = __shfl(first_slot[eq], (int)(meta[eq] & 255u));
+                        if (want[eq] >= 0) {
+                            const int slot = f0 + (int)((meta[eq] >> 8) & 255u);
                             unsigned* dst = nullptr;
-                            if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[e] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
+                            if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[eq] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
                             else {
                                 const int sp = atomicAdd(a.bins.spill_count, 1);
-                                if (sp < a.bins.spill_cap) { dst = a.bins.spill + (size_t)sp * MNE_SPILL_WORDS; *dst++ = (unsigned)want[e]; }
+                                if (sp < a.bins.spill_cap) { dst = a.bins.spill + (size_t)sp * MNE_SPILL_WORDS; *dst++ = (unsigned)want[eq]; }
                                 else atomicAdd(a.bins.dropped, 1);          // caller-sized spill area too small: reported, never silent
                             }
                             if (dst) {
@@ -689,9 +701,20 @@ __global__ __launch_bounds__(64 * MAX_WPB_BWD) void backward_kernel(RenderArgs a
                         }
                     }
                 }
+            } else if (a.sc.plane[0][0][0].grad) {                // NULL: the caller wants no plane gradients (pose-only loops)
+                scatter_chunk<NSETS, TILE>(a.sc, pn, feat, __ballot(live && hf == 0), lane);
             }
-        } else if (a.sc.plane[0][0][0].grad) {                    // NULL: the caller wants no plane gradients (pose-only loops)
-            scatter_chunk<NSETS, TILE>(a.sc, pn, feat, n_here < TILE ? n_here : TILE, lane, a.dbg);
+        }
+        if (RAYGRAD) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { ray_do[q] = wave_sum(ray_do[q]); ray_dd[q] = wave_sum(ray_dd[q]); }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (a.d_rays_o) a.d_rays_o[r * 3 + q] = ray_do[q];
+                    if (a.d_rays_d) a.d_rays_d[r * 3 + q] = ray_dd[q];
+                }
+            }
         }
     }
 }
@@ -846,38 +869,25 @@ template <int HID, int HIDC, bool CP> struct WgShape {
     static constexpr bool ALDS = !(HID == 64 && CP);
 };
 
+// LDS of decode_kernel (tables: forward steps) / ray_kernel (tables by mode; + raws[Spad][4] per wave)
 template <int HID, int HIDC, bool CP>
-static size_t tile_lds_total(bool bwd, int wpb, bool raygrad = false) {
-    typedef WgShape<HID, HIDC, CP> W;
+static size_t table_bytes(int mode) {
     typedef ATab<HID, HIDC, CP> T;
-    const size_t tab = W::ALDS ? (size_t)(raygrad ? T::TOTAL_RAYGRAD : bwd ? T::TOTAL : T::FWD_STEPS) * 64 * sizeof(float) : 0;
-    return tab + (size_t)wpb * tile_wave_lds_bytes(CP ? 2 : 1, raygrad);
+    if (!WgShape<HID, HIDC, CP>::ALDS) return 0;
+    return (size_t)(mode == 3 ? T::TOTAL_RAYGRAD : mode >= 1 ? T::TOTAL : T::FWD_STEPS) * 64 * sizeof(float);
 }
-
 template <int HID, int HIDC, bool CP>
-static int choose_wpb(bool bwd, bool raygrad, int max_wpb) {
+static int fit_waves(size_t tab, size_t per_wave, int max_wpb) {
     int fit = 0;
     for (int k = 1; k <= max_wpb; ++k)
-        if (tile_lds_total<HID, HIDC, CP>(bwd, k, raygrad) <= MNE_LDS_MAX) fit = k;
+        if (tab + (size_t)k * per_wave <= MNE_LDS_MAX) fit = k;
     return fit;
 }
 
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-size_t mne_render_workspace(int R, int S) {
-    const size_t Spad = (size_t)((S + 3) & ~3);
-    return align16((size_t)R * RC_N * sizeof(float)) + align16((size_t)R * sizeof(int)) +
-           align16((size_t)(R + 1) * sizeof(int)) + align16((size_t)R * Spad * sizeof(unsigned short)) +
-           align16(((size_t)R * Spad / TILE + 2) * sizeof(int));
-}
-static void carve_workspace(RenderArgs& a, void* ws) {
-    unsigned char* p = (unsigned char*)ws;
-    const size_t Spad = (size_t)((a.S + 3) & ~3);
-    a.ray_ctx = (float*)p; p += align16((size_t)a.R * RC_N * sizeof(float));
-    a.ccount = (int*)p; p += align16((size_t)a.R * sizeof(int));
-    a.coffset = (int*)p; p += align16((size_t)(a.R + 1) * sizeof(int));
-    a.clist = (unsigned short*)p; p += align16((size_t)a.R * Spad * sizeof(unsigned short));
-    a.tile_ray = (int*)p;
-}
+// backward workspace: ReLU masks [R*S][4] u32
+size_t mne_render_workspace(int R, int S) { return align16((size_t)R * S * 4 * sizeof(unsigned)); }
+static void carve_workspace(RenderArgs& a, void* ws) { a.relu_mask = (unsigned*)ws; }
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
     const int n_tab = a.has_d ? a.n_a + 2 * a.n_b : a.S;
@@ -894,52 +904,57 @@ static int launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
     return 0;
 }
 
+template <int HID, int HIDC, bool CP, int MODE>
+static int launch_ray(const RenderArgs& a, hipStream_t st) {
+    typedef WgShape<HID, HIDC, CP> W;
+    const size_t tab = table_bytes<HID, HIDC, CP>(MODE);
+    const size_t per_wave = (size_t)((a.S + 3) & ~3) * 4 * sizeof(float) + tile_wave_lds_bytes(CP ? 2 : 1, MODE == 3);
+    const int wpb = fit_waves<HID, HIDC, CP>(tab, per_wave, MAX_WPB_RAY);
+    if (wpb < 1) return -4;
+    const size_t lds = tab + (size_t)wpb * per_wave;
+    if (lds > 64 * 1024) MNE_SET_MAX_LDS((ray_kernel<HID, HIDC, CP, W::ALDS, MODE>), MNE_LDS_MAX);
+    long long grid = ((long long)a.R + wpb - 1) / wpb;
+    if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
+    MNE_LAUNCH((ray_kernel<HID, HIDC, CP, W::ALDS, MODE>), (unsigned)grid, 64 * wpb, lds, st, a);
+    return 0;
+}
+
 template <int HID, int HIDC, bool CP>
-static int launch_render(RenderArgs a, int pass1, int bwd, void* workspace, hipStream_t st) {
+static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st) {
     typedef WgShape<HID, HIDC, CP> W;
     const bool raygrad = a.d_rays_o != nullptr || a.d_rays_d != nullptr;
-    if (raygrad && !(bwd && !pass1)) return -5;
-    if (!pass1 && !bwd) return -1;
-    if (pass1) {                                           // raw = decoder(points of every sample)
-        const int wpb = choose_wpb<HID, HIDC, CP>(false, false, MAX_WPB);
+    if (raygrad && mode != 3) return -5;
+    if (mode >= 2) {
+        if (!workspace) return -6;
+        carve_workspace(a, workspace);
+    }
+    {   // decode: every tile (mode 0), or the a-priori prefix of every ray
+        const size_t tab = table_bytes<HID, HIDC, CP>(0);
+        const int wpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(CP ? 2 : 1), MAX_WPB);
         if (wpb < 1) return -4;
-        const size_t lds = tile_lds_total<HID, HIDC, CP>(false, wpb);
+        const size_t lds = tab + (size_t)wpb * tile_wave_lds_bytes(CP ? 2 : 1);
         if (lds > 64 * 1024)        // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
             MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS>), MNE_LDS_MAX);
         const long long ntask = (long long)a.R * ((a.S + TILE - 1) / TILE);
         long long grid = (ntask + wpb - 1) / wpb;
         if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
-        MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS>), (unsigned)grid, 64 * wpb, lds, st, a);
+        RenderArgs d = a;
+        if (mode == 0) { d.ray_counts = nullptr; d.prefix_default = 1 << 30; }
+        if (mode == 3) d.raw = nullptr;                    // raw of the forward call stays untouched
+        MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS>), (unsigned)grid, 64 * wpb, lds, st, d);
+    }
+    if (mode == 0) {
+        const size_t clds = (size_t)4 * ((a.S + 3) & ~3) * 4 * sizeof(float);
+        if (clds > MNE_LDS_MAX) return -4;
+        if (clds > 64 * 1024) MNE_SET_MAX_LDS(composite_kernel, MNE_LDS_MAX);
         a.raw_in = a.raw;
-    }
-    const size_t clds = (size_t)4 * ((a.S + 3) & ~3) * 4 * sizeof(float);
-    if (clds > MNE_LDS_MAX) return -4;
-    if (clds > 64 * 1024) {
-        MNE_SET_MAX_LDS((composite_kernel<false>), MNE_LDS_MAX);
-        MNE_SET_MAX_LDS((composite_kernel<true>), MNE_LDS_MAX);
-    }
-    if (!bwd) {
-        MNE_LAUNCH((composite_kernel<false>), (a.R + 3) / 4, 256, clds, st, a);
+        MNE_LAUNCH(composite_kernel, (a.R + 3) / 4, 256, clds, st, a);
         return 0;
     }
-    if (!workspace) return -6;
-    carve_workspace(a, workspace);
-    MNE_LAUNCH((composite_kernel<true>), (a.R + 3) / 4, 256, clds, st, a);
-    MNE_LAUNCH(scan_kernel, 1, 1024, 0, st, a);
-    const int wpb = choose_wpb<HID, HIDC, CP>(true, raygrad, MAX_WPB_BWD);
-    if (wpb < 1) return -4;
-    const size_t lds = tile_lds_total<HID, HIDC, CP>(true, wpb, raygrad);
-    const long long ntile = ((long long)a.R * a.S + TILE - 1) / TILE;       // upper bound; the kernel reads the real count
-    long long grid = (ntile + wpb - 1) / wpb;
-    if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
-    if (raygrad) {
-        if (lds > 64 * 1024) MNE_SET_MAX_LDS((backward_kernel<HID, HIDC, CP, W::ALDS, true>), MNE_LDS_MAX);
-        MNE_LAUNCH((backward_kernel<HID, HIDC, CP, W::ALDS, true>), (unsigned)grid, 64 * wpb, lds, st, a);
-    } else {
-        if (lds > 64 * 1024) MNE_SET_MAX_LDS((backward_kernel<HID, HIDC, CP, W::ALDS, false>), MNE_LDS_MAX);
-        MNE_LAUNCH((backward_kernel<HID, HIDC, CP, W::ALDS, false>), (unsigned)grid, 64 * wpb, lds, st, a);
-    }
-    return 0;
+    if (mode == 1) return launch_ray<HID, HIDC, CP, 0>(a, st);
+    if (mode == 2) return launch_ray<HID, HIDC, CP, 1>(a, st);
+    if (raygrad) return launch_ray<HID, HIDC, CP, 3>(a, st);
+    return launch_ray<HID, HIDC, CP, 2>(a, st);
 }
 
 template <int HID, int HIDC, bool CP>
@@ -965,8 +980,8 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
     return -2;
 }
 
-int mne_launch_render(const RenderArgs& a, int pass1, int bwd, void* workspace, hipStream_t st) {
-#define CALL(H, HC, CPV) return launch_render<H, HC, CPV>(a, pass1, bwd, workspace, st)
+int mne_launch_render(const RenderArgs& a, int mode, void* workspace, hipStream_t st) {
+#define CALL(H, HC, CPV) return launch_render<H, HC, CPV>(a, mode, workspace, st)
     MNE_DISPATCH(a.sc, CALL, -2);
 #undef CALL
     return -2;

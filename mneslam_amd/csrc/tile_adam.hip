@@ -108,7 +108,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     const int tx0 = local % a.bins.ntx[pidx], ty0 = local / a.bins.ntx[pidx];
     for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int cnt = a.bins.counts[tile];
-    const int n_list = MNE_ABL(a.dbg, 32) ? 0 : (cnt < a.bins.cap ? cnt : a.bins.cap);
+    const int n_list = cnt < a.bins.cap ? cnt : a.bins.cap;
     int n_spill = 0;
     if (cnt > a.bins.cap) {                     // only a tile whose list overflowed has entries in the spill area
         const int ns = *a.bins.spill_count;
@@ -185,8 +185,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
 #pragma unroll
         for (int j = 0; j < PASS_ENTRIES / TILE_GROUPS; ++j) {
             const unsigned row = erow[j * TILE_GROUPS + grp];
-            grow[j] = (row != 0xffffffffu && !MNE_ABL(a.dbg, 256)) ? *(const float4*)(dfeat + (size_t)row * a.row_stride)
-                                                             : make_float4(1.f, 1.f, 1.f, 1.f);
+            grow[j] = row != 0xffffffffu ? *(const float4*)(dfeat + (size_t)row * a.row_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // ---- B: counts -> exclusive start offsets (one wave, 4 cells per lane)
         if (tid < MNE_WAVE) {
@@ -276,7 +275,6 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     // ---- Adam on the tile: 16 rows x (16 cells x 32 ch) = 2048 float4
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        if MNE_ABL(a.dbg, 64) break;
         const int i4 = it * TILE_THREADS + tid;
         const int y = i4 / (MNE_TILE * MNE_C / 4), x4 = i4 % (MNE_TILE * MNE_C / 4);
         const int cell = x4 / (MNE_C / 4), ch4 = x4 % (MNE_C / 4);
@@ -301,10 +299,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     if (tid == 0 && blockIdx.x < 4096)
         ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 8192) * MNE_SPILL_WORDS))[blockIdx.x * 8 + 7] = (unsigned long long)cnt;
 #endif
-    if (tid == 0) {
-        if (a.bins.last_counts) a.bins.last_counts[tile] = cnt;                // source of the next tile_order
-        a.bins.counts[tile] = 0;                                               // ready for the next iteration
-    }
+    if (tid == 0) a.bins.counts[tile] = 0;                                     // ready for the next iteration
 }
 
 void mne_tile_geometry(const mne_scene_t& sc, TileBins& b) {

@@ -78,6 +78,7 @@ class FusedStep:
         self.packed = e(self.lib.mne_packed_decoder_floats(C.byref(self.scene)))
         self.tape = e(R * S, self.lib.mne_tape_row_floats(C.byref(self.scene)))
         self.tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.ray_tiles = torch.zeros(R, device=dev, dtype=torch.int32)
         self.ws_bytes = self.lib.mne_render_workspace_bytes(R, S)
         self.ws = e(self.ws_bytes, dtype=torch.uint8)
         self.partials = e(self.lib.mne_wgrad_partial_floats(C.byref(self.scene)))
@@ -129,6 +130,8 @@ class FusedStep:
                 o.m, o.v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                 o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
                 o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
+        # exact early ray termination (decode only the samples a ray needs; csrc/render.hip); False = decode everything
+        self.early_termination = os.environ.get("MNE_NO_EARLY_TERMINATION", "0") != "1"
         self.events = None          # set to {} to record HIP events around the two dominant launches
         self.overlap = overlap
         self._side, self._ev, self._prefetched, self._planes_pending = None, None, None, False
@@ -232,9 +235,11 @@ class FusedStep:
             self._planes_pending = False
         e0 = self._mark("render")
         _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
-                                        P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals), P(self.packed), P(self.coef),
-                                        P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape),
-                                        R * S, P(self.tape_rows), C.byref(self.bins) if self.bins is not None else None,
+                                        P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals),
+                                        P(self.ray_counts) if self.early_termination else None, P(self.packed),
+                                        P(self.coef), P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape),
+                                        R * S, P(self.tape_rows), P(self.ray_tiles),
+                                        C.byref(self.bins) if self.bins is not None else None,
                                         P(self.ws), self.ws_bytes, st),
                    "mne_render_fused")
         self._mark("render", e0)
@@ -254,14 +259,14 @@ class FusedStep:
                 ev[1].record(side)                      # "planes updated": what the next decode waits for
                 self._planes_pending = True
             # ---- decoder chain on the caller's stream, concurrent with the plane update
-            _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), R * S, P(self.partials),
+            _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.ray_tiles), R, S, P(self.partials),
                                              P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
             if self.shared_decoder:
                 from . import dist as mdist
                 mdist.allreduce_mean_(self.dec_grad)
             self.opt.step(zero_grad=False, grad_buffers=self.grad_map)      # decoder tensors
         else:
-            _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.tape_rows), R * S, P(self.partials),
+            _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.ray_tiles), R, S, P(self.partials),
                                              P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
             if self.shared_decoder:
                 from . import dist as mdist

@@ -138,13 +138,13 @@ class RenderFunction(torch.autograd.Function):
                                           _lib.ptr(tgt_rgb) if want_losses else None, _lib.ptr(tgt_d),
                                           _lib.ptr(z_vals), _lib.ptr(packed), _lib.ptr(rgb), _lib.ptr(depth),
                                           _lib.ptr(disp), _lib.ptr(acc), _lib.ptr(var), _lib.ptr(raw),
-                                          _lib.ptr(ray_sums), st), "mne_render_forward")
+                                          _lib.ptr(ray_sums), None, 0, st), "mne_render_forward")
         losses = torch.zeros(_lib.N_LOSS, **opts)
         if want_losses:
             _lib.check(lib.mne_loss_finalize(R, S, _lib.ptr(ray_sums), _lib.ptr(counts), _lib.ptr(losses), st),
                        "mne_loss_finalize")
         ctx.info, ctx.S, ctx.want_losses = info, S, want_losses
-        ctx.save_for_backward(rays_o_c, rays_d_c, tgt_rgb, tgt_d, z_vals, raw, counts, packed, *params)
+        ctx.save_for_backward(rays_o_c, rays_d_c, tgt_rgb, tgt_d, z_vals, raw, counts, ray_counts, packed, *params)
         ctx.mark_non_differentiable(disp, acc, var, z_vals, raw)
         return rgb, depth, disp, acc, var, z_vals, raw, losses
 
@@ -152,7 +152,7 @@ class RenderFunction(torch.autograd.Function):
     def backward(ctx, g_rgb, g_depth, g_disp, g_acc, g_var, g_z, g_raw, g_losses):
         lib = _lib.load()
         info, S = ctx.info, ctx.S
-        rays_o, rays_d, tgt_rgb, tgt_d, z_vals, raw, counts, packed, *params = ctx.saved_tensors
+        rays_o, rays_d, tgt_rgb, tgt_d, z_vals, raw, counts, ray_counts, packed, *params = ctx.saved_tensors
         n_planes = info["n_planes"]
         planes, dec_w = params[:n_planes], params[n_planes:]
         dev, st = rays_o.device, _lib.stream_for(rays_o)
@@ -176,19 +176,21 @@ class RenderFunction(torch.autograd.Function):
         row = lib.mne_tape_row_floats(C.byref(sc))
         tape = torch.empty(R * S, row, **opts)
         tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        ray_tiles = torch.empty(R, device=dev, dtype=torch.int32)
         ws_bytes = lib.mne_render_workspace_bytes(R, S)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         _lib.check(lib.mne_render_backward(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d),
                                            _lib.ptr(tgt_rgb) if coef is not None else None,
-                                           _lib.ptr(tgt_d), _lib.ptr(z_vals), _lib.ptr(packed), _lib.ptr(raw),
-                                           _lib.ptr(coef), _lib.ptr(_f32c(g_rgb, "g_rgb")),
+                                           _lib.ptr(tgt_d), _lib.ptr(z_vals), _lib.ptr(ray_counts), _lib.ptr(packed),
+                                           _lib.ptr(raw), _lib.ptr(coef), _lib.ptr(_f32c(g_rgb, "g_rgb")),
                                            _lib.ptr(_f32c(g_depth, "g_depth")), _lib.ptr(tape), R * S,
-                                           _lib.ptr(tape_rows), _lib.ptr(d_o), _lib.ptr(d_d), _lib.ptr(ws), ws_bytes, st),
+                                           _lib.ptr(tape_rows), _lib.ptr(ray_tiles), _lib.ptr(d_o), _lib.ptr(d_d),
+                                           _lib.ptr(ws), ws_bytes, st),
                    "mne_render_backward")
         nparam = lib.mne_decoder_param_floats(C.byref(sc))
         partials = torch.empty(lib.mne_wgrad_partial_floats(C.byref(sc)), **opts)
         dgrad = torch.empty(nparam, **opts)
-        _lib.check(lib.mne_decoder_wgrad(C.byref(sc), _lib.ptr(tape), _lib.ptr(tape_rows), R * S, _lib.ptr(partials),
+        _lib.check(lib.mne_decoder_wgrad(C.byref(sc), _lib.ptr(tape), _lib.ptr(ray_tiles), R, S, _lib.ptr(partials),
                                          _lib.ptr(dgrad), info.get("wgrad_impl", 0), st), "mne_decoder_wgrad")
         w_sdf0, w_sdf1, w_col0, w_col1 = dec_w
         n0, n1, n2 = w_col0.numel(), w_col1.numel(), w_sdf0.numel()

@@ -136,6 +136,7 @@ typedef const float* mne_cptr;
 #define MNE_CPTR(p) ((const float*)(p))
 
 #define MNE_WAVE_SYNC() hipemu::wave_sync()
+#define MNE_SCHED_BARRIER() do { } while (0)
 #define MNE_SET_MAX_LDS(kern, bytes) ((void)0)
 inline void __syncthreads() { hipemu::g_ctx->block_bar->arrive_and_wait(); }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
@@ -160,6 +161,9 @@ inline unsigned long long __ballot(int pred) {
     wave_sync();
     return m;
 }
+struct uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }

@@ -55,17 +55,17 @@ def test_argument_validation_without_gpu(lib_path):
     # workspace sizing of the backward: monotone in both arguments, zero for empty batches
     assert lib.mne_render_workspace_bytes(0, 128) == 0 and lib.mne_render_workspace_bytes(16, 0) == 0
     w1, w2, w3 = (lib.mne_render_workspace_bytes(*a) for a in ((64, 43), (64, 128), (2150, 128)))
-    assert 0 < w1 < w2 < w3 and w3 >= 2150 * (16 * 4 + 4 + 4 + 128 * 2)
+    assert 0 < w1 < w2 < w3 and w3 >= 2150 * 128 * 16          # ReLU bit masks: 16 B per sample
     # a well-formed scene with NULL buffers: every entry point of the path rejects it before touching the device
     sc = _lib.Scene()
     sc.n_sets, sc.c_dim, sc.hidden, sc.hidden_color, sc.geo_feat_dim, sc.n_bins = 1, 32, 32, 32, 15, 16
-    assert lib.mne_render_forward(ctypes.byref(sc), ctypes.byref(rc), 8, 43, *([None] * 14)) < 0
+    assert lib.mne_render_forward(ctypes.byref(sc), ctypes.byref(rc), 8, 43, *([None] * 14), 0, None) < 0
     assert b"plane" in lib.mne_last_error()
     assert lib.mne_tile_order(ctypes.byref(sc), None, None) < 0
     assert lib.mne_tile_adam(ctypes.byref(sc), None, None, None, None) < 0
     assert lib.mne_loss_finalize(8, 43, None, None, None, None) < 0 and b"NULL" in lib.mne_last_error()
     assert lib.mne_sample_z(ctypes.byref(rc), 8, None, None, None, 0, 0, None, None, None, None) < 0
-    assert lib.mne_decoder_wgrad(ctypes.byref(sc), None, None, 0, None, None, 0, None) < 0
+    assert lib.mne_decoder_wgrad(ctypes.byref(sc), None, None, 8, 43, None, None, 0, None) < 0
     assert lib.mne_tile_count(None) == 0 and lib.mne_tape_row_floats(None) == 0
     _lib.unload()
 
