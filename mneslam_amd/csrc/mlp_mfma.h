@@ -23,6 +23,15 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MNE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// f32x16 accumulator tile (rows = mfma_row(e, hf) of a 32-row tile, column = this lane's point) -> columns
+// [col0, col0 + 32) of the point's LDS row; nreg = 8 writes only the 16 valid rows of a 16-row result
+__device__ __forceinline__ void acc_to_row(float* prow, int col0, const f32x16& v, int hf, int nreg = 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (4 * q < nreg)
+            *(float4*)(prow + col0 + 8 * q + 4 * hf) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
 // row of a 32-row MFMA tile held in accumulator register r by a lane of half h (= lane >> 5)
 __host__ __device__ constexpr int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -304,19 +304,21 @@ struct DecDims {
     static constexpr int CINB = CP ? (MNE_POS + MNE_FEAT) : MNE_POS;   // where geo starts in the colour input
     static constexpr int CIN = CINB + MNE_GEO;                           // 63 or 127
     static constexpr int CINP = CINB + MNE_OUT1;                         // GEMM view of the colour input: [pos | (cf) | out16]
+    // forward half: [feat 64 | pos 48 | out 16 | h HID | hc HIDC | (cf 64)] -- 64-float chunks [pos|out], [h|hc] (staged stores)
     static constexpr int T_X = 0;
-    static constexpr int T_H = T_X + MNE_IN1;
-    static constexpr int T_OUT = T_H + HID;
-    static constexpr int T_HC = T_OUT + MNE_OUT1;
+    static constexpr int T_OUT = T_X + MNE_IN1;
+    static constexpr int T_H = T_OUT + MNE_OUT1;
+    static constexpr int T_HC = T_H + HID;
     static constexpr int T_CF = T_HC + HIDC;
     static constexpr int T_FWD_END = T_CF + (CP ? MNE_FEAT : 0);
+    // backward half: [dh HID | dhc HIDC | dout 16 | dc 4 | pn 4 | pad 8 | dfeat 64 per plane set]
     static constexpr int T_DH = T_FWD_END;
-    static constexpr int T_DOUT = T_DH + HID;
-    static constexpr int T_DHC = T_DOUT + MNE_OUT1;
-    static constexpr int T_DC = T_DHC + HIDC;
-    static constexpr int T_DFEAT = T_DC + 4;
-    static constexpr int T_PN = T_DFEAT + (CP ? 2 : 1) * MNE_FEAT;
-    static constexpr int ROW = T_PN + 4;
+    static constexpr int T_DHC = T_DH + HID;
+    static constexpr int T_DOUT = T_DHC + HIDC;
+    static constexpr int T_DC = T_DOUT + MNE_OUT1;
+    static constexpr int T_PN = T_DC + 4;
+    static constexpr int T_DFEAT = T_DOUT + 32;
+    static constexpr int ROW = T_DFEAT + (CP ? 2 : 1) * MNE_FEAT;
     // tape column of element c (0 <= c < CINP) of the colour-net input [pos48 | (cf64) | out16]
     __host__ __device__ static constexpr int cin_col(int c) {
         return c < MNE_POS ? T_X + MNE_FEAT + c : (CP && c < MNE_POS + MNE_FEAT) ? T_CF + (c - MNE_POS) : T_OUT + (c - CINB);
@@ -328,3 +330,25 @@ struct DecDims {
     static constexpr int P_SDF1 = P_SDF0 + HID * MNE_IN1;
     static constexpr int NPARAM = P_SDF1 + MNE_OUT1 * HID;
 };
+
+// ---- staged tape stores ----------------------------------------------------------------------------------
+// Tape rows are 1.4-2 KB apart, so a store of "what each lane holds" touches 64 different cache lines with 16 bytes
+// each (store-issue-bound, ~7 B/clk/CU).  Everything that goes to the tape is therefore first laid out as rows in LDS
+// ([32 points][MNE_FS], columns [0, NCOL)) and then written by groups of 8 lanes x float4 = one full 128-B line per
+// point and instruction (8 lines per wave instruction).  `live`: bit s = point s is written.
+template <int NCOL>
+__device__ __forceinline__ void store_rows(const float* rows, float* tape_rows0, int row_stride, int tcol,
+                                           unsigned long long live, int lane) {
+    const int cg = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int slot = it * 8 + (lane >> 3);
+        if ((live >> slot) & 1ull) {
+#pragma unroll
+            for (int hfc = 0; hfc < NCOL / 32; ++hfc)
+                *(float4*)(tape_rows0 + (size_t)slot * row_stride + tcol + hfc * 32 + cg * 4) =
+                    *(const float4*)(rows + slot * MNE_FS + hfc * 32 + cg * 4);
+        }
+    }
+}
+

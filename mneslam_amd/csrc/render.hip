@@ -177,7 +177,8 @@ __device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntil
 }
 
 // Decode tile c of ray r with the calling wave: raw -> a.raw (when given), ReLU masks -> a.relu_mask, forward half of
-// the tape rows -> a.tape.  Returns (r,g,b,sdf) of this lane's point (valid lanes); pnv/u are its coordinates.
+// the tape rows -> a.tape (staged through the wave's LDS rows: full-line stores, see store_rows).  Returns (r,g,b,sdf)
+// of this lane's point (valid lanes); pnv/u are its coordinates, relu its mask words.
 template <int HID, int HIDC, bool CP>
 __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c, int lane, float* pn, float* feat,
                                               const float* atab, float (&pnv)[3], float (&u)[3], uint2& relu) {
@@ -197,8 +198,18 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     MNE_WAVE_SYNC();
     gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
     MNE_WAVE_SYNC();
-    const float* frow = feat + pt * MNE_FS;
+    float* frow = feat + pt * MNE_FS;
     const float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
+    const int n_here = S - c * TILE;
+    const unsigned long long live = n_here >= TILE ? 0xffffffffull : ((1ull << n_here) - 1ull);
+    float* tape0 = a.tape ? a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW : nullptr;
+#ifdef ABL_NO_FWD_TAPE
+    tape0 = nullptr;
+#endif
+    if (tape0) {                                           // plane features: straight from the gathered rows
+        store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
+        if (CP) store_rows<MNE_FEAT>(feat + TILE * MNE_FS, tape0, D::ROW, D::T_CF, live, lane);
+    }
     float pos[24];
     oneblob_half(u, hf, pos);
     MlpState<HID, HIDC> st;
@@ -210,38 +221,32 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
         const size_t e = (size_t)r * S + i;
         if (a.raw && hf == 0) *(float4*)(a.raw + e * 4) = rw;
         if (a.relu_mask) *(uint2*)(a.relu_mask + e * 4 + hf * 2) = relu;
-#ifdef ABL_NO_FWD_TAPE
-        if (false) {
-#else
-        if (a.tape) {                                      // forward half of the tape row (each lane: the part it holds)
-#endif
-            float* row = a.tape + e * D::ROW;
+    }
+    if (tape0) {
+        // [pos 48 | out 16] -> tape columns 64..127, then [h | hc]; the feature rows are dead after the forward chain
+        MNE_WAVE_SYNC();
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                *(float4*)(row + D::T_X + hf * 32 + 4 * q) = *(const float4*)(frow + hf * 32 + 4 * q);
+        for (int q = 0; q < 6; ++q)
+            *(float4*)(frow + hf * 24 + 4 * q) = make_float4(pos[4 * q], pos[4 * q + 1], pos[4 * q + 2], pos[4 * q + 3]);
+        acc_to_row(frow, MNE_POS, st.out, hf, 8);
+        MNE_WAVE_SYNC();
+        store_rows<64>(feat, tape0, D::ROW, D::T_X + MNE_FEAT, live, lane);
+        MNE_WAVE_SYNC();
+        if (HID == 32 && HIDC == 32) {
+            acc_to_row(frow, 0, st.h[0], hf);
+            acc_to_row(frow, 32, st.hc[0], hf);
+            MNE_WAVE_SYNC();
+            store_rows<64>(feat, tape0, D::ROW, D::T_H, live, lane);
+        } else {
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
-                *(float4*)(row + D::T_X + MNE_FEAT + hf * 24 + 4 * q) = make_float4(pos[4 * q], pos[4 * q + 1], pos[4 * q + 2], pos[4 * q + 3]);
-            if (CP) {
+            for (int t = 0; t < NT; ++t) acc_to_row(frow, 32 * t, st.h[t], hf);
+            MNE_WAVE_SYNC();
+            store_rows<HID>(feat, tape0, D::ROW, D::T_H, live, lane);
+            MNE_WAVE_SYNC();
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    *(float4*)(row + D::T_CF + hf * 32 + 4 * q) = *(const float4*)(cfrow + hf * 32 + 4 * q);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                *(float4*)(row + D::T_OUT + 8 * q + 4 * hf) = make_float4(st.out[4 * q], st.out[4 * q + 1], st.out[4 * q + 2], st.out[4 * q + 3]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(float4*)(row + D::T_H + 32 * t + 8 * q + 4 * hf) =
-                        make_float4(st.h[t][4 * q], st.h[t][4 * q + 1], st.h[t][4 * q + 2], st.h[t][4 * q + 3]);
-#pragma unroll
-            for (int t = 0; t < NTC; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(float4*)(row + D::T_HC + 32 * t + 8 * q + 4 * hf) =
-                        make_float4(st.hc[t][4 * q], st.hc[t][4 * q + 1], st.hc[t][4 * q + 2], st.hc[t][4 * q + 3]);
+            for (int t = 0; t < NTC; ++t) acc_to_row(frow, 32 * t, st.hc[t], hf);
+            MNE_WAVE_SYNC();
+            store_rows<HIDC>(feat, tape0, D::ROW, D::T_HC, live, lane);
         }
     }
     return rw;
@@ -557,29 +562,6 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
 #else
             mlp_backward_mfma<HID, HIDC, CP>(mk2.x, mk2.y, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
 #endif
-            float* row = a.tape + e * D::ROW;
-#ifdef ABL_NO_BWD_TAPE
-            if (false) {
-#else
-            if (valid) {
-#endif
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    *(float4*)(row + D::T_DOUT + 8 * q + 4 * hf) = make_float4(dout[4 * q], dout[4 * q + 1], dout[4 * q + 2], dout[4 * q + 3]);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(float4*)(row + D::T_DH + 32 * t + 8 * q + 4 * hf) =
-                            make_float4(dh[t][4 * q], dh[t][4 * q + 1], dh[t][4 * q + 2], dh[t][4 * q + 3]);
-#pragma unroll
-                for (int t = 0; t < NTC; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(float4*)(row + D::T_DHC + 32 * t + 8 * q + 4 * hf) =
-                            make_float4(dhc[t][4 * q], dhc[t][4 * q + 1], dhc[t][4 * q + 2], dhc[t][4 * q + 3]);
-                if (hf == 0) *(float4*)(row + D::T_DC) = make_float4(dc[0], dc[1], dc[2], 0.0f);
-            }
             if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
             if (RAYGRAD) {
                 // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates; every
@@ -609,18 +591,51 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
 #else
             const bool live = valid && contrib;
 #endif
+            const unsigned long long live_rows = __ballot(live && hf == 0), valid_rows = __ballot(valid && hf == 0);
+            float* tape0 = a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW;
+#ifdef ABL_NO_BWD_TAPE
+            const unsigned long long tape_rows_mask = 0ull;
+#else
+            const unsigned long long tape_rows_mask = valid_rows;
+#endif
+            // ---- backward half of the tape rows, staged through the LDS rows (full-line stores, see store_rows)
+            if (a.bins.lists) {                                   // d(feature) rows: read by the binned plane update
+#pragma unroll
+                for (int set = 0; set < NSETS; ++set)
+                    store_rows<MNE_FEAT>(feat + set * TILE * MNE_FS, tape0, D::ROW, D::T_DFEAT + set * MNE_FEAT, live_rows, lane);
+            } else if (a.sc.plane[0][0][0].grad) {                // NULL: the caller wants no plane gradients (pose-only loops)
+                scatter_chunk<NSETS, TILE>(a.sc, pn, feat, live_rows, lane);
+            }
+            MNE_WAVE_SYNC();
+            if (HID == 32 && HIDC == 32) {
+                acc_to_row(frow, 0, dh[0], hf);
+                acc_to_row(frow, 32, dhc[0], hf);
+                MNE_WAVE_SYNC();
+                store_rows<64>(feat, tape0, D::ROW, D::T_DH, tape_rows_mask, lane);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc_to_row(frow, 32 * t, dh[t], hf);
+                MNE_WAVE_SYNC();
+                store_rows<HID>(feat, tape0, D::ROW, D::T_DH, tape_rows_mask, lane);
+                MNE_WAVE_SYNC();
+#pragma unroll
+                for (int t = 0; t < NTC; ++t) acc_to_row(frow, 32 * t, dhc[t], hf);
+                MNE_WAVE_SYNC();
+                store_rows<HIDC>(feat, tape0, D::ROW, D::T_DHC, tape_rows_mask, lane);
+            }
+            MNE_WAVE_SYNC();
+            acc_to_row(frow, 0, dout, hf, 8);                     // [dout 16 | dc 4 | pn 4 | pad 8]
+            if (hf == 0) {
+                *(float4*)(frow + 16) = make_float4(dc[0], dc[1], dc[2], 0.0f);
+                *(float4*)(frow + 20) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+            } else {
+                *(float4*)(frow + 24) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4*)(frow + 28) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            MNE_WAVE_SYNC();
+            store_rows<32>(feat, tape0, D::ROW, D::T_DOUT, tape_rows_mask, lane);
             if (a.bins.lists) {
-                // binned scatter: d(feature) + normalised point go to the tape row, and the sample is appended to
-                // the list of every plane tile its 2x2 footprints touch (tile_adam.hip)
-                if (live) {
-#pragma unroll
-                    for (int set = 0; set < NSETS; ++set)
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            *(float4*)(row + D::T_DFEAT + set * MNE_FEAT + hf * 32 + 4 * q) =
-                                *(const float4*)(feat + set * TILE * MNE_FS + pt * MNE_FS + hf * 32 + 4 * q);
-                    if (hf == 0) *(float4*)(row + D::T_PN) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
-                }
+                // the sample is appended to the list of every plane tile its 2x2 footprints touch (tile_adam.hip).
                 // One returning atomic per DISTINCT tile list per wave: lanes that append to the same list are
                 // grouped with ballots and the group leader reserves the whole run of slots.  Three phases so
                 // that all reservations of a tile are in flight together: (A) grouping, registers only; (B) the
@@ -666,7 +681,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
                     first_slot[q] = 0;
                     if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q], (int)(meta[q] >> 16));
                 }
-                const unsigned trow = (unsigned)e;
+                const unsigned trow = (unsigned)e;                 // tape row of this sample
 #pragma unroll
                 for (int j = 0; j < NSETS * 3; ++j) {
                     const int pidx = 2 * j + hf;
@@ -701,8 +716,6 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
                         }
                     }
                 }
-            } else if (a.sc.plane[0][0][0].grad) {                // NULL: the caller wants no plane gradients (pose-only loops)
-                scatter_chunk<NSETS, TILE>(a.sc, pn, feat, __ballot(live && hf == 0), lane);
             }
         }
         if (RAYGRAD) {
