@@ -87,9 +87,9 @@ typedef struct mne_render_cfg {
  * caller-owned device memory; counts and *spill_count must be zero before the first use (each
  * mne_tile_adam call leaves counts zeroed again; mne_render_fused zeroes *spill_count itself). */
 typedef struct mne_tile_bins {
-    uint32_t* lists;       /* [mne_tile_count()][cap][6]: tape row, packed local corner, 4 weights */
+    uint32_t* lists;       /* [mne_tile_count()][cap][8]: tape row, packed local corner, 4 weights, tile id, 0 (32-byte entries) */
     int32_t* counts;       /* [mne_tile_count()] */
-    uint32_t* spill;       /* [spill_cap][8] overflow entries (tile id, entry, pad) */
+    uint32_t* spill;       /* [spill_cap][8] overflow entries (same layout) */
     int32_t* spill_count;  /* [1] */
     int32_t* order;        /* [mne_tile_count()] scratch: tile processing order (heaviest first) */
     int32_t cap, spill_cap;

@@ -130,69 +130,75 @@ __device__ __forceinline__ void oneblob16(float x, float* out /*16*/, bool inter
 #ifndef MNE_GATHER_INFLIGHT
 #define MNE_GATHER_INFLIGHT 12
 #endif
-template <int NSETS, int NPTS>
-__device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane) {
-    const int cg = lane & 7;
+// Tri-plane features of ONE point for the 8 lanes that share it (cg = lane & 7: float4 chunk of the 128-B rows); the
+// blended rows go to out + set * set_stride + level * 32 + cg * 4 (LDS row or tape row).
+template <int NSETS>
+__device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
     const int kmine = cg < 6 ? cg : cg - 6;                        // this lane's plane: k = lvl * 3 + ori
     const int lvl_m = kmine >= 3 ? 1 : 0, ori_m = kmine - 3 * lvl_m;
     constexpr int NLV = MNE_GATHER_INFLIGHT / 12;                   // levels loaded together
+#pragma unroll
+    for (int set = 0; set < NSETS; ++set) {
+        int Hm = sc.plane[set][0][0].h, Wm = sc.plane[set][0][0].w;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            Hm = kmine == k ? sc.plane[set][k % 3][k / 3].h : Hm;
+            Wm = kmine == k ? sc.plane[set][k % 3][k / 3].w : Wm;
+        }
+        float gx, gy;
+        orient_coords(ori_m, px, py, pz, gx, gy);
+        Bilin bm;
+        bilin_setup(gx, gy, Hm, Wm, bm);
+#pragma unroll
+        for (int l0 = 0; l0 < 2; l0 += NLV) {
+            int off[3 * NLV][4];
+            float wgt[3 * NLV][4];
+#pragma unroll
+            for (int j = 0; j < 3 * NLV; ++j) {
+                const int k = l0 * 3 + j;                               // k = lvl * 3 + ori
+                off[j][0] = mne_bcast8(bm.o00, k); off[j][1] = mne_bcast8(bm.o01, k);
+                off[j][2] = mne_bcast8(bm.o10, k); off[j][3] = mne_bcast8(bm.o11, k);
+                wgt[j][0] = mne_bcast8(bm.w00, k); wgt[j][1] = mne_bcast8(bm.w01, k);
+                wgt[j][2] = mne_bcast8(bm.w10, k); wgt[j][3] = mne_bcast8(bm.w11, k);
+            }
+            MNE_SCHED_BARRIER();
+            float4 v[3 * NLV][4];
+#pragma unroll
+            for (int j = 0; j < 3 * NLV; ++j) {
+                const int k = l0 * 3 + j;
+                const float* base = sc.plane[set][k % 3][k / 3].data + cg * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[j][q] = *(const float4*)(base + off[j][q]);
+            }
+            MNE_SCHED_BARRIER();
+#pragma unroll
+            for (int lv = 0; lv < NLV; ++lv) {
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ori = 0; ori < 3; ++ori) {
+                    const int j = lv * 3 + ori;
+                    float4 acc;
+                    acc.x = v[j][0].x * wgt[j][0]; acc.y = v[j][0].y * wgt[j][0]; acc.z = v[j][0].z * wgt[j][0]; acc.w = v[j][0].w * wgt[j][0];
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) {
+                        acc.x = fmaf(v[j][q].x, wgt[j][q], acc.x); acc.y = fmaf(v[j][q].y, wgt[j][q], acc.y);
+                        acc.z = fmaf(v[j][q].z, wgt[j][q], acc.z); acc.w = fmaf(v[j][q].w, wgt[j][q], acc.w);
+                    }
+                    sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;       // xy + xz + yz
+                }
+                *(float4*)(out + set * set_stride + (l0 + lv) * MNE_C + cg * 4) = sum;
+            }
+        }
+    }
+}
+
+template <int NSETS, int NPTS>
+__device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane) {
+    const int cg = lane & 7;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 8; ++it) {
         const int slot = it * 8 + (lane >> 3);
-        const float px = pn[slot * 4 + 0], py = pn[slot * 4 + 1], pz = pn[slot * 4 + 2];
-#pragma unroll
-        for (int set = 0; set < NSETS; ++set) {
-            int Hm = sc.plane[set][0][0].h, Wm = sc.plane[set][0][0].w;
-#pragma unroll
-            for (int k = 1; k < 6; ++k) {
-                Hm = kmine == k ? sc.plane[set][k % 3][k / 3].h : Hm;
-                Wm = kmine == k ? sc.plane[set][k % 3][k / 3].w : Wm;
-            }
-            float gx, gy;
-            orient_coords(ori_m, px, py, pz, gx, gy);
-            Bilin bm;
-            bilin_setup(gx, gy, Hm, Wm, bm);
-#pragma unroll
-            for (int l0 = 0; l0 < 2; l0 += NLV) {
-                int off[3 * NLV][4];
-                float wgt[3 * NLV][4];
-#pragma unroll
-                for (int j = 0; j < 3 * NLV; ++j) {
-                    const int k = l0 * 3 + j;                               // k = lvl * 3 + ori
-                    off[j][0] = mne_bcast8(bm.o00, k); off[j][1] = mne_bcast8(bm.o01, k);
-                    off[j][2] = mne_bcast8(bm.o10, k); off[j][3] = mne_bcast8(bm.o11, k);
-                    wgt[j][0] = mne_bcast8(bm.w00, k); wgt[j][1] = mne_bcast8(bm.w01, k);
-                    wgt[j][2] = mne_bcast8(bm.w10, k); wgt[j][3] = mne_bcast8(bm.w11, k);
-                }
-                MNE_SCHED_BARRIER();
-                float4 v[3 * NLV][4];
-#pragma unroll
-                for (int j = 0; j < 3 * NLV; ++j) {
-                    const int k = l0 * 3 + j;
-                    const float* base = sc.plane[set][k % 3][k / 3].data + cg * 4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[j][q] = *(const float4*)(base + off[j][q]);
-                }
-                MNE_SCHED_BARRIER();
-#pragma unroll
-                for (int lv = 0; lv < NLV; ++lv) {
-                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int ori = 0; ori < 3; ++ori) {
-                        const int j = lv * 3 + ori;
-                        float4 acc;
-                        acc.x = v[j][0].x * wgt[j][0]; acc.y = v[j][0].y * wgt[j][0]; acc.z = v[j][0].z * wgt[j][0]; acc.w = v[j][0].w * wgt[j][0];
-#pragma unroll
-                        for (int q = 1; q < 4; ++q) {
-                            acc.x = fmaf(v[j][q].x, wgt[j][q], acc.x); acc.y = fmaf(v[j][q].y, wgt[j][q], acc.y);
-                            acc.z = fmaf(v[j][q].z, wgt[j][q], acc.z); acc.w = fmaf(v[j][q].w, wgt[j][q], acc.w);
-                        }
-                        sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;       // xy + xz + yz
-                    }
-                    *(float4*)(feat + set * NPTS * MNE_FS + slot * MNE_FS + (l0 + lv) * MNE_C + cg * 4) = sum;
-                }
-            }
-        }
+        gather_slot<NSETS>(sc, pn[slot * 4 + 0], pn[slot * 4 + 1], pn[slot * 4 + 2], cg, feat + slot * MNE_FS, NPTS * MNE_FS);
     }
 }
 
@@ -352,3 +358,24 @@ __device__ __forceinline__ void store_rows(const float* rows, float* tape_rows0,
     }
 }
 
+// the reverse of store_rows: tape columns [tcol, tcol + NCOL) of the tile's rows -> LDS rows, one batch of coalesced loads
+template <int NCOL>
+__device__ __forceinline__ void load_rows(float* rows, const float* tape_rows0, int row_stride, int tcol,
+                                          unsigned long long live, int lane) {
+    const int cg = lane & 7;
+    float4 v[4][NCOL / 32];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int slot = it * 8 + (lane >> 3);
+        const int src = ((live >> slot) & 1ull) ? slot : 0;            // rows beyond the ray's last sample: any valid row
+#pragma unroll
+        for (int hfc = 0; hfc < NCOL / 32; ++hfc)
+            v[it][hfc] = *(const float4*)(tape_rows0 + (size_t)src * row_stride + tcol + hfc * 32 + cg * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int slot = it * 8 + (lane >> 3);
+#pragma unroll
+        for (int hfc = 0; hfc < NCOL / 32; ++hfc) *(float4*)(rows + slot * MNE_FS + hfc * 32 + cg * 4) = v[it][hfc];
+    }
+}

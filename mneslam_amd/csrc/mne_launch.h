@@ -19,8 +19,8 @@ struct ZArgs {
 
 #define MNE_TILE 16            // plane tile edge (cells) of the binned scatter
 #define MNE_MAX_PLANES 12
-#define MNE_ENTRY_WORDS 6       // list entry: tape row | (lx+1)|(ly+1)<<8 | 4 bilinear weights
-#define MNE_SPILL_WORDS 8       // spill entry: tile id | entry | pad
+#define MNE_ENTRY_WORDS 8       // list / spill entry (32 B): tape row | (lx+1)|(ly+1)<<8 | 4 bilinear weights | tile id | 0
+#define MNE_SPILL_WORDS 8
 
 struct TileBins {
     unsigned* lists;          // [n_tiles][cap][MNE_ENTRY_WORDS]
@@ -48,9 +48,15 @@ struct RenderArgs {
     int prefix_default;         // ray_counts == NULL: a-priori tiles of every ray (ntile = decode everything, 1 = on demand only)
     const float *coef, *g_rgb, *g_depth;
     float* tape;                // [R*S][ROW]; NULL = forward only
+    int tape_row, tape_tx, tape_tcf;   // gather_kernel: row length and the columns of the two feature blocks
     int* tape_rows;             // total number of samples that received gradient
     unsigned* relu_mask;        // [R*S][4]: per lane half (h mask, hc mask)
     int* ray_tiles;             // [R] number of leading 32-sample tiles of each ray whose tape rows are complete
+    int* dec_tiles;             // [R] leading tiles of each ray decode_kernel really decoded (a-priori prefix + its extension)
+    int* defer_list;            // [R] rays the training kernel could not resolve from the decoded prefix
+    int* defer_count;           // [1]
+    const int* ray_list;        // ray_kernel works through this list instead of all rays (NULL = rays 0..R-1)
+    const int* ray_list_count;
     float *d_rays_o, *d_rays_d;
     TileBins bins;              // bins.lists != NULL: binned scatter instead of atomics into plane[].grad
 };

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
             n_cosdf += (!cf && !cb && d > 0.0f);
             // samples that can carry a loss term whatever the decoder says: not behind either truncation band
             // (z sorted: a prefix of the ray).  The render kernels decode at least these (early ray termination).
-            n_need += (d > 0.0f) && (!(z > (d + a.e_T)) || !cb);
+            // A ray without valid depth has no loss term but its first SDF sign change can sit anywhere: all its samples.
+            n_need += (d > 0.0f) ? ((!(z > (d + a.e_T)) || !cb) ? 1 : 0) : 1;
         }
     }
     if (a.has_d) {
@@ -145,6 +146,18 @@ __global__ __launch_bounds__(256) void pack_decoder_kernel(mne_scene_t sc, float
 // -----------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x16 f32x16_zero() { f32x16 v; for (int q = 0; q < 16; ++q) v[q] = 0.0f; return v; }
 
+// -DRENDER_PROFILE (experiments only, profiles/render_phase_times.py): lane 0 stamps the constant 100 MHz clock at phase
+// boundaries into the unused tail of the spill area (decode: first task of every wave; ray: every ray).
+#ifdef RENDER_PROFILE
+#define DEC_STAMP(k) do { if (prof_slot >= 0 && (lane) == 0) \
+    ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 65536) * MNE_SPILL_WORDS))[(size_t)prof_slot * 16 + (k)] = wall_clock64(); } while (0)
+#define RAY_STAMP(k) do { if (a.bins.spill && lane == 0 && (k) < 32) \
+    ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 32768) * MNE_SPILL_WORDS))[(size_t)r * 32 + (k)] = wall_clock64(); } while (0)
+#else
+#define DEC_STAMP(k) do { } while (0)
+#define RAY_STAMP(k) do { } while (0)
+#endif
+
 struct SampleMasks { bool e_front, e_center, e_tail, co_fs, co_sdf; };
 
 __device__ __forceinline__ SampleMasks sample_masks(float z, float d, bool has_t, const RenderArgs& a) {
@@ -169,7 +182,8 @@ __host__ __device__ inline size_t tile_wave_lds_bytes(int nsets, bool raygrad = 
 }
 
 // number of leading tiles of ray r that are decoded a priori (see the file header)
-__device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntile) {
+__device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntile, bool listed = false) {
+    if (listed) return ntile;                    // second pass over the deferred rays: everything is decoded
     if (!a.ray_counts) return a.prefix_default < ntile ? a.prefix_default : ntile;
     const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
     const int t = (need + TILE - 1) / TILE;
@@ -179,42 +193,59 @@ __device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntil
 // Decode tile c of ray r with the calling wave: raw -> a.raw (when given), ReLU masks -> a.relu_mask, forward half of
 // the tape rows -> a.tape (staged through the wave's LDS rows: full-line stores, see store_rows).  Returns (r,g,b,sdf)
 // of this lane's point (valid lanes); pnv/u are its coordinates, relu its mask words.
+// PRE: the plane features of the tile are already in the tape rows (gather_kernel): they are loaded back into the LDS
+// rows with one batch of coalesced loads instead of being gathered here (8 dependent rounds of corner-row loads).
 template <int HID, int HIDC, bool CP>
 __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c, int lane, float* pn, float* feat,
-                                              const float* atab, float (&pnv)[3], float (&u)[3], uint2& relu) {
+                                              const float* atab, float (&pnv)[3], float (&u)[3], uint2& relu, int prof_slot = -1,
+                                              bool PRE = false) {
     typedef DecDims<HID, HIDC, CP> D;
     constexpr int NSETS = CP ? 2 : 1;
     constexpr int NT = HID / 32, NTC = HIDC / 32;
     const int S = a.S, pt = lane & 31, hf = lane >> 5;
     const int i = c * TILE + pt;
     const bool valid = i < S;
+    DEC_STAMP(0);
     const float z = a.z_vals[(size_t)r * S + (valid ? i : S - 1)];
     float p[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) p[k] = a.rays_o[r * 3 + k] + a.rays_d[r * 3 + k] * z;      // scene_rep.py:384
     point_coords(a.sc, p, pnv, u);
-    MNE_WAVE_SYNC();                                       // earlier LDS reads of this wave are done
-    if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
-    MNE_WAVE_SYNC();
-    gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
-    MNE_WAVE_SYNC();
-    float* frow = feat + pt * MNE_FS;
-    const float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
     const int n_here = S - c * TILE;
     const unsigned long long live = n_here >= TILE ? 0xffffffffull : ((1ull << n_here) - 1ull);
     float* tape0 = a.tape ? a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW : nullptr;
 #ifdef ABL_NO_FWD_TAPE
     tape0 = nullptr;
 #endif
-    if (tape0) {                                           // plane features: straight from the gathered rows
-        store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
-        if (CP) store_rows<MNE_FEAT>(feat + TILE * MNE_FS, tape0, D::ROW, D::T_CF, live, lane);
+    MNE_WAVE_SYNC();                                       // earlier LDS reads of this wave are done
+    if (PRE) {
+        DEC_STAMP(1);
+        load_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
+        if (CP) load_rows<MNE_FEAT>(feat + TILE * MNE_FS, tape0, D::ROW, D::T_CF, live, lane);
+        MNE_WAVE_SYNC();
+        DEC_STAMP(2);
+    } else {
+        if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+        MNE_WAVE_SYNC();
+        DEC_STAMP(1);
+        gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+        MNE_WAVE_SYNC();
+        DEC_STAMP(2);
+        if (tape0) {                                       // plane features: straight from the gathered rows
+            store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
+            if (CP) store_rows<MNE_FEAT>(feat + TILE * MNE_FS, tape0, D::ROW, D::T_CF, live, lane);
+        }
     }
+    float* frow = feat + pt * MNE_FS;
+    const float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
+    DEC_STAMP(3);
     float pos[24];
     oneblob_half(u, hf, pos);
+    DEC_STAMP(4);
     MlpState<HID, HIDC> st;
     mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, atab, lane, st);
     const float4 rw = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);      // rows 0..3 live in the lower half
+    DEC_STAMP(5);
     relu = make_uint2(0u, 0u);
     if (a.relu_mask) relu_masks<HID, HIDC>(st, relu.x, relu.y);
     if (valid) {
@@ -249,22 +280,55 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
             store_rows<HIDC>(feat, tape0, D::ROW, D::T_HC, live, lane);
         }
     }
+    DEC_STAMP(6);
     return rw;
 }
 
 #ifndef MAX_WPB
 #define MAX_WPB 12
 #endif
+// -----------------------------------------------------------------------------------------------
+// gather_kernel: tri-plane features of the a-priori samples straight into their tape rows.  The gather is a chain of
+// dependent load rounds; inside decode_kernel (12 waves per CU, LDS- and register-bound) it took 21 of the 34 us a tile
+// needs.  Here it runs by itself: one wave = 8 consecutive samples of a ray, 8 lanes per sample, no LDS, few registers,
+// 32 waves per CU -- the whole batch is in flight at once.  decode_kernel<PRE> then starts from the rows.
+// -----------------------------------------------------------------------------------------------
+template <bool CP>
+__global__ __launch_bounds__(256) void gather_kernel(RenderArgs a, int chunks_per_ray) {
+    typedef DecDims<32, 32, CP> D0;                        // only the hidden-size independent columns are used (T_X = 0)
+    constexpr int NSETS = CP ? 2 : 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long task = (long long)blockIdx.x * 4 + wv;
+    if (task >= (long long)a.R * chunks_per_ray) return;
+    const int k = (int)(task / a.R), r = (int)(task % a.R);       // chunk-major: the skipped chunks cluster at the end
+    const int S = a.S, ntile = (S + TILE - 1) / TILE;
+    const int n_samp = prefix_tiles(a, r, ntile) * TILE;
+    const int i = k * 8 + (lane >> 3);
+    if (k * 8 >= n_samp || k * 8 >= S) return;                    // whole wave leaves together
+    const int ii = i < S ? i : S - 1;
+    const float z = a.z_vals[(size_t)r * S + ii];
+    float p[3], pnv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        p[q] = a.rays_o[r * 3 + q] + a.rays_d[r * 3 + q] * z;                                      // scene_rep.py:384
+        pnv[q] = ((p[q] - a.sc.bound_lo[q]) / (a.sc.bound_hi[q] - a.sc.bound_lo[q])) * 2.0f - 1.0f;  // = point_coords' pn
+    }
+    float* row = a.tape + ((size_t)r * S + ii) * a.tape_row + a.tape_tx;
+    // rows of samples beyond S (last chunk of a ray) are computed on the clamped sample and written twice: harmless
+    gather_slot<NSETS>(a.sc, pnv[0], pnv[1], pnv[2], lane & 7, row, a.tape_tcf - a.tape_tx);
+}
+
 template <int HID, int HIDC, bool CP, bool ALDS>
-__global__ __launch_bounds__(64 * MAX_WPB) void decode_kernel(RenderArgs a) {
+__global__ __launch_bounds__(64 * MAX_WPB) void decode_kernel(RenderArgs a, int pre) {
     typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
     constexpr int TAB_FLOATS = ALDS ? T::FWD_STEPS * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     const int wpb = blockDim.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {             // counters of this call, reset before any consumer runs
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !a.ray_list) {   // counters of this call, reset before any consumer runs
         if (a.tape_rows) *a.tape_rows = 0;
         if (a.bins.spill_count) *a.bins.spill_count = 0;
+        if (a.defer_count) *a.defer_count = 0;
     }
     if (ALDS) {                                            // stage the A tables: the only block-wide step
         float4* dst = (float4*)lds_raw;
@@ -275,17 +339,59 @@ __global__ __launch_bounds__(64 * MAX_WPB) void decode_kernel(RenderArgs a) {
     const float* atab = ALDS ? (const float*)lds_raw : a.packed;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntile = (a.S + TILE - 1) / TILE;
-    const long long ntask = (long long)a.R * ntile;
     float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(NSETS));
     float* feat = pn + TILE * 4;
     // persistent waves over the (tile, ray) tasks, TILE-major: the a-priori tiles of all rays come first, so the
-    // skipped tasks (tiles beyond a ray's prefix) cluster at the end and the real ones spread evenly over the waves
-    for (long long task = (long long)blockIdx.x * wpb + wv; task < ntask; task += (long long)gridDim.x * wpb) {
-        const int c = (int)(task / a.R), r = (int)(task % a.R);
-        if (c >= prefix_tiles(a, r, ntile)) continue;
+    // skipped tasks (tiles beyond a ray's prefix) cluster at the end and the real ones spread evenly over the waves.
+    // List mode (second pass): the REMAINING tiles of the rays the training kernel deferred.
+    int n_done = 0;
+    const int n_rays = a.ray_list ? *a.ray_list_count : a.R;
+    const long long ntask_l = (long long)n_rays * ntile;
+    for (long long task = (long long)blockIdx.x * wpb + wv; task < ntask_l; task += (long long)gridDim.x * wpb) {
+        const int c = (int)(task / n_rays);
+        const int r = a.ray_list ? a.ray_list[(int)(task % n_rays)] : (int)(task % n_rays);
+        if (a.ray_list ? (c < (a.dec_tiles ? a.dec_tiles[r] : prefix_tiles(a, r, ntile))) : (c >= prefix_tiles(a, r, ntile))) continue;
         float pnv[3], u[3];
         uint2 relu;
-        decode_tile<HID, HIDC, CP>(a, r, c, lane, pn, feat, atab, pnv, u, relu);
+        // The wave that decodes the LAST a-priori tile of a ray extends the prefix on the spot while the ray is visibly
+        // unresolved: no sign change from this tile on, or the truncation window behind the sign change runs past the
+        // tile.  (A heuristic that saves a second pass: ray_kernel checks the whole prefix exactly and defers whatever
+        // is still unresolved.)  dec_tiles[r] = tiles decoded in the end.  One decode_tile call site for both uses.
+        const bool resolver = a.dec_tiles && a.ray_counts && !a.ray_list && c == prefix_tiles(a, r, ntile) - 1;
+        int cc = c;
+        bool found = false, have_carry = false, pre_now = pre != 0;
+        float z_lim = 0.0f, s_carry = 0.0f;
+        const float* zr = a.z_vals + (size_t)r * a.S;
+        while (true) {
+#ifdef RENDER_PROFILE
+            const int prof_slot = (a.bins.spill && n_done < 2 && cc == c) ? (int)(blockIdx.x * wpb + wv) * 2 + n_done : -1;
+#else
+            const int prof_slot = -1;
+#endif
+            const float4 rw = decode_tile<HID, HIDC, CP>(a, r, cc, lane, pn, feat, atab, pnv, u, relu, prof_slot, pre_now);
+#ifdef RENDER_PROFILE
+            if (prof_slot >= 0 && lane == 0)
+                ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 65536) * MNE_SPILL_WORDS))[(size_t)prof_slot * 16 + 7] = (unsigned long long)(c + 1);
+#endif
+            if (!resolver) break;
+            const int i0 = cc * TILE, n_in = a.S - i0 < TILE ? a.S - i0 : TILE;
+            const float s_me = rw.w;                                   // valid on lanes < 32 (rows 0..3 of the result)
+            const float s_nx = __shfl_down(s_me, 1);
+            if (!found) {
+                const bool cr = lane < 32 && (lane & 31) + 1 < n_in && s_me * s_nx < 0.0f;
+                const unsigned long long m = __ballot(cr);
+                int f = m ? i0 + __ffsll(m) - 1 : -1;
+                if (have_carry && s_carry * __shfl(s_me, 0) < 0.0f) f = i0 - 1;       // pair across the tile boundary
+                if (f >= 0) { found = true; z_lim = zr[f] + a.win_f; }
+            }
+            if (cc + 1 >= ntile) break;
+            if (found && !(zr[i0 + n_in] < z_lim)) break;              // the window ends before the next tile
+            s_carry = __shfl(s_me, n_in - 1); have_carry = true;
+            ++cc;
+            pre_now = false;                                           // tiles beyond the prefix were not pre-gathered
+        }
+        if (resolver && lane == 0) a.dec_tiles[r] = cc + 1;
+        ++n_done;
     }
 }
 
@@ -308,11 +414,10 @@ __device__ __forceinline__ int first_crossing(const float* raws, int from, int D
 // Maps, loss partial sums and (WITH_GRAD) the per-ray constants of the gradient.  `first` = index of the first sign
 // change (0 when the whole ray has none, scene_rep.py:195-199); all samples with z < z_lim are among the first D.
 template <bool WITH_GRAD>
-__device__ __forceinline__ void composite_ray(const RenderArgs& a, int r, int lane, const float* raws, int D, int first, RayGrad& G) {
-    const int S = a.S;
+__device__ __forceinline__ void composite_ray(const RenderArgs& a, int r, int lane, const float* raws, const float* zr, int D,
+                                              int first, RayGrad& G) {
     const bool has_t = a.target_d != nullptr;
     const float td = has_t ? a.target_d[r] : 0.0f;
-    const float* zr = a.z_vals + (size_t)r * S;
     const float z_lim = zr[first] + a.win_f;                                // scene_rep.py:200
     float wsum = 0.0f;
     for (int i = lane; i < D; i += MNE_WAVE) {
@@ -407,7 +512,7 @@ __global__ __launch_bounds__(256) void composite_kernel(RenderArgs a) {
     MNE_WAVE_SYNC();
     const int f = first_crossing(raws, 0, S, lane);
     RayGrad G;
-    composite_ray<false>(a, r, lane, raws, S, f < 0 ? 0 : f, G);
+    composite_ray<false>(a, r, lane, raws, a.z_vals + (size_t)r * S, S, f < 0 ? 0 : f, G);
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -421,29 +526,62 @@ __global__ __launch_bounds__(256) void composite_kernel(RenderArgs a) {
 #ifndef MAX_WPB_RAY
 #define MAX_WPB_RAY 8
 #endif
+#ifndef MAX_WPB_HOT
+#define MAX_WPB_HOT 12
+#endif
+
+// Run grouping of the list appends.  The samples of a tile lie on ONE ray in order, and a straight line visits every
+// cell block of an axis-aligned lattice in one contiguous stretch -- so lanes that append to the same list are
+// CONSECUTIVE lanes.  A run start is a lane whose list differs from its predecessor's (lanes 0 and 32 always: the two
+// halves handle different planes); leader, rank and length of a lane's run then follow from one ballot with bit
+// arithmetic, in constant time whatever the number of distinct lists (the earlier leader-election loop cost one
+// ballot round per distinct list: 11 us for a tile of 32 spread-out samples).
+__device__ __forceinline__ unsigned run_meta(int w_, int lane) {
+    const int prev = __shfl_up(w_, 1);
+    const bool start = ((lane & 31) == 0) || (w_ != prev);
+    const unsigned long long sm = __ballot(start);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);      // bits 0..lane
+    const int leader = 63 - __clzll(sm & upto);
+    const unsigned long long above = sm & ~upto;
+    const int next = above ? __ffsll(above) - 1 : 64;
+    return (unsigned)leader | ((unsigned)(lane - leader) << 8) | ((unsigned)(next - leader) << 16);
+}
+
+// MODE 0: forward only (maps; early ray termination)
+//      1: (unused)
+//      2: backward with every capability: resolves rays by decoding on demand, produces missing forward tape rows inside
+//         the backward loop.  Used for the backward of an EARLIER forward call (raw_in complete) and, driven by a.ray_list,
+//         for the rays the training kernel deferred.            3: = 2 with ray gradients (R13)
+//      4: TRAINING kernel (the hot one): no decode code at all -- 12 waves per CU instead of 8, every ray of the batch
+//         resident at once.  A ray whose decoded prefix does not resolve it (no sign change yet, or the render window
+//         runs past the prefix) is pushed to a.defer_list and handled afterwards by a MODE 2 launch.
 template <int HID, int HIDC, bool CP, bool ALDS, int MODE>
-__global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
+__global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void ray_kernel(RenderArgs a) {
     typedef DecDims<HID, HIDC, CP> D;
     typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
     constexpr int NT = HID / 32, NTC = HIDC / 32;
-    constexpr bool BWD = MODE >= 1, RAYGRAD = MODE == 3, LATE_DECODE = MODE >= 2;
-    constexpr int TAB_FLOATS = ALDS ? (RAYGRAD ? T::TOTAL_RAYGRAD : BWD ? T::TOTAL : T::FWD_STEPS) * 64 : 0;
+    constexpr bool HOT = MODE == 4, BWD = MODE >= 1, RAYGRAD = MODE == 3, LATE_DECODE = MODE == 2 || MODE == 3;
+    // A tables in LDS: everything the mode needs; the training kernel stages only the backward steps
+    constexpr int TAB_FIRST = HOT ? T::FWD_STEPS : 0;
+    constexpr int TAB_LAST = RAYGRAD ? T::TOTAL_RAYGRAD : BWD ? T::TOTAL : T::FWD_STEPS;
+    constexpr int TAB_FLOATS = ALDS ? (TAB_LAST - TAB_FIRST) * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     const int wpb = blockDim.x >> 6;
     if (ALDS) {
         float4* dst = (float4*)lds_raw;
-        const float4* src = (const float4*)a.packed;
+        const float4* src = (const float4*)(a.packed + TAB_FIRST * 64);
         for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
-    const float* atab = ALDS ? (const float*)lds_raw : a.packed;
+    const float* atab = ALDS ? (const float*)lds_raw - TAB_FIRST * 64 : a.packed;     // indexed by absolute step
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = a.S, Spad = (S + 3) & ~3, ntile = (S + TILE - 1) / TILE;
-    const size_t wave_bytes = (size_t)Spad * 4 * sizeof(float) + tile_wave_lds_bytes(NSETS, RAYGRAD);
+    const size_t wave_bytes = (size_t)Spad * 5 * sizeof(float) + tile_wave_lds_bytes(NSETS, RAYGRAD);
     unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * wave_bytes;
     float* raws = (float*)my;                                     // [Spad][4]
-    float* pn = raws + (size_t)Spad * 4;
+    float* zr = raws + (size_t)Spad * 4;                          // [Spad] this ray's z samples
+    float* pn = zr + Spad;
     float* feat = pn + TILE * 4;
     float* dposL = feat + NSETS * TILE * MNE_FS;                  // RAYGRAD: [32][64] d OneBlob rows
     float* dpnL = dposL + TILE * 64;                              // RAYGRAD: [32][4]  d normalised point
@@ -454,37 +592,59 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
     for (int q = 0; q < MNE_N_LOSS; ++q) cf[q] = (BWD && a.coef) ? a.coef[q] : 0.0f;
     const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
     const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
-    for (int r = blockIdx.x * wpb + wv; r < a.R; r += gridDim.x * wpb) {
-        const float* zr = a.z_vals + (size_t)r * S;
+    const int n_items = a.ray_list ? *a.ray_list_count : a.R;
+    for (int item = blockIdx.x * wpb + wv; item < n_items; item += gridDim.x * wpb) {
+        const int r = a.ray_list ? a.ray_list[item] : item;
+        RAY_STAMP(0);
         const float td = has_t ? a.target_d[r] : 0.0f;
+        float ro[3], rd[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { ro[q] = a.rays_o[r * 3 + q]; rd[q] = a.rays_d[r * 3 + q]; }
         MNE_WAVE_SYNC();                                          // previous ray's LDS reads are done
-        // ---- samples whose raw is known: everything (backward of an earlier forward) or the decoded prefix
-        int t_dec = prefix_tiles(a, r, ntile);                    // tiles with raw / masks / tape rows written
+        // ---- this ray's z and the raw of its known samples -> LDS, one batch of loads (raw beyond the decoded prefix
+        // is never looked at): everything (backward of an earlier forward) or the decoded prefix
+        int t_dec = (a.dec_tiles && !a.ray_list && a.ray_counts) ? a.dec_tiles[r]
+                                                                 : prefix_tiles(a, r, ntile, a.ray_list != nullptr);   // tiles with raw / masks / tape rows written
         int Dn = a.raw_in ? S : (t_dec * TILE < S ? t_dec * TILE : S);
         {
             const float4* src = (const float4*)((a.raw_in ? a.raw_in : a.raw) + (size_t)r * S * 4);
-            for (int i = lane; i < Dn; i += MNE_WAVE) *(float4*)(raws + 4 * i) = src[i];
+            const float* zsrc = a.z_vals + (size_t)r * S;
+            for (int i = lane; i < S; i += MNE_WAVE) {
+                zr[i] = zsrc[i];
+                if (HOT || i < Dn) *(float4*)(raws + 4 * i) = src[i];
+            }
         }
         MNE_WAVE_SYNC();
+        RAY_STAMP(1);
         // ---- resolve: first sign change + every sample inside the render window must be known
         int first = -1, from = 0;
+        bool deferred = false;
         while (true) {
             if (first < 0) first = first_crossing(raws, from, Dn, lane);
             if (Dn >= S) break;
             if (first >= 0 && !(zr[Dn] < zr[first] + a.win_f)) break;       // z sorted: the window ends before sample Dn
-            // decode the next tile on demand (Dn is a multiple of TILE here)
-            float pnv[3], u[3];
-            uint2 relu;
-            const float4 rw = decode_tile<HID, HIDC, CP>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu);
-            const int i = t_dec * TILE + pt;
-            if (i < S && hf == 0) *(float4*)(raws + 4 * i) = rw;
-            MNE_WAVE_SYNC();
-            from = Dn > 0 ? Dn - 1 : 0;
-            ++t_dec;
-            Dn = t_dec * TILE < S ? t_dec * TILE : S;
+            if (HOT) { deferred = true; break; }
+            if (!HOT) {
+                // decode the next tile on demand (Dn is a multiple of TILE here)
+                float pnv[3], u[3];
+                uint2 relu;
+                const float4 rw = decode_tile<HID, HIDC, CP>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu);
+                const int i = t_dec * TILE + pt;
+                if (i < S && hf == 0) *(float4*)(raws + 4 * i) = rw;
+                MNE_WAVE_SYNC();
+                from = Dn > 0 ? Dn - 1 : 0;
+                ++t_dec;
+                Dn = t_dec * TILE < S ? t_dec * TILE : S;
+            }
         }
+        if (HOT && deferred) {
+            if (lane == 0) a.defer_list[atomicAdd(a.defer_count, 1)] = r;
+            continue;
+        }
+        RAY_STAMP(2);
         RayGrad G;
-        composite_ray<BWD>(a, r, lane, raws, Dn, first < 0 ? 0 : first, G);
+        composite_ray<BWD>(a, r, lane, raws, zr, Dn, first < 0 ? 0 : first, G);
+        RAY_STAMP(3);
         if (!BWD) continue;
         // ---- samples that can receive gradient: render window or an active loss mask (exact)
         int last = -1, n_contrib = 0;
@@ -506,7 +666,9 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
             if (a.tape_rows && n_contrib) atomicAdd(a.tape_rows, n_contrib);
         }
         float ray_do[3] = {0.f, 0.f, 0.f}, ray_dd[3] = {0.f, 0.f, 0.f};
+        RAY_STAMP(4);
         for (int c = 0; c < nb; ++c) {
+            RAY_STAMP(5 + 6 * c);
             const int i = c * TILE + pt;
             const bool valid = i < Dn;
             const int ii = valid ? i : Dn - 1;
@@ -514,12 +676,12 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
             float p[3], pnv[3], u[3];
             const size_t e = (size_t)r * S + ii;
             uint2 mk2;
-            if (LATE_DECODE && c >= t_dec) {                      // backward-only call: tape rows of this tile are missing
+            if (LATE_DECODE && c >= t_dec) {                      // tape rows of this tile are missing: decode it now
                 decode_tile<HID, HIDC, CP>(a, r, c, lane, pn, feat, atab, pnv, u, mk2);
                 t_dec = c + 1;
             } else {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) p[q] = a.rays_o[r * 3 + q] + a.rays_d[r * 3 + q] * z;
+                for (int q = 0; q < 3; ++q) p[q] = ro[q] + rd[q] * z;
                 point_coords(a.sc, p, pnv, u);
                 mk2 = *(const uint2*)(a.relu_mask + e * 4 + hf * 2);
             }
@@ -550,6 +712,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
                 contrib = contrib || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) || (use_co && (mk.co_fs || mk.co_sdf));
             }
             MNE_WAVE_SYNC();                                      // feat rows are about to be overwritten
+            RAY_STAMP(6 + 6 * c);
             // ---- MFMA backward chain from the saved ReLU masks; d(feature) rows land in this point's LDS rows.
             // A sample without gradient has ds = dc = 0 and therefore an all-zero backward row.
             float* frow = feat + pt * MNE_FS;
@@ -562,6 +725,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
 #else
             mlp_backward_mfma<HID, HIDC, CP>(mk2.x, mk2.y, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
 #endif
+            RAY_STAMP(7 + 6 * c);
             if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
             if (RAYGRAD) {
                 // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates; every
@@ -634,17 +798,18 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
             }
             MNE_WAVE_SYNC();
             store_rows<32>(feat, tape0, D::ROW, D::T_DOUT, tape_rows_mask, lane);
+            RAY_STAMP(8 + 6 * c);
             if (a.bins.lists) {
-                // the sample is appended to the list of every plane tile its 2x2 footprints touch (tile_adam.hip).
-                // One returning atomic per DISTINCT tile list per wave: lanes that append to the same list are
-                // grouped with ballots and the group leader reserves the whole run of slots.  Three phases so
-                // that all reservations of a tile are in flight together: (A) grouping, registers only; (B) the
-                // leaders' atomics, back to back; (C) slots and entry writes.
-                constexpr int NQ = NSETS * 3 * 4;
-                int want[NQ];
-                unsigned meta[NQ];                                 // leader lane | rank << 8 | group size << 16
+                // The sample is appended to the list of every plane tile its 2x2 footprints touch (tile_adam.hip): one
+                // returning atomic per RUN of lanes with the same list (run_meta), issued back to back for all 12 (24)
+                // (plane, corner-tile) slots of the lane before any result is consumed; then one 32-byte entry per append.
+                constexpr int NJ = NSETS * 3;
+                int want[NJ * 4];
+                unsigned meta[NJ * 4];                             // leader lane | rank << 8 | run length << 16
+                int cix[NJ], ciy[NJ];                              // NW corner of the footprint in each of the lane's planes
+                float wq[NJ][4];
 #pragma unroll
-                for (int j = 0; j < NSETS * 3; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const int pidx = 2 * j + hf;                   // planes in [set][orient][level] order
                     const int ori = (pidx % 6) / 2;
                     const mne_plane_t& pl = a.sc.plane[pidx / 6][ori][pidx % 2];
@@ -652,6 +817,7 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
                     orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
                     Bilin b;
                     bilin_setup(gx, gy, pl.h, pl.w, b);
+                    wq[j][0] = b.w00; wq[j][1] = b.w01; wq[j][2] = b.w10; wq[j][3] = b.w11;
                     const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
                     const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
                     const int base = a.bins.tile_base[pidx], ntx = a.bins.ntx[pidx];
@@ -660,64 +826,48 @@ __global__ __launch_bounds__(64 * MAX_WPB_RAY) void ray_kernel(RenderArgs a) {
                         const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
                         const bool dup = ((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0);   // same tile again
                         const int w_ = (live && !dup) ? base + ty * ntx + tx : -1;
-                        unsigned long long todo = __ballot(w_ >= 0);
-                        unsigned m_ = 0;
-                        while (todo) {
-                            const int leader = __ffsll(todo) - 1;
-                            const int t = __shfl(w_, leader);
-                            const unsigned long long same = __ballot(w_ == t);
-                            if (w_ == t)
-                                m_ = (unsigned)leader | ((unsigned)__popcll(same & ((1ull << lane) - 1ull)) << 8) |
-                                     ((unsigned)__popcll(same) << 16);
-                            todo &= ~same;
-                        }
                         want[j * 4 + q] = w_;
-                        meta[j * 4 + q] = m_;
+                        meta[j * 4 + q] = run_meta(w_, lane);
                     }
+                    cix[j] = b.ix0; ciy[j] = b.iy0;
                 }
-                int first_slot[NQ];
+                RAY_STAMP(9 + 6 * c);
+                int first_slot[NJ * 4];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
+                for (int q = 0; q < NJ * 4; ++q) {
                     first_slot[q] = 0;
                     if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q], (int)(meta[q] >> 16));
                 }
                 const unsigned trow = (unsigned)e;                 // tape row of this sample
 #pragma unroll
-                for (int j = 0; j < NSETS * 3; ++j) {
-                    const int pidx = 2 * j + hf;
-                    const int ori = (pidx % 6) / 2;
-                    const mne_plane_t& pl = a.sc.plane[pidx / 6][ori][pidx % 2];
-                    float gx, gy;
-                    orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
-                    Bilin b;
-                    bilin_setup(gx, gy, pl.h, pl.w, b);
-                    const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
-                    const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int eq = j * 4 + q;
-                        const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
-                        const int f0 = __shfl(first_slot[eq], (int)(meta[eq] & 255u));
-                        if (want[eq] >= 0) {
-                            const int slot = f0 + (int)((meta[eq] >> 8) & 255u);
-                            unsigned* dst = nullptr;
-                            if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[eq] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
-                            else {
-                                const int sp = atomicAdd(a.bins.spill_count, 1);
-                                if (sp < a.bins.spill_cap) { dst = a.bins.spill + (size_t)sp * MNE_SPILL_WORDS; *dst++ = (unsigned)want[eq]; }
-                                else atomicAdd(a.bins.dropped, 1);          // caller-sized spill area too small: reported, never silent
-                            }
-                            if (dst) {
-                                dst[0] = trow;
-                                dst[1] = (unsigned)(b.ix0 - tx * MNE_TILE + 1) | ((unsigned)(b.iy0 - ty * MNE_TILE + 1) << 8);
-                                dst[2] = __float_as_uint(b.w00); dst[3] = __float_as_uint(b.w01);
-                                dst[4] = __float_as_uint(b.w10); dst[5] = __float_as_uint(b.w11);
-                            }
+                for (int eq = 0; eq < NJ * 4; ++eq) {
+                    const int f0 = __shfl(first_slot[eq], (int)(meta[eq] & 255u));
+                    if (want[eq] >= 0) {
+                        const int slot = f0 + (int)((meta[eq] >> 8) & 255u);
+                        unsigned* dst = nullptr;
+                        if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[eq] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
+                        else {
+                            const int sp = atomicAdd(a.bins.spill_count, 1);
+                            if (sp < a.bins.spill_cap) dst = a.bins.spill + (size_t)sp * MNE_ENTRY_WORDS;
+                            else atomicAdd(a.bins.dropped, 1);              // caller-sized spill area too small: reported, never silent
+                        }
+                        if (dst) {
+                            const int j = eq >> 2, q = eq & 3;
+                            // corner relative to the tile this entry goes to (+1: 0 = one cell before the tile)
+                            const int tx = (cix[j] + (q & 1)) / MNE_TILE, ty = (ciy[j] + (q >> 1)) / MNE_TILE;
+                            const unsigned corner = (unsigned)(cix[j] - tx * MNE_TILE + 1) | ((unsigned)(ciy[j] - ty * MNE_TILE + 1) << 8);
+                            *(uint4*)dst = make_uint4(trow, corner, __float_as_uint(wq[j][0]), __float_as_uint(wq[j][1]));
+                            *(uint4*)(dst + 4) = make_uint4(__float_as_uint(wq[j][2]), __float_as_uint(wq[j][3]), (unsigned)want[eq], 0u);
                         }
                     }
                 }
             }
+            RAY_STAMP(10 + 6 * c);
         }
+#ifdef RENDER_PROFILE
+        if (a.bins.spill && lane == 0)
+            ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 32768) * MNE_SPILL_WORDS))[(size_t)r * 32 + 31] = (unsigned long long)nb;
+#endif
         if (RAYGRAD) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) { ray_do[q] = wave_sum(ray_do[q]); ray_dd[q] = wave_sum(ray_dd[q]); }
@@ -887,7 +1037,7 @@ template <int HID, int HIDC, bool CP>
 static size_t table_bytes(int mode) {
     typedef ATab<HID, HIDC, CP> T;
     if (!WgShape<HID, HIDC, CP>::ALDS) return 0;
-    return (size_t)(mode == 3 ? T::TOTAL_RAYGRAD : mode >= 1 ? T::TOTAL : T::FWD_STEPS) * 64 * sizeof(float);
+    return (size_t)(mode == 3 ? T::TOTAL_RAYGRAD : mode >= 1 ? T::TOTAL : T::FWD_STEPS) * 64 * sizeof(float);   // mode 4: see launch_ray
 }
 template <int HID, int HIDC, bool CP>
 static int fit_waves(size_t tab, size_t per_wave, int max_wpb) {
@@ -898,9 +1048,17 @@ static int fit_waves(size_t tab, size_t per_wave, int max_wpb) {
 }
 
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-// backward workspace: ReLU masks [R*S][4] u32
-size_t mne_render_workspace(int R, int S) { return align16((size_t)R * S * 4 * sizeof(unsigned)); }
-static void carve_workspace(RenderArgs& a, void* ws) { a.relu_mask = (unsigned*)ws; }
+// backward workspace: ReLU masks [R*S][4] u32 | deferred-ray list [R] | its length [1]
+size_t mne_render_workspace(int R, int S) {
+    return align16((size_t)R * S * 4 * sizeof(unsigned)) + 2 * align16((size_t)R * sizeof(int)) + 16;
+}
+static void carve_workspace(RenderArgs& a, void* ws) {
+    unsigned char* p = (unsigned char*)ws;
+    a.relu_mask = (unsigned*)p; p += align16((size_t)a.R * a.S * 4 * sizeof(unsigned));
+    a.defer_list = (int*)p; p += align16((size_t)a.R * sizeof(int));
+    a.dec_tiles = (int*)p; p += align16((size_t)a.R * sizeof(int));
+    a.defer_count = (int*)p;
+}
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
     const int n_tab = a.has_d ? a.n_a + 2 * a.n_b : a.S;
@@ -918,17 +1076,44 @@ static int launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
 }
 
 template <int HID, int HIDC, bool CP, int MODE>
-static int launch_ray(const RenderArgs& a, hipStream_t st) {
+static int launch_ray(const RenderArgs& a, hipStream_t st, int max_blocks = MNE_NUM_CU) {
     typedef WgShape<HID, HIDC, CP> W;
-    const size_t tab = table_bytes<HID, HIDC, CP>(MODE);
-    const size_t per_wave = (size_t)((a.S + 3) & ~3) * 4 * sizeof(float) + tile_wave_lds_bytes(CP ? 2 : 1, MODE == 3);
-    const int wpb = fit_waves<HID, HIDC, CP>(tab, per_wave, MAX_WPB_RAY);
+    typedef ATab<HID, HIDC, CP> T;
+    size_t tab = table_bytes<HID, HIDC, CP>(MODE);
+    if (MODE == 4 && W::ALDS) tab = (size_t)(T::TOTAL - T::FWD_STEPS) * 64 * sizeof(float);
+    const size_t per_wave = (size_t)((a.S + 3) & ~3) * 5 * sizeof(float) + tile_wave_lds_bytes(CP ? 2 : 1, MODE == 3);
+    const int wpb = fit_waves<HID, HIDC, CP>(tab, per_wave, MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY);
     if (wpb < 1) return -4;
     const size_t lds = tab + (size_t)wpb * per_wave;
     if (lds > 64 * 1024) MNE_SET_MAX_LDS((ray_kernel<HID, HIDC, CP, W::ALDS, MODE>), MNE_LDS_MAX);
     long long grid = ((long long)a.R + wpb - 1) / wpb;
-    if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
+    if (grid > max_blocks) grid = max_blocks;
     MNE_LAUNCH((ray_kernel<HID, HIDC, CP, W::ALDS, MODE>), (unsigned)grid, 64 * wpb, lds, st, a);
+    return 0;
+}
+
+// pre = true: the a-priori tiles' plane features are gathered by gather_kernel first (needs the tape)
+template <int HID, int HIDC, bool CP>
+static int launch_decode(RenderArgs d, hipStream_t st, bool pre = false) {
+    typedef DecDims<HID, HIDC, CP> D;
+    typedef WgShape<HID, HIDC, CP> W;
+    pre = pre && d.tape && !d.ray_list;
+    if (pre) {
+        d.tape_row = D::ROW; d.tape_tx = D::T_X; d.tape_tcf = D::T_CF;
+        const int chunks = (d.S + 7) / 8;
+        const long long waves = (long long)d.R * chunks;
+        MNE_LAUNCH((gather_kernel<CP>), (unsigned)((waves + 3) / 4), 256, 0, st, d, chunks);
+    }
+    const size_t tab = table_bytes<HID, HIDC, CP>(0);
+    const int wpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(CP ? 2 : 1), MAX_WPB);
+    if (wpb < 1) return -4;
+    const size_t lds = tab + (size_t)wpb * tile_wave_lds_bytes(CP ? 2 : 1);
+    if (lds > 64 * 1024)        // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
+        MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS>), MNE_LDS_MAX);
+    const long long ntask = (long long)d.R * ((d.S + TILE - 1) / TILE);
+    long long grid = (ntask + wpb - 1) / wpb;
+    if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
+    MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS>), (unsigned)grid, 64 * wpb, lds, st, d, pre ? 1 : 0);
     return 0;
 }
 
@@ -942,19 +1127,10 @@ static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st
         carve_workspace(a, workspace);
     }
     {   // decode: every tile (mode 0), or the a-priori prefix of every ray
-        const size_t tab = table_bytes<HID, HIDC, CP>(0);
-        const int wpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(CP ? 2 : 1), MAX_WPB);
-        if (wpb < 1) return -4;
-        const size_t lds = tab + (size_t)wpb * tile_wave_lds_bytes(CP ? 2 : 1);
-        if (lds > 64 * 1024)        // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
-            MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS>), MNE_LDS_MAX);
-        const long long ntask = (long long)a.R * ((a.S + TILE - 1) / TILE);
-        long long grid = (ntask + wpb - 1) / wpb;
-        if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
         RenderArgs d = a;
         if (mode == 0) { d.ray_counts = nullptr; d.prefix_default = 1 << 30; }
         if (mode == 3) d.raw = nullptr;                    // raw of the forward call stays untouched
-        MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS>), (unsigned)grid, 64 * wpb, lds, st, d);
+        if (int rc = launch_decode<HID, HIDC, CP>(d, st, mode >= 2)) return rc;
     }
     if (mode == 0) {
         const size_t clds = (size_t)4 * ((a.S + 3) & ~3) * 4 * sizeof(float);
@@ -965,7 +1141,15 @@ static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st
         return 0;
     }
     if (mode == 1) return launch_ray<HID, HIDC, CP, 0>(a, st);
-    if (mode == 2) return launch_ray<HID, HIDC, CP, 1>(a, st);
+    if (mode == 2) {
+        // training: every ray in the lean kernel; the few it cannot resolve from the decoded prefix are finished by the
+        // full kernel, driven by the deferred list (a handful of workgroups that leave at once when the list is empty)
+        if (int rc = launch_ray<HID, HIDC, CP, 4>(a, st)) return rc;
+        RenderArgs d = a;
+        d.ray_list = a.defer_list; d.ray_list_count = a.defer_count;
+        launch_decode<HID, HIDC, CP>(d, st);               // their remaining tiles, tile-parallel
+        return launch_ray<HID, HIDC, CP, 4>(d, st);        // the same lean kernel: now every listed ray resolves
+    }
     if (raygrad) return launch_ray<HID, HIDC, CP, 3>(a, st);
     return launch_ray<HID, HIDC, CP, 2>(a, st);
 }

@@ -25,9 +25,10 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p = p - o.step_size * (m / denom);
 }
 
-// One list entry = MNE_ENTRY_WORDS uint32 written by the backward kernel: the tape row, the footprint's
-// NW corner relative to the tile (+1, so 0 means "one cell before the tile") and the four bilinear
-// weights (0 for corners outside the plane).  The tile kernel therefore does no coordinate math.
+// One list entry = 32 bytes written by ray_kernel with two 16-byte stores: the tape row, the footprint's
+// NW corner relative to the tile (+1, so 0 means "one cell before the tile"), the four bilinear
+// weights (0 for corners outside the plane) and the tile id (what identifies an entry in the shared spill area).
+// The tile kernel therefore does no coordinate math.
 //
 // Accumulation (per pass of PASS_ENTRIES list entries).  Heavy tiles are the critical path of the launch,
 // and their entries are concentrated: a wall or the floor projects onto a LINE of cells of the planes
@@ -154,23 +155,21 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
             unsigned row = 0xffffffffu;
             const unsigned* ent = nullptr;
             if (e < n_list) ent = lst + (size_t)e * MNE_ENTRY_WORDS;
-            else if (e < n_total) {
-                const unsigned* sp = a.bins.spill + (size_t)(e - n_list) * MNE_SPILL_WORDS;
-                if (sp[0] == (unsigned)tile) ent = sp + 1;
-            }
+            else if (e < n_total) ent = a.bins.spill + (size_t)(e - n_list) * MNE_ENTRY_WORDS;
             if (ent) {
-                unsigned wds[MNE_ENTRY_WORDS];
+                const uint4 e0 = *(const uint4*)ent, e1 = *(const uint4*)(ent + 4);      // one 32-byte entry
+                if (e < n_list || e1.z == (unsigned)tile) {                              // spill entries carry their tile id
+                    row = e0.x;
+                    const int lx = (int)(e0.y & 0xff) - 1, ly = (int)((e0.y >> 8) & 0xff) - 1;
+                    const unsigned wbits[4] = {e0.z, e0.w, e1.x, e1.y};
 #pragma unroll
-                for (int w = 0; w < MNE_ENTRY_WORDS; ++w) wds[w] = ent[w];
-                row = wds[0];
-                const int lx = (int)(wds[1] & 0xff) - 1, ly = (int)((wds[1] >> 8) & 0xff) - 1;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int x = lx + (q & 1), y = ly + (q >> 1);
-                    wq[q] = __uint_as_float(wds[2 + q]);
-                    if (x >= 0 && x < MNE_TILE && y >= 0 && y < MNE_TILE && wq[q] != 0.0f) {
-                        cellk[q] = y * MNE_TILE + x;
-                        rank[q] = atomicAdd(&hist[cellk[q]], 1);
+                    for (int q = 0; q < 4; ++q) {
+                        const int x = lx + (q & 1), y = ly + (q >> 1);
+                        wq[q] = __uint_as_float(wbits[q]);
+                        if (x >= 0 && x < MNE_TILE && y >= 0 && y < MNE_TILE && wq[q] != 0.0f) {
+                            cellk[q] = y * MNE_TILE + x;
+                            rank[q] = atomicAdd(&hist[cellk[q]], 1);
+                        }
                     }
                 }
             }

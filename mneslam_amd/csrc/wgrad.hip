@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
 #define WG_KS 4
 #endif
 #ifndef WG_FUSED_BLOCKS
-#define WG_FUSED_BLOCKS 256          // x 4 waves; measured best next to the concurrent tile_adam_kernel (profiles/r01_wgrad_variants.txt)
+#define WG_FUSED_BLOCKS 256          // x 4 waves; one partial result per workgroup
 #endif
 template <int HID, int HIDC, bool CP>
 __global__ __launch_bounds__(256) void wgrad_fused_kernel(WgradArgs a) {

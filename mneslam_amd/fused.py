@@ -103,7 +103,7 @@ class FusedStep:
                 # still correct (spill area), only slower.
                 tiles_min = min(((p.shape[2] + 15) // 16) * ((p.shape[3] + 15) // 16) for p in self.planes)
                 tile_capacity = int(min(max(4096, 4 * 1.3 * R * S / tiles_min), 1 << 20))
-            self.tile_lists = torch.zeros(n_tiles, tile_capacity, 6, device=dev, dtype=torch.int32)
+            self.tile_lists = torch.zeros(n_tiles, tile_capacity, 8, device=dev, dtype=torch.int32)
             self.tile_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
             if spill_capacity is None:
                 # worst case: every sample appends to 4 tiles of every plane and every entry overflows its list --

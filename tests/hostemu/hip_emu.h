@@ -162,6 +162,8 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
