@@ -116,6 +116,24 @@ typedef struct mne_adam_seg {
     int32_t reserved;
 } mne_adam_seg_t;
 
+/* Device-resident iteration state, for callers that record one mapping iteration into a HIP graph and replay it:
+ * the values that change from one iteration to the next are then read from device memory instead of kernel
+ * arguments.  Entry points that take a `const mne_clock_t* clock` behave as before when it is NULL; otherwise
+ *   iteration used = `iteration` argument + *clock->iteration     (ray sampling keys, jitter counter offset)
+ *   Adam step used = `step` field        + *clock->step_offset    (bias corrections looked up in bias_table)
+ * bias_table[t-1] = (1 - beta1^t, 1 - beta2^t) as doubles, computed by the caller for t = 1..n_table with the betas
+ * of its param groups (all groups must share them); mne_clock_advance adds 1 to both counters (one tiny kernel, the
+ * last node of a recorded iteration). */
+typedef struct mne_clock {
+    const uint64_t* iteration;     /* [1] device */
+    const int32_t* step_offset;    /* [1] device */
+    const double* bias_table;      /* [n_table][2] device */
+    int32_t n_table;
+    int32_t reserved;
+    double beta1, beta2;           /* what bias_table was computed for (checked against the optimizer's) */
+    uint64_t z_offset_stride;      /* mne_sample_z: counter offset used = offset + iteration used * z_offset_stride */
+} mne_clock_t;
+
 /* ---- library ------------------------------------------------------------------------- */
 int mne_abi_version(void);
 const char* mne_last_error(void);
@@ -124,6 +142,8 @@ size_t mne_sizeof_render_cfg(void);
 size_t mne_sizeof_adam_seg(void);
 size_t mne_sizeof_tile_bins(void);
 size_t mne_sizeof_plane_opt(void);
+size_t mne_sizeof_clock(void);
+int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream);
 
 /* Number of samples per ray: n_range_d + n_samples_d with depth guidance, n_samples without
  * (model/scene_rep.py:362-374). */
@@ -143,7 +163,7 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
                     const float* cur_rays, int64_t n_cur_rays, const float* poses, int n_poses,
                     int n_global, int n_cur, const int64_t* idx_global, const int64_t* idx_cur,
                     uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
-                    float* target_d, int64_t* out_idx, void* stream);
+                    float* target_d, int64_t* out_idx, const mne_clock_t* clock, void* stream);
 
 /* ---- R3: z sampling -------------------------------------------------------------------- */
 /* Replaces render_rays' sampling block, model/scene_rep.py:362-381: near-surface linspace around
@@ -159,7 +179,7 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
  * summed in a fixed order; both may be NULL when target_d is NULL).  `target_d` is [R]. */
 int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d, const float* u,
                  const float* lin_tables, uint64_t seed, uint64_t offset, float* z_vals,
-                 int32_t* counts, int32_t* ray_counts, void* stream);
+                 int32_t* counts, int32_t* ray_counts, const mne_clock_t* clock, void* stream);
 
 /* ---- R8 helper: decoder weights in the kernels' packed form ------------------------------ */
 size_t mne_packed_decoder_floats(const mne_scene_t* scene);
@@ -245,7 +265,7 @@ size_t mne_tile_count(const mne_scene_t* scene);
  * few very long lists do not form the tail of the launch.  Call after mne_render_fused, before mne_tile_adam. */
 int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* stream);
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
-                  const mne_tile_bins_t* bins, void* stream);
+                  const mne_tile_bins_t* bins, const mne_clock_t* clock, void* stream);
 
 /* Decoder weight gradients from the tape: dW = sum_rows outer(d_out, in) for the four matrices,
  * written as [w_col0 | w_col1 | w_sdf0 | w_sdf1] (the order of decoder.parameters(),
@@ -263,7 +283,7 @@ int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t
  * (mneslam_mp.py:459-469): one pass, m = lerp(m,g,1-b1); v = b2 v + (1-b2) g^2;
  * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); weight_decay is L2 into g; g is zeroed
  * when zero_grad != 0.  segs is a HOST array of n_seg (<= 32) entries. */
-int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* stream);
+int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, const mne_clock_t* clock, void* stream);
 
 /* ---- point queries (forward only) -------------------------------------------------------- */
 /* Replaces JointEncoding.query_color_sdf / query_sdf / run_network_flat (scene_rep.py:232-331):

@@ -56,6 +56,11 @@ class PlaneOpt(C.Structure):
                 ("eps", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
 
 
+class Clock(C.Structure):
+    _fields_ = [("iteration", C.c_void_p), ("step_offset", C.c_void_p), ("bias_table", C.c_void_p), ("n_table", C.c_int32),
+                ("reserved", C.c_int32), ("beta1", C.c_double), ("beta2", C.c_double), ("z_offset_stride", C.c_uint64)]
+
+
 class GridCfg(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("n_features", C.c_int32), ("base_resolution", C.c_int32),
                 ("log2_hashmap_size", C.c_int32), ("grid_type", C.c_int32), ("reserved", C.c_int32),
@@ -72,9 +77,11 @@ _PROTOS = {
     "mne_sizeof_adam_seg": (C.c_size_t, []),
     "mne_sizeof_tile_bins": (C.c_size_t, []),
     "mne_sizeof_plane_opt": (C.c_size_t, []),
+    "mne_sizeof_clock": (C.c_size_t, []),
+    "mne_clock_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_num_samples": (C.c_int, [C.POINTER(RenderCfg), C.c_int]),
     "mne_sample_z": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
-                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Clock), C.c_void_p]),
     "mne_packed_decoder_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_pack_decoder": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p]),
     "mne_render_forward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 14
@@ -89,14 +96,16 @@ _PROTOS = {
                          + [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_tile_order": (C.c_int, [C.POINTER(Scene), C.POINTER(TileBins), C.c_void_p]),
-    "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.c_void_p]),
+    "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.POINTER(Clock),
+                                C.c_void_p]),
     "mne_sample_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
-                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 6),
+                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5
+                        + [C.POINTER(Clock), C.c_void_p]),
     "mne_decoder_param_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_wgrad_partial_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_decoder_wgrad": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p]),
-    "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.c_void_p]),
+    "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.POINTER(Clock), C.c_void_p]),
     "mne_query_points": (C.c_int, [C.POINTER(Scene), C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "mne_grid_level_table": (C.c_int, [C.POINTER(GridCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_grid_param_count": (C.c_size_t, [C.POINTER(GridCfg)]),
@@ -131,7 +140,7 @@ def load(path=None):
             raise RuntimeError("libmneslam_hip ABI version mismatch")
         for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
                        (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),
-                       (lib.mne_sizeof_plane_opt, PlaneOpt)):
+                       (lib.mne_sizeof_plane_opt, PlaneOpt), (lib.mne_sizeof_clock, Clock)):
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"struct layout mismatch for {st.__name__}: C {fn()} vs ctypes {C.sizeof(st)}")
         _lib = lib

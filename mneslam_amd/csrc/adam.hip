@@ -29,7 +29,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(AdamArgs a) {
     const mne_adam_seg_t& sg = a.seg[s];
     const float wd = (float)sg.weight_decay, omb1 = (float)(1.0 - sg.beta1), b2 = (float)sg.beta2;
     const float omb2 = (float)(1.0 - sg.beta2), eps = (float)sg.eps;
-    const float step_size = a.step_size[s], bc2_sqrt = a.bc2_sqrt[s];
+    float step_size = a.step_size[s], bc2_sqrt = a.bc2_sqrt[s];
+    if (a.clk.bias_table) clock_bias(a.clk, sg.lr, sg.step, step_size, bc2_sqrt);        // graph replay: step from device memory
     const long long base = (blk - a.blk_start[s]) * ADAM_ELEMS_PER_BLOCK;
 #pragma unroll
     for (int it = 0; it < ADAM_VEC_PER_THREAD; ++it) {
@@ -58,6 +59,18 @@ int mne_launch_adam(const AdamArgs& a, hipStream_t st) {
     const long long nblk = a.blk_start[a.n_seg];
     if (nblk <= 0) return 0;
     MNE_LAUNCH(adam_kernel, (unsigned)nblk, ADAM_THREADS, 0, st, a);
+    return 0;
+}
+
+__global__ void clock_advance_kernel(unsigned long long* iteration, int* step_offset) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (iteration) *iteration += 1ull;
+        if (step_offset) *step_offset += 1;
+    }
+}
+
+int mne_launch_clock_advance(unsigned long long* iteration, int* step_offset, hipStream_t st) {
+    MNE_LAUNCH(clock_advance_kernel, 1, 64, 0, st, iteration, step_offset);
     return 0;
 }
 

@@ -9,6 +9,22 @@
 #include "mne_launch.h"
 
 long long mne_adam_blocks_for(long long n);
+int mne_launch_clock_advance(unsigned long long* iteration, int* step_offset, hipStream_t st);
+
+static int fill_clock(const mne_clock_t* c, Clock& out, double beta1, double beta2, bool need_table) {
+    out = Clock{};
+    if (!c) return 0;
+    if (need_table) {
+        if (!c->step_offset || !c->bias_table || c->n_table < 1) return -1;
+        if (c->beta1 != beta1 || c->beta2 != beta2) return -2;
+        out.step_offset = c->step_offset; out.bias_table = c->bias_table; out.n_table = c->n_table;
+    } else {
+        if (!c->iteration) return -1;
+        out.iteration = (const unsigned long long*)c->iteration;
+        out.z_offset_stride = c->z_offset_stride;
+    }
+    return 0;
+}
 
 static thread_local std::string g_err;
 
@@ -61,6 +77,13 @@ size_t mne_sizeof_render_cfg(void) { return sizeof(mne_render_cfg_t); }
 size_t mne_sizeof_adam_seg(void) { return sizeof(mne_adam_seg_t); }
 size_t mne_sizeof_tile_bins(void) { return sizeof(mne_tile_bins_t); }
 size_t mne_sizeof_plane_opt(void) { return sizeof(mne_plane_opt_t); }
+size_t mne_sizeof_clock(void) { return sizeof(mne_clock_t); }
+
+int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream) {
+    if (!iteration && !step_offset) return fail(-1, "mne_clock_advance: NULL argument");
+    mne_launch_clock_advance((unsigned long long*)iteration, step_offset, (hipStream_t)stream);
+    return check_launch("clock_advance");
+}
 
 int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d) {
     if (!cfg) return fail(-1, "cfg is NULL");
@@ -69,7 +92,7 @@ int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d) {
 
 int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d, const float* u,
                  const float* lin_tables, uint64_t seed, uint64_t offset, float* z_vals, int32_t* counts,
-                 int32_t* ray_counts, void* stream) {
+                 int32_t* ray_counts, const mne_clock_t* clock, void* stream) {
     if (!cfg || !z_vals || !lin_tables) return fail(-1, "mne_sample_z: NULL argument");
     if (n_rays <= 0) return 0;
     ZArgs a;
@@ -92,6 +115,7 @@ int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d,
     a.z_vals = z_vals;
     a.counts = counts;
     a.ray_counts = ray_counts;
+    if (fill_clock(clock, a.clk, 0, 0, false)) return fail(-1, "mne_sample_z: incomplete clock");
     hipStream_t st = (hipStream_t)stream;
     if (a.has_d && (!counts || !ray_counts)) return fail(-1, "mne_sample_z: counts and ray_counts buffers required when target_d is given");
     mne_launch_sample_z(a, st);
@@ -257,7 +281,7 @@ int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* 
 }
 
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
-                  const mne_tile_bins_t* bins, void* stream) {
+                  const mne_tile_bins_t* bins, const mne_clock_t* clock, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
     if (!opt || !tape || !bins) return fail(-1, "mne_tile_adam: NULL argument");
     TileAdamArgs a = {};
@@ -273,6 +297,9 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
         o.eps = (float)g.eps; o.wd = (float)g.weight_decay;
         o.step_size = (float)(g.lr / (1.0 - std::pow(g.beta1, (double)g.step)));
         o.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(g.beta2, (double)g.step));
+        o.lr = g.lr; o.step = g.step;
+        if (clock && fill_clock(clock, a.clk, g.beta1, g.beta2, true))
+            return fail(-1, "mne_tile_adam: clock incomplete or made for other betas");
     }
     a.tape = tape;
     a.row_stride = (int)mne_dims_tape_row(*scene);
@@ -286,7 +313,7 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
                     const float* cur_rays, int64_t n_cur_rays, const float* poses, int n_poses,
                     int n_global, int n_cur, const int64_t* idx_global, const int64_t* idx_cur,
                     uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
-                    float* target_d, int64_t* out_idx, void* stream) {
+                    float* target_d, int64_t* out_idx, const mne_clock_t* clock, void* stream) {
     if (!poses || !rays_o || !rays_d || !target_rgb || !target_d || n_poses < 1) return fail(-1, "mne_sample_rays: NULL argument");
     if (n_global < 0 || n_cur < 0) return fail(-1, "mne_sample_rays: negative count");
     if (n_global > 0 && (!kf_rays || n_save < 1 || n_kf_rays < n_global)) return fail(-1, "mne_sample_rays: cannot draw n_global distinct keyframe rays");
@@ -298,6 +325,7 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
     a.n_global = n_global; a.n_cur = n_cur;
     a.idx_global = (const long long*)idx_global; a.idx_cur = (const long long*)idx_cur; a.out_idx = (long long*)out_idx;
     a.rays_o = rays_o; a.rays_d = rays_d; a.target_rgb = target_rgb; a.target_d = target_d;
+    if (fill_clock(clock, a.clk, 0, 0, false)) return fail(-1, "mne_sample_rays: incomplete clock");
     mne_launch_sample_rays(a, seed, iteration, (hipStream_t)stream);
     return check_launch("sample_rays");
 }
@@ -313,7 +341,7 @@ int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t
     return check_launch("decoder_wgrad");
 }
 
-int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* stream) {
+int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, const mne_clock_t* clock, void* stream) {
     if (n_seg < 0 || n_seg > 32) return fail(-1, "mne_adam_step: n_seg must be in [0,32]");
     if (n_seg == 0) return 0;
     if (!segs) return fail(-1, "mne_adam_step: segs is NULL");
@@ -330,6 +358,8 @@ int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* st
         a.step_size[s] = (float)(g.lr / bc1);
         a.bc2_sqrt[s] = (float)std::sqrt(bc2);
         a.blk_start[s + 1] = a.blk_start[s] + mne_adam_blocks_for(g.n);
+        if (clock && fill_clock(clock, a.clk, g.beta1, g.beta2, true))
+            return fail(-1, "mne_adam_step: clock incomplete or made for other betas");
     }
     mne_launch_adam(a, (hipStream_t)stream);
     return check_launch("adam_step");

@@ -7,6 +7,7 @@
 #pragma once
 #include "mne_platform.h"
 #include "mneslam_hip.h"
+#include "mne_launch.h"
 
 #define MNE_WAVE 64
 #define MNE_C 32      // channels per plane (model.c_dim)
@@ -41,6 +42,14 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, 
     }
     uint32_t w = (elem & 3) == 0 ? c0 : (elem & 3) == 1 ? c1 : (elem & 3) == 2 ? c2 : c3;
     return (float)(w >> 8) * (1.0f / 16777216.0f);      // [0,1), 24 bits like torch.rand
+}
+
+// ---- Adam bias corrections from the device clock (graph replay): same double arithmetic as the host path --------
+__device__ __forceinline__ void clock_bias(const Clock& clk, double lr, int step, float& step_size, float& bc2_sqrt) {
+    int t = step + *clk.step_offset;
+    t = t < 1 ? 1 : (t > clk.n_table ? clk.n_table : t);
+    step_size = (float)(lr / clk.bias_table[2 * (t - 1)]);
+    bc2_sqrt = (float)sqrt(clk.bias_table[2 * (t - 1) + 1]);
 }
 
 // ---- coordinates --------------------------------------------------------------------------------

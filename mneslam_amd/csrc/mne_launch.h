@@ -4,6 +4,15 @@
 #include "mne_platform.h"
 #include "mneslam_hip.h"
 
+// device-side view of mne_clock_t (all NULL / 0 = values come from the kernel arguments)
+struct Clock {
+    const unsigned long long* iteration;
+    const int* step_offset;
+    const double* bias_table;
+    int n_table;
+    unsigned long long z_offset_stride;
+};
+
 struct ZArgs {
     int R, S, n_a, n_b, has_d;
     float perturb;
@@ -15,6 +24,7 @@ struct ZArgs {
     float* z_vals;
     int* counts;
     int* ray_counts;     // [R][MNE_N_COUNT] scratch
+    Clock clk;
 };
 
 #define MNE_TILE 16            // plane tile edge (cells) of the binned scatter
@@ -95,7 +105,8 @@ struct SampleRaysArgs {
     long long* out_idx;          // optional [R]: the indices used
     float *rays_o, *rays_d, *target_rgb, *target_d;
     int half_bits_kf, half_bits_cur;
-    unsigned long long key_kf, key_cur;
+    unsigned long long seed, iteration;      // keys are derived from (seed, iteration [+ clock]) inside the kernel
+    Clock clk;
 };
 
 #define MNE_GRID_MAX_LEVELS 32
@@ -122,7 +133,7 @@ struct WgradArgs {
     int n_waves;              // number of partial results
 };
 
-struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, bc2_sqrt; };
+struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, bc2_sqrt; double lr; int step; };
 
 struct TileAdamArgs {
     mne_scene_t sc;
@@ -131,6 +142,7 @@ struct TileAdamArgs {
     const float* tape;
     int row_stride, t_dfeat, t_pn;
     int n_planes;
+    Clock clk;
 };
 
 struct AdamArgs {
@@ -140,6 +152,7 @@ struct AdamArgs {
     long long blk_start[33];  // prefix sum of blocks per segment
     int n_seg;
     int zero_grad;
+    Clock clk;
 };
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st);

@@ -34,20 +34,37 @@ __device__ __forceinline__ uint64_t feistel_index(uint64_t i, uint64_t n, int ha
     return x;
 }
 
+// two independent 64-bit keys from (seed, iteration) -- splitmix64; host and device run the same integer arithmetic
+__host__ __device__ inline void ray_keys(unsigned long long seed, unsigned long long iteration, unsigned long long& key_kf,
+                                         unsigned long long& key_cur) {
+    unsigned long long z = seed * 0x9E3779B97F4A7C15ull + iteration * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
+    unsigned long long k[2];
+    for (int i = 0; i < 2; ++i) {
+        z += 0x9E3779B97F4A7C15ull;
+        unsigned long long x = z;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        k[i] = x ^ (x >> 31);
+    }
+    key_kf = k[0]; key_cur = k[1];
+}
+
 __global__ __launch_bounds__(256) void sample_rays_kernel(SampleRaysArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int R = a.n_global + a.n_cur;
     if (t >= R) return;
+    unsigned long long key_kf, key_cur;
+    ray_keys(a.seed, a.iteration + (a.clk.iteration ? *a.clk.iteration : 0ull), key_kf, key_cur);
     const float* src;
     int pose_id;
     long long idx;
     if (t < a.n_global) {
-        idx = a.idx_global ? a.idx_global[t] : (long long)feistel_index((uint64_t)t, (uint64_t)a.n_kf_rays, a.half_bits_kf, a.key_kf);
+        idx = a.idx_global ? a.idx_global[t] : (long long)feistel_index((uint64_t)t, (uint64_t)a.n_kf_rays, a.half_bits_kf, key_kf);
         src = a.kf_rays + idx * 7;
         pose_id = a.kf_pose_ids ? a.kf_pose_ids[idx / a.n_save] : (int)(idx / a.n_save);
     } else {
         const int j = t - a.n_global;
-        idx = a.idx_cur ? a.idx_cur[j] : (long long)feistel_index((uint64_t)j, (uint64_t)a.n_cur_rays, a.half_bits_cur, a.key_cur);
+        idx = a.idx_cur ? a.idx_cur[j] : (long long)feistel_index((uint64_t)j, (uint64_t)a.n_cur_rays, a.half_bits_cur, key_cur);
         src = a.cur_rays + idx * 7;
         pose_id = a.n_poses - 1;                      // id -1 in the reference: poses[-1]
     }
@@ -72,12 +89,7 @@ static int half_bits_for(long long n) {
 int mne_launch_sample_rays(SampleRaysArgs a, unsigned long long seed, unsigned long long iteration, hipStream_t st) {
     a.half_bits_kf = half_bits_for(a.n_kf_rays);
     a.half_bits_cur = half_bits_for(a.n_cur_rays);
-    // two independent 64-bit keys from (seed, iteration) -- splitmix64
-    unsigned long long z = seed * 0x9E3779B97F4A7C15ull + iteration * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
-    auto next = [&z]() { z += 0x9E3779B97F4A7C15ull; unsigned long long x = z; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-                         x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); };
-    a.key_kf = next();
-    a.key_cur = next();
+    a.seed = seed; a.iteration = iteration;
     const int R = a.n_global + a.n_cur;
     MNE_LAUNCH(sample_rays_kernel, (R + 255) / 256, 256, 0, st, a);
     return 0;

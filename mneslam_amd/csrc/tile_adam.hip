@@ -88,6 +88,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
     __syncthreads();
     for (int t = tid; t < n_tiles; t += 1024) a.bins.order[atomicAdd(&start[31 - __clz(a.bins.counts[t] + 1)], 1)] = t;
 }
+// (A ballot-ranked counting sort without same-address atomics was measured at 14.5 us against 12 us for this one.)
 
 __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a) {
     MNE_DYN_LDS(lds_raw);
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     // Adam operands of this thread's elements, requested BEFORE the list passes so that the HBM stream of the
     // sweep (24 B/param) overlaps the LDS accumulation instead of following it (TILE_PREFETCH: 0 none, 1 p+m, 2 p+m+v)
     constexpr int NIT = (TILE_CELLS * MNE_C / 4) / TILE_THREADS;
-    const PlaneOpt& o = a.opt[pidx];
+    PlaneOpt o = a.opt[pidx];
+    if (a.clk.bias_table) clock_bias(a.clk, o.lr, o.step, o.step_size, o.bc2_sqrt);       // graph replay: step from device memory
     float* P = (float*)pl.data;
     float4 pre_p[NIT], pre_m[NIT], pre_v[NIT];
 #if TILE_PREFETCH

@@ -125,7 +125,7 @@ class RenderFunction(torch.autograd.Function):
         ray_counts = torch.empty(R, _lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
         seed, offset = seed_offset
         _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u_c), _lib.ptr(tables), seed, offset,
-                                    _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), st), "mne_sample_z")
+                                    _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), None, st), "mne_sample_z")
         sc = scene_struct(info, [p.detach() for p in planes], [w.detach() for w in dec_w])
         packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
         _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")

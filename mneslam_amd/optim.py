@@ -36,8 +36,9 @@ class FusedAdam(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p)
         return st
 
-    def segments(self, zero_grad_buffers=None):
-        """ctypes segment array for every parameter that has a gradient (advances the step counts)."""
+    def segments(self, zero_grad_buffers=None, advance=True):
+        """ctypes segment array for every parameter that has a gradient (advances the step counts unless
+        ``advance`` is False: a recorded iteration reads its step from the device clock, ``step`` is then the base)."""
         segs = []
         keep = []
         for group in self.param_groups:
@@ -51,7 +52,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)):
                     raise ValueError("FusedAdam needs dense parameters")
                 st = self._state(p)
-                st["step"] += 1
+                if advance:
+                    st["step"] += 1
                 g = _dense_like(p, g)
                 keep.append(g)
                 s = _lib.AdamSeg()
@@ -60,23 +62,26 @@ class FusedAdam(torch.optim.Optimizer):
                 s.n = p.numel()
                 s.lr, s.beta1, s.beta2 = float(group["lr"]), float(b1), float(b2)
                 s.eps, s.weight_decay = float(group["eps"]), float(group["weight_decay"])
-                s.step = st["step"]
+                s.step = st["step"] if advance else st["step"] + 1
                 segs.append((s, p))
         return segs, keep
 
     @torch.no_grad()
-    def step(self, closure=None, zero_grad=False, grad_buffers=None):
+    def step(self, closure=None, zero_grad=False, grad_buffers=None, clock=None):
+        """``clock`` (mneslam_amd._lib.Clock, graph recording only): the kernel adds the device step offset to the
+        parameters' CURRENT step + 1 and the python step counts are left alone (the caller advances them per replay)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        segs, keep = self.segments(grad_buffers)
+        segs, keep = self.segments(grad_buffers, advance=clock is None)
         if not segs:
             return loss
         lib = _lib.load()
         for i in range(0, len(segs), 32):
             chunk = segs[i:i + 32]
             arr = (_lib.AdamSeg * len(chunk))(*[s for s, _ in chunk])
-            _lib.check(lib.mne_adam_step(arr, len(chunk), 1 if zero_grad else 0, _lib.stream_for(chunk[0][1])),
+            _lib.check(lib.mne_adam_step(arr, len(chunk), 1 if zero_grad else 0,
+                                         C.byref(clock) if clock is not None else None, _lib.stream_for(chunk[0][1])),
                        "mne_adam_step")
         return loss

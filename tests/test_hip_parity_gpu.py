@@ -89,6 +89,40 @@ def test_device_sampler():
     pc.check_device_sampler(DEV)
 
 
+def test_device_clock():
+    pc.check_device_clock(DEV)
+
+
+def test_graph_replay_matches_eager_launches():
+    """The recorded iteration (one hipGraphLaunch per step, iteration / Adam step from the device clock) against the
+    same steps launched one by one: identical ray batches and z samples (bit for bit), same parameters up to the
+    summation order of the plane-gradient lists."""
+    import os
+    import bench
+    from mneslam_amd import configs
+    cfg = configs.bench_office0()
+    cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
+    out = {}
+    for mode in ("eager", "graph"):
+        ag = bench.Agent(cfg, torch.device("cuda"), seed=6, n_keyframes=8, small=True, path="fused", scatter="binned")
+        ag.fused.use_graph = mode == "graph"
+        for it in range(9):
+            ag.step(prefetch=it < 8)
+        ag.fused.check()
+        torch.cuda.synchronize()
+        assert (len(ag.fused._graphs) > 0 and all(ag.fused._graphs.values())) == (mode == "graph")
+        out[mode] = (ag.fused.idx.clone(), ag.fused.z_vals.clone(), ag.fused.losses.clone(),
+                     [p.detach().clone() for lst in ag.model.all_planes for p in lst] + [p.detach().clone() for p in ag.model.decoder.parameters()],
+                     ag.opt._state(ag.fused.planes[0])["step"], ag.fused.iteration)
+    assert torch.equal(out["eager"][0], out["graph"][0]) and torch.equal(out["eager"][1], out["graph"][1])
+    assert out["eager"][4] == out["graph"][4] == 9 and out["eager"][5] == out["graph"][5] == 9
+    assert torch.allclose(out["eager"][2], out["graph"][2], rtol=1e-3, atol=1e-6, equal_nan=True)
+    for a, b in zip(out["eager"][3], out["graph"][3]):
+        d = (a - b).abs()
+        assert torch.isfinite(b).all() and float(d.mean()) < 1e-6 and float((d > 1e-4).float().mean()) < 1e-4
+
+
 @pytest.mark.parametrize("name,one_grid,co,seed", [("mapping3_onegrid_esdf", True, False, 21),
                                                    ("mapping3_colorplanes_cosdf", False, True, 22)])
 @pytest.mark.parametrize("scatter", ["binned", "atomics"])

@@ -80,6 +80,10 @@ def test_queries():
     pc.check_queries(DEV)
 
 
+def test_device_clock():
+    pc.check_device_clock(DEV)
+
+
 def test_corner_indices_bit_exact():
     pc.check_corner_indices(DEV, "fwd_onegrid")
 
