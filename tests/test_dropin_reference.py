@@ -23,6 +23,9 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 
 REF = os.environ.get("MNESLAM_REFERENCE", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+# the emulator runs one OS thread per work-item: the default CPU run keeps one end-to-end case (the reference's Mapper
+# driving this repository's model) and the cheap structural ones; MNE_EMU_FULL=1 runs every case (several minutes each)
+full = pytest.mark.skipif(os.environ.get("MNE_EMU_FULL", "0") != "1", reason="slow emulator case (MNE_EMU_FULL=1)")
 
 from helpers import DEC_KEYS, assert_close, load_golden, n_plane_sets  # noqa: E402
 import parity_cases as pc  # noqa: E402
@@ -109,7 +112,7 @@ def _assert_final(g, m):
         assert_close(sd[k].detach().cpu(), g[f"final.dec.{k}"], rtol=1e-3, atol=1e-4, what=f"decoder {k}")
 
 
-@pytest.mark.parametrize("kf_side", ["reference", "repo"])
+@pytest.mark.parametrize("kf_side", ["reference", pytest.param("repo", marks=full)])
 def test_reference_mapper_drives_repo_model(ref, tmp_path, kf_side):
     """Integration level 1: the reference's UNMODIFIED Mapper.mapping_optimize (its own loop, its own ray assembly)
     on this repository's JointEncoding + FusedAdam reaches the parameters the reference reached with its own model."""
@@ -124,6 +127,20 @@ def test_reference_mapper_drives_repo_model(ref, tmp_path, kf_side):
     _assert_final(g, m)
 
 
+def test_bound_mapper_class_structure(ref):
+    """bind(host Mapper): the mixin sits in front of the reference's class and replaces exactly the two training loops."""
+    Bound = repo_mapper.bind(ref.Mapper, compute="fused", sampler="host")
+    assert Bound.__mro__[1] is repo_mapper.FusedMappingMixin and Bound.__mro__[2] is ref.Mapper
+    for name in ("run", "final_run", "handle_loop_closure", "bound_based_fusion", "load_foreign_model",
+                 "save_keyframe_data_atomic", "__init__"):
+        assert getattr(Bound, name) is getattr(ref.Mapper, name), f"{name} must stay the host's"
+    for name in ("mapping_optimize", "first_frame_mapping"):
+        assert getattr(Bound, name) is getattr(repo_mapper.FusedMappingMixin, name)
+    with pytest.raises(ValueError):
+        repo_mapper.bind(ref.Mapper, compute="autograd", sampler="device")
+
+
+@full
 def test_fused_mixin_over_reference_mapper(ref, tmp_path):
     """Integration level 2: bind(reference Mapper) replaces mapping_optimize by the fused iteration (host RNG draws in
     the reference's order); everything else of the class is the reference's."""
@@ -141,6 +158,7 @@ def test_fused_mixin_over_reference_mapper(ref, tmp_path):
     _assert_final(g, m)
 
 
+@full
 def test_first_frame_mapping_keeps_host_bookkeeping(ref, tmp_path):
     """The fused first-frame loop hands over to the reference's own first_frame_mapping (zero iterations) for the
     bookkeeping of mp_slam/mapper.py:91-116: first keyframe, keyframe_dict entry, flag, dumps, pose files."""

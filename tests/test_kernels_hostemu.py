@@ -97,7 +97,8 @@ def test_device_sampler():
     pc.check_device_sampler(DEV)
 
 
-@pytest.mark.parametrize("scatter", ["binned", pytest.param("atomics", marks=full)])
+@full
+@pytest.mark.parametrize("scatter", ["binned", "atomics"])
 def test_mapping3_fused_path(scatter):
     pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV, compute="fused", scatter=scatter)
 
@@ -113,6 +114,7 @@ def test_mapping3_fused_binned_colorplanes():
     pc.check_mapping3("mapping3_colorplanes_cosdf", False, True, 22, DEV, compute="fused", scatter="binned")
 
 
+@full
 def test_ray_gradients_onegrid():
     pc.check_ray_gradients("fwd_onegrid", False, DEV)
 
