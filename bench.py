@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--share-decoder", action="store_true",
                     help="EXTENSION: all-reduce (mean) the decoder gradient over agents each iteration (RCCL)")
     ap.add_argument("--small", action="store_true", help="tiny planes/frames (functional check, not a benchmark)")
+    ap.add_argument("--mode", default="mapping", choices=["mapping", "render_img"],
+                    help="mapping = the metric (default); render_img = SURVEY 8f row N1: full-frame no-grad renders, the "
+                         "two per keyframe the reference's save_imgs does (with and without depth guidance)")
     return ap.parse_args()
 
 
@@ -185,6 +188,53 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0):
                       f"{torch.__version__}, {cores} threads"}
 
 
+def bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, mdist):
+    """N1: JointEncoding.render_img on whole frames -- one no-grad launch sequence per frame with exact early ray
+    termination.  One step = the reference's per-keyframe pair: a depth-guided render (n_range_d + n_samples_d samples
+    per ray) and a free render (training.n_samples)."""
+    for _ in range(10):
+        agent.step()                                     # a few mapping iterations so that the SDF has a surface
+    torch.cuda.synchronize()
+    m = agent.model
+    m.eval()
+    cam = synthetic.camera_from_config(cfg)
+    cfg_cam_backup = dict(cfg["cam"])
+    cfg["cam"].update(cam, crop_edge=0)                  # render_img reads the camera from the config
+    frames = synthetic.make_frames(2, cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"],
+                                   synthetic.room_from_config(cfg), seed=99)
+    c2w, gt = frames[1]["c2w"].to(device), frames[1]["depth"].to(device)
+    tr = cfg["training"]
+    has_free = bool(tr.get("n_samples"))
+    n_rays = cam["H"] * cam["W"]
+    pts = n_rays * ((tr["n_range_d"] + tr["n_samples_d"]) + (tr["n_samples"] if has_free else 0))
+
+    def pair():
+        d1, c1 = m.render_img(c2w, device, gt_depth=gt)
+        if has_free:
+            m.render_img(c2w, device, gt_depth=None)
+        return d1
+
+    for _ in range(max(args.warmup // 10, 1)):
+        pair()
+    steps = max(args.steps // 20, 3)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d1 = pair()
+    barrier()
+    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, device)
+    cfg["cam"].update(cfg_cam_backup)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "full-frame renders (render_img pairs) / sec", "value": world * steps / elapsed, "unit": "frame pairs/s",
+            "n_gpus": world, "steps": steps, "warmup": max(args.warmup // 10, 1), "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload + "_render_img", "frame": f"{cam['W']}x{cam['H']}", "rays_per_frame": n_rays,
+                       "nominal_point_queries_per_step": pts, "early_ray_termination": True},
+            "nominal_Mpts_per_s": world * steps * pts / elapsed / 1e6,
+            "depth_l1_vs_gt": float((d1.float() - gt)[gt > 0].abs().mean())}), flush=True)
+
+
 def main():
     args = parse_args()
     if not torch.cuda.is_available():
@@ -205,6 +255,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.mode == "render_img":
+        return bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, mdist)
+
     for _ in range(args.warmup):
         agent.step()
     timers = {}
@@ -223,33 +276,47 @@ def main():
         S = cfg["training"]["n_range_d"] + cfg["training"]["n_samples_d"]
         R = cfg["mapping"]["sample"] + agent.n_cur
         n_par = agent.n_plane_params + agent.n_dec_params
-        # algorithmic bytes per launch = SURVEY.md section 8d's per-unit figures x the units the launch processes
-        # (both stated in DESIGN.md):  G = planes x 4 corners x 32 ch x 4 B per point per gather or scatter pass,
-        # 32 B per parameter per optimiser sweep (the reference's read p,g,m,v + write p,m,v + zero g).
-        #   tile_adam_kernel      : scatter of the P' contributing samples (tape rows, read back live) + the sweep
-        #   mne_render_fused call : forward gather of all R*S samples (decode_kernel) + the backward's re-gather of P'
-        #   atomics variant       : adam_kernel = the sweep; the render call also scatters (atomics)
+        # Algorithmic bytes per launch = SURVEY.md section 8d's per-unit figures x the units the launch processes (both stated
+        # in DESIGN.md):  G = planes x 4 corners x 32 ch x 4 B per point per gather or scatter pass; 32 B per parameter
+        # per optimiser sweep (the reference's read p,g,m,v + write p,m,v + zero g).
+        #   tile_adam_kernel : scatter of the P' contributing samples + the sweep over every parameter
+        #   gather_kernel    : gather of the D samples the exact early termination decodes; D is counted from below as
+        #                      the samples of the tiles the backward walks (ray_tiles, read back live), D <= R*S
+        #   decode_kernel, ray_kernel : the MLP forward / composite+backward; no algorithmic HBM bytes (latency-bound)
+        #   atomics variant  : adam_kernel = the sweep; the render call gathers and scatters (atomics)
         G = 3072.0 * (1 if cfg["grid"]["oneGrid"] else 2)
         binned = agent.fused is not None and agent.fused.bins is not None
         p_contrib = float(agent.fused.tape_rows.item()) if agent.fused is not None else float(R * S)
+        decoded = float((agent.fused.ray_tiles[:R].long() * 32).clamp(max=S).sum().item()) if agent.fused is not None else float(R * S)
         if binned:
-            alg = {"adam": p_contrib * G + 32.0 * n_par, "render": (R * S + p_contrib) * G}
-            kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)",
-                    "render": "decode_kernel + composite_kernel + scan_kernel + backward_kernel (one mne_render_fused call)"}
+            alg = {"adam": p_contrib * G + 32.0 * n_par, "gather_kernel": decoded * G, "render": decoded * G}
+            kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)", "gather_kernel": "gather_kernel",
+                    "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
+                    "deferred_pass": "decode_kernel + ray_kernel over the deferred-ray list",
+                    "render": "whole mne_render_fused call (gather + decode + ray + deferred pass)"}
         else:
-            alg = {"adam": 32.0 * n_par, "render": (R * S + 2.0 * p_contrib) * G}
+            alg = {"adam": 32.0 * n_par, "render": (decoded + p_contrib) * G}
             kern = {"adam": "adam_kernel (planes + decoder, one launch)",
-                    "render": "decode_kernel + composite_kernel + scan_kernel + backward_kernel (one mne_render_fused call, atomic scatter)"}
-        dom = max(avg_ms, key=avg_ms.get) if avg_ms else "adam"          # the longest live-measured launch
+                    "render": "whole mne_render_fused call (gather + decode + ray kernels, atomic scatter)"}
+        # the dominant KERNEL = the longest live-measured single launch (the bracket around the whole render call is
+        # reported beside it, not as a kernel, when its kernels are timed individually)
+        single = {k: v for k, v in avg_ms.items() if not (k == "render" and "gather_kernel" in avg_ms)}
+        dom = max(single, key=single.get) if single else "adam"
         dom_ms = avg_ms.get(dom, 0.0)
-        achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM traffic of the same kernel from committed PMC passes (rocprofv3 cannot run inside the timed loop)
-        traffic = None
+        achieved = alg.get(dom, 0.0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM traffic and matrix-pipe busy cycles from committed PMC passes (rocprofv3 cannot run inside the timed loop)
+        traffic, mfma_busy = None, None
         try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
             if (pmc["workload"] == workload and not args.small and args.path == "fused"
                     and pmc["scatter"] == args.scatter and args.hidden == 32):
-                traffic = pmc["hbm_bytes_per_launch"].get(dom)
+                per_k = pmc["per_kernel_hbm_bytes_per_iteration"]
+                tag = {"adam": "tile_adam_kernel"}.get(dom, dom)
+                traffic = sum(v for k, v in per_k.items() if tag in k) or None
+                clk = 2.4e9 * 1024                        # SIMD-cycles per second: 256 CUs x 4 SIMDs at 2.4 GHz
+                mfma_busy = {name: cyc / clk / (avg_ms[name] * 1e-3)
+                             for name in ("decode_kernel", "ray_kernel") if avg_ms.get(name)
+                             for k, cyc in pmc["per_kernel_mfma_busy_cycles_per_iteration"].items() if name in k}
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -266,11 +333,13 @@ def main():
             "psnr_last_iter": psnr, "depth_l1_last_iter": depth_l1,
             "roofline": {"kernel": kern[dom], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms,
+                         "algorithmic_bytes_per_launch": alg.get(dom, 0.0), "avg_launch_ms": dom_ms,
                          "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms > 0) else None,
-                         "contributing_samples_last_iter": p_contrib,
+                         "mfma_busy": mfma_busy,
+                         "contributing_samples_last_iter": p_contrib, "gathered_samples_last_iter_lower_bound": decoded,
+                         "nominal_samples": float(R * S),
                          "other_kernels_avg_ms": {kern[k]: v for k, v in avg_ms.items() if k != dom},
-                         "other_kernels_algorithmic_bytes": {kern[k]: alg[k] for k in alg if k != dom},
+                         "other_kernels_algorithmic_bytes": {kern[k]: alg[k] for k in alg if k != dom and k != "render"},
                          "iteration_algorithmic_bytes": alg["adam"] + alg["render"],
                          "iteration_hbm_frac": (alg["adam"] + alg["render"]) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }

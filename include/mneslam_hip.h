@@ -145,6 +145,12 @@ size_t mne_sizeof_plane_opt(void);
 size_t mne_sizeof_clock(void);
 int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream);
 
+/* Measurement hook (no reference counterpart): up to 5 hipEvent_t handles that the NEXT mne_render_fused call records on its
+ * stream -- [0] before the feature gather, [1] after it, [2] after the prefix decode, [3] after the ray kernel, [4] after
+ * the deferred pass -- so bench.py can time the kernels of that call live.  NULL entries are skipped; the handles are
+ * consumed by that one call.  Process-global, not thread-safe. */
+int mne_profile_marks(void* const* events, int n);
+
 /* Number of samples per ray: n_range_d + n_samples_d with depth guidance, n_samples without
  * (model/scene_rep.py:362-374). */
 int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d);

@@ -85,6 +85,12 @@ int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream) {
     return check_launch("clock_advance");
 }
 
+int mne_profile_marks(void* const* events, int n) {
+    if (n > 0 && !events) return fail(-1, "mne_profile_marks: NULL argument");
+    mne_set_render_marks(events, n);
+    return 0;
+}
+
 int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d) {
     if (!cfg) return fail(-1, "cfg is NULL");
     return has_target_d ? cfg->n_range_d + cfg->n_samples_d : cfg->n_samples;

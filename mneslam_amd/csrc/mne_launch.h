@@ -160,6 +160,7 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
 // mode: 0 = forward, every sample decoded (raw complete);  1 = forward with early ray termination (maps only);
 //       2 = training iteration (decode + backward);  3 = backward of an earlier forward call (raw_in given)
 int mne_launch_render(const RenderArgs& a, int mode, void* workspace, hipStream_t st);
+void mne_set_render_marks(void* const* events, int n);
 size_t mne_render_workspace(int R, int S);
 int mne_launch_query(const QueryArgs& a, hipStream_t st);
 int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStream_t st);

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
         if (a.bins.spill_count) *a.bins.spill_count = 0;
         if (a.defer_count) *a.defer_count = 0;
     }
+    if (a.ray_list && *a.ray_list_count == 0) return;      // second pass with nothing deferred (the usual case)
     if (ALDS) {                                            // stage the A tables: the only block-wide step
         float4* dst = (float4*)lds_raw;
         const float4* src = (const float4*)a.packed;
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
     constexpr int TAB_FLOATS = ALDS ? (TAB_LAST - TAB_FIRST) * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     const int wpb = blockDim.x >> 6;
+    if (a.ray_list && *a.ray_list_count == 0) return;      // second pass with nothing deferred (the usual case)
     if (ALDS) {
         float4* dst = (float4*)lds_raw;
         const float4* src = (const float4*)(a.packed + TAB_FIRST * 64);
@@ -1095,6 +1097,18 @@ static int launch_ray(const RenderArgs& a, hipStream_t st, int max_blocks = MNE_
     return 0;
 }
 
+// Timing marks (mne_profile_marks): events the next training render records between its kernels, so that a benchmark
+// can time gather / decode / ray / deferred pass live without a profiler.  Consumed by one call; not thread-safe.
+static hipEvent_t g_marks[5];
+static int g_n_marks = 0;
+void mne_set_render_marks(void* const* events, int n) {
+    g_n_marks = n < 0 ? 0 : n > 5 ? 5 : n;
+    for (int i = 0; i < g_n_marks; ++i) g_marks[i] = (hipEvent_t)events[i];
+}
+static inline void mark(int i, hipStream_t st) {
+    if (i < g_n_marks && g_marks[i]) (void)hipEventRecord(g_marks[i], st);
+}
+
 // pre = true: the a-priori tiles' plane features are gathered by gather_kernel first (needs the tape)
 template <int HID, int HIDC, bool CP>
 static int launch_decode(RenderArgs d, hipStream_t st, bool pre = false) {
@@ -1105,7 +1119,9 @@ static int launch_decode(RenderArgs d, hipStream_t st, bool pre = false) {
         d.tape_row = D::ROW; d.tape_tx = D::T_X; d.tape_tcf = D::T_CF;
         const int chunks = (d.S + 7) / 8;
         const long long waves = (long long)d.R * chunks;
+        mark(0, st);
         MNE_LAUNCH((gather_kernel<CP>), (unsigned)((waves + 3) / 4), 256, 0, st, d, chunks);
+        mark(1, st);
     }
     const size_t tab = table_bytes<HID, HIDC, CP>(0);
     const int wpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(CP ? 2 : 1), pre ? 8 : MAX_WPB);
@@ -1152,11 +1168,16 @@ static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st
     if (mode == 2) {
         // training: every ray in the lean kernel; the few it cannot resolve from the decoded prefix are finished by the
         // full kernel, driven by the deferred list (a handful of workgroups that leave at once when the list is empty)
+        mark(2, st);
         if (int rc = launch_ray<HID, HIDC, CP, 4>(a, st)) return rc;
+        mark(3, st);
         RenderArgs d = a;
         d.ray_list = a.defer_list; d.ray_list_count = a.defer_count;
         launch_decode<HID, HIDC, CP>(d, st);               // their remaining tiles, tile-parallel
-        return launch_ray<HID, HIDC, CP, 4>(d, st);        // the same lean kernel: now every listed ray resolves
+        const int rc = launch_ray<HID, HIDC, CP, 4>(d, st);    // the same lean kernel: now every listed ray resolves
+        mark(4, st);
+        g_n_marks = 0;
+        return rc;
     }
     if (raygrad) return launch_ray<HID, HIDC, CP, 3>(a, st);
     return launch_ray<HID, HIDC, CP, 2>(a, st);

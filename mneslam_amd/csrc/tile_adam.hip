@@ -66,6 +66,12 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
 #ifndef TILE_PREFETCH
 #define TILE_PREFETCH 0
 #endif
+#ifndef TILE_MIN_WAVES
+#define TILE_MIN_WAVES 4        // waves per SIMD the register allocation must allow: 2 workgroups of 8 waves per CU (LDS-limited)
+#endif
+#ifndef TILE_EMPTY_FAST
+#define TILE_EMPTY_FAST 1
+#endif
 #define TILE_GROUPS (TILE_THREADS / 8)        // 8-lane groups (float4 per lane = one 32-channel row)
 #define TILE_CELLS (MNE_TILE * MNE_TILE)
 static_assert(PASS_ENTRIES <= TILE_THREADS && PASS_ENTRIES <= 256 && PASS_ENTRIES % TILE_GROUPS == 0, "one staged entry per thread; item index must fit 8 bits");
@@ -75,6 +81,10 @@ static_assert(TILE_CELLS == 256, "the prefix step assumes 4 cells per lane of on
 // very long lists (every ray of a keyframe passes through the tile holding its camera centre) start
 // at once instead of forming the tail of the launch.
 __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_tiles) {
+#ifdef TILE_ORDER_IDENTITY        // experiment: spatial order (neighbouring tiles run together), no load balancing
+    for (int t = threadIdx.x; t < n_tiles; t += 1024) a.bins.order[t] = t;
+    return;
+#endif
     __shared__ int hist[32], start[32];
     const int tid = threadIdx.x;
     if (tid < 32) hist[tid] = 0;
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
 }
 // (A ballot-ranked counting sort without same-address atomics was measured at 14.5 us against 12 us for this one.)
 
-__global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a) {
+__global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel(TileAdamArgs a) {
     MNE_DYN_LDS(lds_raw);
     float* g = (float*)lds_raw;                                   // [16][16][32] gradient tile, 32 KiB
     float* stage = g + TILE_CELLS * MNE_C;                        // [PASS_ENTRIES][32] gradient rows of this pass
@@ -108,8 +118,10 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     const mne_plane_t& pl = a.sc.plane[set][(pidx % 6) / 2][lvl];
     const int local = tile - a.bins.tile_base[pidx];
     const int tx0 = local % a.bins.ntx[pidx], ty0 = local / a.bins.ntx[pidx];
-    for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int cnt = a.bins.counts[tile];
+    const bool empty = TILE_EMPTY_FAST && cnt == 0;            // no contribution: the sweep runs with g = 0, LDS untouched
+    if (!empty)
+        for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int n_list = cnt < a.bins.cap ? cnt : a.bins.cap;
     int n_spill = 0;
     if (cnt > a.bins.cap) {                     // only a tile whose list overflowed has entries in the spill area
@@ -124,7 +136,22 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
     if (a.clk.bias_table) clock_bias(a.clk, o.lr, o.step, o.step_size, o.bc2_sqrt);       // graph replay: step from device memory
     float* P = (float*)pl.data;
     float4 pre_p[NIT], pre_m[NIT], pre_v[NIT];
-#if TILE_PREFETCH
+#if TILE_PREFETCH == 3
+    // mode 3: the sweep's operands are requested BEHIND the first pass's entry and tape-row loads (vmcnt retires in
+    // order: waiting for those then leaves these in flight), so they land while steps B..D of that pass run
+    auto fetch_operands = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i4 = it * TILE_THREADS + tid;
+            const int y = i4 / (MNE_TILE * MNE_C / 4), x4 = i4 % (MNE_TILE * MNE_C / 4);
+            const int gy = ty0 * MNE_TILE + y, gx = tx0 * MNE_TILE + x4 / (MNE_C / 4);
+            if (gy < pl.h && gx < pl.w) {
+                const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + (x4 % (MNE_C / 4)) * 4;
+                pre_p[it] = *(const float4*)(P + off); pre_m[it] = *(const float4*)(o.m + off); pre_v[it] = *(const float4*)(o.v + off);
+            }
+        }
+    };
+#elif TILE_PREFETCH
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i4 = it * TILE_THREADS + tid;
@@ -188,6 +215,9 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
             const unsigned row = erow[j * TILE_GROUPS + grp];
             grow[j] = row != 0xffffffffu ? *(const float4*)(dfeat + (size_t)row * a.row_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#if TILE_PREFETCH == 3
+        if (p0 == 0) { MNE_SCHED_BARRIER(); fetch_operands(); MNE_SCHED_BARRIER(); }
+#endif
         // ---- B: counts -> exclusive start offsets (one wave, 4 cells per lane)
         if (tid < MNE_WAVE) {
             const int v0 = hist[4 * tid], v1 = hist[4 * tid + 1], v2 = hist[4 * tid + 2], v3 = hist[4 * tid + 3];
@@ -271,7 +301,10 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
         }
         __syncthreads();
     }
-    __syncthreads();
+    if (!empty) __syncthreads();
+#if TILE_PREFETCH == 3
+    if (n_total == 0) fetch_operands();
+#endif
     TILE_STAMP(5);
     // ---- Adam on the tile: 16 rows x (16 cells x 32 ch) = 2048 float4
 #pragma unroll
@@ -282,17 +315,22 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_adam_kernel(TileAdamArgs a)
         const int gy = ty0 * MNE_TILE + y, gx = tx0 * MNE_TILE + cell;
         if (gy < pl.h && gx < pl.w) {
             const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + ch4 * 4;
+#ifdef TILE_MV_TILEMAJOR      // layout experiment: m and v stored tile-major (each workgroup streams 32 KiB contiguous)
+            const size_t offmv = (size_t)local * (TILE_CELLS * MNE_C) + (size_t)i4 * 4;
+#else
+            const size_t offmv = off;
+#endif
 #if TILE_PREFETCH >= 2
             float4 p = pre_p[it], m = pre_m[it], v = pre_v[it];
 #elif TILE_PREFETCH == 1
             float4 p = pre_p[it], m = pre_m[it], v = *(float4*)(o.v + off);
 #else
-            float4 p = *(float4*)(P + off), m = *(float4*)(o.m + off), v = *(float4*)(o.v + off);
+            float4 p = *(float4*)(P + off), m = *(float4*)(o.m + offmv), v = *(float4*)(o.v + offmv);
 #endif
-            const float4 gg = ((const float4*)g)[i4];
+            const float4 gg = empty ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)g)[i4];
             adam_elem(p.x, gg.x, m.x, v.x, o); adam_elem(p.y, gg.y, m.y, v.y, o);
             adam_elem(p.z, gg.z, m.z, v.z, o); adam_elem(p.w, gg.w, m.w, v.w, o);
-            *(float4*)(P + off) = p; *(float4*)(o.m + off) = m; *(float4*)(o.v + off) = v;
+            *(float4*)(P + off) = p; *(float4*)(o.m + offmv) = m; *(float4*)(o.v + offmv) = v;
         }
     }
     TILE_STAMP(6);

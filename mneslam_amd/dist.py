@@ -114,6 +114,90 @@ def allreduce_mean_(buf):
     return buf
 
 
+# --------------------------------------------------------------------------------------------------------------
+# EXTENSION (BASELINE configs 3-5; the reference has no such exchange): plane gradients of the region two
+# agents both map.  The reference's agents own unrelated lattices (each plane spans its agent's own bound,
+# model/scene_rep.py:96-109), so cells of different agents do not coincide in general; the exchange is defined for
+# agents laid out on ONE global lattice: node spacing h per level, every agent's bound starts on a node of that lattice
+# and spans a whole number of cells.  ``aligned_agent_bounds`` produces such bounds (the overlap boxes of
+# mp_slam/mapper.py:491-509 / configs/Indoor/indoor.yaml:169-173 are then whole sub-rectangles of both agents' planes).
+# --------------------------------------------------------------------------------------------------------------
+def aligned_agent_bounds(global_bound, n_agents, axis, overlap, cell):
+    """Split ``global_bound`` ([3][2]) into ``n_agents`` slabs along ``axis`` that overlap by about ``overlap`` metres,
+    every slab edge on a multiple of ``cell`` from the global lower corner (``cell`` = the coarsest plane cell, which
+    the finer levels divide).  Returns a list of [3][2] bounds."""
+    lo, hi = global_bound[axis]
+    n_cells = int(round((hi - lo) / cell))
+    per = n_cells // n_agents
+    ov = max(int(round(overlap / cell)), 1)
+    out = []
+    for k in range(n_agents):
+        a = max(k * per - (ov // 2 if k else 0), 0)
+        b = n_cells if k == n_agents - 1 else min((k + 1) * per + (ov - ov // 2), n_cells)
+        bnd = [list(map(float, x)) for x in global_bound]
+        bnd[axis] = [lo + a * cell, lo + b * cell]
+        out.append(bnd)
+    return out
+
+
+def overlap_slices(bound_a, bound_b, shape_a, shape_b, axes, tol=1e-4):
+    """Index rectangles of the region both planes cover.  ``bound_*``: [3][2] extents the planes span (node 0 at lo, last
+    node at hi: align_corners=True), ``shape_*`` = (H, W) of the two planes, ``axes`` = (axis of W, axis of H) -- (0,1) for
+    xy, (0,2) for xz, (1,2) for yz.  Returns ((ys_a, xs_a), (ys_b, xs_b)) slices, or None when the boxes do not
+    intersect; raises when the two lattices do not coincide (different node spacing or an offset off the lattice)."""
+    sl = [[None, None], [None, None]]
+    for which, ax in ((1, axes[0]), (0, axes[1])):                      # which: 1 = W (x of the plane), 0 = H
+        na, nb = shape_a[which], shape_b[which]
+        la, ha = bound_a[ax]
+        lb, hb = bound_b[ax]
+        h_a, h_b = (ha - la) / (na - 1), (hb - lb) / (nb - 1)
+        if abs(h_a - h_b) > tol * h_a:
+            raise ValueError(f"axis {ax}: node spacings differ ({h_a} vs {h_b}): the agents do not share a lattice")
+        off = (lb - la) / h_a
+        if abs(off - round(off)) > tol * max(1.0, abs(off)):
+            raise ValueError(f"axis {ax}: peer lattice is shifted by a fraction of a cell")
+        off = int(round(off))
+        lo, hi = max(0, off), min(na - 1, off + nb - 1)                  # node range in a's indices
+        if hi < lo:
+            return None
+        sl[0][which] = slice(lo, hi + 1)
+        sl[1][which] = slice(lo - off, hi - off + 1)
+    return (sl[0][0], sl[0][1]), (sl[1][0], sl[1][1])
+
+
+def exchange_overlap_gradients(grads, shapes_bounds, peer, peer_shapes_bounds):
+    """Add the peer agent's plane gradients over the region both agents map, and hand ours to the peer (pairwise,
+    symmetric; RCCL send/recv over xGMI on GPUs).  ``grads``: list of [1,C,H,W] gradient buffers in all_planes order;
+    ``shapes_bounds`` / ``peer_shapes_bounds``: per plane ((H, W), bound [3][2], axes) of this agent / the peer (exchanged once at
+    start-up).  Planes without overlap are skipped.  Afterwards both agents hold the SUM on the shared cells."""
+    rank = dist.get_rank()
+    for g, (shape, bound, axes), (pshape, pbound, _) in zip(grads, shapes_bounds, peer_shapes_bounds):
+        ov = overlap_slices(bound, pbound, shape, pshape, axes)
+        if ov is None:
+            continue
+        (ys, xs), _ = ov
+        mine = g[:, :, ys, xs].contiguous()
+        theirs = torch.empty_like(mine)
+        if rank < peer:
+            dist.send(mine, peer)
+            dist.recv(theirs, peer)
+        else:
+            dist.recv(theirs, peer)
+            dist.send(mine, peer)
+        g[:, :, ys, xs] += theirs
+
+
+def plane_geometry(model):
+    """((H, W), extended bound as [3][2] floats, plane axes) for every plane of ``model`` in all_planes order."""
+    bound = [[float(lo), float(hi)] for lo, hi in torch.as_tensor(model.bound).cpu()]
+    axes = [(0, 1), (0, 2), (1, 2)]
+    out = []
+    for k, lst in enumerate(model.all_planes):
+        for p in lst:
+            out.append(((p.shape[2], p.shape[3]), bound, axes[k % 3]))
+    return out
+
+
 def max_over_ranks(seconds, device):
     """bench.py timing rule: the job time is the slowest rank's."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -28,7 +28,7 @@ class _null_ctx:
 
 class FusedStep:
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
-                 tile_capacity=None, spill_capacity=None, shared_decoder=False, overlap=True):
+                 tile_capacity=None, spill_capacity=None, shared_decoder=False, overlap=True, overlap_peers=None):
         """scatter="binned": plane gradients are accumulated per 16x16-cell tile in LDS and Adam is applied
         in the same kernel (csrc/tile_adam.hip; no gradient buffers).  scatter="atomics": global
         atomic adds into persistent gradient buffers + the streaming Adam kernel."""
@@ -38,6 +38,11 @@ class FusedStep:
         # EXTENSION (BASELINE multi-GPU configs; not reference behaviour): agents share one decoder, so the
         # decoder gradient is averaged over all ranks (RCCL all-reduce over xGMI) before its Adam step
         self.shared_decoder = shared_decoder
+        # EXTENSION: [(peer rank, peer plane geometry)] of agents on the same global lattice whose bounds overlap ours:
+        # the plane gradients of the shared region are summed pairwise before Adam (dist.exchange_overlap_gradients)
+        self.overlap_peers = list(overlap_peers or [])
+        if self.overlap_peers and scatter != "atomics":
+            raise ValueError("the overlap-region gradient exchange works on gradient buffers: scatter='atomics'")
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("the fused mapping step needs mneslam_amd.optim.FusedAdam "
                             "(slam_glue.create_optimizer builds it with the reference's groups)")
@@ -128,6 +133,11 @@ class FusedStep:
                 st, grp = optimizer._state(p), self.group_of[p]
                 o = self.plane_opt[k]
                 o.m, o.v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                if os.environ.get("MNE_EXP_TILEMAJOR") == "1":       # layout experiment (profiles/r02_var4.sh): private padded m, v
+                    H, W = p.shape[-2:]
+                    n_pad = ((H + 15) // 16) * ((W + 15) // 16) * 8192
+                    self._exp_mv = getattr(self, "_exp_mv", []) + [torch.zeros(2, n_pad, device=dev)]
+                    o.m, o.v = self._exp_mv[-1][0].data_ptr(), self._exp_mv[-1][1].data_ptr()
                 o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
                 o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
         # exact early ray termination (decode only the samples a ray needs; csrc/render.hip); False = decode everything
@@ -204,7 +214,8 @@ class FusedStep:
                         pl.grad = self.grads[n].data_ptr()
                     if self.bins is not None:
                         st = self.opt._state(p)
-                        self.plane_opt[n].m, self.plane_opt[n].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                        if not hasattr(self, "_exp_mv"):
+                            self.plane_opt[n].m, self.plane_opt[n].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                     n += 1
         w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
         self.scene.w_sdf0, self.scene.w_sdf1 = w_sdf0.data_ptr(), w_sdf1.data_ptr()
@@ -352,6 +363,7 @@ class FusedStep:
             main.wait_event(ev[1])
             self._planes_pending = False
         e0 = self._mark("render")
+        marks = self._render_marks(main)
         _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
                                         P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals),
                                         P(self.ray_counts) if self.early_termination else None, P(self.packed),
@@ -361,6 +373,9 @@ class FusedStep:
                                         P(self.ws), self.ws_bytes, st),
                    "mne_render_fused")
         self._mark("render", e0)
+        if marks:
+            for name, a, b in (("gather_kernel", 0, 1), ("decode_kernel", 1, 2), ("ray_kernel", 2, 3), ("deferred_pass", 3, 4)):
+                self.events.setdefault(name, []).append((marks[a], marks[b]))
         if self.bins is not None:
             # ---- plane update on the side stream
             self._after(side, ev[0], main)
@@ -389,6 +404,11 @@ class FusedStep:
             if self.shared_decoder:
                 from . import dist as mdist
                 mdist.allreduce_mean_(self.dec_grad)
+            if self.overlap_peers:
+                from . import dist as mdist
+                geo = mdist.plane_geometry(self.model)
+                for peer, peer_geo in self.overlap_peers:
+                    mdist.exchange_overlap_gradients(self.grads, geo, peer, peer_geo)
             e0 = self._mark("adam")
             self.opt.step(zero_grad=True, grad_buffers=self.grad_map)
             self._mark("adam", e0)
@@ -414,6 +434,18 @@ class FusedStep:
         if self._planes_pending:
             torch.cuda.current_stream(self.device).wait_event(self._ev[1])
             self._planes_pending = False
+
+    def _render_marks(self, stream):
+        """Five events the next mne_render_fused records between its kernels (mne_profile_marks); each is recorded
+        once here so that the handle exists."""
+        if self.events is None or not self.rays_o.is_cuda or self.bins is None:
+            return None
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        for e in marks:
+            e.record(stream)
+        arr = (C.c_void_p * 5)(*[e.cuda_event for e in marks])
+        _lib.check(self.lib.mne_profile_marks(arr, 5), "mne_profile_marks")
+        return marks
 
     def _mark(self, name, start=None, stream=None):
         """HIP events on the launch stream around one launch (bench.py's live kernel timing)."""

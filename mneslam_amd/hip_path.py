@@ -203,6 +203,42 @@ class RenderFunction(torch.autograd.Function):
                 g_sdf0, g_sdf1, g_col0, g_col1)
 
 
+@torch.no_grad()
+def render_maps(info, tables, rays_o, rays_d, target_d, u, seed_offset, planes, dec_w, early_termination=True):
+    """No-grad rendering of any number of rays in one launch sequence (no autograd node, no tape, no backward
+    workspace): mne_sample_z + mne_pack_decoder + mne_render_forward, by default with exact early ray termination --
+    a ray's samples are decoded only up to the last one that can influence its maps.  Returns rgb [R,3], depth, disp,
+    acc, depth_var [R].  What ``render_img`` / teacher renders / visualisation use."""
+    lib = _lib.load()
+    dev, st = rays_o.device, _lib.stream_for(rays_o)
+    rc = info["render_cfg"]
+    R = rays_o.shape[0]
+    has_d = target_d is not None
+    S = lib.mne_num_samples(C.byref(rc), 1 if has_d else 0)
+    rays_o_c, rays_d_c = _f32c(rays_o.detach(), "rays_o"), _f32c(rays_d.detach(), "rays_d")
+    tgt_d = _f32c(target_d.reshape(-1), "target_d") if has_d else None
+    u_c = _f32c(u, "u")
+    opts = dict(device=dev, dtype=torch.float32)
+    z_vals = torch.empty(R, S, **opts)
+    counts = torch.empty(_lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
+    ray_counts = torch.empty(R, _lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
+    seed, offset = seed_offset
+    _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u_c), _lib.ptr(tables), seed, offset,
+                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), None, st), "mne_sample_z")
+    sc = scene_struct(info, [as_channels_last(p.detach()) for p in planes], [w.detach() for w in dec_w])
+    packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
+    _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
+    rgb, depth = torch.empty(R, 3, **opts), torch.empty(R, **opts)
+    disp, acc, var = torch.empty(R, **opts), torch.empty(R, **opts), torch.empty(R, **opts)
+    raw = torch.empty(R, S, 4, **opts)                  # scratch under early termination
+    _lib.check(lib.mne_render_forward(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o_c), _lib.ptr(rays_d_c), None,
+                                      _lib.ptr(tgt_d), _lib.ptr(z_vals), _lib.ptr(packed), _lib.ptr(rgb), _lib.ptr(depth),
+                                      _lib.ptr(disp), _lib.ptr(acc), _lib.ptr(var), _lib.ptr(raw), None,
+                                      _lib.ptr(ray_counts) if early_termination else None,
+                                      _lib.RENDER_EARLY_TERMINATION if early_termination else 0, st), "mne_render_forward")
+    return rgb, depth, disp, acc, var
+
+
 def query_points(info, planes, dec_w, pts, want_raw=True, want_geo=False, want_feat=False, normalised=False,
                  want_corner_idx=False):
     """Forward-only point query (no autograd): raw [N,4], geo [N,15], feat [N,64]

@@ -143,15 +143,10 @@ class JointEncoding(nn.Module):
             raise KeyError("n_samples")            # the reference raises the same
         tables = hip_path.linspace_tables(self.config, has_d, dev)
         seed_offset = (0, 0)
-        if u is None and self.config["training"]["perturb"] > 0.0:
-            R = rays_o.shape[0]
+        if u is None:
             S = (self.config["training"]["n_range_d"] + self.config["training"]["n_samples_d"]) if has_d \
                 else self.config["training"]["n_samples"]
-            if self.jitter_rng == "torch_cpu":
-                u = torch.rand(R, S).to(rays_o)
-            else:
-                seed_offset = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, self._philox_offset)
-                self._philox_offset += (R * S + 3) // 4
+            u, seed_offset = self._jitter(rays_o.shape[0], S, rays_o)
         return hip_path.RenderFunction.apply(info, tables, rays_o, rays_d, target_rgb, target_d, u, seed_offset,
                                              *planes, *dec_w)
 
@@ -174,8 +169,39 @@ class JointEncoding(nn.Module):
                 "e_fs_loss": losses[L.L_E_FS], "e_center_loss": losses[L.L_E_CENTER],
                 "e_tail_loss": losses[L.L_E_TAIL], "psnr": losses[L.L_PSNR:L.L_PSNR + 1]}
 
+    def _jitter(self, R, S, like):
+        """(u, seed_offset) for R x S samples: the reference's CPU draw, or the device generator's counter."""
+        if self.config["training"]["perturb"] <= 0.0:
+            return None, (0, 0)
+        if self.jitter_rng == "torch_cpu":
+            return torch.rand(R, S).to(like), (0, 0)
+        so = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, self._philox_offset)
+        self._philox_offset += (R * S + 3) // 4
+        return None, so
+
+    def render_maps(self, rays_o, rays_d, target_d=None, u=None):
+        """No-grad fast path of ``render_rays`` for any number of rays at once: {rgb, depth, disp_map, acc_map,
+        depth_var} (no z_vals / raw: with exact early ray termination the samples behind a ray's surface are never
+        decoded).  Same sampling, same maps as ``render_rays``."""
+        dev = rays_o.device
+        has_d = target_d is not None
+        if not has_d and not self.config["training"].get("n_samples"):
+            raise KeyError("n_samples")            # the reference raises the same (SURVEY.md A21)
+        tr = self.config["training"]
+        S = (tr["n_range_d"] + tr["n_samples_d"]) if has_d else tr["n_samples"]
+        seed_offset = (0, 0)
+        if u is None:
+            u, seed_offset = self._jitter(rays_o.shape[0], S, rays_o)
+        planes = [p if p.device == dev else p.to(dev) for p in self._flat_planes()]
+        rgb, depth, disp, acc, var = hip_path.render_maps(self._info(), hip_path.linspace_tables(self.config, has_d, dev), rays_o,
+                                                          rays_d, target_d, u, seed_offset, planes, self.decoder.hip_weights())
+        return {"rgb": rgb, "depth": depth, "disp_map": disp, "acc_map": acc, "depth_var": var}
+
     def render_img(self, c2w, device, gt_depth=None):
-        """reference: scene_rep.py:422-473 (depth is returned as float64, A20)."""
+        """reference: scene_rep.py:422-473 (depth is returned as float64, A20).  The reference walks the image in
+        ``ray_batch_size`` = 4096-ray chunks through ``render_rays``; here the whole frame (816 k rays on Replica) is
+        ONE no-grad launch sequence (``render_chunk_rays`` bounds the scratch for very large frames).  With
+        ``jitter_rng == "torch_cpu"`` the jitter is drawn chunk by chunk exactly like the reference does."""
         with torch.no_grad():
             cam = self.config["cam"]
             H, W = cam["H"] - 2 * cam["crop_edge"], cam["W"] - 2 * cam["crop_edge"]
@@ -183,10 +209,19 @@ class JointEncoding(nn.Module):
             rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
             if gt_depth is not None:
                 gt_depth = gt_depth.reshape(-1).unsqueeze(1).to(device)
+            n = rays_d.shape[0]
+            tr = self.config["training"]
+            S = (tr["n_range_d"] + tr["n_samples_d"]) if gt_depth is not None else tr.get("n_samples")
             depths, colors = [], []
-            for i in range(0, rays_d.shape[0], self.ray_batch_size):
-                sl = slice(i, i + self.ray_batch_size)
-                ret = self.render_rays(rays_o[sl], rays_d[sl], target_d=None if gt_depth is None else gt_depth[sl])
+            step = getattr(self, "render_chunk_rays", 1 << 20)
+            for i in range(0, n, step):
+                sl = slice(i, min(i + step, n))
+                u = None
+                if tr["perturb"] > 0.0 and self.jitter_rng == "torch_cpu" and S:
+                    # the reference's draws: one torch.rand(chunk, S) per 4096-ray chunk, in order
+                    u = torch.cat([torch.rand(min(self.ray_batch_size, sl.stop - j), S)
+                                   for j in range(sl.start, sl.stop, self.ray_batch_size)], 0).to(device)
+                ret = self.render_maps(rays_o[sl], rays_d[sl], None if gt_depth is None else gt_depth[sl], u=u)
                 depths.append(ret["depth"].double())
                 colors.append(ret["rgb"])
             return torch.cat(depths, 0).reshape(H, W), torch.cat(colors, 0).reshape(H, W, 3)

@@ -1,53 +1,42 @@
-"""Small host utilities with the reference's names (model/utils.py).  Tensor plumbing only; the
-per-sample math of the hot path lives in the HIP kernels."""
-import numpy as np
+"""Host-side helpers of the scene model: ray generation for whole images and the two normalisations of a point.
+Names follow the reference's model/utils.py because callers of the scene model import them from there; the per-sample
+math of the hot path does not live here (it is in the HIP kernels)."""
 import torch
-import torch.nn.functional as F
+
+
+def pixel_directions(H, W, fx, fy, cx, cy, device="cpu"):
+    """Camera-frame direction of every pixel, [H, W, 3], OpenGL convention: x right, y up, looking down -z; NOT
+    normalised, so that a sample at parameter z lies at image depth z."""
+    u = torch.arange(W, dtype=torch.float32, device=device).expand(H, W)
+    v = torch.arange(H, dtype=torch.float32, device=device).unsqueeze(1).expand(H, W)
+    return torch.stack([(u - cx) / fx, -(v - cy) / fy, torch.full((H, W), -1.0, device=device)], dim=-1)
 
 
 def get_rays(H, W, fx, fy, cx, cy, c2w, device):
-    """Whole-image rays (reference: model/utils.py:7-25).  Returns rays_o, rays_d [H,W,3]."""
-    if isinstance(c2w, np.ndarray):
-        c2w = torch.from_numpy(c2w)
-    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
-    i, j = i.t(), j.t()
-    dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1).to(device)
-    rays_d = torch.sum(dirs.reshape(H, W, 1, 3) * c2w[:3, :3], -1)
-    rays_o = c2w[:3, -1].expand(rays_d.shape)
-    return rays_o, rays_d
+    """Origins and world-frame directions of all H x W pixel rays of a camera with pose ``c2w`` (tensor or ndarray):
+    two [H, W, 3] tensors (reference: model/utils.py:7-25)."""
+    c2w = torch.as_tensor(c2w).to(device=device, dtype=torch.float32)
+    dirs = pixel_directions(H, W, fx, fy, cx, cy, device)
+    rays_d = (dirs.unsqueeze(-2) * c2w[:3, :3]).sum(-1)          # R @ d, accumulated in the reference's order
+    return c2w[:3, 3].expand_as(rays_d), rays_d
 
 
 def normalize_3d_coordinate(p, bound):
-    """[-1,1] normalisation with the extended bound (reference: model/utils.py:27-41)."""
+    """Points -> [-1, 1]^3 of the (extended) bound, the plane-lookup coordinates (reference: model/utils.py:27-41).
+    Returns a new [N, 3] tensor."""
     p = p.reshape(-1, 3)
-    out = torch.empty_like(p)
-    for k in range(3):
-        out[:, k] = ((p[:, k] - bound[k, 0]) / (bound[k, 1] - bound[k, 0])) * 2 - 1.0
-    return out
-
-
-def mse2psnr(x):
-    """reference: model/utils.py:43-47"""
-    return -10.0 * torch.log(x) / torch.log(torch.Tensor([10.0])).to(x)
+    lo, hi = bound[:, 0].to(p), bound[:, 1].to(p)
+    return ((p - lo) / (hi - lo)) * 2 - 1.0
 
 
 def batchify(fn, chunk=1024 * 64):
-    """reference: model/utils.py:106-115 (``chunk=None`` returns ``fn`` itself)."""
+    """``fn`` applied in chunks of ``chunk`` rows and concatenated; ``chunk=None`` hands ``fn`` back unchanged (which is
+    how the decoder's sub-networks end up registered twice in the scene model's state_dict)."""
     if chunk is None:
         return fn
 
-    def ret(inputs, inputs_dir=None):
-        if inputs_dir is not None:
-            return torch.cat([fn(inputs[i:i + chunk], inputs_dir[i:i + chunk])
-                              for i in range(0, inputs.shape[0], chunk)], 0)
-        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
-    return ret
-
-
-def compute_loss(prediction, target, loss_type="l2"):
-    """reference: model/utils.py:147-162"""
-    if loss_type == "l2":
-        return F.mse_loss(prediction, target)
-    if loss_type == "l1":
-        return F.l1_loss(prediction, target)
-    raise Exception("Unsupported loss type")
+    def chunked(*tensors):
+        n = tensors[0].shape[0]
+        parts = [fn(*[t[i:i + chunk] for t in tensors if t is not None]) for i in range(0, n, chunk)]
+        return torch.cat(parts, 0)
+    return chunked

@@ -39,10 +39,12 @@ inline float4 make_float4(float a, float b, float c, float d) { return float4{a,
 inline float2 make_float2(float a, float b) { return float2{a, b}; }
 
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
 typedef int hipError_t;
 #define hipSuccess 0
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return 0; }
 #define hipMemcpyHostToDevice 1

@@ -832,3 +832,101 @@ def check_device_clock(device):
     bad = _lib.Clock(); bad.iteration = clk_iter.data_ptr(); bad.step_offset = clk_step.data_ptr(); bad.bias_table = table.data_ptr()
     bad.n_table, bad.beta1, bad.beta2 = n_table, 0.8, b2
     assert lib.mne_adam_step(arr, 1, 0, C.byref(bad), st) < 0 and b"betas" in lib.mne_last_error()
+
+
+def check_render_maps_fast_path(device):
+    """N1: the no-grad fast path (one launch sequence, exact early ray termination) gives the maps of render_rays --
+    without depth guidance against the reference's golden render, with depth guidance against the full render of the
+    same model; render_img walks a whole frame through it (chunked and unchunked runs must agree bit for bit)."""
+    g = load_golden("render_nodepth")
+    cfg = configs.small_test_config()
+    m = model_from_golden(g, cfg, device).eval()
+    rays_o, rays_d, rgb, d, U = to_dev(fixture_inputs(g), device)
+    out = m.render_maps(rays_o, rays_d, target_d=None, u=U)
+    assert_close(out["rgb"].cpu(), g["rr.rgb"], rtol=1e-4, atol=1e-5, what="rgb (early termination)")
+    assert_close(out["depth"].cpu(), g["rr.depth"], rtol=1e-4, atol=1e-5, what="depth (early termination)")
+    assert_close(out["acc_map"].cpu(), g["rr.acc_map"], rtol=1e-4, atol=1e-5, what="acc")
+    assert_close(out["depth_var"].cpu(), g["rr.depth_var"], rtol=1e-3, atol=1e-5, what="depth_var")
+    assert_close(out["disp_map"].cpu(), g["rr.disp_map"], rtol=1e-4, atol=1e-5, what="disp")
+    # depth-guided: fast path == full render of the same model, bit for bit (same kernels, fewer samples decoded)
+    g2 = load_golden("fwd_onegrid")
+    m2 = model_from_golden(g2, cfg, device).eval()
+    ro, rd, _, dd, U2 = to_dev(fixture_inputs(g2), device)
+    full = m2._render(ro, rd, None, dd, u=U2)
+    fast = m2.render_maps(ro, rd, target_d=dd, u=U2)
+    assert torch.equal(full[0].detach(), fast["rgb"]) and torch.equal(full[1].detach(), fast["depth"])
+    assert torch.equal(full[3].detach(), fast["acc_map"])
+    # whole frame through render_img: chunked like the reference vs one launch sequence
+    cfg3 = configs.small_test_config()
+    cfg3["cam"].update(H=12, W=16, fx=16.0, fy=16.0, cx=8.0, cy=6.0, crop_edge=0)
+    m3 = model_from_golden(g, cfg3, device).eval()
+    c2w = torch.eye(4)
+    c2w[:3, 3] = torch.tensor([0.1, -0.1, 0.0])
+    m3.ray_batch_size = 50
+    torch.manual_seed(3)
+    d_a, c_a = m3.render_img(c2w.to(device), device, gt_depth=None)
+    m3.render_chunk_rays = 64
+    torch.manual_seed(3)
+    d_b, c_b = m3.render_img(c2w.to(device), device, gt_depth=None)
+    assert d_a.dtype == torch.float64 and d_a.shape == (12, 16) and c_a.shape == (12, 16, 3)
+    assert torch.equal(d_a, d_b) and torch.equal(c_a, c_b)
+    # and equal to the reference's own chunk loop over render_rays (same CPU jitter draws, same order)
+    from mneslam_amd.model.utils import get_rays
+    ro3, rd3 = get_rays(12, 16, 16.0, 16.0, 8.0, 6.0, c2w.to(device), device)
+    ro3, rd3 = ro3.reshape(-1, 3), rd3.reshape(-1, 3)
+    torch.manual_seed(3)
+    ref_d = torch.cat([m3.render_rays(ro3[i:i + 50], rd3[i:i + 50], target_d=None)["depth"] for i in range(0, 192, 50)])
+    assert_close(d_a.reshape(-1).float().cpu(), ref_d.detach().cpu(), rtol=1e-5, atol=1e-6, what="render_img vs chunked render_rays")
+
+
+def quality_trajectory(device, cfg, n_iters=40, n_keyframes=4, seed=5, small=True):
+    """Matched-quality evidence: the fused path and the oracle start from the same parameters and are
+    trained on IDENTICAL batches -- every iteration the device draws the rays and the jittered z samples, the oracle
+    (CPU autograd + written-out Adam) is fed the very same rays / targets / samples.  Returns per-iteration PSNR and
+    depth-L1 (mean |depth - d| over rays with 0 < d < depth_trunc) of both."""
+    import bench
+    dev = torch.device(device)
+    ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, small=small, path="fused", scatter="binned")
+    fs, m = ag.fused, ag.model
+    cpu = lambda t: t.detach().to("cpu", copy=True)
+    sc = OracleScene(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64), build=False)
+    sc.all_planes = tuple([cpu(p).contiguous() for p in lst] for lst in m.all_planes)
+    sd = {k: cpu(v) for k, v in m.decoder.state_dict().items()}
+    sc.col_w = [sd["color_net.model.0.weight"], sd["color_net.model.2.weight"]]
+    sc.sdf_w = [sd["sdf_net.model.0.weight"], sd["sdf_net.model.2.weight"]]
+    sc.requires_grad_(True)
+    opt = omap.OracleAdam(sc, cfg)
+    rows = []
+    for it in range(n_iters):
+        ag.step()
+        fs.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        rays_o, rays_d, tgt_rgb, tgt_d, z = cpu(fs.rays_o), cpu(fs.rays_d), cpu(fs.tgt_rgb), cpu(fs.tgt_d), cpu(fs.z_vals)
+        valid = (tgt_d > 0) & (tgt_d < cfg["cam"]["depth_trunc"])
+        L = cpu(fs.losses)
+        hip = (float(L[7]), float((cpu(fs.depth) - tgt_d)[valid].abs().mean()))
+        opt.zero_grad()
+        ret = sc.forward(rays_o, rays_d, tgt_rgb, tgt_d[:, None], impl="grid_sample", z_vals=z)
+        omap.loss_from_ret(cfg, ret, is_co_sdf=cfg["is_co_sdf"]).backward()
+        opt.step()
+        ora = (float(ret["psnr"].detach()), float((ret["depth"].detach() - tgt_d)[valid].abs().mean()))
+        rows.append((it, hip[0], ora[0], hip[1], ora[1]))
+    return rows
+
+
+def check_quality_trajectory(device, n_iters=30):
+    cfg = configs.bench_office0(n_range_d=9, n_samples_d=20)
+    cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
+    cfg["mapping"]["sample"], cfg["mapping"]["min_pixels_cur"] = 256, 32
+    cfg["cam"]["far"] = 4.0
+    rows = quality_trajectory(device, cfg, n_iters=n_iters)
+    # same batches, same start: the two trajectories coincide to rounding for the first iterations and stay within a
+    # small band afterwards (Adam with eps = 1e-15 amplifies fp32 summation-order noise on cells with tiny gradients)
+    for it, p_h, p_o, d_h, d_o in rows[:3]:
+        assert abs(p_h - p_o) < 1e-3 and abs(d_h - d_o) < 1e-4 * max(1.0, d_o), (it, p_h, p_o, d_h, d_o)
+    for it, p_h, p_o, d_h, d_o in rows:
+        assert abs(p_h - p_o) < 0.05 + 0.01 * abs(p_o) and abs(d_h - d_o) < 0.02 * max(d_o, 0.05), (it, p_h, p_o, d_h, d_o)
+    assert rows[-1][1] > rows[0][1] + 1.0, "PSNR did not improve"
+    return rows

@@ -54,6 +54,32 @@ def _worker(rank, world, port, ret):
     g = torch.full((6208,), float(rank + 1))
     mdist.allreduce_mean_(g)
     assert torch.allclose(g, torch.full((6208,), 1.5))
+    # 3b) overlap-region plane gradients (extension): two agents on one global lattice, 0.4 m apart along x
+    from mneslam_amd import dist as md
+    gb = [[-1.0, 1.4], [-1.2, 1.2], [-0.8, 0.8]]
+    b0, b1 = md.aligned_agent_bounds(gb, 2, axis=0, overlap=0.4, cell=0.2)
+    assert b0[0][0] == -1.0 and b1[0][1] == pytest.approx(1.4) and b0[0][1] > b1[0][0]
+    mine_b, peer_b = (b0, b1) if rank == 0 else (b1, b0)
+
+    def geom(bnd, res):                      # planes that span `bnd` with node spacing `res` (xy, xz, yz)
+        n = [int(round((hi - lo) / res)) + 1 for lo, hi in bnd]
+        return [((n[1], n[0]), bnd, (0, 1)), ((n[2], n[0]), bnd, (0, 2)), ((n[2], n[1]), bnd, (1, 2))]
+    my_geo, peer_geo = geom(mine_b, 0.1), geom(peer_b, 0.1)
+    gen = torch.Generator().manual_seed(5 + rank)
+    grads = [torch.randn(1, 4, *shape, generator=gen) for shape, _, _ in my_geo]
+    before = [g_.clone() for g_ in grads]
+    torch.save(before, ret + f".g{rank}")
+    md.exchange_overlap_gradients(grads, my_geo, 1 - rank, peer_geo)
+    dist.barrier()
+    other = torch.load(ret + f".g{1 - rank}")
+    for g_, b_, o_, (shape, bnd, axes), (pshape, pbnd, _) in zip(grads, before, other, my_geo, peer_geo):
+        (ys, xs), (pys, pxs) = md.overlap_slices(bnd, pbnd, shape, pshape, axes)
+        assert (xs.stop - xs.start) * (ys.stop - ys.start) > 0
+        exp = b_.clone()
+        exp[:, :, ys, xs] += o_[:, :, pys, pxs]
+        assert torch.equal(g_, exp)
+    with pytest.raises(ValueError):          # a peer whose lattice is shifted by half a cell is refused
+        md.overlap_slices([[0.0, 1.0]] * 3, [[0.05, 1.05]] * 3, (11, 11), (11, 11), (0, 1))
     # 4) timing rule
     assert mdist.max_over_ranks(0.1 * (rank + 1), dev) == pytest.approx(0.2)
     dist.destroy_process_group()

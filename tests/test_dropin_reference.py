@@ -221,6 +221,19 @@ def test_keyframe_database_matches_reference(ref):
             assert torch.equal(torch.as_tensor(u).double(), torch.as_tensor(v).double())
 
 
+def test_ray_helpers_match_reference(ref):
+    """get_rays / normalize_3d_coordinate of this repository (own implementations) == the reference's, bit for bit."""
+    from model import utils as ref_utils
+    from mneslam_amd.model import utils as repo_utils
+    c2w = torch.randn(4, 4, generator=torch.Generator().manual_seed(1))
+    for H, W, fx, fy, cx, cy in [(680, 1200, 600.0, 600.0, 599.0, 339.0), (460, 620, 577.0, 578.0, 308.0, 232.0), (12, 16, 16.0, 16.0, 8.0, 6.0)]:
+        a, b = ref_utils.get_rays(H, W, fx, fy, cx, cy, c2w, "cpu"), repo_utils.get_rays(H, W, fx, fy, cx, cy, c2w, "cpu")
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    p = torch.randn(100, 3)
+    bound = torch.tensor([[-3.0, 3.02], [-4.0, 2.52], [-2.0, 2.52]])
+    assert torch.equal(ref_utils.normalize_3d_coordinate(p.clone(), bound), repo_utils.normalize_3d_coordinate(p, bound))
+
+
 def test_state_dict_keys_and_plane_shapes_match_reference(ref):
     """same state_dict keys / shapes (incl. the duplicated color_net / sdf_net aliases and the empty
     embedpos_fn.params) and the same logical plane shapes as the reference's JointEncoding, for both grid modes."""

@@ -93,6 +93,15 @@ def test_device_clock():
     pc.check_device_clock(DEV)
 
 
+def test_quality_trajectory_matches_oracle_on_identical_batches():
+    """Matched PSNR / depth-L1: fused path vs oracle trained on the batches the device drew."""
+    pc.check_quality_trajectory(DEV, n_iters=30)
+
+
+def test_render_maps_fast_path_and_render_img():
+    pc.check_render_maps_fast_path(DEV)
+
+
 def test_graph_replay_matches_eager_launches():
     """The recorded iteration (one hipGraphLaunch per step, iteration / Adam step from the device clock) against the
     same steps launched one by one: identical ray batches and z samples (bit for bit), same parameters up to the
@@ -350,3 +359,34 @@ def test_baseline_config_shapes_full_batch_properties(workload):
     assert all(x == x and x < 1e4 for x in hist["binned"])          # finite (every iteration draws a different batch)
     for x, y in zip(hist["binned"], hist["atomics"]):
         assert abs(x - y) <= 1e-3 * abs(y)
+
+
+def test_rccl_branch_single_rank():
+    """The RCCL (backend "nccl") branch of the multi-agent plumbing on a real GPU, world size 1: process-group set-up of
+    dist.init_agents, a collective on a device tensor, the pose gather and bench.py's timing rule.  (8-GPU runs are the
+    driver's; the 2-agent logic is covered on CPU with gloo.)"""
+    import os
+    import torch.distributed as dist
+    from mneslam_amd import dist as mdist
+    env = {k: os.environ.get(k) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    try:
+        world = int(os.environ["WORLD_SIZE"])
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=world, device_id=dev)
+        g = torch.full((6208,), 3.0, device=dev)
+        dist.all_reduce(g)                                   # 24.8 KB decoder-gradient buffer through RCCL
+        mdist.allreduce_mean_(g)
+        assert torch.equal(g, torch.full_like(g, 3.0))
+        poses = mdist.gather_keyframe_poses(torch.eye(4, device=dev)[None], torch.arange(1))
+        assert len(poses) == 1 and poses[0][0].shape == (1, 4, 4)
+        assert mdist.max_over_ranks(0.25, dev) == pytest.approx(0.25)
+        dist.barrier()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -84,6 +84,10 @@ def test_device_clock():
     pc.check_device_clock(DEV)
 
 
+def test_render_maps_fast_path_and_render_img():
+    pc.check_render_maps_fast_path(DEV)
+
+
 def test_corner_indices_bit_exact():
     pc.check_corner_indices(DEV, "fwd_onegrid")
 
