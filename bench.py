@@ -30,8 +30,9 @@ if REPO not in sys.path:
 
 from mneslam_amd import configs, slam_glue, synthetic  # noqa: E402
 from mneslam_amd.model.keyframe import KeyFrameDatabase  # noqa: E402
-from mneslam_amd.fused import FusedStep  # noqa: E402
+from mneslam_amd.fused import FusedStep, HashFusedStep  # noqa: E402
 from mneslam_amd.model.scene_rep import JointEncoding  # noqa: E402
+from mneslam_amd.model.scene_rep_hash import HashJointEncoding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
@@ -45,7 +46,7 @@ def parse_args():
     ap.add_argument("--config", default="office0", choices=sorted(configs.WORKLOADS),
                     help="workload (mneslam_amd/configs.py::WORKLOADS): office0 = BASELINE configs[1] as wired (the metric's "
                          "configuration, default); apartment / scannet / indoor = the single-agent shapes of configs[2..4]")
-    ap.add_argument("--hidden", type=int, default=32, choices=[32, 64])
+    ap.add_argument("--hidden", type=int, default=None, choices=[32, 64], help="decoder width (default: the workload's own)")
     ap.add_argument("--path", default="fused", choices=["fused", "autograd"],
                     help="fused = FusedStep + device sampler (default); autograd = the reference's call sequence")
     ap.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
@@ -89,15 +90,22 @@ class Agent:
         self.cur_rays = torch.cat([cur["direction"], cur["rgb"], cur["depth"][..., None]], -1).reshape(-1, 7).to(device)
         self.poses = torch.stack([f["c2w"] for f in frames]).to(device)          # [n_kf+1,4,4]; last = current
         bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64, device=device)
-        self.model = JointEncoding(cfg, bb).to(device).train()
+        self.hash = cfg.get("scene_encoding") == "hash"
+        self.model = (HashJointEncoding if self.hash else JointEncoding)(cfg, bb).to(device).train()
         self.model.jitter_rng = "device"
         self.opt = slam_glue.create_optimizer(self.model, cfg)
         self.n_cur = max(cfg["mapping"]["sample"] // n_keyframes, cfg["mapping"]["min_pixels_cur"])
-        self.n_plane_params = sum(p.numel() for lst in self.model.all_planes for p in lst)
+        self.n_plane_params = (self.model.embed_fn.params.numel() if self.hash
+                               else sum(p.numel() for lst in self.model.all_planes for p in lst))
         self.n_dec_params = sum(p.numel() for p in self.model.decoder.parameters())
         self.last = None
         self.fused = None
-        if path == "fused":
+        if self.hash:
+            if path != "fused":
+                raise SystemExit("the hash-grid workload runs the fused step only")
+            self.fused = HashFusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device)
+            self.fused.seed = seed
+        elif path == "fused":
             self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device,
                                    scatter=scatter, shared_decoder=share_decoder,
                                    overlap=overlap and os.environ.get("MNE_NO_OVERLAP", "0") != "1")
@@ -159,7 +167,18 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0):
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(seed)
     bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
-    sc = OracleScene(cfg, bb, generator=gen).requires_grad_(True)
+    if cfg.get("scene_encoding") == "hash":
+        from oracle import hashgrid
+        from oracle.scene_rep import OracleHashScene, make_decoder_weights
+        grid = dict(n_levels=16, n_features=2, base_resolution=16, log2_hashmap_size=cfg["grid"]["hash_size"],
+                    per_level_scale=float(2.0 ** (math.log2(cfg["grid"].get("desired_resolution", 512) / 16) / 15)))
+        table = (torch.rand(hashgrid.n_params(**grid), generator=gen) * 2 - 1) * 1e-4
+        sc = OracleHashScene(cfg, bb, table, grid)
+        cfg_dec = dict(cfg, model=dict(cfg["model"], input_ch=64))
+        sc.sdf_w, sc.col_w = make_decoder_weights(type(sc.pc).from_dict(cfg_dec), gen)
+        sc.requires_grad_(True)
+    else:
+        sc = OracleScene(cfg, bb, generator=gen).requires_grad_(True)
     opt = omap.OracleAdam(sc, cfg)
     n = cfg["mapping"]["sample"] + max(cfg["mapping"]["sample"] // n_keyframes, cfg["mapping"]["min_pixels_cur"])
     frames = synthetic.make_frames(1, 68, 120, 60.0, 60.0, 59.0, 33.0, synthetic.OFFICE0_ROOM, seed=seed)
@@ -243,7 +262,8 @@ def main():
     rank, world, device = mdist.init_agents()          # one process per GPU; RCCL when WORLD_SIZE > 1
     import torch.distributed as dist
     make_cfg, workload = configs.WORKLOADS[args.config]
-    cfg = make_cfg(args.hidden)
+    cfg = make_cfg(args.hidden) if args.hidden else make_cfg()
+    args.hidden = cfg["decoder"]["hidden_dim"]
     if args.small:
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
@@ -288,7 +308,15 @@ def main():
         binned = agent.fused is not None and agent.fused.bins is not None
         p_contrib = float(agent.fused.tape_rows.item()) if agent.fused is not None else float(R * S)
         decoded = float((agent.fused.ray_tiles[:R].long() * 32).clamp(max=S).sum().item()) if agent.fused is not None else float(R * S)
-        if binned:
+        if agent.hash:
+            # hash grid: 16 levels x 8 corners x 2 features x 4 B = 1,024 B per point per gather or scatter pass
+            Gh = agent.model.embed_fn.cfg.n_levels * 8 * agent.model.embed_fn.cfg.n_features * 4.0
+            alg = {"hash_gather": R * S * Gh, "hash_scatter": p_contrib * Gh, "adam": 32.0 * n_par, "render": 0.0}
+            kern = {"hash_gather": "hash_rows_kernel<false> (grid gather into the tape)", "hash_scatter": "hash_rows_kernel<true> (atomic scatter)",
+                    "adam": "adam_kernel (table + decoder, one launch)", "wgrad": "wgrad kernels",
+                    "render": "whole mne_render_fused_features call (decode + ray kernels; MFMA / latency, no algorithmic HBM bytes)"}
+            alg["iteration"] = alg["hash_gather"] + alg["hash_scatter"] + alg["adam"]
+        elif binned:
             alg = {"adam": p_contrib * G + 32.0 * n_par, "gather_kernel": decoded * G, "render": decoded * G}
             kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)", "gather_kernel": "gather_kernel",
                     "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
@@ -300,7 +328,7 @@ def main():
                     "render": "whole mne_render_fused call (gather + decode + ray kernels, atomic scatter)"}
         # the dominant KERNEL = the longest live-measured single launch (the bracket around the whole render call is
         # reported beside it, not as a kernel, when its kernels are timed individually)
-        single = {k: v for k, v in avg_ms.items() if not (k == "render" and "gather_kernel" in avg_ms)}
+        single = {k: v for k, v in avg_ms.items() if not (k == "render" and ("gather_kernel" in avg_ms or agent.hash))}
         dom = max(single, key=single.get) if single else "adam"
         dom_ms = avg_ms.get(dom, 0.0)
         achieved = alg.get(dom, 0.0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -327,7 +355,8 @@ def main():
             "config": {"workload": workload + ("_SMALL" if args.small else ""),
                        "rays_per_iter": R, "samples_per_ray": S, "plane_params": agent.n_plane_params,
                        "decoder_params": agent.n_dec_params, "mlp_hidden": args.hidden, "keyframes": args.keyframes,
-                       "frame": f"{agent.W}x{agent.H}", "path": args.path, "scatter": args.scatter if args.path == "fused" else "atomics", "agents": world,
+                       "frame": f"{agent.W}x{agent.H}", "path": args.path, "scatter": "hash-atomics" if agent.hash else args.scatter if args.path == "fused" else "atomics", "agents": world,
+                       "encoding": "hash grid (parity unpinned: tinycudann is not in the reference tree)" if agent.hash else "tri-planes (as wired)",
                        "parallelism": f"agent-per-gpu x{world}, " + ("decoder-gradient all-reduce (extension)" if args.share_decoder
                                                                      else "no data-path collective")},
             "psnr_last_iter": psnr, "depth_l1_last_iter": depth_l1,
@@ -339,9 +368,9 @@ def main():
                          "contributing_samples_last_iter": p_contrib, "gathered_samples_last_iter_lower_bound": decoded,
                          "nominal_samples": float(R * S),
                          "other_kernels_avg_ms": {kern[k]: v for k, v in avg_ms.items() if k != dom},
-                         "other_kernels_algorithmic_bytes": {kern[k]: alg[k] for k in alg if k != dom and k != "render"},
-                         "iteration_algorithmic_bytes": alg["adam"] + alg["render"],
-                         "iteration_hbm_frac": (alg["adam"] + alg["render"]) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "other_kernels_algorithmic_bytes": {kern[k]: alg[k] for k in alg if k != dom and k not in ("render", "iteration")},
+                         "iteration_algorithmic_bytes": alg.get("iteration", alg["adam"] + alg["render"]),
+                         "iteration_hbm_frac": alg.get("iteration", alg["adam"] + alg["render"]) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, args.keyframes, args.cpu_iters)

@@ -225,6 +225,7 @@ int mne_loss_coef(const mne_render_cfg_t* cfg, int n_rays, int n_samples, const 
 /* ---- backward of R4-R10 (+R13) ----------------------------------------------------------- */
 /* Floats per tape row (one row per SAMPLE: row = ray * n_samples + sample). */
 size_t mne_tape_row_floats(const mne_scene_t* scene);
+size_t mne_tape_dfeat_offset(const mne_scene_t* scene);    /* column of the d(feature) half of a row ([64 * n_sets] floats) */
 /* Replaces loss.backward() through the graph built by JointEncoding.forward
  * (mp_slam/mapper.py:159): accumulates plane gradients into scene->plane[..].grad (atomic adds,
  * buffers must be zeroed by the caller / the fused Adam; ALL grad pointers NULL = no plane gradients
@@ -328,6 +329,30 @@ int mne_grid_encode(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, co
 /* d(params) += scatter of dout [N][n_levels*n_features] (dparams pre-zeroed by the caller) */
 int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, const float* dout,
                              float* dparams, void* stream);
+
+/* ---- NS-a: the mapping iteration with a multiresolution hash grid as the scene encoding (Co-SLAM wiring, the call the
+ * reference keeps commented out at model/scene_rep.py:160,243,250; parity unpinned like the encoding itself) ---------
+ * The decoder, compositing, losses and their backward are the tri-plane path's kernels: the feature half of a tape row
+ * ([64] floats at column 0 of row ray*n_samples + sample) is filled by mne_hash_gather -- the grid's n_levels*2 features,
+ * the remaining columns stay zero -- instead of by the plane gather, and the 64-wide first decoder layer simply has dead
+ * input columns.  One iteration:
+ *   mne_hash_gather            x = (o + d*z - bb_lo) / (bb_hi - bb_lo) per sample (the OneBlob input), 8 corners x 16 levels
+ *   mne_render_fused_features  = mne_render_fused without plane gather / scatter and without early termination; the
+ *                                d(feature) rows of every sample of the first ray_tiles[r] tiles of ray r are left in the
+ *                                tape (column mne_tape_dfeat_offset)
+ *   mne_hash_scatter           grad_table += w * d(feature)  (global_atomic_add_f32; grad_table zeroed by the caller)
+ *   mne_decoder_wgrad, mne_adam_step (table + decoder segments, zero_grad fused)
+ * scene: bounding box, decoder dims and weights are read; the plane descriptors are ignored.  cfg: n_features 2, <= 16 levels. */
+int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                    const float* rays_d, const float* z_vals, const float* table, float* tape, void* stream);
+int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                              const float* rays_o, const float* rays_d, const float* target_rgb, const float* target_d,
+                              const float* z_vals, const float* packed_decoder, const float* coef, float* rgb, float* depth,
+                              float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                              int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream);
+int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                     const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles,
+                     float* grad_table, void* stream);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,7 @@ _PROTOS = {
     "mne_loss_finalize": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_loss_coef": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_tape_row_floats": (C.c_size_t, [C.POINTER(Scene)]),
+    "mne_tape_dfeat_offset": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_render_backward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 12
                             + [C.c_int64] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
     "mne_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -113,6 +114,10 @@ _PROTOS = {
     "mne_grid_encode": (C.c_int, [C.POINTER(GridCfg), C.c_int64] + [C.c_void_p] * 5),
     "mne_grid_encode_backward": (C.c_int, [C.POINTER(GridCfg), C.c_int64] + [C.c_void_p] * 4),
     "mne_encode_oneblob": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_hash_gather": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "mne_render_fused_features": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 12
+                                  + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mne_hash_scatter": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 7),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -57,6 +57,18 @@ def bench_office0(n_range_d=32, n_samples_d=96, hidden=32):
     return cfg
 
 
+def bench_office0_hash(hidden=64, hash_size=19, desired_resolution=512):
+    """BASELINE.json configs[1] in its LITERAL form (SURVEY.md section 8d, C2 as-north-star): the factory defaults of
+    ``get_encoder('HashGrid')`` (model/encodings.py:6-10: 16 levels x 2 features, base 16, T = 2^19, finest 512:
+    10,492,048 table entries' floats) + 2x64 MLPs, 2048 global rays x 128 samples.  ``scene_encoding: hash`` selects
+    the wiring the reference keeps commented out (model/scene_rep.py:160); ``grid.hash_size`` is then a live key."""
+    cfg = bench_office0(hidden=hidden)
+    cfg["scene_encoding"] = "hash"
+    cfg["grid"]["hash_size"] = hash_size
+    cfg["grid"]["desired_resolution"] = desired_resolution
+    return cfg
+
+
 def _overlay(base, over):
     for k, v in over.items():
         if isinstance(v, dict) and isinstance(base.get(k), dict):
@@ -139,6 +151,7 @@ WORKLOADS = {
     "apartment": (lambda hidden=32: _overlay(apartment_agent(1), {"decoder": {"hidden_dim": hidden, "hidden_dim_color": hidden}}),
                   "replica_apart1_agent1_triplane_2048x43"),
     "scannet": (lambda hidden=32: scannet_scene0000(hidden), "scannet_scene0000_colorplanes_2048x117"),
+    "office0_hash": (lambda hidden=64: bench_office0_hash(hidden=hidden), "replica_office0_hashT19_2x64_2048x128"),
     "indoor": (lambda hidden=32: _overlay(indoor_agent(0), {"decoder": {"hidden_dim": hidden, "hidden_dim_color": hidden}}),
                "ins_indoor_agent0_triplane_2048x1045"),
 }

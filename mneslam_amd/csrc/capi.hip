@@ -39,7 +39,7 @@ static int check_launch(const char* what) {
     return 0;
 }
 
-static int check_scene(const mne_scene_t* sc, bool need_grad) {
+static int check_scene(const mne_scene_t* sc, bool need_grad, bool need_planes = true) {
     if (!sc) return fail(-1, "scene is NULL");
     if (sc->n_sets != 1 && sc->n_sets != 2) return fail(-1, "n_sets must be 1 (oneGrid) or 2 (with colour planes)");
     if (sc->c_dim != 32) return fail(-1, "model.c_dim must be 32 in this build");
@@ -47,7 +47,7 @@ static int check_scene(const mne_scene_t* sc, bool need_grad) {
     if (sc->geo_feat_dim != 15) return fail(-1, "decoder.geo_feat_dim must be 15 in this build");
     if (!((sc->hidden == 32 && sc->hidden_color == 32) || (sc->hidden == 64 && sc->hidden_color == 64)))
         return fail(-2, "decoder hidden_dim/hidden_dim_color must both be 32 or both 64 in this build");
-    for (int s = 0; s < sc->n_sets; ++s)
+    for (int s = 0; need_planes && s < sc->n_sets; ++s)
         for (int o = 0; o < 3; ++o)
             for (int l = 0; l < 2; ++l) {
                 const mne_plane_t& p = sc->plane[s][o][l];
@@ -130,13 +130,14 @@ int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d,
 
 size_t mne_packed_decoder_floats(const mne_scene_t* scene) { return scene ? mne_dims_packed(*scene) : 0; }
 size_t mne_tape_row_floats(const mne_scene_t* scene) { return scene ? mne_dims_tape_row(*scene) : 0; }
+size_t mne_tape_dfeat_offset(const mne_scene_t* scene) { return scene ? mne_dims_tape_dfeat(*scene) : 0; }
 size_t mne_decoder_param_floats(const mne_scene_t* scene) { return scene ? mne_dims_nparam(*scene) : 0; }
 size_t mne_wgrad_partial_floats(const mne_scene_t* scene) {
     return scene ? mne_dims_nparam(*scene) * (size_t)mne_wgrad_waves() : 0;
 }
 
 int mne_pack_decoder(const mne_scene_t* scene, float* packed, void* stream) {
-    if (int rc = check_scene(scene, false)) return rc;
+    if (int rc = check_scene(scene, false, false)) return rc;
     if (!packed) return fail(-1, "mne_pack_decoder: packed is NULL");
     if (int rc = mne_launch_pack(*scene, packed, (hipStream_t)stream)) return fail(rc, "unsupported decoder shape");
     return check_launch("pack_decoder");
@@ -237,13 +238,15 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
     return check_launch("render_backward");
 }
 
-int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+}   // extern "C"
+
+static int render_fused(bool ext_feat, const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                      const float* rays_o, const float* rays_d, const float* target_rgb,
                      const float* target_d, const float* z_vals, const int32_t* ray_counts,
                      const float* packed_decoder, const float* coef, float* rgb, float* depth, float* raw,
                      float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, int32_t* ray_tiles,
                      const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream) {
-    if (int rc = check_scene(scene, bins == nullptr)) return rc;
+    if (int rc = check_scene(scene, bins == nullptr && !ext_feat, !ext_feat)) return rc;
     if (!cfg || !rays_o || !rays_d || !target_rgb || !target_d || !z_vals || !packed_decoder || !coef || !raw ||
         !tape || !tape_rows || !ray_tiles || !workspace)
         return fail(-1, "mne_render_fused: NULL argument");
@@ -261,10 +264,34 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
     a.prefix_default = 1 << 30;                     // no counts: decode every sample up front
     a.rgb = rgb; a.depth = depth; a.raw = raw; a.ray_sums = ray_sums;
     a.tape = tape; a.tape_rows = tape_rows; a.ray_tiles = ray_tiles;
+    a.ext_feat = ext_feat ? 1 : 0;
     if (bins)
         if (int rc = fill_bins(scene, bins, a.bins)) return rc;
     if (int rc = mne_launch_render(a, 2, workspace, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_fused");
+}
+
+extern "C" {
+
+int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                     const float* rays_o, const float* rays_d, const float* target_rgb,
+                     const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                     const float* packed_decoder, const float* coef, float* rgb, float* depth, float* raw,
+                     float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, int32_t* ray_tiles,
+                     const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream) {
+    return render_fused(false, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, ray_counts,
+                        packed_decoder, coef, rgb, depth, raw, ray_sums, tape, tape_capacity_rows, tape_rows, ray_tiles, bins,
+                        workspace, workspace_bytes, stream);
+}
+
+int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                              const float* rays_o, const float* rays_d, const float* target_rgb, const float* target_d,
+                              const float* z_vals, const float* packed_decoder, const float* coef, float* rgb, float* depth,
+                              float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                              int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream) {
+    return render_fused(true, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, nullptr,
+                        packed_decoder, coef, rgb, depth, raw, ray_sums, tape, tape_capacity_rows, tape_rows, ray_tiles, nullptr,
+                        workspace, workspace_bytes, stream);
 }
 
 size_t mne_tile_count(const mne_scene_t* scene) {
@@ -338,7 +365,7 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
 
 int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* ray_tiles, int n_rays, int n_samples,
                       float* partials, float* grad_out, int impl, void* stream) {
-    if (int rc = check_scene(scene, false)) return rc;
+    if (int rc = check_scene(scene, false, false)) return rc;
     if (!tape || !ray_tiles || !grad_out || (impl != 1 && !partials)) return fail(-1, "mne_decoder_wgrad: NULL argument");
     if (n_rays < 1 || n_samples < 1) return fail(-1, "mne_decoder_wgrad: empty batch");
     WgradArgs a = {};
@@ -450,6 +477,48 @@ int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const flo
     a.n = n_pts; a.x = x; a.dout = dout; a.dparams = dparams;
     mne_launch_grid(a, 1, (hipStream_t)stream);
     return check_launch("grid_encode_backward");
+}
+
+}  // extern "C"
+
+static int fill_hash_rows(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                          const float* rays_d, const float* z_vals, float* tape, GridArgs& a) {
+    if (int rc = fill_grid(cfg, a)) return rc;
+    if (int rc = check_scene(scene, false, false)) return rc;
+    if (cfg->n_features != 2 || cfg->n_levels > 16) return fail(-2, "the fused form needs 2 features per level and at most 16 levels");
+    if (scene->n_sets != 1) return fail(-2, "the fused hash-grid form has one feature set (no colour planes)");
+    if (!rays_o || !rays_d || !z_vals || !tape) return fail(-1, "hash rows: NULL argument");
+    a.R = n_rays; a.S = n_samples;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.tape = tape;
+    a.row_stride = (int)mne_dims_tape_row(*scene); a.col_x = 0; a.col_d = (int)mne_dims_tape_dfeat(*scene);
+    for (int k = 0; k < 3; ++k) { a.bb_lo[k] = scene->bb_lo[k]; a.bb_hi[k] = scene->bb_hi[k]; }
+    a.bb_is_f64 = scene->bb_is_f64;
+    return 0;
+}
+
+extern "C" {
+
+int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                    const float* rays_d, const float* z_vals, const float* table, float* tape, void* stream) {
+    GridArgs a = {};
+    if (int rc = fill_hash_rows(cfg, scene, n_rays, n_samples, rays_o, rays_d, z_vals, tape, a)) return rc;
+    if (!table) return fail(-1, "mne_hash_gather: NULL argument");
+    if (n_rays <= 0) return 0;
+    a.params = table;
+    mne_launch_hash_rows(a, 0, (hipStream_t)stream);
+    return check_launch("hash_gather");
+}
+
+int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                     const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles,
+                     float* grad_table, void* stream) {
+    GridArgs a = {};
+    if (int rc = fill_hash_rows(cfg, scene, n_rays, n_samples, rays_o, rays_d, z_vals, (float*)tape, a)) return rc;
+    if (!ray_tiles || !grad_table) return fail(-1, "mne_hash_scatter: NULL argument");
+    if (n_rays <= 0) return 0;
+    a.ray_tiles = ray_tiles; a.dparams = grad_table;
+    mne_launch_hash_rows(a, 1, (hipStream_t)stream);
+    return check_launch("hash_scatter");
 }
 
 }  // extern "C"

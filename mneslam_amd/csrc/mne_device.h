@@ -55,16 +55,17 @@ __device__ __forceinline__ void clock_bias(const Clock& clk, double lr, int step
 // ---- coordinates --------------------------------------------------------------------------------
 // Plane lookup uses the EXTENDED bound -> [-1,1] (model/utils.py:38-40); OneBlob uses the RAW
 // bounding box -> [0,1], in fp64 when the box is float64 (model/scene_rep.py:292).
+__device__ __forceinline__ float unit_coord(float p, double bb_lo, double bb_hi, bool is_f64) {
+    if (is_f64) return (float)(((double)p - bb_lo) / (bb_hi - bb_lo));
+    const float lo = (float)bb_lo, hi = (float)bb_hi;
+    return (p - lo) / (hi - lo);
+}
+
 __device__ __forceinline__ void point_coords(const mne_scene_t& sc, const float p[3], float pn[3], float u[3]) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         pn[k] = ((p[k] - sc.bound_lo[k]) / (sc.bound_hi[k] - sc.bound_lo[k])) * 2.0f - 1.0f;
-        if (sc.bb_is_f64) {
-            u[k] = (float)(((double)p[k] - sc.bb_lo[k]) / (sc.bb_hi[k] - sc.bb_lo[k]));
-        } else {
-            float lo = (float)sc.bb_lo[k], hi = (float)sc.bb_hi[k];
-            u[k] = (p[k] - lo) / (hi - lo);
-        }
+        u[k] = unit_coord(p[k], sc.bb_lo[k], sc.bb_hi[k], sc.bb_is_f64 != 0);
     }
 }
 

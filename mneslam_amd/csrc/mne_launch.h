@@ -54,6 +54,7 @@ struct RenderArgs {
     const float *rays_o, *rays_d, *target_rgb, *target_d, *z_vals, *packed;
     float *rgb, *depth, *disp, *acc, *depth_var, *raw, *ray_sums;
     const float* raw_in;        // backward-only call: raw of ALL samples from the forward call (NULL otherwise)
+    int ext_feat;                // feature rows come from the caller (tape columns T_X..): no plane gather, no plane scatter
     const int* ray_counts;      // [R][MNE_N_COUNT] from sample_z (slot MNE_C_NEED = a-priori sample count)
     int prefix_default;         // ray_counts == NULL: a-priori tiles of every ray (ntile = decode everything, 1 = on demand only)
     const float *coef, *g_rgb, *g_depth;
@@ -122,6 +123,13 @@ struct GridArgs {
     int n_levels, n_features, out_dim;
     float scale[MNE_GRID_MAX_LEVELS];
     unsigned res[MNE_GRID_MAX_LEVELS], size[MNE_GRID_MAX_LEVELS], offset[MNE_GRID_MAX_LEVELS];
+    // fused form (hash_rows_kernel): the points are the samples of a ray batch, the outputs rows of the tape
+    const float* rays_o; const float* rays_d; const float* z_vals;      // [R][3], [R][3], [R][S]
+    const int* ray_tiles;        // backward: only the first ray_tiles[r] tiles of ray r hold d(feature) rows
+    float* tape;                 // [R*S][row_stride]; features at column col_x, d(feature) at column col_d
+    int R, S, row_stride, col_x, col_d;
+    double bb_lo[3], bb_hi[3];   // raw bounding box: x = (p - lo) / (hi - lo), as the OneBlob input
+    int bb_is_f64;
 };
 
 struct WgradArgs {
@@ -161,6 +169,7 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
 //       2 = training iteration (decode + backward);  3 = backward of an earlier forward call (raw_in given)
 int mne_launch_render(const RenderArgs& a, int mode, void* workspace, hipStream_t st);
 void mne_set_render_marks(void* const* events, int n);
+int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st);
 size_t mne_render_workspace(int R, int S);
 int mne_launch_query(const QueryArgs& a, hipStream_t st);
 int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStream_t st);

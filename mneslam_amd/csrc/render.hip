@@ -768,7 +768,11 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
             const unsigned long long tape_rows_mask = valid_rows;
 #endif
             // ---- backward half of the tape rows, staged through the LDS rows (full-line stores, see store_rows)
-            if (a.bins.lists) {                                   // d(feature) rows: read by the binned plane update
+            if (a.ext_feat) {                                     // caller-owned encoding: d(feature) rows of every valid sample
+#pragma unroll                                                    // (all-zero rows for samples without gradient)
+                for (int set = 0; set < NSETS; ++set)
+                    store_rows<MNE_FEAT>(feat + set * TILE * MNE_FS, tape0, D::ROW, D::T_DFEAT + set * MNE_FEAT, valid_rows, lane);
+            } else if (a.bins.lists) {                            // d(feature) rows: read by the binned plane update
 #pragma unroll
                 for (int set = 0; set < NSETS; ++set)
                     store_rows<MNE_FEAT>(feat + set * TILE * MNE_FS, tape0, D::ROW, D::T_DFEAT + set * MNE_FEAT, live_rows, lane);
@@ -1115,7 +1119,7 @@ static int launch_decode(RenderArgs d, hipStream_t st, bool pre = false) {
     typedef DecDims<HID, HIDC, CP> D;
     typedef WgShape<HID, HIDC, CP> W;
     pre = pre && d.tape && !d.ray_list;
-    if (pre) {
+    if (pre && !d.ext_feat) {
         d.tape_row = D::ROW; d.tape_tx = D::T_X; d.tape_tcf = D::T_CF;
         const int chunks = (d.S + 7) / 8;
         const long long waves = (long long)d.R * chunks;

@@ -73,30 +73,7 @@ class FusedStep:
                     st["grad_buffer"] = torch.zeros_like(p.data)
                 self.grads.append(st["grad_buffer"])
         self.scene = hip_path.scene_struct(self.info, [p.data for p in self.planes], [w.data for w in self.dec_w], self.grads)
-        e = lambda *shape, dtype=f32: torch.empty(*shape, device=dev, dtype=dtype)
-        self.rays_o, self.rays_d, self.tgt_rgb, self.tgt_d = e(R, 3), e(R, 3), e(R, 3), e(R)
-        self.idx = e(R, dtype=torch.int64)
-        self.z_vals, self.raw = e(R, S), e(R, S, 4)
-        self.counts, self.ray_counts = e(_lib.N_COUNT, dtype=torch.int32), e(R, _lib.N_COUNT, dtype=torch.int32)
-        self.coef, self.ray_sums, self.losses = e(_lib.N_LOSS), e(R, _lib.N_LOSS), torch.zeros(_lib.N_LOSS, device=dev)
-        self.rgb, self.depth = e(R, 3), e(R)
-        self.packed = e(self.lib.mne_packed_decoder_floats(C.byref(self.scene)))
-        self.tape = e(R * S, self.lib.mne_tape_row_floats(C.byref(self.scene)))
-        self.tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
-        self.ray_tiles = torch.zeros(R, device=dev, dtype=torch.int32)
-        self.ws_bytes = self.lib.mne_render_workspace_bytes(R, S)
-        self.ws = e(self.ws_bytes, dtype=torch.uint8)
-        self.partials = e(self.lib.mne_wgrad_partial_floats(C.byref(self.scene)))
-        self.dec_grad = e(self.lib.mne_decoder_param_floats(C.byref(self.scene)))
-        co = config["is_co_sdf"] if is_co_sdf is None else is_co_sdf
-        self.loss_w = torch.tensor(slam_glue.loss_weight_vector(config, co) + [0.0], device=dev, dtype=f32)
-        self.tables = hip_path.linspace_tables(config, True, dev)
-        w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
-        n0, n1, n2 = w_col0.numel(), w_col1.numel(), w_sdf0.numel()
-        self.dec_grad_views = {w_col0: self.dec_grad[:n0].view_as(w_col0), w_col1: self.dec_grad[n0:n0 + n1].view_as(w_col1),
-                               w_sdf0: self.dec_grad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0),
-                               w_sdf1: self.dec_grad[n0 + n1 + n2:].view_as(w_sdf1)}
-        self.grad_map = dict(self.dec_grad_views)
+        self._alloc_buffers(config, is_co_sdf)
         self.bins = None
         if scatter == "atomics":
             self.grad_map.update({p: g for p, g in zip(self.planes, self.grads)})
@@ -140,15 +117,46 @@ class FusedStep:
                     o.m, o.v = self._exp_mv[-1][0].data_ptr(), self._exp_mv[-1][1].data_ptr()
                 o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
                 o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
+        self._finish_init(overlap)
+
+    def _alloc_buffers(self, config, is_co_sdf):
+        """Batch, output, tape and decoder-gradient buffers (everything that does not depend on the scene encoding)."""
+        dev, f32, R, S = self.device, torch.float32, self.R, self.S
+        e = lambda *shape, dtype=f32: torch.empty(*shape, device=dev, dtype=dtype)
+        self.rays_o, self.rays_d, self.tgt_rgb, self.tgt_d = e(R, 3), e(R, 3), e(R, 3), e(R)
+        self.idx = e(R, dtype=torch.int64)
+        self.z_vals, self.raw = e(R, S), e(R, S, 4)
+        self.counts, self.ray_counts = e(_lib.N_COUNT, dtype=torch.int32), e(R, _lib.N_COUNT, dtype=torch.int32)
+        self.coef, self.ray_sums, self.losses = e(_lib.N_LOSS), e(R, _lib.N_LOSS), torch.zeros(_lib.N_LOSS, device=dev)
+        self.rgb, self.depth = e(R, 3), e(R)
+        self.packed = e(self.lib.mne_packed_decoder_floats(C.byref(self.scene)))
+        self.tape = e(R * S, self.lib.mne_tape_row_floats(C.byref(self.scene)))
+        self.tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.ray_tiles = torch.zeros(R, device=dev, dtype=torch.int32)
+        self.ws_bytes = self.lib.mne_render_workspace_bytes(R, S)
+        self.ws = e(self.ws_bytes, dtype=torch.uint8)
+        self.partials = e(self.lib.mne_wgrad_partial_floats(C.byref(self.scene)))
+        self.dec_grad = e(self.lib.mne_decoder_param_floats(C.byref(self.scene)))
+        co = config["is_co_sdf"] if is_co_sdf is None else is_co_sdf
+        self.loss_w = torch.tensor(slam_glue.loss_weight_vector(config, co) + [0.0], device=dev, dtype=f32)
+        self.tables = hip_path.linspace_tables(config, True, dev)
+        w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
+        n0, n1, n2 = w_col0.numel(), w_col1.numel(), w_sdf0.numel()
+        self.dec_grad_views = {w_col0: self.dec_grad[:n0].view_as(w_col0), w_col1: self.dec_grad[n0:n0 + n1].view_as(w_col1),
+                               w_sdf0: self.dec_grad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0),
+                               w_sdf1: self.dec_grad[n0 + n1 + n2:].view_as(w_sdf1)}
+        self.grad_map = dict(self.dec_grad_views)
+
+    def _finish_init(self, overlap):
         # exact early ray termination (decode only the samples a ray needs; csrc/render.hip); False = decode everything
         self.early_termination = os.environ.get("MNE_NO_EARLY_TERMINATION", "0") != "1"
         # Steady-state iterations can be recorded into a HIP graph and replayed (device sampler, prefetching steps): one
         # hipGraphLaunch per iteration, iteration counter / Adam step read from a device clock.  OFF by default: the
         # iteration is GPU-bound and its ~20 launches are enqueued far ahead anyway -- measured 0.570 ms per iteration
         # replayed against 0.533 ms launched one by one (profiles/r02_graph.txt); MNE_GRAPH=1 or use_graph = True turns it on.
-        self.use_graph = os.environ.get("MNE_GRAPH", "0") == "1" and self.device.type == "cuda" and scatter == "binned"
+        self.use_graph = (os.environ.get("MNE_GRAPH", "0") == "1" and self.device.type == "cuda" and self.bins is not None)
         self._graphs = {}
-        self.events = None          # set to {} to record HIP events around the two dominant launches
+        self.events = None          # set to {} to record HIP events around the dominant launches
         self.overlap = overlap
         self._side, self._ev, self._prefetched, self._planes_pending = None, None, None, False
         self.iteration = 0
@@ -463,3 +471,96 @@ class FusedStep:
         return {"rgb": self.rgb[:n], "depth": self.depth[:n], "rgb_loss": L[_lib.L_RGB], "depth_loss": L[_lib.L_DEPTH],
                 "co_sdf_loss": L[_lib.L_CO_SDF], "co_fs_loss": L[_lib.L_CO_FS], "e_fs_loss": L[_lib.L_E_FS],
                 "e_center_loss": L[_lib.L_E_CENTER], "e_tail_loss": L[_lib.L_E_TAIL], "psnr": L[_lib.L_PSNR:_lib.L_PSNR + 1]}
+
+
+class HashFusedStep(FusedStep):
+    """The mapping iteration of ``model.scene_rep_hash.HashJointEncoding`` (EXTENSION: the hash-grid wiring the reference
+    keeps commented out, parity unpinned).  Same batch sampler, decoder / compositing / loss kernels, weight-gradient
+    and Adam kernels as FusedStep; the plane gather and the binned plane update are replaced by
+
+        mne_hash_gather -> mne_render_fused_features -> mne_hash_scatter -> ... -> mne_adam_step(table + decoder)
+
+    on one stream (include/mneslam_hip.h, section NS-a).  Every sample is decoded (no early ray termination: the tiles a
+    ray needs beyond its a-priori prefix would have to be gathered on demand inside decode_kernel)."""
+
+    def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None):
+        if not isinstance(optimizer, FusedAdam):
+            raise TypeError("the fused mapping step needs mneslam_amd.optim.FusedAdam")
+        if getattr(model, "embed_fn", None) is None:
+            raise TypeError("HashFusedStep drives a HashJointEncoding")
+        self.scatter, self.shared_decoder, self.overlap_peers = "hash", False, []
+        self.lib = _lib.load()
+        self.model, self.opt, self.cfg, self.R = model, optimizer, config, int(n_rays)
+        self.device = torch.device(device)
+        self.info = model._info()
+        self.rc = self.info["render_cfg"]
+        self.S = self.lib.mne_num_samples(C.byref(self.rc), 1)
+        self.planes, self.grads, self.bins = [], None, None
+        self.table = model.embed_fn.params
+        if self.table.device.type != self.device.type:
+            raise ValueError("the hash table must live on the compute device")
+        self.grid_cfg = model.embed_fn.cfg
+        self.dec_w = model.decoder.hip_weights()
+        self.scene = hip_path.scene_struct(self.info, [], [w.data for w in self.dec_w], None)
+        self.scene.n_sets = 1
+        self._alloc_buffers(config, is_co_sdf)
+        self.tape.zero_()                                  # feature columns the grid does not fill must read as zero
+        st = optimizer._state(self.table)
+        if "grad_buffer" not in st:
+            st["grad_buffer"] = torch.zeros_like(self.table.data)
+        self.table_grad = st["grad_buffer"]
+        self.grad_map[self.table] = self.table_grad
+        self._finish_init(overlap=False)
+        self.early_termination = False
+
+    def _refresh_pointers(self):
+        w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
+        self.scene.w_sdf0, self.scene.w_sdf1 = w_sdf0.data_ptr(), w_sdf1.data_ptr()
+        self.scene.w_col0, self.scene.w_col1 = w_col0.data_ptr(), w_col1.data_ptr()
+
+    def check(self):
+        self.synchronize()
+
+    def step(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global=None, idx_cur=None, u=None,
+             prefetch=False):
+        lib, P = self.lib, _lib.ptr
+        R, S = int(n_global + n_cur), self.S
+        if R > self.R or R < 1:
+            raise ValueError(f"this step was built for at most {self.R} rays, got {n_global}+{n_cur}")
+        self.n_active = R
+        self._refresh_pointers()
+        st = _lib.stream_for(self.rays_o)
+        host_batch = idx_global is not None or idx_cur is not None or u is not None
+        key = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
+        if host_batch or self._prefetched != key:
+            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st)
+        self._prefetched = None
+        sc, gc = C.byref(self.scene), C.byref(self.grid_cfg)
+        _lib.check(lib.mne_pack_decoder(sc, P(self.packed), st), "mne_pack_decoder")
+        e0 = self._mark("hash_gather")
+        _lib.check(lib.mne_hash_gather(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.table.data),
+                                       P(self.tape), st), "mne_hash_gather")
+        self._mark("hash_gather", e0)
+        e0 = self._mark("render")
+        _lib.check(lib.mne_render_fused_features(sc, C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb),
+                                                 P(self.tgt_d), P(self.z_vals), P(self.packed), P(self.coef), P(self.rgb),
+                                                 P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape), R * S,
+                                                 P(self.tape_rows), P(self.ray_tiles), P(self.ws), self.ws_bytes, st),
+                   "mne_render_fused_features")
+        self._mark("render", e0)
+        e0 = self._mark("hash_scatter")
+        _lib.check(lib.mne_hash_scatter(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.tape),
+                                        P(self.ray_tiles), P(self.table_grad), st), "mne_hash_scatter")
+        self._mark("hash_scatter", e0)
+        e0 = self._mark("wgrad")
+        _lib.check(lib.mne_decoder_wgrad(sc, P(self.tape), P(self.ray_tiles), R, S, P(self.partials), P(self.dec_grad),
+                                         self.model.wgrad_impl, st), "mne_decoder_wgrad")
+        self._mark("wgrad", e0)
+        e0 = self._mark("adam")
+        self.opt.step(zero_grad=True, grad_buffers=self.grad_map)            # table + decoder tensors, one launch
+        self._mark("adam", e0)
+        _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
+        self.iteration += 1
+        if prefetch and not host_batch:
+            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st)
+            self._prefetched = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)

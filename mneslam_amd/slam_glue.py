@@ -72,6 +72,10 @@ def create_optimizer(model, config, optimizer_cls=FusedAdam):
     """Wrap every plane in ``nn.Parameter`` IN PLACE in the model's lists and build Adam with the
     reference's groups: decoder {lr_decoder, weight_decay 1e-6}, planes {lr_embed, eps 1e-15},
     colour planes {lr_embed_color, eps 1e-15}, betas (0.9, 0.99)."""
+    if getattr(model, "embed_fn", None) is not None:       # hash-grid wiring (model/scene_rep_hash.py): Co-SLAM's two groups
+        return optimizer_cls([{"params": list(model.decoder.parameters()), "weight_decay": 1e-6, "lr": config["mapping"]["lr_decoder"]},
+                              {"params": list(model.embed_fn.parameters()), "eps": 1e-15, "lr": config["mapping"]["lr_embed"]}],
+                             betas=(0.9, 0.99))
     one_grid = config["grid"]["oneGrid"]
     sets = model.all_planes
     planes_para, c_planes_para = [], []

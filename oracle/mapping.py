@@ -59,7 +59,7 @@ class OracleAdam:
     def __init__(self, scene: OracleScene, cfg):
         m = cfg["mapping"]
         self.groups = [AdamGroup(scene.decoder_list(), m["lr_decoder"], eps=1e-8, weight_decay=1e-6)]
-        geo = [p for lst in scene.all_planes[:3] for p in lst]
+        geo = [p for lst in scene.all_planes[:3] for p in lst] if scene.all_planes else scene.plane_list()    # hash wiring: the table
         # reference order inside the group: xy[coarse,fine], xz[...], yz[...]  (mneslam_mp.py:453-457)
         self.groups.append(AdamGroup(geo, m["lr_embed"], eps=1e-15))
         if not scene.pc.one_grid:

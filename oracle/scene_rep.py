@@ -390,3 +390,37 @@ class OracleScene:
                     co_sdf_loss=co_sdf, co_fs_loss=co_fs, e_fs_loss=e_fs, e_center_loss=e_center,
                     e_tail_loss=e_tail, psnr=psnr, z_vals=z, raw=rd["raw"], depth_var=rd["depth_var"],
                     acc_map=rd["acc_map"], disp_map=rd["disp_map"])
+
+
+# --------------------------------------------------------------------------------------
+# hash-grid wiring (PARITY UNPINNED: the reference keeps this call commented out, model/scene_rep.py:160,243)
+# --------------------------------------------------------------------------------------
+class OracleHashScene(OracleScene):
+    """OracleScene whose first decoder input is the multiresolution hash grid of oracle/hashgrid.py evaluated at the
+    OneBlob input u = (p - bb_lo) / (bb_hi - bb_lo) (Co-SLAM's ``embed_fn(inputs_flat)``), placed in the first
+    n_levels*F columns of the decoder's 64-wide feature slot; the other columns are zero.  Checker for the build's own
+    HashFusedStep: there is no reference behaviour to pin it to."""
+
+    def __init__(self, cfg_dict, bounding_box, table, grid, scales=None):
+        super().__init__(cfg_dict, bounding_box, build=False)
+        self.table, self.grid, self.scales = table, dict(grid), scales
+        self.all_planes = ()
+
+    def plane_list(self):
+        return [self.table]
+
+    def grid_features(self, flat):
+        from .hashgrid import grid_encode
+        bb = self.bounding_box
+        u = ((flat - bb[:, 0]) / (bb[:, 1] - bb[:, 0])).float()
+        f = grid_encode(u, self.table, scales=self.scales, **self.grid)
+        return torch.cat([f, torch.zeros(f.shape[0], 64 - f.shape[1], dtype=f.dtype)], dim=-1)
+
+    def query_color_sdf(self, pts, impl="explicit", return_parts=False):
+        flat = pts.reshape(-1, 3)
+        feat, pos = self.grid_features(flat), self.embed_pos(flat)
+        raw = decode(self.sdf_w, self.col_w, feat, pos, None)
+        return (raw, dict(feat=feat, pos=pos)) if return_parts else raw
+
+    def query_sdf(self, pts, return_geo=False, embed=False, impl="explicit"):
+        raise NotImplementedError

@@ -764,6 +764,107 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
             "rgb_l1": float((rgb - ret["rgb"].detach()).abs().mean()), "depth_l1": float((depth - ret["depth"].detach()).abs().mean())}
 
 
+def hash_test_config(hash_size=12, hidden=32, desired_resolution=128):
+    """A reduced hash-grid workload: small table (collisions on the fine levels), office0 bound, 11 + 32 samples."""
+    cfg = configs.bench_office0_hash(hidden=hidden, hash_size=hash_size, desired_resolution=desired_resolution)
+    cfg["training"]["n_range_d"], cfg["training"]["n_samples_d"] = 11, 32
+    cfg["mapping"]["sample"] = 256
+    return cfg
+
+
+def check_hash_fused_step_vs_oracle(device, cfg, n_keyframes=3, seed=5, warm_steps=0, small=True):
+    """HashFusedStep (hash-grid wiring, EXTENSION, parity unpinned) against one iteration of the build's own CPU oracle
+    (oracle.scene_rep.OracleHashScene + oracle.hashgrid) on the same device-drawn batch and parameters:
+      table indices     uint32, bit-exact (HIP grid kernel vs oracle/hashgrid.py) on the batch's sample positions
+      rgb / depth       mean L1 < 1e-4, elementwise rtol 1e-4;   raw on every sample;   7 losses + psnr rtol 1e-4
+      decoder grads     rtol 2e-3;   table grad (= exp_avg / (1 - beta1) after the first step) rtol 2e-3
+      post-Adam table and decoder."""
+    import bench
+    from oracle.scene_rep import OracleHashScene
+    dev = torch.device(device)
+    ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, small=small, path="fused")
+    fs, m = ag.fused, ag.model
+    for _ in range(warm_steps):
+        ag.step()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    cpu = lambda t: t.detach().to("cpu", copy=True)
+    table0 = cpu(m.embed_fn.params)
+    dec0 = {k: cpu(v) for k, v in m.decoder.state_dict().items()}
+    dec_params = list(m.decoder.parameters())
+    st_table0 = {k: (cpu(v) if torch.is_tensor(v) else v) for k, v in ag.opt._state(m.embed_fn.params).items()}
+    dec_state0 = [{k: (cpu(v) if torch.is_tensor(v) else v) for k, v in ag.opt._state(p).items()} for p in dec_params]
+    ag.step()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    R, S = fs.R, fs.S
+    rays_o, rays_d, tgt_rgb, tgt_d, z = cpu(fs.rays_o), cpu(fs.rays_d), cpu(fs.tgt_rgb), cpu(fs.tgt_d), cpu(fs.z_vals)
+    gc = m.embed_fn.cfg
+    scales, ress, sizes, offsets = m.embed_fn.level_table()
+    grid = dict(n_levels=gc.n_levels, n_features=gc.n_features, base_resolution=gc.base_resolution,
+                per_level_scale=gc.per_level_scale, log2_hashmap_size=gc.log2_hashmap_size)
+    bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
+    sc = OracleHashScene(cfg, bb, table0.clone(), grid, scales=scales)
+    sc.col_w = [dec0["color_net.model.0.weight"], dec0["color_net.model.2.weight"]]
+    sc.sdf_w = [dec0["sdf_net.model.0.weight"], dec0["sdf_net.model.2.weight"]]
+    assert float(sc.sdf_w[0][:, gc.n_levels * gc.n_features:64].abs().max()) == 0.0, "dead feature columns must stay zero"
+    sc.requires_grad_(True)
+    # ---- integer table indices on this batch's positions: HIP stand-alone kernel vs oracle, bit-exact
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]).reshape(-1, 3)
+    u = ((pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0])).float()
+    sub = torch.randperm(u.shape[0], generator=torch.Generator().manual_seed(1))[:4096]
+    idx_hip = m.embed_fn.indices(u[sub].to(dev)).cpu()
+    from oracle import hashgrid
+    for l in range(gc.n_levels):
+        idx_ref, _ = hashgrid.grid_indices(u[sub], scales[l], ress[l], sizes[l])
+        assert torch.equal(idx_hip[:, l], idx_ref), f"hash indices differ at level {l}"
+    opt = omap.OracleAdam(sc, cfg)
+    for g_, states in zip(opt.groups, [dec_state0, [st_table0]]):
+        if states and states[0].get("step", 0):
+            g_.t = int(states[0]["step"])
+            g_.m = [st["exp_avg"].clone() for st in states]
+            g_.v = [st["exp_avg_sq"].clone() for st in states]
+    ret = sc.forward(rays_o, rays_d, tgt_rgb, tgt_d[:, None], z_vals=z)
+    omap.loss_from_ret(cfg, ret, is_co_sdf=cfg["is_co_sdf"]).backward()
+    rgb, depth = cpu(fs.rgb), cpu(fs.depth)
+    assert float((rgb - ret["rgb"].detach()).abs().mean()) < 1e-4 and float((depth - ret["depth"].detach()).abs().mean()) < 1e-4
+    assert_close(rgb, ret["rgb"].detach(), rtol=1e-4, atol=2e-5, what="rgb")
+    assert_close(depth, ret["depth"].detach(), rtol=1e-4, atol=2e-5, what="depth")
+    assert_close(cpu(fs.raw), ret["raw"].detach(), rtol=1e-4, atol=2e-5, what="raw (every sample is decoded)")
+    L = cpu(fs.losses)
+    for k, key in enumerate(LOSS_KEYS):
+        assert_close(L[k], ret[key].detach().reshape(()), rtol=1e-4, atol=1e-7, what=key)
+    # the single Adam launch of this path zeroes every gradient accumulator (decoder included): on a first step the
+    # gradients are read back from the first moments, m1 = (1 - b1) (g + wd p)
+    if not st_table0.get("step", 0):
+        grp = ag.opt.param_groups[0]
+        for w_hip, w0, w, nm in zip(dec_params, [dec0[k] for k in DEC_KEYS], sc.decoder_list(), DEC_KEYS):
+            ref = w.grad + grp["weight_decay"] * w0.detach()
+            got = cpu(ag.opt._state(w_hip)["exp_avg"]) / (1.0 - grp["betas"][0])
+            assert_close(got, ref, rtol=2e-3, atol=2e-5 * max(1.0, float(ref.abs().max())), what=f"decoder grad {nm}")
+    st_t = ag.opt._state(m.embed_fn.params)
+    ref = sc.table.grad
+    assert float(ref.abs().max()) > 0
+    if not st_table0.get("step", 0):
+        b1 = ag.opt.param_groups[1]["betas"][0]
+        g_hip = cpu(st_t["exp_avg"]) / (1.0 - b1)
+        assert_close(g_hip, ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()), what="table grad")
+    assert float(cpu(fs.table_grad).abs().max()) == 0.0, "the Adam kernel leaves the gradient accumulator zeroed"
+    opt.step()
+    assert_close(cpu(st_t["exp_avg"]), opt.groups[1].m[0], rtol=2e-3, atol=2e-6 * float(opt.groups[1].m[0].abs().max()), what="table exp_avg")
+    lr = ag.opt.param_groups[1]["lr"]
+    d = (cpu(m.embed_fn.params) - sc.table.detach()).abs()
+    assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 2e-3, \
+        f"table after Adam: mean {float(d.mean()):.3e}, outliers {float((d > 0.05 * lr).float().mean()):.3e}"
+    touched = ref != 0
+    assert float(touched.float().mean()) > 0.001
+    for w_hip, w_ref, nm in zip(dec_params, sc.decoder_list(), DEC_KEYS):
+        d = (cpu(w_hip) - w_ref.detach()).abs()
+        lr = ag.opt.param_groups[0]["lr"]
+        assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 5e-3, f"decoder {nm} after Adam"
+    return {"R": R, "S": S, "touched_entries": int(touched.sum()), "rgb_l1": float((rgb - ret["rgb"].detach()).abs().mean())}
+
+
 def check_device_clock(device):
     """mne_clock_t: iteration / Adam step read from device memory (graph replay) give bit-identical results to the same
     values passed as arguments -- ray sampling keys, the jitter counter offset, the bias corrections of both Adam kernels."""

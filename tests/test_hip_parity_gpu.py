@@ -1,6 +1,7 @@
 """Parity of the HIP path on a real MI355X (through the C ABI of libmneslam_hip.so) against the
 golden vectors captured from the reference and against the CPU oracle.  Run by the driver with
 ``-m gpu``; bodies shared with the host-emulator run live in tests/parity_cases.py."""
+import math
 import os
 
 import pytest
@@ -390,3 +391,38 @@ def test_rccl_branch_single_rank():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+# ------------------------------------------------------------------------------------------------------------
+# NS-a: the hash-grid wiring (EXTENSION; parity unpinned -- tinycudann is not in the reference tree, the checker is the
+# build's own oracle/hashgrid.py + oracle.scene_rep.OracleHashScene)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hash_size,hidden,warm", [(12, 32, 0), (14, 64, 0), (14, 64, 3)])
+def test_hash_grid_fused_step_vs_oracle(hash_size, hidden, warm):
+    """Reduced tables (heavy collisions on the hashed levels), 256 + 100 rays x 43 samples: table indices bit-exact,
+    forward / losses / gradients / post-Adam state against the oracle on the device-drawn batch."""
+    cfg = pc.hash_test_config(hash_size=hash_size, hidden=hidden)
+    out = pc.check_hash_fused_step_vs_oracle(DEV, cfg, n_keyframes=3, seed=5, warm_steps=warm, small=True)
+    assert out["S"] == 43 and out["touched_entries"] > 1000
+
+
+def test_hash_grid_headline_config_vs_oracle():
+    """BASELINE configs[1] in its literal form: 16 levels, T = 2^19 (10.49 M table floats), 2x64 MLPs, 2048 + 512 rays x
+    128 samples, 1200x680 frames -- one fused iteration vs the oracle on the same batch."""
+    from mneslam_amd import configs
+    cfg = configs.bench_office0_hash()
+    out = pc.check_hash_fused_step_vs_oracle(DEV, cfg, n_keyframes=4, seed=3, warm_steps=2, small=False)
+    assert out["R"] == 2048 + 512 and out["S"] == 128
+
+
+def test_hash_grid_training_learns():
+    """The hash-grid iteration trains: PSNR rises and depth L1 falls over 150 prefetching iterations at full size."""
+    import bench
+    from mneslam_amd import configs
+    ag = bench.Agent(configs.bench_office0_hash(), torch.device("cuda"), seed=1, n_keyframes=5, path="fused")
+    ag.step()
+    p0, d0 = ag.quality()
+    for it in range(150):
+        ag.step(prefetch=it < 149)
+    p1, d1 = ag.quality()
+    assert math.isfinite(p1) and p1 > p0 + 3.0 and d1 < 0.5 * d0, (p0, d0, p1, d1)

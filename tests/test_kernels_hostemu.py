@@ -182,3 +182,15 @@ def test_bench_path_step_vs_oracle():
     """The bench path (device sampler + Philox jitter + FusedStep) vs one oracle iteration on the same batch."""
     out = pc.check_fused_step_vs_oracle(DEV, _tiny_bench_cfg(), n_keyframes=3, seed=2, small=True, impl="explicit")
     assert out["contributing"] > 0
+
+
+def test_hash_grid_fused_step_vs_oracle():
+    """NS-a: the hash-grid mapping iteration (hash gather -> external-feature render -> atomic scatter -> Adam over the table)
+    against the build's own oracle; bit-exact table indices; tiny sizes for the emulator."""
+    cfg = pc.hash_test_config(hash_size=9, hidden=32, desired_resolution=64)
+    cfg["training"]["n_range_d"], cfg["training"]["n_samples_d"] = 9, 20
+    cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["mapping"]["sample"], cfg["mapping"]["min_pixels_cur"] = 24, 8
+    cfg["cam"]["far"] = 4.0
+    out = pc.check_hash_fused_step_vs_oracle(DEV, cfg, n_keyframes=3, seed=2, small=True)
+    assert out["touched_entries"] > 0
