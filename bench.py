@@ -312,8 +312,14 @@ def main():
             # hash grid: 16 levels x 8 corners x 2 features x 4 B = 1,024 B per point per gather or scatter pass
             Gh = agent.model.embed_fn.cfg.n_levels * 8 * agent.model.embed_fn.cfg.n_features * 4.0
             alg = {"hash_gather": R * S * Gh, "hash_scatter": p_contrib * Gh, "adam": 32.0 * n_par, "render": 0.0}
-            kern = {"hash_gather": "hash_rows_kernel<false> (grid gather into the tape)", "hash_scatter": "hash_rows_kernel<true> (atomic scatter)",
-                    "adam": "adam_kernel (table + decoder, one launch)", "wgrad": "wgrad kernels",
+            slices = agent.fused.table_update != "atomics"
+            if slices:       # the table update = scatter + Adam sweep of the table in one call
+                alg["hash_scatter"] += 32.0 * agent.n_plane_params
+                alg["adam"] = 32.0 * agent.n_dec_params
+            kern = {"hash_gather": "hash_rows_kernel<false> (grid gather into the tape)",
+                    "hash_scatter": ("hash_offsets + hash_pack + hash_slice_adam + hash_dense_adam kernels (LDS slices, Adam fused; one mne_hash_slice_adam call)"
+                                     if slices else "hash_scatter_runs_kernel (run-reduced global atomics)"),
+                    "adam": "adam_kernel (decoder)" if slices else "adam_kernel (table + decoder, one launch)", "wgrad": "wgrad kernels",
                     "render": "whole mne_render_fused_features call (decode + ray kernels; MFMA / latency, no algorithmic HBM bytes)"}
             alg["iteration"] = alg["hash_gather"] + alg["hash_scatter"] + alg["adam"]
         elif binned:
@@ -355,7 +361,7 @@ def main():
             "config": {"workload": workload + ("_SMALL" if args.small else ""),
                        "rays_per_iter": R, "samples_per_ray": S, "plane_params": agent.n_plane_params,
                        "decoder_params": agent.n_dec_params, "mlp_hidden": args.hidden, "keyframes": args.keyframes,
-                       "frame": f"{agent.W}x{agent.H}", "path": args.path, "scatter": "hash-atomics" if agent.hash else args.scatter if args.path == "fused" else "atomics", "agents": world,
+                       "frame": f"{agent.W}x{agent.H}", "path": args.path, "scatter": ("hash-" + agent.fused.table_update) if agent.hash else args.scatter if args.path == "fused" else "atomics", "agents": world,
                        "encoding": "hash grid (parity unpinned: tinycudann is not in the reference tree)" if agent.hash else "tri-planes (as wired)",
                        "parallelism": f"agent-per-gpu x{world}, " + ("decoder-gradient all-reduce (extension)" if args.share_decoder
                                                                      else "no data-path collective")},

@@ -337,19 +337,32 @@ int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const flo
  * the remaining columns stay zero -- instead of by the plane gather, and the 64-wide first decoder layer simply has dead
  * input columns.  One iteration:
  *   mne_hash_gather            x = (o + d*z - bb_lo) / (bb_hi - bb_lo) per sample (the OneBlob input), 8 corners x 16 levels
- *   mne_render_fused_features  = mne_render_fused without plane gather / scatter and without early termination; the
- *                                d(feature) rows of every sample of the first ray_tiles[r] tiles of ray r are left in the
- *                                tape (column mne_tape_dfeat_offset)
+ *   mne_render_fused_features  = mne_render_fused without plane gather / scatter: every decode reads its features from the
+ *                                tape (ray_counts as in mne_render_fused: exact early termination of the DECODE; the
+ *                                gather above still fills every row); the d(feature) rows of every sample of the first
+ *                                ray_tiles[r] tiles of ray r are left in the tape (column mne_tape_dfeat_offset)
  *   mne_hash_scatter           grad_table += w * d(feature)  (global_atomic_add_f32; grad_table zeroed by the caller)
  *   mne_decoder_wgrad, mne_adam_step (table + decoder segments, zero_grad fused)
+ *   -- or, instead of mne_hash_scatter + the table's Adam segment --
+ *   mne_hash_slice_adam        the table update without global atomics and without a gradient buffer: one workgroup per
+ *                              slice of 16384 entries of one level accumulates the slice's gradient in LDS while walking
+ *                              over the iteration's backward rows (packed level-major into `workspace`,
+ *                              mne_hash_workspace_bytes), then applies Adam (opt: moments with the table's layout, step
+ *                              1-based) to the slice.  Same arithmetic as grid_sampler-style scatter + torch.optim.Adam;
+ *                              only the fp32 summation order differs.
  * scene: bounding box, decoder dims and weights are read; the plane descriptors are ignored.  cfg: n_features 2, <= 16 levels. */
+size_t mne_hash_workspace_bytes(int n_rays, int n_samples);       /* + mne_hash_scratch_floats(cfg) * 4, rounded up to 256 */
+size_t mne_hash_scratch_floats(const mne_grid_cfg_t* cfg);          /* leading floats of the workspace: zero before the first call */
+int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                        const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles, float* table,
+                        const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
 int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                     const float* rays_d, const float* z_vals, const float* table, float* tape, void* stream);
 int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                               const float* rays_o, const float* rays_d, const float* target_rgb, const float* target_d,
-                              const float* z_vals, const float* packed_decoder, const float* coef, float* rgb, float* depth,
-                              float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                              int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream);
+                              const float* z_vals, const int32_t* ray_counts, const float* packed_decoder, const float* coef,
+                              float* rgb, float* depth, float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows,
+                              int32_t* tape_rows, int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream);
 int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                      const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles,
                      float* grad_table, void* stream);

@@ -286,10 +286,10 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
 
 int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                               const float* rays_o, const float* rays_d, const float* target_rgb, const float* target_d,
-                              const float* z_vals, const float* packed_decoder, const float* coef, float* rgb, float* depth,
-                              float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                              int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream) {
-    return render_fused(true, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, nullptr,
+                              const float* z_vals, const int32_t* ray_counts, const float* packed_decoder, const float* coef,
+                              float* rgb, float* depth, float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows,
+                              int32_t* tape_rows, int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream) {
+    return render_fused(true, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, ray_counts,
                         packed_decoder, coef, rgb, depth, raw, ray_sums, tape, tape_capacity_rows, tape_rows, ray_tiles, nullptr,
                         workspace, workspace_bytes, stream);
 }
@@ -509,6 +509,49 @@ int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_r
     return check_launch("hash_gather");
 }
 
+size_t mne_hash_workspace_bytes(int n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    const size_t rows = (size_t)n_rays * n_samples;
+    return (((size_t)n_rays + 1) * sizeof(int) + 255) / 256 * 256 + rows * sizeof(float4) + rows * 16 * sizeof(float2);
+}
+
+/* floats at the front of the workspace that must be ZERO on entry to mne_hash_slice_adam (it leaves them zero again):
+ * the gradient scratch of the dense levels, whose rows are split over several workgroups */
+size_t mne_hash_scratch_floats(const mne_grid_cfg_t* cfg) {
+    GridArgs a = {};
+    if (fill_grid(cfg, a)) return 0;
+    return (size_t)mne_hash_scratch_entries(a) * 2;
+}
+
+int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                        const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles, float* table,
+                        const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream) {
+    GridArgs a = {};
+    if (int rc = fill_hash_rows(cfg, scene, n_rays, n_samples, rays_o, rays_d, z_vals, (float*)tape, a)) return rc;
+    if (!ray_tiles || !table || !opt || !workspace) return fail(-1, "mne_hash_slice_adam: NULL argument");
+    if (!opt->m || !opt->v || opt->step < 1) return fail(-1, "mne_hash_slice_adam: bad optimizer state");
+    if (n_rays <= 0) return 0;
+    const size_t scratch = (mne_hash_scratch_floats(cfg) * sizeof(float) + 255) / 256 * 256;
+    if (workspace_bytes < scratch + mne_hash_workspace_bytes(n_rays, n_samples)) return fail(-1, "mne_hash_slice_adam: workspace too small");
+    a.ray_tiles = ray_tiles; a.params = table;
+    a.dparams = (float*)workspace;
+    unsigned char* w = (unsigned char*)workspace + scratch;
+    a.offs = (int*)w; w += (((size_t)n_rays + 1) * sizeof(int) + 255) / 256 * 256;
+    a.pack_cap = (long long)n_rays * n_samples;
+    a.xs = (float4*)w; w += (size_t)a.pack_cap * sizeof(float4);
+    a.dfeat_lv = (float2*)w;
+    PlaneOpt& o = a.opt;
+    o.m = opt->m; o.v = opt->v;
+    o.omb1 = (float)(1.0 - opt->beta1); o.b2 = (float)opt->beta2; o.omb2 = (float)(1.0 - opt->beta2);
+    o.eps = (float)opt->eps; o.wd = (float)opt->weight_decay;
+    o.step_size = (float)(opt->lr / (1.0 - std::pow(opt->beta1, (double)opt->step)));
+    o.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(opt->beta2, (double)opt->step));
+    o.lr = opt->lr; o.step = opt->step;
+    if (const char* m = std::getenv("MNE_HASH_LEVELS")) a.n_levels = std::atoi(m) < a.n_levels ? std::atoi(m) : a.n_levels;   // profiling only
+    mne_launch_hash_slice_adam(a, (hipStream_t)stream);
+    return check_launch("hash_slice_adam");
+}
+
 int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                      const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles,
                      float* grad_table, void* stream) {
@@ -517,7 +560,9 @@ int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_
     if (!ray_tiles || !grad_table) return fail(-1, "mne_hash_scatter: NULL argument");
     if (n_rays <= 0) return 0;
     a.ray_tiles = ray_tiles; a.dparams = grad_table;
-    mne_launch_hash_rows(a, 1, (hipStream_t)stream);
+    static const int impl = std::getenv("MNE_HASH_SCATTER") ? std::atoi(std::getenv("MNE_HASH_SCATTER")) : 2;   // 1: one atomic pair per (sample, corner)
+    if (const char* m = std::getenv("MNE_HASH_LEVELS")) a.n_levels = std::atoi(m) < a.n_levels ? std::atoi(m) : a.n_levels;   // profiling only
+    mne_launch_hash_rows(a, impl == 1 ? 1 : 2, (hipStream_t)stream);
     return check_launch("hash_scatter");
 }
 

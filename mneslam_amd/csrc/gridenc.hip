@@ -123,7 +123,335 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(GridArgs a) {
     }
 }
 
+// ---- scatter with run reduction -------------------------------------------------------------------------------------
+// The atomic units behind the L2 retire roughly one LINE operation per 60-100 ps chip-wide whatever the kernel does
+// (profiles/r02_hash_scatter.txt: 33 M scattered float atomics = 1.87 ms; the tri-plane atomics path, 32 floats per line
+// operation, lands on the same rate), and on the coarse levels thousands of samples hit the same few table entries.
+// Consecutive samples of a ray walk through the grid cell by cell, so one wave takes 64 CONSECUTIVE samples of one ray
+// at one level: lanes in the same cell form contiguous runs (ballot of "cell differs from my neighbour's"), the eight
+// corner contributions of a run are summed with a segmented wave scan, and only the last lane of each run issues the
+// sixteen atomics.  Level 0 (31 cm cells): one or two runs per wave instead of 64 lanes.
+__global__ __launch_bounds__(256) void hash_scatter_runs_kernel(GridArgs a) {
+    const int lane = threadIdx.x & 63;
+    // blocks of 4 waves, level-minor: the 16 levels of a sample group run close together (its tape lines stay in L2)
+    const int level = (int)(blockIdx.x % (unsigned)a.n_levels);
+    const long long wave = (long long)(blockIdx.x / (unsigned)a.n_levels) * 4 + (threadIdx.x >> 6);
+    const int chunks = (a.S + 63) / 64;
+    if (wave >= (long long)a.R * chunks) return;
+    const int r = (int)(wave / chunks), s0 = (int)(wave % chunks) * 64;
+    int n_rows = a.ray_tiles[r] * 32;
+    n_rows = n_rows < a.S ? n_rows : a.S;
+    if (s0 >= n_rows) return;                                         // the whole wave leaves together
+    const bool in = s0 + lane < n_rows;
+    const long long row = (long long)r * a.S + (in ? s0 + lane : n_rows - 1);
+    const float z = a.z_vals[row];
+    const float scale = a.scale[level];
+    const uint32_t res = a.res[level], size = a.size[level], off = a.offset[level];
+    const bool dense = (unsigned long long)res * res * res <= size;
+    float frac[3];
+    uint32_t cell[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float p = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;
+        const float x = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
+        const float pos = fmaf(scale, x, 0.5f);
+        const float fl = floorf(pos);
+        cell[d] = (uint32_t)(int)fl;
+        frac[d] = pos - fl;
+    }
+    float2 g = *(const float2*)(a.tape + (size_t)row * a.row_stride + a.col_d + level * 2);
+    if (!in) g = make_float2(0.f, 0.f);
+    // runs of lanes in the same cell (rows past the end count as their own cell)
+    const uint32_t ckey = in ? (cell[0] * 73856093u) ^ (cell[1] * 19349663u) ^ (cell[2] * 83492791u) : 0xffffffffu - (uint32_t)lane;
+    const uint32_t pk = __shfl_up(ckey, 1);
+    const uint32_t p0 = __shfl_up(cell[0], 1), p1 = __shfl_up(cell[1], 1), p2 = __shfl_up(cell[2], 1);
+    const bool head = lane == 0 || pk != ckey || !in || p0 != cell[0] || p1 != cell[1] || p2 != cell[2];
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int start = 63 - __clzll(below);                            // first lane of my run
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    const bool scan = heads != ~0ull;                                 // wave-uniform: some run is longer than one lane
+    float* gt = a.dparams + (size_t)off * 2;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float w = 1.0f;
+        uint32_t cc[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if ((c >> d) & 1) { cc[d] = cell[d] + 1u; w *= frac[d]; }
+            else { cc[d] = cell[d]; w *= 1.0f - frac[d]; }
+        }
+        float vx = w * g.x, vy = w * g.y;
+        if (scan) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float ux = __shfl_up(vx, d), uy = __shfl_up(vy, d);
+                if (lane - d >= start) { vx += ux; vy += uy; }
+            }
+        }
+        if (tail && in && (vx != 0.0f || vy != 0.0f)) {
+            const uint32_t idx = grid_index(cc[0], cc[1], cc[2], res, size, dense);
+            unsafeAtomicAdd(gt + (size_t)idx * 2, vx);
+            unsafeAtomicAdd(gt + (size_t)idx * 2 + 1, vy);
+        }
+    }
+}
+
+// ---- table update without atomics: slices of the table accumulated in LDS, Adam fused ------------------------------------
+// Global float atomics retire at ~20 G/s chip-wide (previous section), and the samples of one iteration touch millions of
+// distinct table entries, so no reduction in front of the atomics gets the scatter under ~0.5 ms.  The table itself,
+// though, is barely larger than the chip's LDS (5.25 M entries x 8 B = 42 MB vs 256 x 160 KB), and what has to be
+// examined per sample is tiny.  So the roles are turned around, as in tile_adam.hip: one workgroup OWNS a slice of
+// HASH_SLICE entries of one level, keeps its gradient in LDS, walks over ALL backward rows of the iteration (their grid
+// input x and this level's d(feature), packed level-major by hash_pack_kernel so that the walk is a coalesced stream
+// out of L2), adds the corners that fall into its slice with ds_add_f32, and applies Adam to the slice: no gradient
+// buffer in HBM, no global atomics, the table and its moments are read and written once with plain coalesced accesses.
+// Walking cost: ~150 instructions per (row, workgroup) -- the kernel is VALU-bound, see HASH_SLICE below.
+// slice = 16384 entries = 128 KiB of LDS, one workgroup of 1024 threads per CU: the walk is VALU-bound (~150
+// instructions per row and workgroup at one wave instruction per 4 cycles and SIMD), so what counts is the number of
+// (row, workgroup) visits = rows x table bytes / slice bytes.  Measured: 8192 entries x 512 threads (two per CU) 499 us,
+// 16384 x 1024 383 us; unroll 1/2/4/8: 654/577/556/548 us; without the LDS atomics 481 of 556 us
+// (profiles/r02_hash_slices_variants.txt).
+#ifndef HASH_SLICE
+#define HASH_SLICE 16384
+#endif
+#ifndef HASH_SLICE_THREADS
+#define HASH_SLICE_THREADS 1024
+#endif
+#ifndef HASH_UNROLL
+#define HASH_UNROLL 4
+#endif
+
+// first packed row of every ray: exclusive scan of min(ray_tiles[r] * 32, S), one workgroup
+__global__ __launch_bounds__(1024) void hash_offsets_kernel(GridArgs a) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < a.R; base += 1024) {
+        const int r = base + tid;
+        int n = 0;
+        if (r < a.R) { n = a.ray_tiles[r] * 32; n = n < a.S ? n : a.S; }
+        part[tid] = n;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (r < a.R) a.offs[r] = carry + part[tid] - n;
+        __syncthreads();
+        if (tid == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) a.offs[a.R] = carry;
+}
+
+// 16 consecutive backward rows of one ray per workgroup: x of each row, and the rows' d(feature) transposed to level-major
+__global__ __launch_bounds__(256) void hash_pack_kernel(GridArgs a) {
+    __shared__ float2 tr[16][17];
+    const int groups = (a.S + 15) / 16;
+    const int r = blockIdx.x / groups, s0 = (blockIdx.x % groups) * 16;
+    int n_rows = a.ray_tiles[r] * 32;
+    n_rows = n_rows < a.S ? n_rows : a.S;
+    if (s0 >= n_rows) return;
+    const int tid = threadIdx.x, lv = tid & 15, rr = tid >> 4;
+    const bool in = s0 + rr < n_rows;
+    const long long row = (long long)r * a.S + s0 + rr;
+    float2 g = make_float2(0.f, 0.f);
+    if (in && lv < a.n_levels) g = *(const float2*)(a.tape + (size_t)row * a.row_stride + a.col_d + lv * 2);
+    tr[rr][lv] = g;
+    const long long k0 = a.offs[r] + s0;
+    if (lv == 0 && in) {
+        const float z = a.z_vals[row];
+        float x[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float p = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;              // scene_rep.py:384
+            x[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
+        }
+        a.xs[k0 + rr] = make_float4(x[0], x[1], x[2], 0.0f);
+    }
+    __syncthreads();
+    const int rr2 = tid & 15, lv2 = tid >> 4;                        // 16 adjacent lanes = 16 consecutive packed rows of one level
+    if (s0 + rr2 < n_rows && lv2 < a.n_levels) a.dfeat_lv[(size_t)lv2 * a.pack_cap + k0 + rr2] = tr[rr2][lv2];
+}
+
+// Workgroups of one level: slices x replicas.  A dense (coarse) level has few slices and EVERY sample hits them: its rows
+// are split over `replicas` workgroups (LDS float atomics retire ~0.7 G lane-ops/s per CU: one workgroup taking all
+// 2 M corner updates of level 0 ran 2.9 ms), which then add their non-zero sums into a small gradient scratch with global
+// atomics; hash_dense_adam_kernel finishes those levels.  Hashed levels: one workgroup per slice, Adam fused.
+#ifndef HASH_LEVEL_WGS
+#define HASH_LEVEL_WGS 64
+#endif
+#ifdef HASH_ABL_NO_LDS_ADD          // timing experiment: the walk without the LDS atomics (plain racing stores)
+#define HASH_LDS_ADD(p, v) (*(p) = (v))
+#else
+#define HASH_LDS_ADD(p, v) atomicAdd((p), (v))
+#endif
+__host__ __device__ __forceinline__ int hash_slices_of(const GridArgs& a, int level) { return (int)((a.size[level] + HASH_SLICE - 1) / HASH_SLICE); }
+__host__ __device__ __forceinline__ bool hash_level_dense(const GridArgs& a, int level) {
+    return (unsigned long long)a.res[level] * a.res[level] * a.res[level] <= a.size[level];
+}
+__host__ __device__ __forceinline__ int hash_replicas_of(const GridArgs& a, int level) {
+    if (!hash_level_dense(a, level)) return 1;
+    const int r = HASH_LEVEL_WGS / hash_slices_of(a, level);
+    return r < 1 ? 1 : r;
+}
+
+__global__ __launch_bounds__(HASH_SLICE_THREADS, HASH_SLICE_THREADS / 128) void hash_slice_adam_kernel(GridArgs a) {
+    MNE_DYN_LDS(lds_raw);
+    float* acc = (float*)lds_raw;                                    // [HASH_SLICE][2] gradient of this slice
+    const int tid = threadIdx.x;
+    int level = 0, k = blockIdx.x;
+    while (level + 1 < a.n_levels && k >= hash_slices_of(a, level) * hash_replicas_of(a, level)) {
+        k -= hash_slices_of(a, level) * hash_replicas_of(a, level);
+        ++level;
+    }
+    const int n_rep = hash_replicas_of(a, level), rep = k % n_rep;
+    k /= n_rep;
+    const uint32_t res = a.res[level], size = a.size[level], off = a.offset[level];
+    const uint32_t lo = (uint32_t)k * HASH_SLICE;
+    const uint32_t n_ent = size - lo < HASH_SLICE ? size - lo : HASH_SLICE;
+    const bool dense = (unsigned long long)res * res * res <= size;
+    const bool pow2 = (size & (size - 1u)) == 0u;
+    const float scale = a.scale[level];
+    for (int i = tid; i < HASH_SLICE * 2 / 4; i += HASH_SLICE_THREADS) ((float4*)acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int n_live = a.offs[a.R];
+    const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
+    // The walk over this replica's share of the rows, HASH_UNROLL rows per thread in flight (the stream comes out of L2 /
+    // Infinity Cache: latency, not bytes).  (Tried for the dense levels and dropped: a segmented wave scan in front of
+    // the LDS atomics -- 96 dependent ds_bpermute per 64 rows, 1.7 ms for level 0's workgroup; per-thread contiguous row
+    // chunks -- 2.9 ms; profiles/r02_hash_slices_*.txt.)
+    const int row_lo = (int)((long long)n_live * rep / n_rep), row_hi = (int)((long long)n_live * (rep + 1) / n_rep);
+    const int n_iter = (row_hi - row_lo + HASH_SLICE_THREADS - 1) / HASH_SLICE_THREADS;
+    for (int it = 0; it < n_iter; it += HASH_UNROLL) {
+        float2 gq[HASH_UNROLL];
+        float4 xq[HASH_UNROLL];
+        bool inq[HASH_UNROLL];
+#pragma unroll
+        for (int q = 0; q < HASH_UNROLL; ++q) {
+            const int i = row_lo + (it + q) * HASH_SLICE_THREADS + tid;
+            inq[q] = i < row_hi;
+            gq[q] = make_float2(0.f, 0.f); xq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (inq[q]) { gq[q] = gl[i]; xq[q] = a.xs[i]; }
+        }
+#pragma unroll
+        for (int q = 0; q < HASH_UNROLL; ++q) {
+            const float2 g = gq[q];
+            const float4 x = xq[q];
+            if (!(inq[q] && (g.x != 0.0f || g.y != 0.0f))) continue;
+            float frac[3];
+            uint32_t cell[3];
+            const float xv[3] = {x.x, x.y, x.z};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float pos = fmaf(scale, xv[d], 0.5f);
+                const float fl = floorf(pos);
+                cell[d] = (uint32_t)(int)fl;
+                frac[d] = pos - fl;
+            }
+            const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
+            if (dense) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t e = grid_index(cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1), res, size, true) - lo;
+                    if (e < n_ent) {
+                        const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];     // product order of grid_kernel
+                        HASH_LDS_ADD(acc + 2 * e, w * g.x);
+                        HASH_LDS_ADD(acc + 2 * e + 1, w * g.y);
+                    }
+                }
+            } else {
+                // (a ^ b ^ c) & m == (a & m) ^ (b & m) ^ (c & m): mask the six components once when the level size is 2^n
+                const uint32_t msk = pow2 ? size - 1u : 0xffffffffu;
+                const uint32_t hx[2] = {cell[0] & msk, (cell[0] + 1u) & msk};
+                const uint32_t hy[2] = {(cell[1] * 2654435761u) & msk, ((cell[1] + 1u) * 2654435761u) & msk};
+                const uint32_t hz[2] = {(cell[2] * 805459861u) & msk, ((cell[2] + 1u) * 805459861u) & msk};
+                const uint32_t hxy[4] = {hx[0] ^ hy[0], hx[1] ^ hy[0], hx[0] ^ hy[1], hx[1] ^ hy[1]};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t h = hxy[c & 3] ^ hz[(c >> 2) & 1];
+                    const uint32_t e = (pow2 ? h : (h % size)) - lo;
+                    if (e < n_ent) {
+                        const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];
+                        HASH_LDS_ADD(acc + 2 * e, w * g.x);
+                        HASH_LDS_ADD(acc + 2 * e + 1, w * g.y);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (n_rep > 1) {                                                 // partial sums of a dense level: into the gradient scratch
+        float* gs = a.dparams + ((size_t)off + lo) * 2;
+        for (uint32_t e = tid; e < n_ent * 2; e += HASH_SLICE_THREADS)
+            if (acc[e] != 0.0f) unsafeAtomicAdd(gs + e, acc[e]);
+        return;
+    }
+    // ---- Adam on the slice: entries are float2, moments have the table's layout
+    const PlaneOpt o = a.opt;
+    float2* P = (float2*)a.params + off + lo;
+    float2* M = (float2*)o.m + off + lo;
+    float2* V = (float2*)o.v + off + lo;
+    for (uint32_t e = tid; e < n_ent; e += HASH_SLICE_THREADS) {
+        float2 p = P[e], m = M[e], v = V[e];
+        const float2 g = *(const float2*)(acc + 2 * e);
+        adam_elem(p.x, g.x, m.x, v.x, o);
+        adam_elem(p.y, g.y, m.y, v.y, o);
+        P[e] = p; M[e] = m; V[e] = v;
+    }
+}
+
+// Adam over the levels whose gradient went through the scratch (float2 entries [0, n_ent)); leaves the scratch zeroed
+__global__ __launch_bounds__(256) void hash_dense_adam_kernel(GridArgs a, unsigned n_ent) {
+    const unsigned e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_ent) return;
+    const PlaneOpt o = a.opt;
+    float2* G = (float2*)a.dparams;
+    float2 p = ((float2*)a.params)[e], m = ((float2*)o.m)[e], v = ((float2*)o.v)[e];
+    const float2 g = G[e];
+    adam_elem(p.x, g.x, m.x, v.x, o);
+    adam_elem(p.y, g.y, m.y, v.y, o);
+    ((float2*)a.params)[e] = p; ((float2*)o.m)[e] = m; ((float2*)o.v)[e] = v;
+    G[e] = make_float2(0.f, 0.f);
+}
+
+int mne_hash_slice_count(const GridArgs& a) {
+    int n = 0;
+    for (int l = 0; l < a.n_levels; ++l) n += hash_slices_of(a, l) * hash_replicas_of(a, l);
+    return n;
+}
+
+// entries (float2) at the front of the table whose levels are updated through the gradient scratch
+unsigned mne_hash_scratch_entries(const GridArgs& a) {
+    unsigned n = 0;
+    for (int l = 0; l < a.n_levels; ++l)
+        if (hash_replicas_of(a, l) > 1) n = a.offset[l] + a.size[l];
+    return n;
+}
+
+int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st) {
+    if (a.R <= 0) return 0;
+    MNE_LAUNCH(hash_offsets_kernel, 1, 1024, 0, st, a);
+    MNE_LAUNCH(hash_pack_kernel, (unsigned)(a.R * ((a.S + 15) / 16)), 256, 0, st, a);
+    const size_t lds = (size_t)HASH_SLICE * 2 * sizeof(float);
+    MNE_SET_MAX_LDS(hash_slice_adam_kernel, MNE_LDS_MAX);
+    MNE_LAUNCH(hash_slice_adam_kernel, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, lds, st, a);
+    const unsigned n_dense = mne_hash_scratch_entries(a);
+    if (n_dense) MNE_LAUNCH(hash_dense_adam_kernel, (n_dense + 255) / 256, 256, 0, st, a, n_dense);
+    return 0;
+}
+
 int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st) {
+    if (bwd == 2) {
+        const long long waves = (long long)a.R * ((a.S + 63) / 64);
+        if (waves > 0) MNE_LAUNCH(hash_scatter_runs_kernel, (unsigned)((waves + 3) / 4) * a.n_levels, 256, 0, st, a);
+        return 0;
+    }
     const long long n = (long long)a.R * a.S * 16;
     if (n <= 0) return 0;
     if (bwd) MNE_LAUNCH(hash_rows_kernel<true>, (unsigned)((n + 255) / 256), 256, 0, st, a);

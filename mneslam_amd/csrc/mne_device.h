@@ -52,6 +52,15 @@ __device__ __forceinline__ void clock_bias(const Clock& clk, double lr, int step
     bc2_sqrt = (float)sqrt(clk.bias_table[2 * (t - 1) + 1]);
 }
 
+// ---- one Adam element (torch.optim.Adam single-tensor arithmetic; constants prepared on the host in double) ------
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const PlaneOpt& o) {
+    if (o.wd != 0.0f) g = g + o.wd * p;
+    m = m + (g - m) * o.omb1;
+    v = v * o.b2 + o.omb2 * (g * g);
+    const float denom = sqrtf(v) / o.bc2_sqrt + o.eps;
+    p = p - o.step_size * (m / denom);
+}
+
 // ---- coordinates --------------------------------------------------------------------------------
 // Plane lookup uses the EXTENDED bound -> [-1,1] (model/utils.py:38-40); OneBlob uses the RAW
 // bounding box -> [0,1], in fp64 when the box is float64 (model/scene_rep.py:292).

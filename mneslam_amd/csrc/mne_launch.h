@@ -110,6 +110,8 @@ struct SampleRaysArgs {
     Clock clk;
 };
 
+struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, bc2_sqrt; double lr; int step; };
+
 #define MNE_GRID_MAX_LEVELS 32
 #define MNE_GRID_MAX_F 8
 struct GridArgs {
@@ -130,6 +132,12 @@ struct GridArgs {
     int R, S, row_stride, col_x, col_d;
     double bb_lo[3], bb_hi[3];   // raw bounding box: x = (p - lo) / (hi - lo), as the OneBlob input
     int bb_is_f64;
+    // slice form (hash_slice_adam_kernel): packed backward rows + Adam state of the table
+    int* offs;                   // [R+1] first packed row of each ray (exclusive scan of its backward rows)
+    float4* xs;                  // [R*S] packed: grid input x of each backward row
+    float2* dfeat_lv;            // [n_levels][R*S] packed: d(feature) of each backward row, level-major
+    long long pack_cap;          // R*S
+    PlaneOpt opt;                // table optimizer state and step constants
 };
 
 struct WgradArgs {
@@ -141,7 +149,6 @@ struct WgradArgs {
     int n_waves;              // number of partial results
 };
 
-struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, bc2_sqrt; double lr; int step; };
 
 struct TileAdamArgs {
     mne_scene_t sc;
@@ -170,6 +177,9 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
 int mne_launch_render(const RenderArgs& a, int mode, void* workspace, hipStream_t st);
 void mne_set_render_marks(void* const* events, int n);
 int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st);
+int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st);
+int mne_hash_slice_count(const GridArgs& a);
+unsigned mne_hash_scratch_entries(const GridArgs& a);
 size_t mne_render_workspace(int R, int S);
 int mne_launch_query(const QueryArgs& a, hipStream_t st);
 int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStream_t st);

@@ -16,6 +16,7 @@
 #define MNE_LAUNCH(kern, grid, block, lds, stream, ...) \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
 #define hipLaunchOrEmu2D(kern, gx, gy, block, stream, ...) hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(block), 0, stream, __VA_ARGS__)
+#define MNE_LDS_MAX (160 * 1024)      // LDS per CU on gfx950
 #define MNE_SET_MAX_LDS(kern, bytes) (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 #define MNE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 // Decoder weights are wave-uniform: reading them through the constant address space makes the

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
         // is still unresolved.)  dec_tiles[r] = tiles decoded in the end.  One decode_tile call site for both uses.
         const bool resolver = a.dec_tiles && a.ray_counts && !a.ray_list && c == prefix_tiles(a, r, ntile) - 1;
         int cc = c;
-        bool found = false, have_carry = false, pre_now = pre != 0;
+        bool found = false, have_carry = false, pre_now = pre != 0 || a.ext_feat != 0;   // ext_feat: every row's features are in the tape
         float z_lim = 0.0f, s_carry = 0.0f;
         const float* zr = a.z_vals + (size_t)r * a.S;
         while (true) {
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
             if (found && !(zr[i0 + n_in] < z_lim)) break;              // the window ends before the next tile
             s_carry = __shfl(s_me, n_in - 1); have_carry = true;
             ++cc;
-            pre_now = false;                                           // tiles beyond the prefix were not pre-gathered
+            pre_now = a.ext_feat != 0;                                 // tiles beyond the prefix were not pre-gathered
         }
         if (resolver && lane == 0) a.dec_tiles[r] = cc + 1;
         ++n_done;
@@ -1035,7 +1035,6 @@ int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStr
 // Workgroup shape of the tile kernels: the A tables (staged in LDS except for the largest decoder,
 // which reads them through L2) plus one private region per wave.  The grid is persistent: at most
 // one workgroup per CU (the LDS footprint allows no more), each wave striding over the tile tasks.
-#define MNE_LDS_MAX (160 * 1024)
 #define MNE_NUM_CU 256
 template <int HID, int HIDC, bool CP> struct WgShape {
     static constexpr bool ALDS = !(HID == 64 && CP);

@@ -17,13 +17,6 @@
 #include "mne_device.h"
 #include "mne_launch.h"
 
-__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const PlaneOpt& o) {
-    if (o.wd != 0.0f) g = g + o.wd * p;
-    m = m + (g - m) * o.omb1;
-    v = v * o.b2 + o.omb2 * (g * g);
-    const float denom = sqrtf(v) / o.bc2_sqrt + o.eps;
-    p = p - o.step_size * (m / denom);
-}
 
 // One list entry = 32 bytes written by ray_kernel with two 16-byte stores: the tape row, the footprint's
 // NW corner relative to the tile (+1, so 0 means "one cell before the tile"), the four bilinear

@@ -480,8 +480,8 @@ class HashFusedStep(FusedStep):
 
         mne_hash_gather -> mne_render_fused_features -> mne_hash_scatter -> ... -> mne_adam_step(table + decoder)
 
-    on one stream (include/mneslam_hip.h, section NS-a).  Every sample is decoded (no early ray termination: the tiles a
-    ray needs beyond its a-priori prefix would have to be gathered on demand inside decode_kernel)."""
+    on one stream (include/mneslam_hip.h, section NS-a).  The grid features of EVERY sample are gathered (the tiles a ray
+    needs beyond its a-priori prefix are only known while decoding); the decode itself terminates rays early, exactly."""
 
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None):
         if not isinstance(optimizer, FusedAdam):
@@ -509,14 +509,31 @@ class HashFusedStep(FusedStep):
         if "grad_buffer" not in st:
             st["grad_buffer"] = torch.zeros_like(self.table.data)
         self.table_grad = st["grad_buffer"]
-        self.grad_map[self.table] = self.table_grad
-        self._finish_init(overlap=False)
-        self.early_termination = False
+        # table update: "slices" = LDS-accumulated slices + fused Adam (no atomics, no gradient buffer; default);
+        # "atomics" = run-reduced global atomics into a gradient buffer + the streaming Adam kernel
+        self.table_update = os.environ.get("MNE_HASH_UPDATE", "slices")
+        if self.table_update == "atomics":
+            self.grad_map[self.table] = self.table_grad
+        else:
+            scratch = (self.lib.mne_hash_scratch_floats(C.byref(self.grid_cfg)) * 4 + 255) // 256 * 256
+            self.hash_ws_bytes = scratch + self.lib.mne_hash_workspace_bytes(self.R, self.S)
+            self.hash_ws = torch.zeros(self.hash_ws_bytes, device=self.device, dtype=torch.uint8)
+            grp = next(g for g in optimizer.param_groups if any(p is self.table for p in g["params"]))
+            o = self.table_opt = _lib.PlaneOpt()
+            o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
+            o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
+        self._finish_init(overlap=os.environ.get("MNE_NO_OVERLAP", "0") != "1")
+        self._decoder_pending = False
 
     def _refresh_pointers(self):
         w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
         self.scene.w_sdf0, self.scene.w_sdf1 = w_sdf0.data_ptr(), w_sdf1.data_ptr()
         self.scene.w_col0, self.scene.w_col1 = w_col0.data_ptr(), w_col1.data_ptr()
+
+    def synchronize(self):
+        if self._decoder_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._ev[1])
+            self._decoder_pending = False
 
     def check(self):
         self.synchronize()
@@ -530,6 +547,15 @@ class HashFusedStep(FusedStep):
         self.n_active = R
         self._refresh_pointers()
         st = _lib.stream_for(self.rays_o)
+        main = side = None
+        if self.rays_o.is_cuda and self.overlap and self.table_update != "atomics":
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.device)
+                self._ev = [torch.cuda.Event() for _ in range(2)]
+            main, side = torch.cuda.current_stream(self.device), self._side
+            if self._decoder_pending:                         # previous step's decoder update (side stream)
+                main.wait_event(self._ev[1])
+                self._decoder_pending = False
         host_batch = idx_global is not None or idx_cur is not None or u is not None
         key = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
         if host_batch or self._prefetched != key:
@@ -543,24 +569,49 @@ class HashFusedStep(FusedStep):
         self._mark("hash_gather", e0)
         e0 = self._mark("render")
         _lib.check(lib.mne_render_fused_features(sc, C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb),
-                                                 P(self.tgt_d), P(self.z_vals), P(self.packed), P(self.coef), P(self.rgb),
+                                                 P(self.tgt_d), P(self.z_vals),
+                                                 P(self.ray_counts) if self.early_termination else None, P(self.packed), P(self.coef), P(self.rgb),
                                                  P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape), R * S,
                                                  P(self.tape_rows), P(self.ray_tiles), P(self.ws), self.ws_bytes, st),
                    "mne_render_fused_features")
         self._mark("render", e0)
+        if side is not None:
+            self._ev[0].record(main)
+            side.wait_event(self._ev[0])
+            # decoder chain (weight gradients -> decoder Adam) on the side stream, concurrent with the table update
+            # (VALU-bound, one 1024-thread workgroup per CU: leaves registers and LDS for the weight-gradient blocks)
+            with torch.cuda.stream(side):
+                e0 = self._mark("wgrad", stream=side)
+                _lib.check(lib.mne_decoder_wgrad(sc, P(self.tape), P(self.ray_tiles), R, S, P(self.partials), P(self.dec_grad),
+                                                 self.model.wgrad_impl, C.c_void_p(side.cuda_stream)), "mne_decoder_wgrad")
+                self._mark("wgrad", e0, stream=side)
+                self.opt.step(zero_grad=True, grad_buffers=self.grad_map)
+                self._ev[1].record(side)
+            self._decoder_pending = True
         e0 = self._mark("hash_scatter")
-        _lib.check(lib.mne_hash_scatter(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.tape),
-                                        P(self.ray_tiles), P(self.table_grad), st), "mne_hash_scatter")
+        if self.table_update == "atomics":
+            _lib.check(lib.mne_hash_scatter(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.tape),
+                                            P(self.ray_tiles), P(self.table_grad), st), "mne_hash_scatter")
+        else:
+            stt, o = self.opt._state(self.table), self.table_opt
+            stt["step"] += 1
+            o.m, o.v, o.step = stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr(), stt["step"]
+            _lib.check(lib.mne_hash_slice_adam(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.tape),
+                                               P(self.ray_tiles), P(self.table.data), C.byref(o), P(self.hash_ws),
+                                               self.hash_ws_bytes, st), "mne_hash_slice_adam")
         self._mark("hash_scatter", e0)
-        e0 = self._mark("wgrad")
-        _lib.check(lib.mne_decoder_wgrad(sc, P(self.tape), P(self.ray_tiles), R, S, P(self.partials), P(self.dec_grad),
-                                         self.model.wgrad_impl, st), "mne_decoder_wgrad")
-        self._mark("wgrad", e0)
-        e0 = self._mark("adam")
-        self.opt.step(zero_grad=True, grad_buffers=self.grad_map)            # table + decoder tensors, one launch
-        self._mark("adam", e0)
+        if side is None:
+            e0 = self._mark("wgrad")
+            _lib.check(lib.mne_decoder_wgrad(sc, P(self.tape), P(self.ray_tiles), R, S, P(self.partials), P(self.dec_grad),
+                                             self.model.wgrad_impl, st), "mne_decoder_wgrad")
+            self._mark("wgrad", e0)
+            e0 = self._mark("adam")
+            self.opt.step(zero_grad=True, grad_buffers=self.grad_map)            # (table +) decoder tensors, one launch
+            self._mark("adam", e0)
         _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
         self.iteration += 1
         if prefetch and not host_batch:
             self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st)
             self._prefetched = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
+        else:
+            self.synchronize()                                # whatever the caller enqueues next sees the updated decoder
