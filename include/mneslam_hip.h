@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MNE_ABI_VERSION 2
+#define MNE_ABI_VERSION 3
 
 /* orientation index of a plane triple, as in JointEncoding.all_planes (scene_rep.py:117) */
 enum { MNE_XY = 0, MNE_XZ = 1, MNE_YZ = 2 };
@@ -42,9 +42,15 @@ enum { MNE_C_VALID = 0, MNE_C_E_FRONT = 1, MNE_C_E_CENTER = 2, MNE_C_E_TAIL = 3,
        MNE_N_COUNT = 8 };
 
 typedef struct mne_plane {
-    const float* data;   /* [h][w][c_dim] */
+    const float* data;   /* [h][w][c_dim] fp32: the parameter (what Adam updates, what the reference's tensor holds) */
     float* grad;         /* same layout; accumulated into (atomics); NULL when not needed */
     int32_t h, w;
+    /* EXTENSION (BASELINE configs[4], "fp16 features + fp32 accumulate"; not reference behaviour): optional IEEE
+     * half-precision copy of `data`, same [h][w][c_dim] layout (64-byte corner rows).  When non-NULL every lookup
+     * reads it instead of `data` (interpolation and everything after it stay fp32) and mne_tile_adam rewrites it
+     * (round-to-nearest-even of the updated fp32 parameter) together with `data`.  Kept in step by the caller
+     * otherwise (mne_adam_step does not know about it). */
+    void* half_data;
 } mne_plane_t;
 
 /* One JointEncoding's tensors (model/scene_rep.py:15-26, :85-181). */

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmneslam_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 N_LOSS = 8
 N_COUNT = 8
 C_NEED = 6
@@ -21,7 +21,7 @@ L_RGB, L_DEPTH, L_CO_SDF, L_CO_FS, L_E_FS, L_E_CENTER, L_E_TAIL, L_PSNR = range(
 
 
 class Plane(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("grad", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32)]
+    _fields_ = [("data", C.c_void_p), ("grad", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("half_data", C.c_void_p)]
 
 
 class Scene(C.Structure):

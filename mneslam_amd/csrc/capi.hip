@@ -54,6 +54,8 @@ static int check_scene(const mne_scene_t* sc, bool need_grad, bool need_planes =
                 if (!p.data || p.h < 1 || p.w < 1) return fail(-1, "plane pointer/shape missing");
                 if (need_grad && !p.grad) return fail(-1, "plane gradient buffer missing");
                 if ((long long)p.h * p.w * sc->c_dim >= (1ll << 31)) return fail(-1, "plane too large for 32-bit offsets");
+                if ((p.half_data != nullptr) != (sc->plane[0][0][0].half_data != nullptr))
+                    return fail(-1, "half-precision plane copies must be given for every plane or for none");
             }
     if (!sc->w_sdf0 || !sc->w_sdf1 || !sc->w_col0 || !sc->w_col1) return fail(-1, "decoder weight pointer missing");
     return 0;

@@ -151,6 +151,17 @@ __device__ __forceinline__ void oneblob16(float x, float* out /*16*/, bool inter
 #endif
 // Tri-plane features of ONE point for the 8 lanes that share it (cg = lane & 7: float4 chunk of the 128-B rows); the
 // blended rows go to out + set * set_stride + level * 32 + cg * 4 (LDS row or tape row).
+// Four channels of one corner row: from the fp32 parameter, or from its half-precision copy when the scene has one
+// (element offset e is the same in both; the branch is uniform over the launch).
+__device__ __forceinline__ float4 plane_row4(const mne_plane_t& pl, int e) {
+    if (pl.half_data) {
+        union { uint2 u; _Float16 h[4]; } r;
+        r.u = *(const uint2*)((const _Float16*)pl.half_data + e);
+        return make_float4((float)r.h[0], (float)r.h[1], (float)r.h[2], (float)r.h[3]);
+    }
+    return *(const float4*)(pl.data + e);
+}
+
 template <int NSETS>
 __device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
     const int kmine = cg < 6 ? cg : cg - 6;                        // this lane's plane: k = lvl * 3 + ori
@@ -185,9 +196,9 @@ __device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, flo
 #pragma unroll
             for (int j = 0; j < 3 * NLV; ++j) {
                 const int k = l0 * 3 + j;
-                const float* base = sc.plane[set][k % 3][k / 3].data + cg * 4;
+                const mne_plane_t& pl = sc.plane[set][k % 3][k / 3];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[j][q] = *(const float4*)(base + off[j][q]);
+                for (int q = 0; q < 4; ++q) v[j][q] = plane_row4(pl, cg * 4 + off[j][q]);
             }
             MNE_SCHED_BARRIER();
 #pragma unroll
@@ -249,9 +260,8 @@ __device__ __forceinline__ void gather_coord_grad(const mne_scene_t& sc, const f
                     const float ux = ((gx + 1.0f) / 2.0f) * (float)(pl.w - 1), uy = ((gy + 1.0f) / 2.0f) * (float)(pl.h - 1);
                     const float fx = fminf((float)(pl.w - 1), fmaxf(ux, 0.0f)), fy = fminf((float)(pl.h - 1), fmaxf(uy, 0.0f));
                     const float x0 = floorf(fx), y0 = floorf(fy);
-                    const float* base = pl.data + cg * 4;
-                    const float4 v00 = *(const float4*)(base + b.o00), v01 = *(const float4*)(base + b.o01);
-                    const float4 v10 = *(const float4*)(base + b.o10), v11 = *(const float4*)(base + b.o11);
+                    const float4 v00 = plane_row4(pl, cg * 4 + b.o00), v01 = plane_row4(pl, cg * 4 + b.o01);
+                    const float4 v10 = plane_row4(pl, cg * 4 + b.o10), v11 = plane_row4(pl, cg * 4 + b.o11);
                     const bool xin = b.ix0 + 1 < pl.w, yin = b.iy0 + 1 < pl.h;
                     // dot(dfeat, corner) over this lane's 4 channels; absent corners count as zero
                     const float d00 = df.x * v00.x + df.y * v00.y + df.z * v00.z + df.w * v00.w;

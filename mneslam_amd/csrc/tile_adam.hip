@@ -324,6 +324,11 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             adam_elem(p.x, gg.x, m.x, v.x, o); adam_elem(p.y, gg.y, m.y, v.y, o);
             adam_elem(p.z, gg.z, m.z, v.z, o); adam_elem(p.w, gg.w, m.w, v.w, o);
             *(float4*)(P + off) = p; *(float4*)(o.m + offmv) = m; *(float4*)(o.v + offmv) = v;
+            if (pl.half_data) {                                   // half-precision copy the lookups read (round to nearest even)
+                union { uint2 u; _Float16 h[4]; } r;
+                r.h[0] = (_Float16)p.x; r.h[1] = (_Float16)p.y; r.h[2] = (_Float16)p.z; r.h[3] = (_Float16)p.w;
+                *(uint2*)((_Float16*)pl.half_data + off) = r.u;
+            }
         }
     }
     TILE_STAMP(6);

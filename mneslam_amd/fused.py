@@ -28,7 +28,8 @@ class _null_ctx:
 
 class FusedStep:
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
-                 tile_capacity=None, spill_capacity=None, shared_decoder=False, overlap=True, overlap_peers=None):
+                 tile_capacity=None, spill_capacity=None, shared_decoder=False, overlap=True, overlap_peers=None,
+                 plane_storage="fp32"):
         """scatter="binned": plane gradients are accumulated per 16x16-cell tile in LDS and Adam is applied
         in the same kernel (csrc/tile_adam.hip; no gradient buffers).  scatter="atomics": global
         atomic adds into persistent gradient buffers + the streaming Adam kernel."""
@@ -72,7 +73,19 @@ class FusedStep:
                 if "grad_buffer" not in st:
                     st["grad_buffer"] = torch.zeros_like(p.data)
                 self.grads.append(st["grad_buffer"])
-        self.scene = hip_path.scene_struct(self.info, [p.data for p in self.planes], [w.data for w in self.dec_w], self.grads)
+        # EXTENSION (BASELINE configs[4]: "fp16 features + fp32 accumulate"; not reference behaviour): the lookups read a
+        # half-precision copy of every plane (64-byte corner rows instead of 128), interpolation and everything after it
+        # stay fp32, Adam updates the fp32 parameters and tile_adam_kernel rewrites the copy in the same pass.
+        if plane_storage not in ("fp32", "fp16"):
+            raise ValueError("plane_storage must be fp32|fp16")
+        if plane_storage == "fp16" and scatter != "binned":
+            raise ValueError("fp16 plane storage is maintained by the binned plane update (scatter='binned')")
+        self.plane_storage, self.halves, self._half_src = plane_storage, None, None
+        if plane_storage == "fp16":
+            self.halves = [p.data.to(torch.float16).contiguous(memory_format=torch.channels_last) for p in self.planes]
+            self._half_src = [p.data_ptr() for p in self.planes]
+        self.scene = hip_path.scene_struct(self.info, [p.data for p in self.planes], [w.data for w in self.dec_w], self.grads,
+                                           self.halves)
         self._alloc_buffers(config, is_co_sdf)
         self.bins = None
         if scatter == "atomics":
@@ -218,6 +231,9 @@ class FusedStep:
                         raise ValueError("fused step needs channels_last planes (a plane was re-bound with another layout)")
                     pl = self.scene.plane[s][o][l]
                     pl.data = p.data_ptr()
+                    if self.halves is not None and self._half_src[n] != p.data_ptr():     # plane re-bound: refresh its copy
+                        self.halves[n].copy_(p.data)
+                        self._half_src[n] = p.data_ptr()
                     if self.grads is not None:
                         pl.grad = self.grads[n].data_ptr()
                     if self.bins is not None:
@@ -428,6 +444,14 @@ class FusedStep:
         elif self._planes_pending:                                # whatever the caller enqueues next sees the updated planes
             main.wait_event(ev[1])
             self._planes_pending = False
+
+    def refresh_half_planes(self):
+        """Re-derive the half-precision copies from the fp32 planes (after planes were modified in place by anything
+        other than this step, e.g. a peer's map copied in with ``p.data.copy_``)."""
+        if self.halves is not None:
+            self.synchronize()
+            for h, p in zip(self.halves, self.planes):
+                h.copy_(p.data)
 
     def check(self):
         """Host-synchronising sanity check (call once per mapping_optimize, not per step): raises if list entries

@@ -44,7 +44,7 @@ def as_channels_last(plane):
     return plane.contiguous(memory_format=torch.channels_last)
 
 
-def scene_struct(model_info, planes_cl, dec_w, grads=None):
+def scene_struct(model_info, planes_cl, dec_w, grads=None, halves=None):
     """Fill mne_scene_t.  ``planes_cl``: flat list in all_planes order
     (xy[coarse,fine], xz[...], yz[...], then the colour planes); ``grads``: same order or None."""
     sc = _lib.Scene()
@@ -62,6 +62,7 @@ def scene_struct(model_info, planes_cl, dec_w, grads=None):
                 pl.data = p.data_ptr()
                 pl.h, pl.w = p.shape[2], p.shape[3]
                 pl.grad = grads[s * 6 + o * 2 + l].data_ptr() if grads is not None else None
+                pl.half_data = halves[s * 6 + o * 2 + l].data_ptr() if halves is not None else None
     for k in range(3):
         sc.bound_lo[k], sc.bound_hi[k] = model_info["bound_lo"][k], model_info["bound_hi"][k]
         sc.bb_lo[k], sc.bb_hi[k] = model_info["bb_lo"][k], model_info["bb_hi"][k]

@@ -649,7 +649,7 @@ def out_contrib(fs):
 
 
 def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0, small=False, impl="grid_sample",
-                               scatter="binned"):
+                               scatter="binned", plane_storage="fp32"):
     """The BENCH path -- bench.Agent: device Feistel ray sampler, Philox jitter, FusedStep on two streams --
     against ONE oracle iteration on the SAME device-drawn batch: the batch (ray indices, rays, targets, z samples)
     is copied back from the device, the oracle (CPU autograd) evaluates forward, the seven losses, backward and
@@ -663,8 +663,10 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     Works at any size (full office0: 38.4 M parameters, 2150 x 128 samples; ~2 s of oracle time)."""
     import bench
     dev = torch.device(device)
-    ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, small=small, path="fused", scatter=scatter)
+    ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, small=small, path="fused", scatter=scatter,
+                     plane_storage=plane_storage)
     fs, m = ag.fused, ag.model
+    half = plane_storage == "fp16"         # EXTENSION: the lookups see round-to-nearest-even fp16 copies of the planes
     for _ in range(warm_steps):
         ag.step()
     fs.synchronize()
@@ -700,7 +702,7 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     assert_close(tgt_d, ref_dep[:, 0], rtol=0, atol=0, what="target depth")
     # ---- oracle scene with the pre-step parameters
     sc = OracleScene(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64), build=False)
-    sc.all_planes = tuple([p.contiguous() for p in lst] for lst in planes0)
+    sc.all_planes = tuple([(p.half().float() if half else p).contiguous() for p in lst] for lst in planes0)
     sc.col_w = [dec0["color_net.model.0.weight"], dec0["color_net.model.2.weight"]]
     sc.sdf_w = [dec0["sdf_net.model.0.weight"], dec0["sdf_net.model.2.weight"]]
     sc.requires_grad_(True)
@@ -746,7 +748,14 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
             ref = ref_p.grad
             assert_close(g_hip, ref, rtol=2e-3, atol=2e-5 * max(1e-6, float(ref.abs().max())), what=f"plane grad {k}")
     # ---- Adam
+    if half:                                   # gradients were taken at the rounded values; Adam moves the fp32 parameters
+        with torch.no_grad():
+            for ref_p, p0 in zip(sc.plane_list(), [p for lst in planes0 for p in lst]):
+                ref_p.copy_(p0)
     opt.step()
+    if half:
+        for k, (h, p) in enumerate(zip(fs.halves, flat_planes)):
+            assert torch.equal(cpu(h), cpu(p).half()), f"half-precision copy of plane {k} is not the rounded parameter"
     for k, (p, ref_p, g_m) in enumerate(zip(flat_planes, sc.plane_list(), opt.groups[1].m + (opt.groups[2].m if len(opt.groups) > 2 else []))):
         st = ag.opt._state(p)
         assert_close(cpu(st["exp_avg"]), g_m, rtol=2e-3, atol=2e-6 * max(1e-6, float(g_m.abs().max())), what=f"exp_avg {k}")

@@ -103,8 +103,10 @@ def test_render_maps_fast_path_and_render_img():
     pc.check_render_maps_fast_path(DEV)
 
 
-def test_graph_replay_matches_eager_launches():
-    """The recorded iteration (one hipGraphLaunch per step, iteration / Adam step from the device clock) against the
+@pytest.mark.parametrize("plane_storage", ["fp32", "fp16"])
+def test_graph_replay_matches_eager_launches(plane_storage):
+    """(fp16: BASELINE configs[4] words it "fp16 features + fp32 accumulate, hipGraph-captured mapping iteration".)
+    The recorded iteration (one hipGraphLaunch per step, iteration / Adam step from the device clock) against the
     same steps launched one by one: identical ray batches and z samples (bit for bit), same parameters up to the
     summation order of the plane-gradient lists."""
     import os
@@ -115,7 +117,8 @@ def test_graph_replay_matches_eager_launches():
     cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
     out = {}
     for mode in ("eager", "graph"):
-        ag = bench.Agent(cfg, torch.device("cuda"), seed=6, n_keyframes=8, small=True, path="fused", scatter="binned")
+        ag = bench.Agent(cfg, torch.device("cuda"), seed=6, n_keyframes=8, small=True, path="fused", scatter="binned",
+                         plane_storage=plane_storage)
         ag.fused.use_graph = mode == "graph"
         for it in range(9):
             ag.step(prefetch=it < 8)
@@ -426,3 +429,36 @@ def test_hash_grid_training_learns():
         ag.step(prefetch=it < 149)
     p1, d1 = ag.quality()
     assert math.isfinite(p1) and p1 > p0 + 3.0 and d1 < 0.5 * d0, (p0, d0, p1, d1)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# NS-b: half-precision plane storage (EXTENSION; the oracle sees the same round-to-nearest-even values)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("workload,rays,warm", [("office0", 2048, 0), ("office0", 2048, 3), ("indoor", 256, 2)])
+def test_fp16_plane_storage_step_vs_oracle(workload, rays, warm):
+    """Full plane sizes: the lookups read fp16 copies, interpolation / decoder / compositing / gradients / Adam stay fp32;
+    forward, losses, gradients and the post-Adam fp32 parameters against the oracle evaluated at the rounded planes; the
+    copies equal the rounded parameters after the step."""
+    from mneslam_amd import configs
+    cfg = configs.WORKLOADS[workload][0]()
+    cfg["mapping"]["sample"] = rays
+    out = pc.check_fused_step_vs_oracle(DEV, cfg, n_keyframes=4, seed=9, warm_steps=warm, plane_storage="fp16")
+    assert out["contributing"] > 0
+
+
+def test_fp16_plane_storage_trains_like_fp32():
+    """Matched quality of the extension: 200 iterations on the same device-drawn batches, fp16 vs fp32 plane storage:
+    PSNR within 0.5 dB and depth L1 within 10 % at the end (the planes are N(0, 0.01^2)-scale features: fp16 keeps 11
+    bits of each)."""
+    import bench
+    from mneslam_amd import configs
+    res = {}
+    for ps in ("fp32", "fp16"):
+        ag = bench.Agent(configs.bench_office0(), torch.device("cuda"), seed=2, n_keyframes=5, path="fused", plane_storage=ps)
+        hist = []
+        for it in range(200):
+            ag.step(prefetch=it < 199)
+            if it >= 180:
+                hist.append(ag.quality())
+        res[ps] = (sum(h[0] for h in hist) / len(hist), sum(h[1] for h in hist) / len(hist))
+    assert abs(res["fp16"][0] - res["fp32"][0]) < 0.5 and abs(res["fp16"][1] - res["fp32"][1]) < 0.1 * res["fp32"][1], res
