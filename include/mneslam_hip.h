@@ -102,7 +102,13 @@ typedef struct mne_tile_bins {
     int32_t* dropped;      /* [1] sticky: entries that fit neither their list nor the spill area (their gradient is
                             * LOST); never reset by the library.  A spill area of n_rays*n_samples*6*n_sets*4 entries
                             * cannot overflow.  Must be zero-initialised by the caller; check it after a run. */
+    /* Optional (both or neither): long lists are processed by several workgroups whose partial gradient tiles are
+     * combined in this scratch (load balance; results differ only in summation order).  With them, `order` must hold
+     * mne_tile_count() + MNE_TILE_SPLIT_PARTS entries. */
+    float* split_scratch;  /* [MNE_TILE_SPLIT_PARTS][16*16*c_dim] */
+    int32_t* split_state;  /* [mne_tile_count() + 1], zero-initialised by the caller, left zeroed by mne_tile_adam */
 } mne_tile_bins_t;
+#define MNE_TILE_SPLIT_PARTS 2048
 
 /* Adam state and hyper-parameters of one plane, in JointEncoding.all_planes order
  * ([set][xy,xz,yz][coarse,fine]) for mne_tile_adam. */

@@ -204,6 +204,8 @@ static int fill_bins(const mne_scene_t* scene, const mne_tile_bins_t* bins, Tile
     out.lists = bins->lists; out.counts = bins->counts; out.spill = bins->spill;
     out.spill_count = bins->spill_count; out.order = bins->order; out.cap = bins->cap; out.spill_cap = bins->spill_cap;
     out.dropped = bins->dropped;
+    if ((bins->split_scratch != nullptr) != (bins->split_state != nullptr)) return fail(-1, "tile bins: split_scratch and split_state go together");
+    out.split_scratch = bins->split_scratch; out.split_state = bins->split_state;
     mne_tile_geometry(*scene, out);
     return 0;
 }
@@ -309,7 +311,11 @@ int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* 
     TileAdamArgs a = {};
     a.sc = *scene;
     a.n_planes = scene->n_sets * 6;
-    a.bins.counts = bins->counts; a.bins.order = bins->order;
+    a.bins.counts = bins->counts; a.bins.order = bins->order; a.bins.cap = bins->cap;
+    a.bins.split_scratch = bins->split_scratch; a.bins.split_state = bins->split_state;
+    const char* sm = std::getenv("MNE_TILE_SPLIT_MIN");                   // tests force splitting on tiny scenes
+    const int split_min = sm ? std::atoi(sm) : 1024;
+    a.bins.split_min = split_min < 1 ? 1 : split_min;
     mne_tile_geometry(*scene, a.bins);
     mne_launch_tile_order(a, (hipStream_t)stream);
     return check_launch("tile_order");
@@ -337,6 +343,7 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
             return fail(-1, "mne_tile_adam: clock incomplete or made for other betas");
     }
     a.tape = tape;
+    a.n_tiles = a.bins.tile_base[a.n_planes];
     a.row_stride = (int)mne_dims_tape_row(*scene);
     a.t_dfeat = (int)mne_dims_tape_dfeat(*scene);
     a.t_pn = (int)mne_dims_tape_pn(*scene);

@@ -40,6 +40,9 @@ struct TileBins {
     int* order;               // [n_tiles] processing order of tile_adam_kernel (heaviest lists first)
     int cap, spill_cap;
     int* dropped;             // sticky count of entries lost to a full spill area
+    float* split_scratch;     // [MNE_TILE_SPLIT_PARTS][16*16*32] partial gradient tiles of split lists (NULL: never split)
+    int* split_state;         // [n_tiles + 1]: arrival counters per tile (zero between calls), [n_tiles] = number of work items
+    int split_min;            // lists up to this length are never split
     int tile_base[MNE_MAX_PLANES + 1];   // first tile id of each plane ([set][orient][level] order)
     int ntx[MNE_MAX_PLANES];             // tiles per plane row
 };
@@ -156,7 +159,7 @@ struct TileAdamArgs {
     PlaneOpt opt[MNE_MAX_PLANES];
     const float* tape;
     int row_stride, t_dfeat, t_pn;
-    int n_planes;
+    int n_planes, n_tiles;
     Clock clk;
 };
 

@@ -17,6 +17,11 @@
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
 #define hipLaunchOrEmu2D(kern, gx, gy, block, stream, ...) hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(block), 0, stream, __VA_ARGS__)
 #define MNE_LDS_MAX (160 * 1024)      // LDS per CU on gfx950
+// inter-workgroup hand-off inside one launch (cdna_hip_programming.md, Guideline 16): drain this wave's stores, agent-scope
+// release / acquire by one lane
+#define MNE_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MNE_FENCE_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define MNE_FENCE_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define MNE_SET_MAX_LDS(kern, bytes) (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 #define MNE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 // Decoder weights are wave-uniform: reading them through the constant address space makes the

@@ -62,6 +62,9 @@
 #ifndef TILE_MIN_WAVES
 #define TILE_MIN_WAVES 4        // waves per SIMD the register allocation must allow: 2 workgroups of 8 waves per CU (LDS-limited)
 #endif
+#ifndef MNE_TILE_SPLIT_MIN
+#define MNE_TILE_SPLIT_MIN 1024     // entries: shorter lists are never split (a part costs a 32 KiB slab round trip + ~5 us of fences)
+#endif
 #ifndef TILE_EMPTY_FAST
 #define TILE_EMPTY_FAST 1
 #endif
@@ -73,23 +76,59 @@ static_assert(TILE_CELLS == 256, "the prefix step assumes 4 cells per lane of on
 // Processing order: tiles bucketed by floor(log2(list length + 1)), heaviest bucket first, so the few
 // very long lists (every ray of a keyframe passes through the tile holding its camera centre) start
 // at once instead of forming the tail of the launch.
+// Work items of tile_adam_kernel.  item = tile | part << 20 | parts << 26 (parts = 0: the whole list).  A list longer than
+// `split` entries is cut into parts of equal length that different workgroups accumulate (each in its own LDS tile);
+// their partial gradient tiles meet in the split scratch and the part that arrives last applies Adam.  Without this the
+// longest lists ARE the launch: ScanNet with colour planes (12 planes, 2 M entries) ran 0.82 ms, INS Indoor (1045
+// samples per ray into 750 tiles, 15 k entries per list on average) 4.2 ms, against 0.2 / 1.0 ms of balanced work.
+// split = max(MNE_TILE_SPLIT_MIN, 2 * total entries / MNE_TILE_SPLIT_PARTS): at most MNE_TILE_SPLIT_PARTS split items.
+// Split items come first in `order` (item index = scratch slot), then the whole tiles, heaviest bucket first.
 __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_tiles) {
+    __shared__ int hist[32], start[32];
+    __shared__ int total, n_split;
+    const int tid = threadIdx.x;
+    int* n_items = a.bins.split_state ? a.bins.split_state + n_tiles : nullptr;
 #ifdef TILE_ORDER_IDENTITY        // experiment: spatial order (neighbouring tiles run together), no load balancing
-    for (int t = threadIdx.x; t < n_tiles; t += 1024) a.bins.order[t] = t;
+    for (int t = tid; t < n_tiles; t += 1024) a.bins.order[t] = t;
+    if (tid == 0 && n_items) *n_items = n_tiles;
     return;
 #endif
-    __shared__ int hist[32], start[32];
-    const int tid = threadIdx.x;
     if (tid < 32) hist[tid] = 0;
+    if (tid == 0) { total = 0; n_split = 0; }
     __syncthreads();
-    for (int t = tid; t < n_tiles; t += 1024) atomicAdd(&hist[31 - __clz(a.bins.counts[t] + 1)], 1);
+    int mine = 0;
+    for (int t = tid; t < n_tiles; t += 1024) { const int c = a.bins.counts[t]; mine += c < a.bins.cap ? c : a.bins.cap; }
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+    if ((tid & 63) == 0 && mine) atomicAdd(&total, mine);
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int b = 31; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
+    int split = 0x7fffffff;
+    if (a.bins.split_scratch) {
+        split = (int)((2ll * total + MNE_TILE_SPLIT_PARTS - 1) / MNE_TILE_SPLIT_PARTS);
+        split = split < a.bins.split_min ? a.bins.split_min : split;
+    }
+    // split items first, whole tiles into their length buckets
+    for (int t = tid; t < n_tiles; t += 1024) {
+        const int c0 = a.bins.counts[t], c = c0 < a.bins.cap ? c0 : a.bins.cap;
+        if (c > split) {
+            int np = (c + split - 1) / split;
+            np = np > 63 ? 63 : np;
+            const int base = atomicAdd(&n_split, np);
+            for (int q = 0; q < np; ++q) a.bins.order[base + q] = (int)((unsigned)t | ((unsigned)q << 20) | ((unsigned)np << 26));
+        } else {
+            atomicAdd(&hist[31 - __clz(c0 + 1)], 1);
+        }
     }
     __syncthreads();
-    for (int t = tid; t < n_tiles; t += 1024) a.bins.order[atomicAdd(&start[31 - __clz(a.bins.counts[t] + 1)], 1)] = t;
+    if (tid == 0) {
+        int acc = n_split;
+        for (int b = 31; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
+        if (n_items) *n_items = acc;
+    }
+    __syncthreads();
+    for (int t = tid; t < n_tiles; t += 1024) {
+        const int c0 = a.bins.counts[t], c = c0 < a.bins.cap ? c0 : a.bins.cap;
+        if (c <= split) a.bins.order[atomicAdd(&start[31 - __clz(c0 + 1)], 1)] = t;
+    }
 }
 // (A ballot-ranked counting sort without same-address atomics was measured at 14.5 us against 12 us for this one.)
 
@@ -104,7 +143,9 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     __shared__ int n_contrib;
     const int tid = threadIdx.x;
     TILE_STAMP(0);
-    const int tile = a.bins.order[blockIdx.x];
+    if (a.bins.split_state && (int)blockIdx.x >= a.bins.split_state[a.n_tiles]) return;       // the grid covers the item CAPACITY
+    const unsigned item = (unsigned)a.bins.order[blockIdx.x];
+    const int tile = (int)(item & 0xfffffu), part = (int)((item >> 20) & 63u), n_parts = (item >> 26) ? (int)(item >> 26) : 1;
     int pidx = 0;
     while (pidx + 1 < a.n_planes && tile >= a.bins.tile_base[pidx + 1]) ++pidx;
     const int set = pidx / 6, lvl = pidx % 2;                                 // [set][orient][level]
@@ -164,11 +205,15 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     const float* dfeat = a.tape + a.t_dfeat + set * MNE_FEAT + lvl * MNE_C + sub * 4;
     // passes over the list, then over the spill area (spill entries of other tiles contribute nothing)
     const int n_total = n_list + n_spill;
+    // this part's share of the list; the last part also scans the spill area
+    const int chunk = (n_list + n_parts - 1) / n_parts;
+    const int e_lo = part * chunk;
+    const int e_hi = part == n_parts - 1 ? n_total : ((part + 1) * chunk < n_list ? (part + 1) * chunk : n_list);
     TILE_STAMP(1);
-    for (int p0 = 0; p0 < n_total; p0 += PASS_ENTRIES) {
+    for (int p0 = e_lo; p0 < e_hi; p0 += PASS_ENTRIES) {
         for (int i = tid; i < TILE_CELLS; i += TILE_THREADS) hist[i] = 0;
         __syncthreads();
-        if (p0 == 0) TILE_STAMP(2);
+        if (p0 == e_lo) TILE_STAMP(2);
         // ---- A: this thread's entry (kept in registers), its contributions ranked per cell
         int cellk[4] = {-1, -1, -1, -1}, rank[4] = {0, 0, 0, 0};
         float wq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -176,8 +221,8 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         if (tid < PASS_ENTRIES) {
             unsigned row = 0xffffffffu;
             const unsigned* ent = nullptr;
-            if (e < n_list) ent = lst + (size_t)e * MNE_ENTRY_WORDS;
-            else if (e < n_total) ent = a.bins.spill + (size_t)(e - n_list) * MNE_ENTRY_WORDS;
+            if (e < e_hi && e < n_list) ent = lst + (size_t)e * MNE_ENTRY_WORDS;
+            else if (e < e_hi) ent = a.bins.spill + (size_t)(e - n_list) * MNE_ENTRY_WORDS;
             if (ent) {
                 const uint4 e0 = *(const uint4*)ent, e1 = *(const uint4*)(ent + 4);      // one 32-byte entry
                 if (e < n_list || e1.z == (unsigned)tile) {                              // spill entries carry their tile id
@@ -198,7 +243,7 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             erow[tid] = row;
         }
         __syncthreads();
-        if (p0 == 0) TILE_STAMP(3);
+        if (p0 == e_lo) TILE_STAMP(3);
         // ---- every entry's gradient row (this plane level: 32 floats) is fetched ONCE per pass, by the
         // 8-lane groups round-robin, all loads in flight together; its (up to four) corner contributions
         // then read it from LDS.  The loads overlap steps B and C.
@@ -209,7 +254,7 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             grow[j] = row != 0xffffffffu ? *(const float4*)(dfeat + (size_t)row * a.row_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #if TILE_PREFETCH == 3
-        if (p0 == 0) { MNE_SCHED_BARRIER(); fetch_operands(); MNE_SCHED_BARRIER(); }
+        if (p0 == e_lo) { MNE_SCHED_BARRIER(); fetch_operands(); MNE_SCHED_BARRIER(); }
 #endif
         // ---- B: counts -> exclusive start offsets (one wave, 4 cells per lane)
         if (tid < MNE_WAVE) {
@@ -237,7 +282,7 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
 #pragma unroll
         for (int j = 0; j < PASS_ENTRIES / TILE_GROUPS; ++j) *(float4*)(stage + (j * TILE_GROUPS + grp) * MNE_C + sub * 4) = grow[j];
         __syncthreads();
-        if (p0 == 0) TILE_STAMP(4);
+        if (p0 == e_lo) TILE_STAMP(4);
         // ---- D: equal ranges of the sorted contributions, one per 8-lane group; a run of equal cells is
         // summed by the group in whose range it STARTS (that group reads on past its range end, the next
         // one skips to the end of the run using the start offsets), so the LDS tile is only ever
@@ -296,8 +341,39 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     }
     if (!empty) __syncthreads();
 #if TILE_PREFETCH == 3
-    if (n_total == 0) fetch_operands();
+    if (e_hi <= e_lo) fetch_operands();
 #endif
+    if (n_parts > 1) {
+        // ---- partial tile -> split scratch; the part that arrives last sums all of them and goes on to Adam.
+        // Hand-off between workgroups on possibly different XCDs (L2s not coherent): plain stores, every wave drains
+        // its stores, one lane releases at agent scope, then takes a ticket; the last arriver acquires and reads.
+        float* slab = a.bins.split_scratch + (size_t)blockIdx.x * (TILE_CELLS * MNE_C);
+        for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)slab)[i] = ((const float4*)g)[i];
+        MNE_DRAIN_STORES();
+        __syncthreads();
+        if (tid == 0) {
+            MNE_FENCE_RELEASE_AGENT();
+            MNE_DRAIN_STORES();
+            n_contrib = atomicAdd(a.bins.split_state + tile, 1);                 // (n_contrib: the one small LDS word, reused as the ticket)
+        }
+        __syncthreads();
+        if (n_contrib != n_parts - 1) return;
+        if (tid == 0) MNE_FENCE_ACQUIRE_AGENT();
+        __syncthreads();
+        const float* first = a.bins.split_scratch + (size_t)(blockIdx.x - part) * (TILE_CELLS * MNE_C);   // parts are consecutive items
+        for (int q = 0; q < n_parts; ++q) {
+            if (q == part) continue;
+            const float4* other = (const float4*)(first + (size_t)q * (TILE_CELLS * MNE_C));
+            for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) {
+                float4 t = ((float4*)g)[i];
+                const float4 u = other[i];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                ((float4*)g)[i] = t;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) a.bins.split_state[tile] = 0;                                  // arrival counter ready for the next call
+    }
     TILE_STAMP(5);
     // ---- Adam on the tile: 16 rows x (16 cells x 32 ch) = 2048 float4
 #pragma unroll
@@ -365,6 +441,7 @@ int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st) {
     if (n_tiles <= 0) return 0;
     const size_t lds = (size_t)(TILE_CELLS + PASS_ENTRIES) * MNE_C * sizeof(float);
     if (lds > 32 * 1024) MNE_SET_MAX_LDS(tile_adam_kernel, lds);        // static LDS (keys, weights, counters) comes on top
-    MNE_LAUNCH(tile_adam_kernel, n_tiles, TILE_THREADS, lds, st, a);
+    const int grid = n_tiles + (a.bins.split_scratch ? MNE_TILE_SPLIT_PARTS : 0);          // item capacity; surplus workgroups leave at once
+    MNE_LAUNCH(tile_adam_kernel, grid, TILE_THREADS, lds, st, a);
     return 0;
 }

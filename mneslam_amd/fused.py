@@ -113,8 +113,15 @@ class FusedStep:
             # processing order of the tiles (heaviest lists first), recomputed every iteration from that iteration's list
             # lengths.  (Sorting by the PREVIOUS iteration's lengths after the plane update, off the critical path, was
             # measured: tile_adam_kernel 244 us instead of 225 us, iteration 557 us instead of 544 us -- profiles/r02_order_ab.txt.)
-            self.tile_order = torch.arange(n_tiles, device=dev, dtype=torch.int32)
+            # long lists are cut into parts processed by several workgroups (load balance; tile_adam.hip): scratch for their
+            # partial gradient tiles + arrival counters.  MNE_NO_TILE_SPLIT=1 keeps one workgroup per tile (A/B).
+            split = os.environ.get("MNE_NO_TILE_SPLIT", "0") != "1"
+            self.tile_order = torch.arange(n_tiles + (_lib.TILE_SPLIT_PARTS if split else 0), device=dev, dtype=torch.int32)
             b.order = self.tile_order.data_ptr()
+            if split:
+                self.split_scratch = torch.empty(_lib.TILE_SPLIT_PARTS, 16 * 16 * 32, device=dev)
+                self.split_state = torch.zeros(n_tiles + 1, device=dev, dtype=torch.int32)
+                b.split_scratch, b.split_state = self.split_scratch.data_ptr(), self.split_state.data_ptr()
             b.cap, b.spill_cap = tile_capacity, spill_capacity
             b.dropped = self.dropped.data_ptr()
             self.bins = b

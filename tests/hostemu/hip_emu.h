@@ -140,6 +140,9 @@ typedef const float* mne_cptr;
 #define MNE_WAVE_SYNC() hipemu::wave_sync()
 #define MNE_SCHED_BARRIER() do { } while (0)
 #define MNE_LDS_MAX (160 * 1024)
+#define MNE_DRAIN_STORES() do { } while (0)
+#define MNE_FENCE_RELEASE_AGENT() std::atomic_thread_fence(std::memory_order_seq_cst)
+#define MNE_FENCE_ACQUIRE_AGENT() std::atomic_thread_fence(std::memory_order_seq_cst)
 #define MNE_SET_MAX_LDS(kern, bytes) ((void)0)
 inline void __syncthreads() { hipemu::g_ctx->block_bar->arrive_and_wait(); }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }

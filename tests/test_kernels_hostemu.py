@@ -202,3 +202,11 @@ def test_bench_path_step_fp16_plane_storage_vs_oracle():
     out = pc.check_fused_step_vs_oracle(DEV, _tiny_bench_cfg(), n_keyframes=3, seed=2, small=True, impl="explicit",
                                         plane_storage="fp16")
     assert out["contributing"] > 0
+
+
+def test_bench_path_step_with_split_tile_lists(monkeypatch):
+    """Long tile lists are cut into parts accumulated by several workgroups and combined by the last arriver
+    (tile_adam.hip); forced here on a tiny scene with MNE_TILE_SPLIT_MIN."""
+    monkeypatch.setenv("MNE_TILE_SPLIT_MIN", "4")
+    out = pc.check_fused_step_vs_oracle(DEV, _tiny_bench_cfg(), n_keyframes=3, seed=2, small=True, impl="explicit")
+    assert out["contributing"] > 0
