@@ -321,6 +321,12 @@ __global__ __launch_bounds__(256) void gather_kernel(RenderArgs a, int chunks_pe
 
 // WPB: waves per workgroup the kernel is compiled for (12 for the fused gather+MLP form: latency hiding matters most;
 // 8 for the pre-gathered form: 256 registers per lane, no spills -- measured 0.531 vs 0.538 ms per iteration)
+// Tiles the resolver wave may decode beyond a ray's a-priori prefix before it leaves the rest to the deferred pass: the
+// extension is SERIAL in one wave (34 us per tile); INS Indoor has 33 tiles per ray and rays that cross empty space:
+// unbounded 606 it/s, 4 tiles 791, 2 tiles 828, 1 tile 846; office0 / ScanNet within noise (profiles/r02_resolver_ext.txt).
+#ifndef MNE_RESOLVER_MAX_EXT
+#define MNE_RESOLVER_MAX_EXT 1
+#endif
 template <int HID, int HIDC, bool CP, bool ALDS, int WPB>
 __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre) {
     typedef ATab<HID, HIDC, CP> T;
@@ -390,6 +396,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
             }
             if (cc + 1 >= ntile) break;
             if (found && !(zr[i0 + n_in] < z_lim)) break;              // the window ends before the next tile
+            if (cc - c >= MNE_RESOLVER_MAX_EXT) break;                 // a long unresolved stretch is cheaper tile-parallel (deferred pass)
             s_carry = __shfl(s_me, n_in - 1); have_carry = true;
             ++cc;
             pre_now = a.ext_feat != 0;                                 // tiles beyond the prefix were not pre-gathered
