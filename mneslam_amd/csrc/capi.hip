@@ -269,6 +269,7 @@ static int render_fused(bool ext_feat, const mne_scene_t* scene, const mne_rende
     a.rgb = rgb; a.depth = depth; a.raw = raw; a.ray_sums = ray_sums;
     a.tape = tape; a.tape_rows = tape_rows; a.ray_tiles = ray_tiles;
     a.ext_feat = ext_feat ? 1 : 0;
+    if (const char* c = std::getenv("MNE_HOT_LDS_SAMPLES")) a.lds_samples = std::atoi(c);      // tests force the two-pass split on small S
     if (bins)
         if (int rc = fill_bins(scene, bins, a.bins)) return rc;
     if (int rc = mne_launch_render(a, 2, workspace, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");

@@ -241,9 +241,8 @@ __device__ __forceinline__ void relu_masks(const MlpState<HID, HIDC>& S, unsigne
 // both lanes of the pair); mh / mhc: relu_masks of the forward.  Outputs: dh, dout, dhc (tape) and d(feature)
 // rows written to LDS (dfrow / dcfrow = the point's rows; each lane writes the rows it holds).
 template <int HID, int HIDC, bool CP>
-__device__ __forceinline__ void mlp_backward_mfma(unsigned mh, unsigned mhc, float ds, const float (&dc)[3],
-                                                  const float* atab, int lane, f32x16 (&dh)[HID / 32],
-                                                  f32x16& dout, f32x16 (&dhc)[HIDC / 32], float* dfrow, float* dcfrow) {
+__device__ __forceinline__ void mlp_backward_color(unsigned mhc, float ds, const float (&dc)[3], const float* atab, int lane,
+                                                   f32x16& dout, f32x16 (&dhc)[HIDC / 32], float* dcfrow) {
     typedef ATab<HID, HIDC, CP> T;
     const int h = lane >> 5;
     const float* A = atab + lane;
@@ -281,6 +280,14 @@ __device__ __forceinline__ void mlp_backward_mfma(unsigned mh, unsigned mhc, flo
                 *(float4*)(dcfrow + 32 * rt + 8 * q + 4 * h) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
         }
     }
+}
+
+template <int HID, int HIDC, bool CP>
+__device__ __forceinline__ void mlp_backward_sdf(unsigned mh, const float* atab, int lane, f32x16 (&dh)[HID / 32],
+                                                 const f32x16& dout, float* dfrow) {
+    typedef ATab<HID, HIDC, CP> T;
+    const int h = lane >> 5;
+    const float* A = atab + lane;
 #pragma unroll
     for (int t = 0; t < T::NT; ++t) {
         f32x16 acc;
@@ -304,6 +311,15 @@ __device__ __forceinline__ void mlp_backward_mfma(unsigned mh, unsigned mhc, flo
         for (int q = 0; q < 4; ++q)
             *(float4*)(dfrow + 32 * rt + 8 * q + 4 * h) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     }
+}
+
+// the whole chain: colour net (writes the colour planes' d(feature) rows), then sdf net (geometry planes' rows)
+template <int HID, int HIDC, bool CP>
+__device__ __forceinline__ void mlp_backward_mfma(unsigned mh, unsigned mhc, float ds, const float (&dc)[3],
+                                                  const float* atab, int lane, f32x16 (&dh)[HID / 32],
+                                                  f32x16& dout, f32x16 (&dhc)[HIDC / 32], float* dfrow, float* dcfrow) {
+    mlp_backward_color<HID, HIDC, CP>(mhc, ds, dc, atab, lane, dout, dhc, dcfrow);
+    mlp_backward_sdf<HID, HIDC, CP>(mh, atab, lane, dh, dout, dfrow);
 }
 
 // d(total)/d(OneBlob channel) rows of this lane's point -> LDS row dprow[0..63] (48 used): both nets'

@@ -294,7 +294,8 @@ __device__ __forceinline__ void gather_coord_grad(const mne_scene_t& sc, const f
 // `live`: bit s set = slot s holds a sample that receives gradient (the others have an all-zero row).
 template <int NSETS, int NPTS>
 __device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float* pn, const float* dfeat,
-                                              unsigned long long live, int lane) {
+                                              unsigned long long live, int lane, int set_lo = 0, int set_hi = NSETS,
+                                              bool one_buffer = false) {      // one_buffer: dfeat holds the rows of set_lo only
     const int c = lane & 31, half = lane >> 5;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 2; ++it) {
@@ -303,9 +304,10 @@ __device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float
             const float px = pn[slot * 4 + 0], py = pn[slot * 4 + 1], pz = pn[slot * 4 + 2];
 #pragma unroll
             for (int set = 0; set < NSETS; ++set) {
+                if (set < set_lo || set >= set_hi) continue;
 #pragma unroll
                 for (int lvl = 0; lvl < 2; ++lvl) {
-                    const float g = dfeat[set * NPTS * MNE_FS + slot * MNE_FS + lvl * MNE_C + c];
+                    const float g = dfeat[(one_buffer ? 0 : set) * NPTS * MNE_FS + slot * MNE_FS + lvl * MNE_C + c];
 #pragma unroll
                     for (int ori = 0; ori < 3; ++ori) {
                         const mne_plane_t& pl = sc.plane[set][ori][lvl];

@@ -57,6 +57,7 @@ struct RenderArgs {
     const float *rays_o, *rays_d, *target_rgb, *target_d, *z_vals, *packed;
     float *rgb, *depth, *disp, *acc, *depth_var, *raw, *ray_sums;
     const float* raw_in;        // backward-only call: raw of ALL samples from the forward call (NULL otherwise)
+    int lds_samples;             // ray_kernel: samples of a ray its LDS arrays hold (0 = all S); rays that need more are deferred
     int ext_feat;                // feature rows come from the caller (tape columns T_X..): no plane gather, no plane scatter
     const int* ray_counts;      // [R][MNE_N_COUNT] from sample_z (slot MNE_C_NEED = a-priori sample count)
     int prefix_default;         // ray_counts == NULL: a-priori tiles of every ray (ntile = decode everything, 1 = on demand only)
@@ -69,6 +70,9 @@ struct RenderArgs {
     int* dec_tiles;             // [R] leading tiles of each ray decode_kernel really decoded (a-priori prefix + its extension)
     int* defer_list;            // [R] rays the training kernel could not resolve from the decoded prefix
     int* defer_count;           // [1]
+    int* long_list;             // [R] rays whose decoded prefix exceeds the first pass's LDS sample cap (long rays only)
+    int* long_count;            // [1]
+    int list_keeps_prefix;      // list pass over long_list: tiles decoded so far = dec_tiles[r] (not "everything")
     const int* ray_list;        // ray_kernel works through this list instead of all rays (NULL = rays 0..R-1)
     const int* ray_list_count;
     float *d_rays_o, *d_rays_d;

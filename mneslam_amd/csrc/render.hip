@@ -338,6 +338,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
         if (a.tape_rows) *a.tape_rows = 0;
         if (a.bins.spill_count) *a.bins.spill_count = 0;
         if (a.defer_count) *a.defer_count = 0;
+        if (a.long_count) *a.long_count = 0;
     }
     if (a.ray_list && *a.ray_list_count == 0) return;      // second pass with nothing deferred (the usual case)
     if (ALDS) {                                            // stage the A tables: the only block-wide step
@@ -588,14 +589,21 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
     }
     const float* atab = ALDS ? (const float*)lds_raw - TAB_FIRST * 64 : a.packed;     // indexed by absolute step
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int S = a.S, Spad = (S + 3) & ~3, ntile = (S + TILE - 1) / TILE;
-    const size_t wave_bytes = (size_t)Spad * 5 * sizeof(float) + tile_wave_lds_bytes(NSETS, RAYGRAD);
+    const int S = a.S, ntile = (S + TILE - 1) / TILE;
+    const int L = (a.lds_samples > 0 && a.lds_samples < S) ? a.lds_samples : S;       // samples the per-wave LDS arrays hold
+    const int Spad = (L + 3) & ~3;
+    // Training kernel with colour planes: ONE set of 32 LDS rows per wave -- the colour net's d(feature) rows leave for
+    // the tape before the sdf net's rows are produced -- so that more waves fit beside the tables (ScanNet: 6 -> 11 per CU,
+    // i.e. all 2150 rays in one round instead of two).
+    constexpr bool SEQ = HOT && CP;
+    constexpr int LSETS = SEQ ? 1 : NSETS;
+    const size_t wave_bytes = (size_t)Spad * 5 * sizeof(float) + tile_wave_lds_bytes(LSETS, RAYGRAD);
     unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * wave_bytes;
     float* raws = (float*)my;                                     // [Spad][4]
     float* zr = raws + (size_t)Spad * 4;                          // [Spad] this ray's z samples
     float* pn = zr + Spad;
     float* feat = pn + TILE * 4;
-    float* dposL = feat + NSETS * TILE * MNE_FS;                  // RAYGRAD: [32][64] d OneBlob rows
+    float* dposL = feat + LSETS * TILE * MNE_FS;                  // RAYGRAD: [32][64] d OneBlob rows
     float* dpnL = dposL + TILE * 64;                              // RAYGRAD: [32][4]  d normalised point
     const int pt = lane & 31, hf = lane >> 5;
     const bool has_t = a.target_d != nullptr;
@@ -615,15 +623,19 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
         MNE_WAVE_SYNC();                                          // previous ray's LDS reads are done
         // ---- this ray's z and the raw of its known samples -> LDS, one batch of loads (raw beyond the decoded prefix
         // is never looked at): everything (backward of an earlier forward) or the decoded prefix
-        int t_dec = (a.dec_tiles && !a.ray_list && a.ray_counts) ? a.dec_tiles[r]
-                                                                 : prefix_tiles(a, r, ntile, a.ray_list != nullptr);   // tiles with raw / masks / tape rows written
+        int t_dec = (a.dec_tiles && (!a.ray_list || a.list_keeps_prefix) && a.ray_counts)
+                        ? a.dec_tiles[r] : prefix_tiles(a, r, ntile, a.ray_list != nullptr);   // tiles with raw / masks / tape rows written
         int Dn = a.raw_in ? S : (t_dec * TILE < S ? t_dec * TILE : S);
+        if (L < S && Dn + 1 > L) {                                // (HOT only) the decoded prefix does not fit this launch's LDS:
+            if (lane == 0) a.long_list[atomicAdd(a.long_count, 1)] = r;            // next pass: the same kernel sized for S
+            continue;
+        }
         {
             const float4* src = (const float4*)((a.raw_in ? a.raw_in : a.raw) + (size_t)r * S * 4);
             const float* zsrc = a.z_vals + (size_t)r * S;
-            for (int i = lane; i < S; i += MNE_WAVE) {
+            for (int i = lane; i < L; i += MNE_WAVE) {
                 zr[i] = zsrc[i];
-                if (HOT || i < Dn) *(float4*)(raws + 4 * i) = src[i];
+                if (i < Dn) *(float4*)(raws + 4 * i) = src[i];
             }
         }
         MNE_WAVE_SYNC();
@@ -728,17 +740,34 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
             // ---- MFMA backward chain from the saved ReLU masks; d(feature) rows land in this point's LDS rows.
             // A sample without gradient has ds = dc = 0 and therefore an all-zero backward row.
             float* frow = feat + pt * MNE_FS;
-            float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
+            float* cfrow = SEQ ? frow : feat + TILE * MNE_FS + pt * MNE_FS;
             f32x16 dh[NT], dout, dhc[NTC];
+#ifdef ABL_NO_APPEND
+            const bool live = false;
+#else
+            const bool live = valid && contrib;
+#endif
+            const unsigned long long live_rows = __ballot(live && hf == 0), valid_rows = __ballot(valid && hf == 0);
+            float* tape0 = a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW;
+            if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
 #ifdef ABL_NO_BWD_MFMA
             dout = f32x16_zero(); dout[0] = ds + dc[0];
             for (int t = 0; t < NT; ++t) dh[t] = f32x16_zero();
             for (int t = 0; t < NTC; ++t) dhc[t] = f32x16_zero();
 #else
-            mlp_backward_mfma<HID, HIDC, CP>(mk2.x, mk2.y, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
+            if (SEQ) {
+                mlp_backward_color<HID, HIDC, CP>(mk2.y, ds, dc, atab, lane, dout, dhc, cfrow);
+                MNE_WAVE_SYNC();
+                if (a.ext_feat) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT + MNE_FEAT, valid_rows, lane);
+                else if (a.bins.lists) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT + MNE_FEAT, live_rows, lane);
+                else if (a.sc.plane[0][0][0].grad) scatter_chunk<NSETS, TILE>(a.sc, pn, feat, live_rows, lane, 1, 2, true);
+                MNE_WAVE_SYNC();
+                mlp_backward_sdf<HID, HIDC, CP>(mk2.x, atab, lane, dh, dout, frow);
+            } else {
+                mlp_backward_mfma<HID, HIDC, CP>(mk2.x, mk2.y, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
+            }
 #endif
             RAY_STAMP(7 + 6 * c);
-            if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
             if (RAYGRAD) {
                 // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates; every
                 // point of the tile belongs to this ray: summed over the wave, stored once at the end
@@ -762,13 +791,6 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
                 }
             }
             MNE_WAVE_SYNC();
-#ifdef ABL_NO_APPEND
-            const bool live = false;
-#else
-            const bool live = valid && contrib;
-#endif
-            const unsigned long long live_rows = __ballot(live && hf == 0), valid_rows = __ballot(valid && hf == 0);
-            float* tape0 = a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW;
 #ifdef ABL_NO_BWD_TAPE
             const unsigned long long tape_rows_mask = 0ull;
 #else
@@ -777,14 +799,14 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
             // ---- backward half of the tape rows, staged through the LDS rows (full-line stores, see store_rows)
             if (a.ext_feat) {                                     // caller-owned encoding: d(feature) rows of every valid sample
 #pragma unroll                                                    // (all-zero rows for samples without gradient)
-                for (int set = 0; set < NSETS; ++set)
+                for (int set = 0; set < LSETS; ++set)
                     store_rows<MNE_FEAT>(feat + set * TILE * MNE_FS, tape0, D::ROW, D::T_DFEAT + set * MNE_FEAT, valid_rows, lane);
             } else if (a.bins.lists) {                            // d(feature) rows: read by the binned plane update
 #pragma unroll
-                for (int set = 0; set < NSETS; ++set)
+                for (int set = 0; set < LSETS; ++set)
                     store_rows<MNE_FEAT>(feat + set * TILE * MNE_FS, tape0, D::ROW, D::T_DFEAT + set * MNE_FEAT, live_rows, lane);
             } else if (a.sc.plane[0][0][0].grad) {                // NULL: the caller wants no plane gradients (pose-only loops)
-                scatter_chunk<NSETS, TILE>(a.sc, pn, feat, live_rows, lane);
+                scatter_chunk<NSETS, TILE>(a.sc, pn, feat, live_rows, lane, 0, LSETS);
             }
             MNE_WAVE_SYNC();
             if (HID == 32 && HIDC == 32) {
@@ -1043,6 +1065,9 @@ int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStr
 // which reads them through L2) plus one private region per wave.  The grid is persistent: at most
 // one workgroup per CU (the LDS footprint allows no more), each wave striding over the tile tasks.
 #define MNE_NUM_CU 256
+#ifndef MNE_HOT_LDS_SAMPLES
+#define MNE_HOT_LDS_SAMPLES 256
+#endif
 template <int HID, int HIDC, bool CP> struct WgShape {
     static constexpr bool ALDS = !(HID == 64 && CP);
 };
@@ -1065,14 +1090,16 @@ static int fit_waves(size_t tab, size_t per_wave, int max_wpb) {
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 // backward workspace: ReLU masks [R*S][4] u32 | deferred-ray list [R] | its length [1]
 size_t mne_render_workspace(int R, int S) {
-    return align16((size_t)R * S * 4 * sizeof(unsigned)) + 2 * align16((size_t)R * sizeof(int)) + 16;
+    return align16((size_t)R * S * 4 * sizeof(unsigned)) + 3 * align16((size_t)R * sizeof(int)) + 32;
 }
 static void carve_workspace(RenderArgs& a, void* ws) {
     unsigned char* p = (unsigned char*)ws;
     a.relu_mask = (unsigned*)p; p += align16((size_t)a.R * a.S * 4 * sizeof(unsigned));
     a.defer_list = (int*)p; p += align16((size_t)a.R * sizeof(int));
     a.dec_tiles = (int*)p; p += align16((size_t)a.R * sizeof(int));
+    a.long_list = (int*)p; p += align16((size_t)a.R * sizeof(int));
     a.defer_count = (int*)p;
+    a.long_count = (int*)(p + 16);
 }
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
@@ -1090,13 +1117,21 @@ static int launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
     return 0;
 }
 
+static int ray_lds_cap(const RenderArgs& a) { return a.lds_samples > 0 ? a.lds_samples : MNE_HOT_LDS_SAMPLES; }   // (tests pass a small cap)
+
 template <int HID, int HIDC, bool CP, int MODE>
-static int launch_ray(const RenderArgs& a, hipStream_t st, int max_blocks = MNE_NUM_CU) {
+static int launch_ray(RenderArgs a, hipStream_t st, int max_blocks = MNE_NUM_CU) {
     typedef WgShape<HID, HIDC, CP> W;
     typedef ATab<HID, HIDC, CP> T;
     size_t tab = table_bytes<HID, HIDC, CP>(MODE);
     if (MODE == 4 && W::ALDS) tab = (size_t)(T::TOTAL - T::FWD_STEPS) * 64 * sizeof(float);
-    const size_t per_wave = (size_t)((a.S + 3) & ~3) * 5 * sizeof(float) + tile_wave_lds_bytes(CP ? 2 : 1, MODE == 3);
+    // Training kernel, first pass: LDS for MNE_HOT_LDS_SAMPLES samples per ray instead of S (INS Indoor: S = 1045 would
+    // leave room for 4 waves per CU, i.e. 1024 of 2150 rays at a time); the few rays whose decoded prefix is longer
+    // go to the second pass, which is sized for S.
+    const int cap = ray_lds_cap(a);
+    a.lds_samples = (MODE == 4 && !a.ray_list && a.S > cap) ? cap : 0;
+    const int L = a.lds_samples ? a.lds_samples : a.S;
+    const size_t per_wave = (size_t)((L + 3) & ~3) * 5 * sizeof(float) + tile_wave_lds_bytes((CP && MODE != 4) ? 2 : 1, MODE == 3);
     const int wpb = fit_waves<HID, HIDC, CP>(tab, per_wave, MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY);
     if (wpb < 1) return -4;
     const size_t lds = tab + (size_t)wpb * per_wave;
@@ -1180,6 +1215,11 @@ static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st
         // full kernel, driven by the deferred list (a handful of workgroups that leave at once when the list is empty)
         mark(2, st);
         if (int rc = launch_ray<HID, HIDC, CP, 4>(a, st)) return rc;
+        if (ray_lds_cap(a) < a.S) {        // long rays: those whose decoded prefix exceeded the first pass's LDS, same kernel sized for S
+            RenderArgs l = a;
+            l.ray_list = a.long_list; l.ray_list_count = a.long_count; l.list_keeps_prefix = 1;
+            if (int rc = launch_ray<HID, HIDC, CP, 4>(l, st)) return rc;
+        }
         mark(3, st);
         RenderArgs d = a;
         d.ray_list = a.defer_list; d.ray_list_count = a.defer_count;

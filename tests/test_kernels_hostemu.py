@@ -210,3 +210,12 @@ def test_bench_path_step_with_split_tile_lists(monkeypatch):
     monkeypatch.setenv("MNE_TILE_SPLIT_MIN", "4")
     out = pc.check_fused_step_vs_oracle(DEV, _tiny_bench_cfg(), n_keyframes=3, seed=2, small=True, impl="explicit")
     assert out["contributing"] > 0
+
+
+def test_bench_path_step_with_capped_ray_lds(monkeypatch):
+    """The training ray kernel's first pass keeps only MNE_HOT_LDS_SAMPLES samples of a ray in LDS (more waves per CU on
+    long rays, INS Indoor: S = 1045); rays whose decoded prefix is longer are finished by the second pass.  Forced here
+    on S = 29 with a cap of 16."""
+    monkeypatch.setenv("MNE_HOT_LDS_SAMPLES", "16")
+    out = pc.check_fused_step_vs_oracle(DEV, _tiny_bench_cfg(), n_keyframes=3, seed=2, small=True, impl="explicit")
+    assert out["contributing"] > 0
