@@ -353,9 +353,10 @@ def main():
                 tag = {"adam": "tile_adam_kernel"}.get(dom, dom)
                 traffic = sum(v for k, v in per_k.items() if tag in k) or None
                 clk = 2.4e9 * 1024                        # SIMD-cycles per second: 256 CUs x 4 SIMDs at 2.4 GHz
-                mfma_busy = {name: cyc / clk / (avg_ms[name] * 1e-3)
-                             for name in ("decode_kernel", "ray_kernel") if avg_ms.get(name)
-                             for k, cyc in pmc["per_kernel_mfma_busy_cycles_per_iteration"].items() if name in k}
+                # (the counters are per iteration: the first-pass launch carries practically all of a kernel's cycles)
+                mfma_busy = {name: sum(cyc for k, cyc in pmc["per_kernel_mfma_busy_cycles_per_iteration"].items() if name in k)
+                             / clk / (avg_ms[name] * 1e-3)
+                             for name in ("decode_kernel", "ray_kernel") if avg_ms.get(name)}
         except (OSError, KeyError, ValueError):
             pass
         out = {

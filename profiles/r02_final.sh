@@ -2,7 +2,7 @@
 # round-2 measurement pass: parity tests, smoke, default bench, other workloads, render_img, kernel table + timeline,
 # PMC traffic / SQ counters, matched-quality trajectory
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 3000 gpurun_out/bench_default.json
 for c in "--hidden 64" "--config apartment" "--config scannet" "--config scannet --hidden 64" "--config indoor" "--scatter atomics" "--path autograd --steps 50"; do
