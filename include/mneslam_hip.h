@@ -157,6 +157,15 @@ size_t mne_sizeof_plane_opt(void);
 size_t mne_sizeof_clock(void);
 int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream);
 
+/* Device-side hand-off between two streams of one process (no reference counterpart): the producer stream ends with
+ * mne_flag_set(flag, v), the consumer stream runs mne_flag_wait(flag, v) where it needs the producer's results; the wait
+ * returns as soon as the word has reached v (wrap-around compare), gives up after ~2 s and then sets *timeout = 1.
+ * Used by the fused step to keep its critical kernels on one stream without an event wait behind the long plane update
+ * (an event wait there costs ~15-18 us of queue idle time on this runtime).  The producer's launch MUST be enqueued before
+ * the consumer's wait is, or be guaranteed to run concurrently. */
+int mne_flag_set(uint32_t* flag, uint32_t value, void* stream);
+int mne_flag_wait(const uint32_t* flag, uint32_t value, uint32_t* timeout, void* stream);
+
 /* Measurement hook (no reference counterpart): up to 5 hipEvent_t handles that the NEXT mne_render_fused call records on its
  * stream -- [0] before the feature gather, [1] after it, [2] after the prefix decode, [3] after the ray kernel, [4] after
  * the deferred pass -- so bench.py can time the kernels of that call live.  NULL entries are skipped; the handles are

@@ -84,6 +84,8 @@ _PROTOS = {
     "mne_sizeof_clock": (C.c_size_t, []),
     "mne_clock_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_profile_marks": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "mne_flag_set": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "mne_flag_wait": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mne_num_samples": (C.c_int, [C.POINTER(RenderCfg), C.c_int]),
     "mne_sample_z": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Clock), C.c_void_p]),

@@ -87,6 +87,18 @@ int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream) {
     return check_launch("clock_advance");
 }
 
+int mne_flag_set(uint32_t* flag, uint32_t value, void* stream) {
+    if (!flag) return fail(-1, "mne_flag_set: NULL argument");
+    mne_launch_flag(flag, value, nullptr, 0, (hipStream_t)stream);
+    return check_launch("flag_set");
+}
+
+int mne_flag_wait(const uint32_t* flag, uint32_t value, uint32_t* timeout, void* stream) {
+    if (!flag || !timeout) return fail(-1, "mne_flag_wait: NULL argument");
+    mne_launch_flag((unsigned*)flag, value, timeout, 1, (hipStream_t)stream);
+    return check_launch("flag_wait");
+}
+
 int mne_profile_marks(void* const* events, int n) {
     if (n > 0 && !events) return fail(-1, "mne_profile_marks: NULL argument");
     mne_set_render_marks(events, n);

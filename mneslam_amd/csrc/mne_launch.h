@@ -183,6 +183,7 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
 //       2 = training iteration (decode + backward);  3 = backward of an earlier forward call (raw_in given)
 int mne_launch_render(const RenderArgs& a, int mode, void* workspace, hipStream_t st);
 void mne_set_render_marks(void* const* events, int n);
+int mne_launch_flag(unsigned* flag, unsigned value, unsigned* timeout, int wait, hipStream_t st);
 int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st);
 int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st);
 int mne_hash_slice_count(const GridArgs& a);

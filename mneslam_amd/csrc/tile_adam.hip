@@ -405,11 +405,7 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         const int gy = ty0 * MNE_TILE + y, gx = tx0 * MNE_TILE + cell;
         if (gy < pl.h && gx < pl.w) {
             const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + ch4 * 4;
-#ifdef TILE_MV_TILEMAJOR      // layout experiment: m and v stored tile-major (each workgroup streams 32 KiB contiguous)
-            const size_t offmv = (size_t)local * (TILE_CELLS * MNE_C) + (size_t)i4 * 4;
-#else
-            const size_t offmv = off;
-#endif
+            const size_t offmv = off;    // (moments stored tile-major were measured: no DRAM-locality effect, profiles/r02_tile_adam_variants.txt)
 #if TILE_PREFETCH >= 2
             float4 p = pre_p[it], m = pre_m[it], v = pre_v[it];
 #elif TILE_PREFETCH == 1

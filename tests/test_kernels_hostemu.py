@@ -51,6 +51,7 @@ def test_forward_colorplanes():
     pc.check_forward("fwd_colorplanes", DEV)
 
 
+@full
 def test_backward_onegrid_esdf():
     pc.check_backward("fwd_onegrid", False, DEV)
 
@@ -80,10 +81,12 @@ def test_queries():
     pc.check_queries(DEV)
 
 
+@full
 def test_device_clock():
     pc.check_device_clock(DEV)
 
 
+@full
 def test_render_maps_fast_path_and_render_img():
     pc.check_render_maps_fast_path(DEV)
 
@@ -196,6 +199,7 @@ def test_hash_grid_fused_step_vs_oracle():
     assert out["touched_entries"] > 0
 
 
+@full
 def test_bench_path_step_fp16_plane_storage_vs_oracle():
     """NS-b: lookups read half-precision copies of the planes (EXTENSION); the oracle sees the same rounded values,
     Adam moves the fp32 parameters, tile_adam_kernel keeps the copies equal to the rounded parameters."""
@@ -212,6 +216,7 @@ def test_bench_path_step_with_split_tile_lists(monkeypatch):
     assert out["contributing"] > 0
 
 
+@full
 def test_bench_path_step_with_capped_ray_lds(monkeypatch):
     """The training ray kernel's first pass keeps only MNE_HOT_LDS_SAMPLES samples of a ray in LDS (more waves per CU on
     long rays, INS Indoor: S = 1045); rays whose decoded prefix is longer are finished by the second pass.  Forced here
