@@ -23,8 +23,9 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 
 REF = os.environ.get("MNESLAM_REFERENCE", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
-# the emulator runs one OS thread per work-item: the default CPU run keeps one end-to-end case (the reference's Mapper
-# driving this repository's model) and the cheap structural ones; MNE_EMU_FULL=1 runs every case (several minutes each)
+# the emulator runs one OS thread per work-item: the default CPU run keeps the cheap structural cases; MNE_EMU_FULL=1 runs
+# every case, including the end-to-end ones (the reference's own Mapper driving this repository's model through
+# first_frame_mapping / mapping_optimize against the golden post-step parameters: ~5 minutes each)
 full = pytest.mark.skipif(os.environ.get("MNE_EMU_FULL", "0") != "1", reason="slow emulator case (MNE_EMU_FULL=1)")
 
 from helpers import DEC_KEYS, assert_close, load_golden, n_plane_sets  # noqa: E402
@@ -112,7 +113,7 @@ def _assert_final(g, m):
         assert_close(sd[k].detach().cpu(), g[f"final.dec.{k}"], rtol=1e-3, atol=1e-4, what=f"decoder {k}")
 
 
-@pytest.mark.parametrize("kf_side", ["reference", pytest.param("repo", marks=full)])
+@pytest.mark.parametrize("kf_side", [pytest.param("reference", marks=full), pytest.param("repo", marks=full)])   # ~5 min each on the emulator
 def test_reference_mapper_drives_repo_model(ref, tmp_path, kf_side):
     """Integration level 1: the reference's UNMODIFIED Mapper.mapping_optimize (its own loop, its own ray assembly)
     on this repository's JointEncoding + FusedAdam reaches the parameters the reference reached with its own model."""

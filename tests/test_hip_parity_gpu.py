@@ -462,3 +462,18 @@ def test_fp16_plane_storage_trains_like_fp32():
                 hist.append(ag.quality())
         res[ps] = (sum(h[0] for h in hist) / len(hist), sum(h[1] for h in hist) / len(hist))
     assert abs(res["fp16"][0] - res["fp32"][0]) < 0.5 and abs(res["fp16"][1] - res["fp32"][1]) < 0.1 * res["fp32"][1], res
+
+
+def test_forced_split_lists_and_capped_ray_lds(monkeypatch):
+    """The two load-balance mechanisms that only engage on large shapes -- tile lists split over several workgroups
+    (tile_adam.hip) and the training ray kernel's LDS sample cap with its long-ray pass (render.hip) -- forced on a small
+    scene and checked against the oracle like every other fused step."""
+    from mneslam_amd import configs
+    monkeypatch.setenv("MNE_TILE_SPLIT_MIN", "16")
+    monkeypatch.setenv("MNE_HOT_LDS_SAMPLES", "48")
+    cfg = configs.bench_office0()
+    cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["planes_res"] = {"coarse": 0.2, "fine": 0.1, "bound_dividable": 0.2}
+    cfg["mapping"]["sample"] = 512
+    out = pc.check_fused_step_vs_oracle(DEV, cfg, n_keyframes=4, seed=11, warm_steps=2, small=True)
+    assert out["contributing"] > 1000

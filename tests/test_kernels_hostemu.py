@@ -208,6 +208,7 @@ def test_bench_path_step_fp16_plane_storage_vs_oracle():
     assert out["contributing"] > 0
 
 
+@full
 def test_bench_path_step_with_split_tile_lists(monkeypatch):
     """Long tile lists are cut into parts accumulated by several workgroups and combined by the last arriver
     (tile_adam.hip); forced here on a tiny scene with MNE_TILE_SPLIT_MIN."""
