@@ -315,7 +315,8 @@ def main():
         if agent.hash:
             # hash grid: 16 levels x 8 corners x 2 features x 4 B = 1,024 B per point per gather or scatter pass
             Gh = agent.model.embed_fn.cfg.n_levels * 8 * agent.model.embed_fn.cfg.n_features * 4.0
-            alg = {"hash_gather": R * S * Gh, "hash_scatter": p_contrib * Gh, "adam": 32.0 * n_par, "render": 0.0}
+            n_gather = decoded if agent.fused.early_termination else float(R * S)       # rows the gather fills (counted from below)
+            alg = {"hash_gather": n_gather * Gh, "hash_scatter": p_contrib * Gh, "adam": 32.0 * n_par, "render": 0.0}
             slices = agent.fused.table_update != "atomics"
             if slices:       # the table update = scatter + Adam sweep of the table in one call
                 alg["hash_scatter"] += 32.0 * agent.n_plane_params
@@ -324,6 +325,8 @@ def main():
                     "hash_scatter": ("hash_offsets + hash_pack + hash_slice_adam + hash_dense_adam kernels (LDS slices, Adam fused; one mne_hash_slice_adam call)"
                                      if slices else "hash_scatter_runs_kernel (run-reduced global atomics)"),
                     "adam": "adam_kernel (decoder)" if slices else "adam_kernel (table + decoder, one launch)", "wgrad": "wgrad kernels",
+                    "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
+                    "deferred_pass": "hash gather + decode_kernel + ray_kernel over the deferred-ray list",
                     "render": "whole mne_render_fused_features call (decode + ray kernels; MFMA / latency, no algorithmic HBM bytes)"}
             alg["iteration"] = alg["hash_gather"] + alg["hash_scatter"] + alg["adam"]
         elif binned:

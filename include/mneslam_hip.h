@@ -359,8 +359,11 @@ int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const flo
  * input columns.  One iteration:
  *   mne_hash_gather            x = (o + d*z - bb_lo) / (bb_hi - bb_lo) per sample (the OneBlob input), 8 corners x 16 levels
  *   mne_render_fused_features  = mne_render_fused without plane gather / scatter: every decode reads its features from the
- *                                tape (ray_counts as in mne_render_fused: exact early termination of the DECODE; the
- *                                gather above still fills every row); the d(feature) rows of every sample of the first
+ *                                tape (ray_counts as in mne_render_fused: exact early termination).  With grid_cfg + table
+ *                                the call does the gather itself and only where rows can be decoded: the a-priori tiles of
+ *                                every ray plus the resolver's extension first, the remaining rows of the deferred rays
+ *                                before the second pass (then mne_hash_gather is not needed); NULL, NULL: the caller has
+ *                                filled every row; the d(feature) rows of every sample of the first
  *                                ray_tiles[r] tiles of ray r are left in the tape (column mne_tape_dfeat_offset)
  *   mne_hash_scatter           grad_table += w * d(feature)  (global_atomic_add_f32; grad_table zeroed by the caller)
  *   mne_decoder_wgrad, mne_adam_step (table + decoder segments, zero_grad fused)
@@ -383,7 +386,8 @@ int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* 
                               const float* rays_o, const float* rays_d, const float* target_rgb, const float* target_d,
                               const float* z_vals, const int32_t* ray_counts, const float* packed_decoder, const float* coef,
                               float* rgb, float* depth, float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows,
-                              int32_t* tape_rows, int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream);
+                              int32_t* tape_rows, int32_t* ray_tiles, void* workspace, size_t workspace_bytes,
+                              const mne_grid_cfg_t* grid_cfg, const float* table, void* stream);
 int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                      const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles,
                      float* grad_table, void* stream);

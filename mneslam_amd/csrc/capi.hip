@@ -256,7 +256,10 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
 
 }   // extern "C"
 
-static int render_fused(bool ext_feat, const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+static int fill_hash_rows(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                          const float* rays_d, const float* z_vals, float* tape, GridArgs& a);
+
+static int render_fused(bool ext_feat, const GridArgs* ext_grid, const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                      const float* rays_o, const float* rays_d, const float* target_rgb,
                      const float* target_d, const float* z_vals, const int32_t* ray_counts,
                      const float* packed_decoder, const float* coef, float* rgb, float* depth, float* raw,
@@ -281,6 +284,7 @@ static int render_fused(bool ext_feat, const mne_scene_t* scene, const mne_rende
     a.rgb = rgb; a.depth = depth; a.raw = raw; a.ray_sums = ray_sums;
     a.tape = tape; a.tape_rows = tape_rows; a.ray_tiles = ray_tiles;
     a.ext_feat = ext_feat ? 1 : 0;
+    a.ext_grid = ext_grid;
     if (const char* c = std::getenv("MNE_HOT_LDS_SAMPLES")) a.lds_samples = std::atoi(c);      // tests force the two-pass split on small S
     if (bins)
         if (int rc = fill_bins(scene, bins, a.bins)) return rc;
@@ -296,7 +300,7 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
                      const float* packed_decoder, const float* coef, float* rgb, float* depth, float* raw,
                      float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, int32_t* ray_tiles,
                      const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream) {
-    return render_fused(false, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, ray_counts,
+    return render_fused(false, nullptr, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, ray_counts,
                         packed_decoder, coef, rgb, depth, raw, ray_sums, tape, tape_capacity_rows, tape_rows, ray_tiles, bins,
                         workspace, workspace_bytes, stream);
 }
@@ -305,10 +309,17 @@ int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* 
                               const float* rays_o, const float* rays_d, const float* target_rgb, const float* target_d,
                               const float* z_vals, const int32_t* ray_counts, const float* packed_decoder, const float* coef,
                               float* rgb, float* depth, float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows,
-                              int32_t* tape_rows, int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream) {
-    return render_fused(true, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, ray_counts,
-                        packed_decoder, coef, rgb, depth, raw, ray_sums, tape, tape_capacity_rows, tape_rows, ray_tiles, nullptr,
-                        workspace, workspace_bytes, stream);
+                              int32_t* tape_rows, int32_t* ray_tiles, void* workspace, size_t workspace_bytes,
+                              const mne_grid_cfg_t* grid_cfg, const float* table, void* stream) {
+    GridArgs g = {};
+    if (grid_cfg || table) {                          // the call gathers the hash-grid rows itself, only where they can be decoded
+        if (!grid_cfg || !table) return fail(-1, "mne_render_fused_features: grid_cfg and table go together");
+        if (int rc = fill_hash_rows(grid_cfg, scene, n_rays, n_samples, rays_o, rays_d, z_vals, tape, g)) return rc;
+        g.params = table;
+    }
+    return render_fused(true, grid_cfg ? &g : nullptr, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals,
+                        ray_counts, packed_decoder, coef, rgb, depth, raw, ray_sums, tape, tape_capacity_rows, tape_rows, ray_tiles,
+                        nullptr, workspace, workspace_bytes, stream);
 }
 
 size_t mne_tile_count(const mne_scene_t* scene) {

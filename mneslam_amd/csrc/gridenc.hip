@@ -68,10 +68,25 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void hash_rows_kernel(GridArgs a) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int level = (int)(gid & 15);
-    const long long row = gid >> 4;
+    long long row = gid >> 4;
     if (row >= (long long)a.R * a.S || level >= a.n_levels) return;
-    const int r = (int)(row / a.S), s = (int)(row % a.S);
+    int r = (int)(row / a.S);
+    const int s = (int)(row % a.S);
     if (BWD && a.ray_tiles && s >= a.ray_tiles[r] * 32) return;
+    if (!BWD && a.ray_counts) {
+        // forward under early termination: the first pass fills the tiles decode_kernel can reach (a-priori prefix + the
+        // resolver's extension), the list pass the rest of the rays that were deferred
+        if (a.ray_list) {
+            if (r >= *a.ray_list_count) return;
+            r = a.ray_list[r];
+            row = (long long)r * a.S + s;
+        }
+        const int ntile = (a.S + 31) / 32;
+        const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
+        int t = (need + 31) / 32;
+        t = (t < 1 ? 1 : (t > ntile ? ntile : t)) + MNE_RESOLVER_MAX_EXT;         // = prefix_tiles() of render.hip + extension
+        if (a.ray_list ? s < t * 32 : s >= t * 32) return;
+    }
     const float z = a.z_vals[row];
     const float scale = a.scale[level];
     const uint32_t res = a.res[level], size = a.size[level], off = a.offset[level];

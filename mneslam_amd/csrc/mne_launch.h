@@ -47,6 +47,7 @@ struct TileBins {
     int ntx[MNE_MAX_PLANES];             // tiles per plane row
 };
 
+struct GridArgs;
 struct RenderArgs {
     mne_scene_t sc;
     int R, S;
@@ -58,6 +59,7 @@ struct RenderArgs {
     float *rgb, *depth, *disp, *acc, *depth_var, *raw, *ray_sums;
     const float* raw_in;        // backward-only call: raw of ALL samples from the forward call (NULL otherwise)
     int lds_samples;             // ray_kernel: samples of a ray its LDS arrays hold (0 = all S); rays that need more are deferred
+    const struct GridArgs* ext_grid;   // ext_feat: hash grid whose rows this call gathers itself (host pointer; NULL = the caller filled the tape)
     int ext_feat;                // feature rows come from the caller (tape columns T_X..): no plane gather, no plane scatter
     const int* ray_counts;      // [R][MNE_N_COUNT] from sample_z (slot MNE_C_NEED = a-priori sample count)
     int prefix_default;         // ray_counts == NULL: a-priori tiles of every ray (ntile = decode everything, 1 = on demand only)
@@ -119,6 +121,11 @@ struct SampleRaysArgs {
 
 struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, bc2_sqrt; double lr; int step; };
 
+// Tiles the resolver wave of decode_kernel may decode beyond a ray's a-priori prefix before it leaves the rest to the
+// deferred pass (render.hip); the hash gather fills exactly that many tiles ahead.
+#ifndef MNE_RESOLVER_MAX_EXT
+#define MNE_RESOLVER_MAX_EXT 1
+#endif
 #define MNE_GRID_MAX_LEVELS 32
 #define MNE_GRID_MAX_F 8
 struct GridArgs {
@@ -145,6 +152,10 @@ struct GridArgs {
     float2* dfeat_lv;            // [n_levels][R*S] packed: d(feature) of each backward row, level-major
     long long pack_cap;          // R*S
     PlaneOpt opt;                // table optimizer state and step constants
+    // gather restricted to the rows the exact early termination can decode (inside mne_render_fused_features)
+    const int* ray_counts;       // [R][MNE_N_COUNT]: rows [0, (a-priori tiles + MNE_RESOLVER_MAX_EXT) * 32) of every ray; NULL = all rows
+    const int* ray_list;         // second pass: the remaining rows of the listed (deferred) rays
+    const int* ray_list_count;
 };
 
 struct WgradArgs {

@@ -324,9 +324,6 @@ __global__ __launch_bounds__(256) void gather_kernel(RenderArgs a, int chunks_pe
 // Tiles the resolver wave may decode beyond a ray's a-priori prefix before it leaves the rest to the deferred pass: the
 // extension is SERIAL in one wave (34 us per tile); INS Indoor has 33 tiles per ray and rays that cross empty space:
 // unbounded 606 it/s, 4 tiles 791, 2 tiles 828, 1 tile 846; office0 / ScanNet within noise (profiles/r02_resolver_ext.txt).
-#ifndef MNE_RESOLVER_MAX_EXT
-#define MNE_RESOLVER_MAX_EXT 1
-#endif
 template <int HID, int HIDC, bool CP, bool ALDS, int WPB>
 __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre) {
     typedef ATab<HID, HIDC, CP> T;
@@ -1195,6 +1192,13 @@ static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st
         if (!workspace) return -6;
         carve_workspace(a, workspace);
     }
+    if (mode == 2 && a.ext_feat && a.ext_grid) {          // hash-grid rows of the tiles the first pass can decode
+        GridArgs g = *a.ext_grid;
+        g.ray_counts = a.ray_counts; g.ray_list = nullptr; g.ray_list_count = nullptr;
+        mark(0, st);
+        mne_launch_hash_rows(g, 0, st);
+        mark(1, st);
+    }
     {   // decode: every tile (mode 0), or the a-priori prefix of every ray
         RenderArgs d = a;
         if (mode == 0) { d.ray_counts = nullptr; d.prefix_default = 1 << 30; }
@@ -1223,6 +1227,11 @@ static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st
         mark(3, st);
         RenderArgs d = a;
         d.ray_list = a.defer_list; d.ray_list_count = a.defer_count;
+        if (a.ext_feat && a.ext_grid && a.ray_counts) {    // the deferred rays' remaining hash-grid rows
+            GridArgs g = *a.ext_grid;
+            g.ray_counts = a.ray_counts; g.ray_list = a.defer_list; g.ray_list_count = a.defer_count;
+            mne_launch_hash_rows(g, 0, st);
+        }
         launch_decode<HID, HIDC, CP>(d, st);               // their remaining tiles, tile-parallel
         const int rc = launch_ray<HID, HIDC, CP, 4>(d, st);    // the same lean kernel: now every listed ray resolves
         mark(4, st);

@@ -548,10 +548,10 @@ class FusedStep:
         if self._side_pending:
             self._join_side(torch.cuda.current_stream(self.device))
 
-    def _render_marks(self, stream):
+    def _render_marks(self, stream, force=False):
         """Five events the next mne_render_fused records between its kernels (mne_profile_marks); each is recorded
         once here so that the handle exists."""
-        if self.events is None or not self.rays_o.is_cuda or self.bins is None:
+        if self.events is None or not self.rays_o.is_cuda or (self.bins is None and not force):
             return None
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         for e in marks:
@@ -668,18 +668,25 @@ class HashFusedStep(FusedStep):
         self._prefetched = None
         sc, gc = C.byref(self.scene), C.byref(self.grid_cfg)
         _lib.check(lib.mne_pack_decoder(sc, P(self.packed), st), "mne_pack_decoder")
-        e0 = self._mark("hash_gather")
-        _lib.check(lib.mne_hash_gather(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.table.data),
-                                       P(self.tape), st), "mne_hash_gather")
-        self._mark("hash_gather", e0)
+        inline_gather = self.early_termination           # the render call gathers only the rows it can decode
+        if not inline_gather:
+            e0 = self._mark("hash_gather")
+            _lib.check(lib.mne_hash_gather(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.table.data),
+                                           P(self.tape), st), "mne_hash_gather")
+            self._mark("hash_gather", e0)
         e0 = self._mark("render")
+        marks = self._render_marks(torch.cuda.current_stream(self.device) if self.rays_o.is_cuda else None, force=True)
         _lib.check(lib.mne_render_fused_features(sc, C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb),
                                                  P(self.tgt_d), P(self.z_vals),
                                                  P(self.ray_counts) if self.early_termination else None, P(self.packed), P(self.coef), P(self.rgb),
                                                  P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape), R * S,
-                                                 P(self.tape_rows), P(self.ray_tiles), P(self.ws), self.ws_bytes, st),
+                                                 P(self.tape_rows), P(self.ray_tiles), P(self.ws), self.ws_bytes,
+                                                 gc if inline_gather else None, P(self.table.data) if inline_gather else None, st),
                    "mne_render_fused_features")
         self._mark("render", e0)
+        if marks:
+            for name, a, b in ((("hash_gather", 0, 1),) if inline_gather else ()) + (("decode_kernel", 1, 2), ("ray_kernel", 2, 3), ("deferred_pass", 3, 4)):
+                self.events.setdefault(name, []).append((marks[a], marks[b]))
         if side is not None:
             self._ev[0].record(main)
             side.wait_event(self._ev[0])
