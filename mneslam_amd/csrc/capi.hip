@@ -545,7 +545,8 @@ int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_r
 size_t mne_hash_workspace_bytes(int n_rays, int n_samples) {
     if (n_rays <= 0 || n_samples <= 0) return 0;
     const size_t rows = (size_t)n_rays * n_samples;
-    return (((size_t)n_rays + 1) * sizeof(int) + 255) / 256 * 256 + rows * sizeof(float4) + rows * 16 * sizeof(float2);
+    return (((size_t)n_rays + 1) * sizeof(int) + 255) / 256 * 256 + rows * sizeof(float4) + rows * 16 * sizeof(float2) +
+           rows * 16 * sizeof(uint32_t);
 }
 
 /* floats at the front of the workspace that must be ZERO on entry to mne_hash_slice_adam (it leaves them zero again):
@@ -572,7 +573,8 @@ int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int
     a.offs = (int*)w; w += (((size_t)n_rays + 1) * sizeof(int) + 255) / 256 * 256;
     a.pack_cap = (long long)n_rays * n_samples;
     a.xs = (float4*)w; w += (size_t)a.pack_cap * sizeof(float4);
-    a.dfeat_lv = (float2*)w;
+    a.dfeat_lv = (float2*)w; w += (size_t)a.pack_cap * 16 * sizeof(float2);
+    a.masks = std::getenv("MNE_HASH_NO_MASKS") ? nullptr : (unsigned*)w;        // (A/B switch: walk every row)
     PlaneOpt& o = a.opt;
     o.m = opt->m; o.v = opt->v;
     o.omb1 = (float)(1.0 - opt->beta1); o.b2 = (float)opt->beta2; o.omb2 = (float)(1.0 - opt->beta2);

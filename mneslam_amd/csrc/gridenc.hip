@@ -237,6 +237,28 @@ __global__ __launch_bounds__(256) void hash_scatter_runs_kernel(GridArgs a) {
 #define HASH_UNROLL 4
 #endif
 
+// Workgroups of one level: slices x replicas.  A dense (coarse) level has few slices and EVERY sample hits them: its rows
+// are split over `replicas` workgroups (LDS float atomics retire ~0.7 G lane-ops/s per CU: one workgroup taking all
+// 2 M corner updates of level 0 ran 2.9 ms), which then add their non-zero sums into a small gradient scratch with global
+// atomics; hash_dense_adam_kernel finishes those levels.  Hashed levels: one workgroup per slice, Adam fused.
+#ifndef HASH_LEVEL_WGS
+#define HASH_LEVEL_WGS 64
+#endif
+#ifdef HASH_ABL_NO_LDS_ADD          // timing experiment: the walk without the LDS atomics (plain racing stores)
+#define HASH_LDS_ADD(p, v) (*(p) = (v))
+#else
+#define HASH_LDS_ADD(p, v) atomicAdd((p), (v))
+#endif
+__host__ __device__ __forceinline__ int hash_slices_of(const GridArgs& a, int level) { return (int)((a.size[level] + HASH_SLICE - 1) / HASH_SLICE); }
+__host__ __device__ __forceinline__ bool hash_level_dense(const GridArgs& a, int level) {
+    return (unsigned long long)a.res[level] * a.res[level] * a.res[level] <= a.size[level];
+}
+__host__ __device__ __forceinline__ int hash_replicas_of(const GridArgs& a, int level) {
+    if (!hash_level_dense(a, level)) return 1;
+    const int r = HASH_LEVEL_WGS / hash_slices_of(a, level);
+    return r < 1 ? 1 : r;
+}
+
 // first packed row of every ray: exclusive scan of min(ray_tiles[r] * 32, S), one workgroup
 __global__ __launch_bounds__(1024) void hash_offsets_kernel(GridArgs a) {
     __shared__ int part[1024];
@@ -265,8 +287,20 @@ __global__ __launch_bounds__(1024) void hash_offsets_kernel(GridArgs a) {
 }
 
 // 16 consecutive backward rows of one ray per workgroup: x of each row, and the rows' d(feature) transposed to level-major
+// The pack kernel leaves one 32-bit word per (row, hashed level) with the bits of the slices its eight corners fall into
+// (0 for rows without gradient; inside the bounding box cell_x < 2^14, so the slice = index >> 14 depends on the (y, z)
+// corner pair only: at most four bits); a slice workgroup then streams 4 bytes per row and looks at the row itself only
+// when its bit is set (1 row in 8 on T = 2^19 levels).
+__device__ __forceinline__ bool hash_level_masked(const GridArgs& a, int level) {
+    const uint32_t size = a.size[level];
+    return a.masks && !hash_level_dense(a, level) && (size & (size - 1u)) == 0u && size <= 32u * HASH_SLICE &&
+           (HASH_SLICE & (HASH_SLICE - 1)) == 0;
+}
+
 __global__ __launch_bounds__(256) void hash_pack_kernel(GridArgs a) {
     __shared__ float2 tr[16][17];
+    __shared__ unsigned trm[16][17];
+    __shared__ float xs_l[16][4];
     const int groups = (a.S + 15) / 16;
     const int r = blockIdx.x / groups, s0 = (blockIdx.x % groups) * 16;
     int n_rows = a.ray_tiles[r] * 32;
@@ -288,32 +322,31 @@ __global__ __launch_bounds__(256) void hash_pack_kernel(GridArgs a) {
             x[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
         }
         a.xs[k0 + rr] = make_float4(x[0], x[1], x[2], 0.0f);
+        xs_l[rr][0] = x[0]; xs_l[rr][1] = x[1]; xs_l[rr][2] = x[2];
     }
     __syncthreads();
+    unsigned m = 0u;
+    if (in && lv < a.n_levels && (g.x != 0.0f || g.y != 0.0f)) {
+        m = 0xffffffffu;
+        if (hash_level_masked(a, lv)) {
+            const float scale = a.scale[lv];
+            const uint32_t msk = a.size[lv] - 1u;
+            const uint32_t cx = (uint32_t)(int)floorf(fmaf(scale, xs_l[rr][0], 0.5f));
+            const uint32_t cy = (uint32_t)(int)floorf(fmaf(scale, xs_l[rr][1], 0.5f)), cz = (uint32_t)(int)floorf(fmaf(scale, xs_l[rr][2], 0.5f));
+            const uint32_t hx[2] = {cx, cx + 1u};                  // (samples outside the bounding box have wrapped cells: all 8 corners count)
+            const uint32_t hy[2] = {cy * 2654435761u, (cy + 1u) * 2654435761u}, hz[2] = {cz * 805459861u, (cz + 1u) * 805459861u};
+            m = 0u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m |= 1u << (((hx[q & 1] ^ hy[(q >> 1) & 1] ^ hz[q >> 2]) & msk) / HASH_SLICE);
+        }
+    }
+    trm[rr][lv] = m;
+    __syncthreads();
     const int rr2 = tid & 15, lv2 = tid >> 4;                        // 16 adjacent lanes = 16 consecutive packed rows of one level
-    if (s0 + rr2 < n_rows && lv2 < a.n_levels) a.dfeat_lv[(size_t)lv2 * a.pack_cap + k0 + rr2] = tr[rr2][lv2];
-}
-
-// Workgroups of one level: slices x replicas.  A dense (coarse) level has few slices and EVERY sample hits them: its rows
-// are split over `replicas` workgroups (LDS float atomics retire ~0.7 G lane-ops/s per CU: one workgroup taking all
-// 2 M corner updates of level 0 ran 2.9 ms), which then add their non-zero sums into a small gradient scratch with global
-// atomics; hash_dense_adam_kernel finishes those levels.  Hashed levels: one workgroup per slice, Adam fused.
-#ifndef HASH_LEVEL_WGS
-#define HASH_LEVEL_WGS 64
-#endif
-#ifdef HASH_ABL_NO_LDS_ADD          // timing experiment: the walk without the LDS atomics (plain racing stores)
-#define HASH_LDS_ADD(p, v) (*(p) = (v))
-#else
-#define HASH_LDS_ADD(p, v) atomicAdd((p), (v))
-#endif
-__host__ __device__ __forceinline__ int hash_slices_of(const GridArgs& a, int level) { return (int)((a.size[level] + HASH_SLICE - 1) / HASH_SLICE); }
-__host__ __device__ __forceinline__ bool hash_level_dense(const GridArgs& a, int level) {
-    return (unsigned long long)a.res[level] * a.res[level] * a.res[level] <= a.size[level];
-}
-__host__ __device__ __forceinline__ int hash_replicas_of(const GridArgs& a, int level) {
-    if (!hash_level_dense(a, level)) return 1;
-    const int r = HASH_LEVEL_WGS / hash_slices_of(a, level);
-    return r < 1 ? 1 : r;
+    if (s0 + rr2 < n_rows && lv2 < a.n_levels) {
+        a.dfeat_lv[(size_t)lv2 * a.pack_cap + k0 + rr2] = tr[rr2][lv2];
+        if (a.masks) a.masks[(size_t)lv2 * a.pack_cap + k0 + rr2] = trm[rr2][lv2];
+    }
 }
 
 __global__ __launch_bounds__(HASH_SLICE_THREADS, HASH_SLICE_THREADS / 128) void hash_slice_adam_kernel(GridArgs a) {
@@ -342,7 +375,70 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS, HASH_SLICE_THREADS / 128) void 
     // the LDS atomics -- 96 dependent ds_bpermute per 64 rows, 1.7 ms for level 0's workgroup; per-thread contiguous row
     // chunks -- 2.9 ms; profiles/r02_hash_slices_*.txt.)
     const int row_lo = (int)((long long)n_live * rep / n_rep), row_hi = (int)((long long)n_live * (rep + 1) / n_rep);
-    const int n_iter = (row_hi - row_lo + HASH_SLICE_THREADS - 1) / HASH_SLICE_THREADS;
+    int n_iter = (row_hi - row_lo + HASH_SLICE_THREADS - 1) / HASH_SLICE_THREADS;
+    if (hash_level_masked(a, level)) {
+        // ---- masked walk: 4 bytes per row; the rows whose mask has this slice's bit are collected per wave (ballot +
+        // prefix popcount into a 128-entry LDS ring) and processed 64 at a time with every lane busy
+        const int lane = tid & 63, wv = tid >> 6;
+        unsigned* ring = (unsigned*)(acc + (size_t)HASH_SLICE * 2) + wv * 128;
+        const unsigned* mk = a.masks + (size_t)level * a.pack_cap;
+        const uint32_t msk = size - 1u;
+        int head = 0, fill = 0;                                       // wave-uniform
+        auto process = [&](int count) {                               // the first `count` ring entries, one per lane
+            if (lane < count) {
+                const int i = (int)ring[(head + lane) & 127];
+                const float2 g = gl[i];
+                const float4 x = a.xs[i];
+                float frac[3];
+                uint32_t cell[3];
+                const float xv[3] = {x.x, x.y, x.z};
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float pos = fmaf(scale, xv[d], 0.5f);
+                    const float fl = floorf(pos);
+                    cell[d] = (uint32_t)(int)fl;
+                    frac[d] = pos - fl;
+                }
+                const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
+                const uint32_t hx[2] = {cell[0] & msk, (cell[0] + 1u) & msk};
+                const uint32_t hy[2] = {(cell[1] * 2654435761u) & msk, ((cell[1] + 1u) * 2654435761u) & msk};
+                const uint32_t hz[2] = {(cell[2] * 805459861u) & msk, ((cell[2] + 1u) * 805459861u) & msk};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t e = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) - lo;
+                    if (e < n_ent) {
+                        const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];     // product order of grid_kernel
+                        HASH_LDS_ADD(acc + 2 * e, w * g.x);
+                        HASH_LDS_ADD(acc + 2 * e + 1, w * g.y);
+                    }
+                }
+            }
+        };
+        for (int it = 0; it < n_iter; it += HASH_UNROLL) {
+            unsigned mq[HASH_UNROLL];
+#pragma unroll
+            for (int q = 0; q < HASH_UNROLL; ++q) {
+                const int i = row_lo + (it + q) * HASH_SLICE_THREADS + tid;
+                mq[q] = i < row_hi ? mk[i] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < HASH_UNROLL; ++q) {
+                const bool hit = (mq[q] >> k) & 1u;
+                const unsigned long long b = __ballot(hit);
+                if (b == 0ull) continue;
+                if (hit) ring[(head + fill + __popcll(b & ((1ull << lane) - 1ull))) & 127] = (unsigned)(row_lo + (it + q) * HASH_SLICE_THREADS + tid);
+                fill += __popcll(b);
+                MNE_WAVE_SYNC();
+                if (fill >= 64) {
+                    process(64);
+                    head = (head + 64) & 127; fill -= 64;
+                    MNE_WAVE_SYNC();
+                }
+            }
+        }
+        if (fill > 0) process(fill);
+        n_iter = 0;                                                   // the generic walk below is skipped
+    }
     for (int it = 0; it < n_iter; it += HASH_UNROLL) {
         float2 gq[HASH_UNROLL];
         float4 xq[HASH_UNROLL];
@@ -453,7 +549,7 @@ int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st) {
     if (a.R <= 0) return 0;
     MNE_LAUNCH(hash_offsets_kernel, 1, 1024, 0, st, a);
     MNE_LAUNCH(hash_pack_kernel, (unsigned)(a.R * ((a.S + 15) / 16)), 256, 0, st, a);
-    const size_t lds = (size_t)HASH_SLICE * 2 * sizeof(float);
+    const size_t lds = (size_t)HASH_SLICE * 2 * sizeof(float) + (size_t)(HASH_SLICE_THREADS / 64) * 128 * sizeof(unsigned);   // + per-wave rings
     MNE_SET_MAX_LDS(hash_slice_adam_kernel, MNE_LDS_MAX);
     MNE_LAUNCH(hash_slice_adam_kernel, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, lds, st, a);
     const unsigned n_dense = mne_hash_scratch_entries(a);

@@ -150,6 +150,7 @@ struct GridArgs {
     int* offs;                   // [R+1] first packed row of each ray (exclusive scan of its backward rows)
     float4* xs;                  // [R*S] packed: grid input x of each backward row
     float2* dfeat_lv;            // [n_levels][R*S] packed: d(feature) of each backward row, level-major
+    unsigned* masks;             // [n_levels][R*S] packed: bit k = some corner of the row falls into slice k of the level (hashed levels)
     long long pack_cap;          // R*S
     PlaneOpt opt;                // table optimizer state and step constants
     // gather restricted to the rows the exact early termination can decode (inside mne_render_fused_features)
