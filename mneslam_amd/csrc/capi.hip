@@ -338,7 +338,7 @@ int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* 
     a.bins.counts = bins->counts; a.bins.order = bins->order; a.bins.cap = bins->cap;
     a.bins.split_scratch = bins->split_scratch; a.bins.split_state = bins->split_state;
     const char* sm = std::getenv("MNE_TILE_SPLIT_MIN");                   // tests force splitting on tiny scenes
-    const int split_min = sm ? std::atoi(sm) : 1024;
+    const int split_min = sm ? std::atoi(sm) : MNE_TILE_SPLIT_MIN_DEFAULT;
     a.bins.split_min = split_min < 1 ? 1 : split_min;
     mne_tile_geometry(*scene, a.bins);
     mne_launch_tile_order(a, (hipStream_t)stream);

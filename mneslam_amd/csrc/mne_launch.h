@@ -43,6 +43,8 @@ struct TileBins {
     float* split_scratch;     // [MNE_TILE_SPLIT_PARTS][16*16*32] partial gradient tiles of split lists (NULL: never split)
     int* split_state;         // [n_tiles + 1]: arrival counters per tile (zero between calls), [n_tiles] = number of work items
     int split_min;            // lists up to this length are never split
+#define MNE_TILE_SPLIT_MIN_DEFAULT 4096   // a part costs a 32 KiB slab round trip + ~5 us of fences: 256..2048 cost office0 1-3 %,
+                                          // 8192 costs Indoor 3 % (profiles/r02_tile_split_min.txt)
     int tile_base[MNE_MAX_PLANES + 1];   // first tile id of each plane ([set][orient][level] order)
     int ntx[MNE_MAX_PLANES];             // tiles per plane row
 };
@@ -59,7 +61,6 @@ struct RenderArgs {
     float *rgb, *depth, *disp, *acc, *depth_var, *raw, *ray_sums;
     const float* raw_in;        // backward-only call: raw of ALL samples from the forward call (NULL otherwise)
     int lds_samples;             // ray_kernel: samples of a ray its LDS arrays hold (0 = all S); rays that need more are deferred
-    const struct GridArgs* ext_grid;   // ext_feat: hash grid whose rows this call gathers itself (host pointer; NULL = the caller filled the tape)
     int ext_feat;                // feature rows come from the caller (tape columns T_X..): no plane gather, no plane scatter
     const int* ray_counts;      // [R][MNE_N_COUNT] from sample_z (slot MNE_C_NEED = a-priori sample count)
     int prefix_default;         // ray_counts == NULL: a-priori tiles of every ray (ntile = decode everything, 1 = on demand only)
@@ -79,6 +80,8 @@ struct RenderArgs {
     const int* ray_list_count;
     float *d_rays_o, *d_rays_d;
     TileBins bins;              // bins.lists != NULL: binned scatter instead of atomics into plane[].grad
+    // host-side only (kernels never read it; kept LAST so that the kernels' argument layout does not move):
+    const struct GridArgs* ext_grid;   // ext_feat: hash grid whose rows this call gathers itself (NULL = the caller filled the tape)
 };
 
 struct LossArgs {

@@ -62,9 +62,6 @@
 #ifndef TILE_MIN_WAVES
 #define TILE_MIN_WAVES 4        // waves per SIMD the register allocation must allow: 2 workgroups of 8 waves per CU (LDS-limited)
 #endif
-#ifndef MNE_TILE_SPLIT_MIN
-#define MNE_TILE_SPLIT_MIN 1024     // entries: shorter lists are never split (a part costs a 32 KiB slab round trip + ~5 us of fences)
-#endif
 #ifndef TILE_EMPTY_FAST
 #define TILE_EMPTY_FAST 1
 #endif
@@ -81,7 +78,7 @@ static_assert(TILE_CELLS == 256, "the prefix step assumes 4 cells per lane of on
 // their partial gradient tiles meet in the split scratch and the part that arrives last applies Adam.  Without this the
 // longest lists ARE the launch: ScanNet with colour planes (12 planes, 2 M entries) ran 0.82 ms, INS Indoor (1045
 // samples per ray into 750 tiles, 15 k entries per list on average) 4.2 ms, against 0.2 / 1.0 ms of balanced work.
-// split = max(MNE_TILE_SPLIT_MIN, 2 * total entries / MNE_TILE_SPLIT_PARTS): at most MNE_TILE_SPLIT_PARTS split items.
+// split = max(split_min (4096 by default), 2 * total entries / MNE_TILE_SPLIT_PARTS): at most MNE_TILE_SPLIT_PARTS split items.
 // Split items come first in `order` (item index = scratch slot), then the whole tiles, heaviest bucket first.
 __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_tiles) {
     __shared__ int hist[32], start[32];
