@@ -335,7 +335,8 @@ def main():
             kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)", "gather_kernel": "gather_kernel",
                     "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
                     "deferred_pass": "decode_kernel + ray_kernel over the deferred-ray list",
-                    "render": "whole mne_render_fused call (gather + decode + ray + deferred pass)"}
+                    "bin_kernel": "bin_kernel (list appends of the binned plane update)",
+                    "render": "whole mne_render_fused call (gather + decode + ray + deferred pass + bin)"}
         else:
             alg = {"adam": 32.0 * n_par, "render": (decoded + p_contrib) * G}
             kern = {"adam": "adam_kernel (planes + decoder, one launch)",

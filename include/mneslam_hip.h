@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MNE_ABI_VERSION 3
+#define MNE_ABI_VERSION 4
 
 /* orientation index of a plane triple, as in JointEncoding.all_planes (scene_rep.py:117) */
 enum { MNE_XY = 0, MNE_XZ = 1, MNE_YZ = 2 };
@@ -155,22 +155,8 @@ size_t mne_sizeof_adam_seg(void);
 size_t mne_sizeof_tile_bins(void);
 size_t mne_sizeof_plane_opt(void);
 size_t mne_sizeof_clock(void);
+size_t mne_sizeof_fused_opts(void);
 int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream);
-
-/* Device-side hand-off between two streams of one process (no reference counterpart): the producer stream ends with
- * mne_flag_set(flag, v), the consumer stream runs mne_flag_wait(flag, v) where it needs the producer's results; the wait
- * returns as soon as the word has reached v (wrap-around compare), gives up after ~2 s and then sets *timeout = 1.
- * Used by the fused step to keep its critical kernels on one stream without an event wait behind the long plane update
- * (an event wait there costs ~15-18 us of queue idle time on this runtime).  The producer's launch MUST be enqueued before
- * the consumer's wait is, or be guaranteed to run concurrently. */
-int mne_flag_set(uint32_t* flag, uint32_t value, void* stream);
-int mne_flag_wait(const uint32_t* flag, uint32_t value, uint32_t* timeout, void* stream);
-
-/* Measurement hook (no reference counterpart): up to 5 hipEvent_t handles that the NEXT mne_render_fused call records on its
- * stream -- [0] before the feature gather, [1] after it, [2] after the prefix decode, [3] after the ray kernel, [4] after
- * the deferred pass -- so bench.py can time the kernels of that call live.  NULL entries are skipped; the handles are
- * consumed by that one call.  Process-global, not thread-safe. */
-int mne_profile_marks(void* const* events, int n);
 
 /* Number of samples per ray: n_range_d + n_samples_d with depth guidance, n_samples without
  * (model/scene_rep.py:362-374). */
@@ -269,6 +255,26 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
                         int32_t* ray_tiles, float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* Optional per-call extras of the fused training call (NULL = none of them).  No field is kept by the library: the
+ * call is stateless, whatever carries over from one iteration to the next lives in caller-owned device memory. */
+typedef struct mne_fused_opts {
+    /* Measurement: up to 6 hipEvent_t handles that THIS call records on its stream -- [0] before the feature gather, [1]
+     * after it, [2] after the prefix decode, [3] after the ray kernel, [4] after the deferred pass, [5] after the list
+     * appends (bin_kernel) -- so that bench.py can time the kernels of the call live (HIP events on the launch stream).
+     * NULL entries are skipped. */
+    void* const* timing_events;
+    int32_t n_timing_events;
+    int32_t lds_samples_cap;   /* 0 = default (256): samples of a ray the training kernel's first pass keeps in LDS */
+    /* Adaptive a-priori prefix (exact in either mode, only the schedule changes): [4] int32 of caller-owned device
+     * memory, zero-initialised once and handed to every call of one training run.  The exact early ray termination
+     * decodes each ray's a-priori prefix tile-parallel and finishes the rays that turn out unresolved in a second
+     * (deferred) pass; while the SDF is untrained most rays are unresolved and the second pass costs more than it saves.
+     * word 0 = mode of THIS call (0: prefix + deferred pass, 1: decode every sample a priori), rewritten at the end of
+     * the call from the fraction of rays the prefix did not (mode 0) / would not (mode 1) resolve: > 1/8 switches to mode
+     * 1, < 1/16 back to mode 0.  word 1 = that count (scratch); words 2, 3 reserved.  NULL = always mode 0. */
+    int32_t* adapt_state;
+} mne_fused_opts_t;
+
 /* Fused training form of the two calls above (what Mapper.mapping_optimize runs per iteration), with early ray
  * termination: decodes every ray up to the last sample it needs (tile-parallel for the samples ray_counts marks,
  * on demand for the rest), composites (rgb, depth, ray_sums like mne_render_forward) and back-propagates with the
@@ -279,7 +285,8 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
                      const float* target_d, const float* z_vals, const int32_t* ray_counts,
                      const float* packed_decoder, const float* coef, float* rgb, float* depth, float* raw,
                      float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, int32_t* ray_tiles,
-                     const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream);
+                     const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, const mne_fused_opts_t* opts,
+                     void* stream);
 
 /* Binned scatter + Adam for the planes (see csrc/tile_adam.hip): with `bins` given, mne_render_fused
  * does not touch plane[].grad; it appends every contributing sample to the lists of the 16x16-cell
@@ -387,7 +394,7 @@ int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* 
                               const float* z_vals, const int32_t* ray_counts, const float* packed_decoder, const float* coef,
                               float* rgb, float* depth, float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows,
                               int32_t* tape_rows, int32_t* ray_tiles, void* workspace, size_t workspace_bytes,
-                              const mne_grid_cfg_t* grid_cfg, const float* table, void* stream);
+                              const mne_grid_cfg_t* grid_cfg, const float* table, const mne_fused_opts_t* opts, void* stream);
 int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                      const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles,
                      float* grad_table, void* stream);

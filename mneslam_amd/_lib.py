@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmneslam_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 N_LOSS = 8
 N_COUNT = 8
 C_NEED = 6
@@ -65,6 +65,12 @@ class Clock(C.Structure):
                 ("reserved", C.c_int32), ("beta1", C.c_double), ("beta2", C.c_double), ("z_offset_stride", C.c_uint64)]
 
 
+class FusedOpts(C.Structure):
+    """mne_fused_opts_t: per-call extras of mne_render_fused / mne_render_fused_features."""
+    _fields_ = [("timing_events", C.POINTER(C.c_void_p)), ("n_timing_events", C.c_int32), ("lds_samples_cap", C.c_int32),
+                ("adapt_state", C.c_void_p)]
+
+
 class GridCfg(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("n_features", C.c_int32), ("base_resolution", C.c_int32),
                 ("log2_hashmap_size", C.c_int32), ("grid_type", C.c_int32), ("reserved", C.c_int32),
@@ -82,10 +88,8 @@ _PROTOS = {
     "mne_sizeof_tile_bins": (C.c_size_t, []),
     "mne_sizeof_plane_opt": (C.c_size_t, []),
     "mne_sizeof_clock": (C.c_size_t, []),
+    "mne_sizeof_fused_opts": (C.c_size_t, []),
     "mne_clock_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mne_profile_marks": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
-    "mne_flag_set": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
-    "mne_flag_wait": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mne_num_samples": (C.c_int, [C.POINTER(RenderCfg), C.c_int]),
     "mne_sample_z": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Clock), C.c_void_p]),
@@ -101,7 +105,8 @@ _PROTOS = {
                             + [C.c_int64] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
     "mne_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mne_render_fused": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 13
-                         + [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_void_p]),
+                         + [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.POINTER(FusedOpts),
+                            C.c_void_p]),
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_tile_order": (C.c_int, [C.POINTER(Scene), C.POINTER(TileBins), C.c_void_p]),
     "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.POINTER(Clock),
@@ -123,7 +128,7 @@ _PROTOS = {
     "mne_hash_gather": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 6),
     "mne_render_fused_features": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 13
                                   + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GridCfg), C.c_void_p,
-                                     C.c_void_p]),
+                                     C.POINTER(FusedOpts), C.c_void_p]),
     "mne_hash_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mne_hash_scratch_floats": (C.c_size_t, [C.POINTER(GridCfg)]),
     "mne_hash_slice_adam": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 6
@@ -157,7 +162,8 @@ def load(path=None):
             raise RuntimeError("libmneslam_hip ABI version mismatch")
         for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
                        (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),
-                       (lib.mne_sizeof_plane_opt, PlaneOpt), (lib.mne_sizeof_clock, Clock)):
+                       (lib.mne_sizeof_plane_opt, PlaneOpt), (lib.mne_sizeof_clock, Clock),
+                       (lib.mne_sizeof_fused_opts, FusedOpts)):
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"struct layout mismatch for {st.__name__}: C {fn()} vs ctypes {C.sizeof(st)}")
         _lib = lib

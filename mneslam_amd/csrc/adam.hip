@@ -74,41 +74,4 @@ int mne_launch_clock_advance(unsigned long long* iteration, int* step_offset, hi
     return 0;
 }
 
-// ---- device-side hand-off between two streams ----------------------------------------------------------------------------
-// A stream-wait on an event costs ~15-18 us of idle queue time on this runtime whenever it sits behind a long kernel
-// (profiles/r01_gap_analysis.txt), even when the event has long fired.  The fused step's critical chain therefore stays
-// on ONE stream, and the one thing it needs from the other stream (next batch + repacked decoder) is signalled through
-// a device word: the producer stream ends with flag_set_kernel, the consumer stream runs flag_wait_kernel (one lane
-// polling with s_sleep; the word is monotonic, so a value that is already there passes at once).  The wait gives up
-// after ~2 s and raises *timeout instead of hanging the queue.
-__global__ void flag_set_kernel(unsigned* flag, unsigned value) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-#ifndef MNE_HOST_EMU
-        __threadfence();
-        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        *flag = value;
-#endif
-    }
-}
-
-__global__ void flag_wait_kernel(const unsigned* flag, unsigned value, unsigned* timeout) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-#ifndef MNE_HOST_EMU
-    const unsigned long long t0 = wall_clock64();                      // 100 MHz
-    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000ull) { *timeout = 1u; break; }
-    }
-#else
-    if ((int)(*flag - value) < 0) *timeout = 1u;                        // the emulator runs launches in order: must already be set
-#endif
-}
-
-int mne_launch_flag(unsigned* flag, unsigned value, unsigned* timeout, int wait, hipStream_t st) {
-    if (wait) MNE_LAUNCH(flag_wait_kernel, 1, 64, 0, st, (const unsigned*)flag, value, timeout);
-    else MNE_LAUNCH(flag_set_kernel, 1, 64, 0, st, flag, value);
-    return 0;
-}
-
 long long mne_adam_blocks_for(long long n) { return (n + ADAM_ELEMS_PER_BLOCK - 1) / ADAM_ELEMS_PER_BLOCK; }

@@ -80,29 +80,12 @@ size_t mne_sizeof_adam_seg(void) { return sizeof(mne_adam_seg_t); }
 size_t mne_sizeof_tile_bins(void) { return sizeof(mne_tile_bins_t); }
 size_t mne_sizeof_plane_opt(void) { return sizeof(mne_plane_opt_t); }
 size_t mne_sizeof_clock(void) { return sizeof(mne_clock_t); }
+size_t mne_sizeof_fused_opts(void) { return sizeof(mne_fused_opts_t); }
 
 int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream) {
     if (!iteration && !step_offset) return fail(-1, "mne_clock_advance: NULL argument");
     mne_launch_clock_advance((unsigned long long*)iteration, step_offset, (hipStream_t)stream);
     return check_launch("clock_advance");
-}
-
-int mne_flag_set(uint32_t* flag, uint32_t value, void* stream) {
-    if (!flag) return fail(-1, "mne_flag_set: NULL argument");
-    mne_launch_flag(flag, value, nullptr, 0, (hipStream_t)stream);
-    return check_launch("flag_set");
-}
-
-int mne_flag_wait(const uint32_t* flag, uint32_t value, uint32_t* timeout, void* stream) {
-    if (!flag || !timeout) return fail(-1, "mne_flag_wait: NULL argument");
-    mne_launch_flag((unsigned*)flag, value, timeout, 1, (hipStream_t)stream);
-    return check_launch("flag_wait");
-}
-
-int mne_profile_marks(void* const* events, int n) {
-    if (n > 0 && !events) return fail(-1, "mne_profile_marks: NULL argument");
-    mne_set_render_marks(events, n);
-    return 0;
 }
 
 int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d) {
@@ -180,7 +163,7 @@ int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, in
     const bool early = (flags & MNE_RENDER_EARLY_TERMINATION) != 0;
     a.ray_counts = early ? ray_counts : nullptr;
     a.prefix_default = early ? 1 : (1 << 30);
-    if (int rc = mne_launch_render(a, early ? 1 : 0, nullptr, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    if (int rc = mne_launch_render(a, early ? 1 : 0, nullptr, RenderHost{}, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_forward");
 }
 
@@ -250,7 +233,7 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
     a.coef = coef; a.g_rgb = g_rgb; a.g_depth = g_depth;
     a.tape = tape; a.tape_rows = tape_rows; a.ray_tiles = ray_tiles;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d;
-    if (int rc = mne_launch_render(a, 3, workspace, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    if (int rc = mne_launch_render(a, 3, workspace, RenderHost{}, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_backward");
 }
 
@@ -264,7 +247,7 @@ static int render_fused(bool ext_feat, const GridArgs* ext_grid, const mne_scene
                      const float* target_d, const float* z_vals, const int32_t* ray_counts,
                      const float* packed_decoder, const float* coef, float* rgb, float* depth, float* raw,
                      float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, int32_t* ray_tiles,
-                     const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream) {
+                     const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, const mne_fused_opts_t* opts, void* stream) {
     if (int rc = check_scene(scene, bins == nullptr && !ext_feat, !ext_feat)) return rc;
     if (!cfg || !rays_o || !rays_d || !target_rgb || !target_d || !z_vals || !packed_decoder || !coef || !raw ||
         !tape || !tape_rows || !ray_tiles || !workspace)
@@ -284,11 +267,19 @@ static int render_fused(bool ext_feat, const GridArgs* ext_grid, const mne_scene
     a.rgb = rgb; a.depth = depth; a.raw = raw; a.ray_sums = ray_sums;
     a.tape = tape; a.tape_rows = tape_rows; a.ray_tiles = ray_tiles;
     a.ext_feat = ext_feat ? 1 : 0;
-    a.ext_grid = ext_grid;
+    RenderHost host;
+    host.ext_grid = ext_grid;
     if (const char* c = std::getenv("MNE_HOT_LDS_SAMPLES")) a.lds_samples = std::atoi(c);      // tests force the two-pass split on small S
+    if (opts) {
+        if (opts->n_timing_events < 0 || opts->n_timing_events > 6 || (opts->n_timing_events > 0 && !opts->timing_events))
+            return fail(-1, "mne_fused_opts: timing_events holds 0..6 event handles");
+        host.marks = opts->timing_events; host.n_marks = opts->n_timing_events;
+        if (opts->lds_samples_cap > 0) a.lds_samples = opts->lds_samples_cap;
+        a.adapt = ray_counts ? opts->adapt_state : nullptr;       // without per-ray counts everything is decoded a priori anyway
+    }
     if (bins)
         if (int rc = fill_bins(scene, bins, a.bins)) return rc;
-    if (int rc = mne_launch_render(a, 2, workspace, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    if (int rc = mne_launch_render(a, 2, workspace, host, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_fused");
 }
 
@@ -299,10 +290,10 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
                      const float* target_d, const float* z_vals, const int32_t* ray_counts,
                      const float* packed_decoder, const float* coef, float* rgb, float* depth, float* raw,
                      float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, int32_t* ray_tiles,
-                     const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, void* stream) {
+                     const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, const mne_fused_opts_t* opts, void* stream) {
     return render_fused(false, nullptr, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, ray_counts,
                         packed_decoder, coef, rgb, depth, raw, ray_sums, tape, tape_capacity_rows, tape_rows, ray_tiles, bins,
-                        workspace, workspace_bytes, stream);
+                        workspace, workspace_bytes, opts, stream);
 }
 
 int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
@@ -310,7 +301,7 @@ int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* 
                               const float* z_vals, const int32_t* ray_counts, const float* packed_decoder, const float* coef,
                               float* rgb, float* depth, float* raw, float* ray_sums, float* tape, int64_t tape_capacity_rows,
                               int32_t* tape_rows, int32_t* ray_tiles, void* workspace, size_t workspace_bytes,
-                              const mne_grid_cfg_t* grid_cfg, const float* table, void* stream) {
+                              const mne_grid_cfg_t* grid_cfg, const float* table, const mne_fused_opts_t* opts, void* stream) {
     GridArgs g = {};
     if (grid_cfg || table) {                          // the call gathers the hash-grid rows itself, only where they can be decoded
         if (!grid_cfg || !table) return fail(-1, "mne_render_fused_features: grid_cfg and table go together");
@@ -319,7 +310,7 @@ int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* 
     }
     return render_fused(true, grid_cfg ? &g : nullptr, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals,
                         ray_counts, packed_decoder, coef, rgb, depth, raw, ray_sums, tape, tape_capacity_rows, tape_rows, ray_tiles,
-                        nullptr, workspace, workspace_bytes, stream);
+                        nullptr, workspace, workspace_bytes, opts, stream);
 }
 
 size_t mne_tile_count(const mne_scene_t* scene) {

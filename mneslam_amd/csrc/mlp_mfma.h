@@ -32,6 +32,33 @@ __device__ __forceinline__ void acc_to_row(float* prow, int col0, const f32x16& 
             *(float4*)(prow + col0 + 8 * q + 4 * hf) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// A-table access: row `step` of the packed tables, this lane's element.
+//   GTAB = false: `atab` is an LDS (or, in small forward-only kernels, a plain global) pointer: one ds_read / global_load
+//                 with an immediate offset per MFMA operand.
+//   GTAB = true : the tables of the largest decoder (2x64 + colour planes, 124 KiB) do not fit beside the per-wave LDS of
+//                 the decode / autograd-backward kernels and are read through L2 with BUFFER loads: one shared 128-bit
+//                 resource in SGPRs, one VGPR (lane * 4), the row offset as scalar offset.  With flat global loads the
+//                 13-bit immediate reaches 16 rows, so the compiler kept ~20 64-bit row base addresses live across the
+//                 MFMA chains and spilled 2-6 KiB per lane (profiles/r02 spill table).
+template <bool GTAB, int BIAS = 0>
+struct ATabRef {
+    const float* A;
+    __device__ __forceinline__ ATabRef(const float* atab, int lane) : A(atab + lane - BIAS * 64) {}
+    __device__ __forceinline__ float at(int step) const { return A[step * 64]; }
+};
+#ifndef MNE_HOST_EMU
+template <int BIAS>
+struct ATabRef<true, BIAS> {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;
+    __device__ __forceinline__ ATabRef(const float* atab, int lane)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc((void*)atab, 0, 0x7fffffff, 0x00020000)), voff(lane * 4) {}
+    __device__ __forceinline__ float at(int step) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (step - BIAS) * 256, 0));
+    }
+};
+#endif
+
 // row of a 32-row MFMA tile held in accumulator register r by a lane of half h (= lane >> 5)
 __host__ __device__ constexpr int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -153,12 +180,12 @@ __device__ __forceinline__ void oneblob_half(const float u[3], int h, float (&po
 }
 
 // frow / cfrow: LDS feature rows of this lane's POINT (64 floats each); the lane reads its level half.
-template <int HID, int HIDC, bool CP>
+template <int HID, int HIDC, bool CP, bool GTAB = false>
 __device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float* cfrow, const float (&pos)[24],
                                                  const float* atab, int lane, MlpState<HID, HIDC>& S) {
     typedef ATab<HID, HIDC, CP> T;
     const int h = lane >> 5;
-    const float* A = atab + lane;
+    const ATabRef<GTAB> A(atab, lane);
     const float* fh = frow + h * 32;
     const float* ch = cfrow + h * 32;
 #pragma unroll
@@ -169,13 +196,13 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float*
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float4 x = *(const float4*)(fh + 4 * q);
-            acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 4 * q + 0) * 64], x.x, acc);
-            acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 4 * q + 1) * 64], x.y, acc);
-            acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 4 * q + 2) * 64], x.z, acc);
-            acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 4 * q + 3) * 64], x.w, acc);
+            acc = MNE_MFMA(A.at(T::OFF_L1 + t * T::L1S + 4 * q + 0), x.x, acc);
+            acc = MNE_MFMA(A.at(T::OFF_L1 + t * T::L1S + 4 * q + 1), x.y, acc);
+            acc = MNE_MFMA(A.at(T::OFF_L1 + t * T::L1S + 4 * q + 2), x.z, acc);
+            acc = MNE_MFMA(A.at(T::OFF_L1 + t * T::L1S + 4 * q + 3), x.w, acc);
         }
 #pragma unroll
-        for (int s = 0; s < 24; ++s) acc = MNE_MFMA(A[(T::OFF_L1 + t * T::L1S + 32 + s) * 64], pos[s], acc);
+        for (int s = 0; s < 24; ++s) acc = MNE_MFMA(A.at(T::OFF_L1 + t * T::L1S + 32 + s), pos[s], acc);
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = fmaxf(acc[e], 0.0f);
         S.h[t] = acc;
@@ -185,7 +212,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float*
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 16 * T::NT; ++s) acc = MNE_MFMA(A[(T::OFF_L2 + s) * 64], S.h[s >> 4][s & 15], acc);
+        for (int s = 0; s < 16 * T::NT; ++s) acc = MNE_MFMA(A.at(T::OFF_L2 + s), S.h[s >> 4][s & 15], acc);
         S.out = acc;
     }
 #pragma unroll
@@ -195,19 +222,19 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float*
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
         const int base = T::OFF_C1 + t * T::C1S;
 #pragma unroll
-        for (int s = 0; s < 24; ++s) acc = MNE_MFMA(A[(base + s) * 64], pos[s], acc);
+        for (int s = 0; s < 24; ++s) acc = MNE_MFMA(A.at(base + s), pos[s], acc);
         if (CP) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float4 x = *(const float4*)(ch + 4 * q);
-                acc = MNE_MFMA(A[(base + 24 + 4 * q + 0) * 64], x.x, acc);
-                acc = MNE_MFMA(A[(base + 24 + 4 * q + 1) * 64], x.y, acc);
-                acc = MNE_MFMA(A[(base + 24 + 4 * q + 2) * 64], x.z, acc);
-                acc = MNE_MFMA(A[(base + 24 + 4 * q + 3) * 64], x.w, acc);
+                acc = MNE_MFMA(A.at(base + 24 + 4 * q + 0), x.x, acc);
+                acc = MNE_MFMA(A.at(base + 24 + 4 * q + 1), x.y, acc);
+                acc = MNE_MFMA(A.at(base + 24 + 4 * q + 2), x.z, acc);
+                acc = MNE_MFMA(A.at(base + 24 + 4 * q + 3), x.w, acc);
             }
         }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc = MNE_MFMA(A[(base + 24 + (CP ? 32 : 0) + s) * 64], S.out[s], acc);
+        for (int s = 0; s < 8; ++s) acc = MNE_MFMA(A.at(base + 24 + (CP ? 32 : 0) + s), S.out[s], acc);
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = fmaxf(acc[e], 0.0f);
         S.hc[t] = acc;
@@ -217,7 +244,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float*
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 16 * T::NTC; ++s) acc = MNE_MFMA(A[(T::OFF_C2 + s) * 64], S.hc[s >> 4][s & 15], acc);
+        for (int s = 0; s < 16 * T::NTC; ++s) acc = MNE_MFMA(A.at(T::OFF_C2 + s), S.hc[s >> 4][s & 15], acc);
         S.rgb = acc;
     }
 }
@@ -240,19 +267,22 @@ __device__ __forceinline__ void relu_masks(const MlpState<HID, HIDC>& S, unsigne
 // Backward data path.  ds/dc: d(total)/d(sdf), d(total)/d(raw rgb) of this lane's point (identical on
 // both lanes of the pair); mh / mhc: relu_masks of the forward.  Outputs: dh, dout, dhc (tape) and d(feature)
 // rows written to LDS (dfrow / dcfrow = the point's rows; each lane writes the rows it holds).
-template <int HID, int HIDC, bool CP>
+// BIAS (backward functions): `atab` points at table step BIAS (the training kernel stages only the backward steps in LDS;
+// a pointer biased at run time instead pushed the ds_read offsets of the 2x64 tables past the 64 KiB immediate range and
+// cost an address register per MFMA operand).
+template <int HID, int HIDC, bool CP, int BIAS = 0, bool GTAB = false>
 __device__ __forceinline__ void mlp_backward_color(unsigned mhc, float ds, const float (&dc)[3], const float* atab, int lane,
                                                    f32x16& dout, f32x16 (&dhc)[HIDC / 32], float* dcfrow) {
     typedef ATab<HID, HIDC, CP> T;
     const int h = lane >> 5;
-    const float* A = atab + lane;
+    const ATabRef<GTAB, BIAS> A(atab, lane);
 #pragma unroll
     for (int t = 0; t < T::NTC; ++t) {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-        acc = MNE_MFMA(A[(T::OFF_B1 + 2 * t + 0) * 64], h ? dc[1] : dc[0], acc);
-        acc = MNE_MFMA(A[(T::OFF_B1 + 2 * t + 1) * 64], h ? 0.0f : dc[2], acc);
+        acc = MNE_MFMA(A.at(T::OFF_B1 + 2 * t + 0), h ? dc[1] : dc[0], acc);
+        acc = MNE_MFMA(A.at(T::OFF_B1 + 2 * t + 1), h ? 0.0f : dc[2], acc);
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = ((mhc >> (16 * t + e)) & 1u) ? acc[e] : 0.0f;
         dhc[t] = acc;
@@ -262,7 +292,7 @@ __device__ __forceinline__ void mlp_backward_color(unsigned mhc, float ds, const
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 16 * T::NTC; ++s) acc = MNE_MFMA(A[(T::OFF_B2 + s) * 64], dhc[s >> 4][s & 15], acc);
+        for (int s = 0; s < 16 * T::NTC; ++s) acc = MNE_MFMA(A.at(T::OFF_B2 + s), dhc[s >> 4][s & 15], acc);
         if (h == 0) acc[0] = ds;            // row m = 0 is the sdf output
         dout = acc;
     }
@@ -274,7 +304,7 @@ __device__ __forceinline__ void mlp_backward_color(unsigned mhc, float ds, const
             for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 16 * T::NTC; ++s)
-                acc = MNE_MFMA(A[(T::OFF_B2C + rt * 16 * T::NTC + s) * 64], dhc[s >> 4][s & 15], acc);
+                acc = MNE_MFMA(A.at(T::OFF_B2C + rt * 16 * T::NTC + s), dhc[s >> 4][s & 15], acc);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *(float4*)(dcfrow + 32 * rt + 8 * q + 4 * h) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -282,19 +312,19 @@ __device__ __forceinline__ void mlp_backward_color(unsigned mhc, float ds, const
     }
 }
 
-template <int HID, int HIDC, bool CP>
+template <int HID, int HIDC, bool CP, int BIAS = 0, bool GTAB = false>
 __device__ __forceinline__ void mlp_backward_sdf(unsigned mh, const float* atab, int lane, f32x16 (&dh)[HID / 32],
                                                  const f32x16& dout, float* dfrow) {
     typedef ATab<HID, HIDC, CP> T;
     const int h = lane >> 5;
-    const float* A = atab + lane;
+    const ATabRef<GTAB, BIAS> A(atab, lane);
 #pragma unroll
     for (int t = 0; t < T::NT; ++t) {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc = MNE_MFMA(A[(T::OFF_B3 + 8 * t + s) * 64], dout[s], acc);
+        for (int s = 0; s < 8; ++s) acc = MNE_MFMA(A.at(T::OFF_B3 + 8 * t + s), dout[s], acc);
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = ((mh >> (16 * t + e)) & 1u) ? acc[e] : 0.0f;
         dh[t] = acc;
@@ -306,7 +336,7 @@ __device__ __forceinline__ void mlp_backward_sdf(unsigned mh, const float* atab,
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
         for (int s = 0; s < 16 * T::NT; ++s)
-            acc = MNE_MFMA(A[(T::OFF_B4 + rt * 16 * T::NT + s) * 64], dh[s >> 4][s & 15], acc);
+            acc = MNE_MFMA(A.at(T::OFF_B4 + rt * 16 * T::NT + s), dh[s >> 4][s & 15], acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *(float4*)(dfrow + 32 * rt + 8 * q + 4 * h) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -314,22 +344,22 @@ __device__ __forceinline__ void mlp_backward_sdf(unsigned mh, const float* atab,
 }
 
 // the whole chain: colour net (writes the colour planes' d(feature) rows), then sdf net (geometry planes' rows)
-template <int HID, int HIDC, bool CP>
+template <int HID, int HIDC, bool CP, int BIAS = 0, bool GTAB = false>
 __device__ __forceinline__ void mlp_backward_mfma(unsigned mh, unsigned mhc, float ds, const float (&dc)[3],
                                                   const float* atab, int lane, f32x16 (&dh)[HID / 32],
                                                   f32x16& dout, f32x16 (&dhc)[HIDC / 32], float* dfrow, float* dcfrow) {
-    mlp_backward_color<HID, HIDC, CP>(mhc, ds, dc, atab, lane, dout, dhc, dcfrow);
-    mlp_backward_sdf<HID, HIDC, CP>(mh, atab, lane, dh, dout, dfrow);
+    mlp_backward_color<HID, HIDC, CP, BIAS, GTAB>(mhc, ds, dc, atab, lane, dout, dhc, dcfrow);
+    mlp_backward_sdf<HID, HIDC, CP, BIAS, GTAB>(mh, atab, lane, dh, dout, dfrow);
 }
 
 // d(total)/d(OneBlob channel) rows of this lane's point -> LDS row dprow[0..63] (48 used): both nets'
 // first layers, chained into one accumulator per 32-row tile.  Ray-gradient variant only.
-template <int HID, int HIDC, bool CP>
+template <int HID, int HIDC, bool CP, bool GTAB = false>
 __device__ __forceinline__ void mlp_backward_dpos(const f32x16 (&dh)[HID / 32], const f32x16 (&dhc)[HIDC / 32],
                                                   const float* atab, int lane, float* dprow) {
     typedef ATab<HID, HIDC, CP> T;
     const int h = lane >> 5;
-    const float* A = atab + lane;
+    const ATabRef<GTAB> A(atab, lane);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         f32x16 acc;
@@ -337,10 +367,10 @@ __device__ __forceinline__ void mlp_backward_dpos(const f32x16 (&dh)[HID / 32], 
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
         for (int s = 0; s < 16 * T::NT; ++s)
-            acc = MNE_MFMA(A[(T::OFF_P1 + rt * 16 * T::NT + s) * 64], dh[s >> 4][s & 15], acc);
+            acc = MNE_MFMA(A.at(T::OFF_P1 + rt * 16 * T::NT + s), dh[s >> 4][s & 15], acc);
 #pragma unroll
         for (int s = 0; s < 16 * T::NTC; ++s)
-            acc = MNE_MFMA(A[(T::OFF_P2 + rt * 16 * T::NTC + s) * 64], dhc[s >> 4][s & 15], acc);
+            acc = MNE_MFMA(A.at(T::OFF_P2 + rt * 16 * T::NTC + s), dhc[s >> 4][s & 15], acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *(float4*)(dprow + 32 * rt + 8 * q + 4 * h) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);

@@ -294,13 +294,13 @@ __device__ __forceinline__ void gather_coord_grad(const mne_scene_t& sc, const f
 // `live`: bit s set = slot s holds a sample that receives gradient (the others have an all-zero row).
 template <int NSETS, int NPTS>
 __device__ __forceinline__ void scatter_chunk(const mne_scene_t& sc, const float* pn, const float* dfeat,
-                                              unsigned long long live, int lane, int set_lo = 0, int set_hi = NSETS,
+                                              unsigned live, int lane, int set_lo = 0, int set_hi = NSETS,
                                               bool one_buffer = false) {      // one_buffer: dfeat holds the rows of set_lo only
     const int c = lane & 31, half = lane >> 5;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 2; ++it) {
         const int slot = it * 2 + half;
-        if ((live >> slot) & 1ull) {
+        if ((live >> slot) & 1u) {
             const float px = pn[slot * 4 + 0], py = pn[slot * 4 + 1], pz = pn[slot * 4 + 2];
 #pragma unroll
             for (int set = 0; set < NSETS; ++set) {
@@ -372,15 +372,16 @@ struct DecDims {
 // Tape rows are 1.4-2 KB apart, so a store of "what each lane holds" touches 64 different cache lines with 16 bytes
 // each (store-issue-bound, ~7 B/clk/CU).  Everything that goes to the tape is therefore first laid out as rows in LDS
 // ([32 points][MNE_FS], columns [0, NCOL)) and then written by groups of 8 lanes x float4 = one full 128-B line per
-// point and instruction (8 lines per wave instruction).  `live`: bit s = point s is written.
+// point and instruction (8 lines per wave instruction).  `live`: bit s = point s is written (32 points: a 32-bit mask --
+// a 64-bit one made the compiler keep four per-lane 64-bit bit constants alive across the whole tile loop).
 template <int NCOL>
 __device__ __forceinline__ void store_rows(const float* rows, float* tape_rows0, int row_stride, int tcol,
-                                           unsigned long long live, int lane) {
+                                           unsigned live, int lane) {
     const int cg = lane & 7;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int slot = it * 8 + (lane >> 3);
-        if ((live >> slot) & 1ull) {
+        if ((live >> slot) & 1u) {
 #pragma unroll
             for (int hfc = 0; hfc < NCOL / 32; ++hfc)
                 *(float4*)(tape_rows0 + (size_t)slot * row_stride + tcol + hfc * 32 + cg * 4) =
@@ -392,13 +393,13 @@ __device__ __forceinline__ void store_rows(const float* rows, float* tape_rows0,
 // the reverse of store_rows: tape columns [tcol, tcol + NCOL) of the tile's rows -> LDS rows, one batch of coalesced loads
 template <int NCOL>
 __device__ __forceinline__ void load_rows(float* rows, const float* tape_rows0, int row_stride, int tcol,
-                                          unsigned long long live, int lane) {
+                                          unsigned live, int lane) {
     const int cg = lane & 7;
     float4 v[4][NCOL / 32];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int slot = it * 8 + (lane >> 3);
-        const int src = ((live >> slot) & 1ull) ? slot : 0;            // rows beyond the ray's last sample: any valid row
+        const int src = ((live >> slot) & 1u) ? slot : 0;              // rows beyond the ray's last sample: any valid row
 #pragma unroll
         for (int hfc = 0; hfc < NCOL / 32; ++hfc)
             v[it][hfc] = *(const float4*)(tape_rows0 + (size_t)src * row_stride + tcol + hfc * 32 + cg * 4);

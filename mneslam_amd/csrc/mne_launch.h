@@ -61,12 +61,19 @@ struct RenderArgs {
     float *rgb, *depth, *disp, *acc, *depth_var, *raw, *ray_sums;
     const float* raw_in;        // backward-only call: raw of ALL samples from the forward call (NULL otherwise)
     int lds_samples;             // ray_kernel: samples of a ray its LDS arrays hold (0 = all S); rays that need more are deferred
+#if defined(MNE_ARGS_PAD) && MNE_ARGS_PAD > 0
+    // LAYOUT FUZZ (tests only, -DMNE_ARGS_PAD=N builds under mneslam_amd/_fuzz/): dummy bytes in the middle of the kernel
+    // argument block.  No kernel reads them; a kernel whose results change with N is miscompiled or racy.
+    char args_pad[MNE_ARGS_PAD];
+#endif
     int ext_feat;                // feature rows come from the caller (tape columns T_X..): no plane gather, no plane scatter
     const int* ray_counts;      // [R][MNE_N_COUNT] from sample_z (slot MNE_C_NEED = a-priori sample count)
     int prefix_default;         // ray_counts == NULL: a-priori tiles of every ray (ntile = decode everything, 1 = on demand only)
     const float *coef, *g_rgb, *g_depth;
     float* tape;                // [R*S][ROW]; NULL = forward only
     int tape_row, tape_tx, tape_tcf;   // gather_kernel: row length and the columns of the two feature blocks
+    int tape_tpn, tape_tdfeat;         // bin_kernel / scatter_kernel: columns of (pn.xyz, live flag) and of the d(feature) rows
+    int plane_grads;                   // the backward leaves d(feature) rows of the samples with gradient in the tape (0: pose-only loops)
     int* tape_rows;             // total number of samples that received gradient
     unsigned* relu_mask;        // [R*S][4]: per lane half (h mask, hc mask)
     int* ray_tiles;             // [R] number of leading 32-sample tiles of each ray whose tape rows are complete
@@ -79,9 +86,17 @@ struct RenderArgs {
     const int* ray_list;        // ray_kernel works through this list instead of all rays (NULL = rays 0..R-1)
     const int* ray_list_count;
     float *d_rays_o, *d_rays_d;
+    int adapt_update;           // this launch is the last ray launch of the call: it rewrites adapt[0] for the next call
+    int* adapt;                 // optional [4] device words: [0] = decode every sample a priori in this call, [1] = rays the a-priori
+                                // prefix did / would not resolve (mne_fused_opts_t::adapt_state)
     TileBins bins;              // bins.lists != NULL: binned scatter instead of atomics into plane[].grad
-    // host-side only (kernels never read it; kept LAST so that the kernels' argument layout does not move):
-    const struct GridArgs* ext_grid;   // ext_feat: hash grid whose rows this call gathers itself (NULL = the caller filled the tape)
+};
+
+// host-side extras of one training render (never part of a kernel argument block)
+struct RenderHost {
+    const struct GridArgs* ext_grid = nullptr;   // ext_feat: hash grid whose rows the call gathers itself (NULL = the caller filled the tape)
+    void* const* marks = nullptr;                // hipEvent_t handles recorded between the kernels (mne_fused_opts_t::timing_events)
+    int n_marks = 0;
 };
 
 struct LossArgs {
@@ -196,9 +211,7 @@ int mne_launch_sample_z(const ZArgs& a, hipStream_t st);
 int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
 // mode: 0 = forward, every sample decoded (raw complete);  1 = forward with early ray termination (maps only);
 //       2 = training iteration (decode + backward);  3 = backward of an earlier forward call (raw_in given)
-int mne_launch_render(const RenderArgs& a, int mode, void* workspace, hipStream_t st);
-void mne_set_render_marks(void* const* events, int n);
-int mne_launch_flag(unsigned* flag, unsigned value, unsigned* timeout, int wait, hipStream_t st);
+int mne_launch_render(const RenderArgs& a, int mode, void* workspace, const RenderHost& host, hipStream_t st);
 int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st);
 int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st);
 int mne_hash_slice_count(const GridArgs& a);

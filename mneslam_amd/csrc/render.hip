@@ -183,9 +183,16 @@ __host__ __device__ inline size_t tile_wave_lds_bytes(int nsets, bool raygrad = 
 }
 
 // number of leading tiles of ray r that are decoded a priori (see the file header)
+// a-priori tiles of ray r from its loss-mask count alone (what the exact early termination decodes tile-parallel)
+__device__ __forceinline__ int apriori_tiles(const RenderArgs& a, int r, int ntile) {
+    const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
+    const int t = (need + TILE - 1) / TILE;
+    return t < 1 ? 1 : (t > ntile ? ntile : t);
+}
 __device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntile, bool listed = false) {
     if (listed) return ntile;                    // second pass over the deferred rays: everything is decoded
     if (!a.ray_counts) return a.prefix_default < ntile ? a.prefix_default : ntile;
+    if (a.adapt && a.adapt[0]) return ntile;     // adaptive schedule, mode 1: most rays would be deferred -> decode everything a priori
     const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
     const int t = (need + TILE - 1) / TILE;
     return t < 1 ? 1 : (t > ntile ? ntile : t);
@@ -196,7 +203,7 @@ __device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntil
 // of this lane's point (valid lanes); pnv/u are its coordinates, relu its mask words.
 // PRE: the plane features of the tile are already in the tape rows (gather_kernel): they are loaded back into the LDS
 // rows with one batch of coalesced loads instead of being gathered here (8 dependent rounds of corner-row loads).
-template <int HID, int HIDC, bool CP>
+template <int HID, int HIDC, bool CP, bool GTAB = false>
 __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c, int lane, float* pn, float* feat,
                                               const float* atab, float (&pnv)[3], float (&u)[3], uint2& relu, int prof_slot = -1,
                                               bool PRE = false) {
@@ -213,7 +220,7 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     for (int k = 0; k < 3; ++k) p[k] = a.rays_o[r * 3 + k] + a.rays_d[r * 3 + k] * z;      // scene_rep.py:384
     point_coords(a.sc, p, pnv, u);
     const int n_here = S - c * TILE;
-    const unsigned long long live = n_here >= TILE ? 0xffffffffull : ((1ull << n_here) - 1ull);
+    const unsigned live = n_here >= TILE ? 0xffffffffu : ((1u << n_here) - 1u);
     float* tape0 = a.tape ? a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW : nullptr;
 #ifdef ABL_NO_FWD_TAPE
     tape0 = nullptr;
@@ -244,7 +251,7 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     oneblob_half(u, hf, pos);
     DEC_STAMP(4);
     MlpState<HID, HIDC> st;
-    mlp_forward_mfma<HID, HIDC, CP>(frow, cfrow, pos, atab, lane, st);
+    mlp_forward_mfma<HID, HIDC, CP, GTAB>(frow, cfrow, pos, atab, lane, st);
     const float4 rw = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);      // rows 0..3 live in the lower half
     DEC_STAMP(5);
     relu = make_uint2(0u, 0u);
@@ -285,9 +292,10 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     return rw;
 }
 
-#ifndef MAX_WPB
-#define MAX_WPB 12
-#endif
+// Waves per workgroup decode_kernel is compiled for: 8 = 256 registers per lane, no spills in any decoder shape (a
+// 12-wave build for the inline-gather form hid a little more latency and spilled 16-376 B per lane: dropped in round 3,
+// see DESIGN.md 9.3 for why spills are treated as defects here).
+#define DECODE_WPB 8
 // -----------------------------------------------------------------------------------------------
 // gather_kernel: tri-plane features of the a-priori samples straight into their tape rows.  The gather is a chain of
 // dependent load rounds; inside decode_kernel (12 waves per CU, LDS- and register-bound) it took 21 of the 34 us a tile
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
 #else
             const int prof_slot = -1;
 #endif
-            const float4 rw = decode_tile<HID, HIDC, CP>(a, r, cc, lane, pn, feat, atab, pnv, u, relu, prof_slot, pre_now);
+            const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, cc, lane, pn, feat, atab, pnv, u, relu, prof_slot, pre_now);
 #ifdef RENDER_PROFILE
             if (prof_slot >= 0 && lane == 0)
                 ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 65536) * MNE_SPILL_WORDS))[(size_t)prof_slot * 16 + 7] = (unsigned long long)(c + 1);
@@ -564,8 +572,16 @@ __device__ __forceinline__ unsigned run_meta(int w_, int lane) {
 //      4: TRAINING kernel (the hot one): no decode code at all -- 12 waves per CU instead of 8, every ray of the batch
 //         resident at once.  A ray whose decoded prefix does not resolve it (no sign change yet, or the render window
 //         runs past the prefix) is pushed to a.defer_list and handled afterwards by a MODE 2 launch.
+#ifndef MNE_HOT64CP_WPB
+#define MNE_HOT64CP_WPB 8       // 2x64 + colour planes: 46 KiB of backward tables in LDS leave room for 9 waves; 8 = 256 registers
+#endif
+// waves per workgroup a ray_kernel instantiation is compiled for (= its register budget: 512 / ceil(waves / 4) per lane)
+// (MODE 3, ray gradients: 4 waves = the whole register file of a SIMD per wave -- its extra d(OneBlob) / d(coordinate) stages
+// spilled 0.4-6 KiB per lane at 8 waves; it serves the 100-iteration pose loops of loop closure, not the mapping iteration)
+#define RAY_WPB(HID, CP, MODE) ((MODE) == 4 ? (((HID) == 64 && (CP)) ? MNE_HOT64CP_WPB : MAX_WPB_HOT) : (MODE) == 3 ? 4 : MAX_WPB_RAY)
+
 template <int HID, int HIDC, bool CP, bool ALDS, int MODE>
-__global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void ray_kernel(RenderArgs a) {
+__global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(RenderArgs a) {
     typedef DecDims<HID, HIDC, CP> D;
     typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
@@ -577,6 +593,14 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
     constexpr int TAB_FLOATS = ALDS ? (TAB_LAST - TAB_FIRST) * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     const int wpb = blockDim.x >> 6;
+    if (HOT && a.adapt && a.adapt_update && blockIdx.x == 0 && threadIdx.x == 0) {
+        // Adaptive schedule (mne_fused_opts_t::adapt_state), decided by the LAST ray launch of a call for the NEXT call:
+        // n = rays the a-priori prefix did not (mode 0: the deferred list) / would not (mode 1: counted below) resolve
+        const int mode = a.adapt[0];
+        const int n = mode ? a.adapt[1] : *a.ray_list_count;
+        a.adapt[0] = mode ? (n * 16 >= a.R ? 1 : 0) : (n * 8 > a.R ? 1 : 0);
+        a.adapt[1] = 0;
+    }
     if (a.ray_list && *a.ray_list_count == 0) return;      // second pass with nothing deferred (the usual case)
     if (ALDS) {
         float4* dst = (float4*)lds_raw;
@@ -584,7 +608,8 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
         for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
-    const float* atab = ALDS ? (const float*)lds_raw - TAB_FIRST * 64 : a.packed;     // indexed by absolute step
+    const float* atab = ALDS ? (const float*)lds_raw : a.packed;      // ALDS: table step TAB_FIRST onwards (BIAS below)
+    constexpr int BIAS = ALDS ? TAB_FIRST : 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = a.S, ntile = (S + TILE - 1) / TILE;
     const int L = (a.lds_samples > 0 && a.lds_samples < S) ? a.lds_samples : S;       // samples the per-wave LDS arrays hold
@@ -593,6 +618,9 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
     // the tape before the sdf net's rows are produced -- so that more waves fit beside the tables (ScanNet: 6 -> 11 per CU,
     // i.e. all 2150 rays in one round instead of two).
     constexpr bool SEQ = HOT && CP;
+    // 2x64 decoders: d(hidden) of the colour net is written to the tape before the sdf net's backward (32 registers less
+    // across its chain); not with ray gradients, which need both nets' d(hidden) for the OneBlob input gradient
+    constexpr bool EARLY_DHC = HID == 64 && BWD && !RAYGRAD;
     constexpr int LSETS = SEQ ? 1 : NSETS;
     const size_t wave_bytes = (size_t)Spad * 5 * sizeof(float) + tile_wave_lds_bytes(LSETS, RAYGRAD);
     unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * wave_bytes;
@@ -649,7 +677,7 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
                 // decode the next tile on demand (Dn is a multiple of TILE here)
                 float pnv[3], u[3];
                 uint2 relu;
-                const float4 rw = decode_tile<HID, HIDC, CP>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu);
+                const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu);
                 const int i = t_dec * TILE + pt;
                 if (i < S && hf == 0) *(float4*)(raws + 4 * i) = rw;
                 MNE_WAVE_SYNC();
@@ -661,6 +689,14 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
         if (HOT && deferred) {
             if (lane == 0) a.defer_list[atomicAdd(a.defer_count, 1)] = r;
             continue;
+        }
+        if (HOT && a.adapt && a.adapt[0] && (!a.ray_list || a.list_keeps_prefix)) {
+            // mode 1 (every sample was decoded a priori): would the a-priori prefix plus the resolver's extension have
+            // resolved this ray?  Feeds the decision to go back to mode 0.
+            int t_ap = apriori_tiles(a, r, ntile) + MNE_RESOLVER_MAX_EXT;
+            const int D_ap = t_ap * TILE < S ? t_ap * TILE : S;
+            const bool resolved = D_ap >= S || (first >= 0 && first + 1 < D_ap && !(zr[D_ap] < zr[first] + a.win_f));
+            if (!resolved && lane == 0) atomicAdd(a.adapt + 1, 1);
         }
         RAY_STAMP(2);
         RayGrad G;
@@ -698,7 +734,7 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
             const size_t e = (size_t)r * S + ii;
             uint2 mk2;
             if (LATE_DECODE && c >= t_dec) {                      // tape rows of this tile are missing: decode it now
-                decode_tile<HID, HIDC, CP>(a, r, c, lane, pn, feat, atab, pnv, u, mk2);
+                decode_tile<HID, HIDC, CP, !ALDS>(a, r, c, lane, pn, feat, atab, pnv, u, mk2);
                 t_dec = c + 1;
             } else {
 #pragma unroll
@@ -744,7 +780,7 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
 #else
             const bool live = valid && contrib;
 #endif
-            const unsigned long long live_rows = __ballot(live && hf == 0), valid_rows = __ballot(valid && hf == 0);
+            const unsigned live_rows = (unsigned)__ballot(live && hf == 0), valid_rows = (unsigned)__ballot(valid && hf == 0);
             float* tape0 = a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW;
             if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
 #ifdef ABL_NO_BWD_MFMA
@@ -752,16 +788,26 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
             for (int t = 0; t < NT; ++t) dh[t] = f32x16_zero();
             for (int t = 0; t < NTC; ++t) dhc[t] = f32x16_zero();
 #else
-            if (SEQ) {
-                mlp_backward_color<HID, HIDC, CP>(mk2.y, ds, dc, atab, lane, dout, dhc, cfrow);
+            if (SEQ || EARLY_DHC) {
+                // colour net first; what it produces leaves for the tape before the sdf net's chain starts, so that
+                // its registers (and, with colour planes, its LDS rows) are free again
+                mlp_backward_color<HID, HIDC, CP, BIAS, !ALDS>(mk2.y, ds, dc, atab, lane, dout, dhc, cfrow);
                 MNE_WAVE_SYNC();
-                if (a.ext_feat) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT + MNE_FEAT, valid_rows, lane);
-                else if (a.bins.lists) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT + MNE_FEAT, live_rows, lane);
-                else if (a.sc.plane[0][0][0].grad) scatter_chunk<NSETS, TILE>(a.sc, pn, feat, live_rows, lane, 1, 2, true);
-                MNE_WAVE_SYNC();
-                mlp_backward_sdf<HID, HIDC, CP>(mk2.x, atab, lane, dh, dout, frow);
+                if (SEQ) {
+                    if (a.ext_feat) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT + MNE_FEAT, valid_rows, lane);
+                    else if (a.plane_grads) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT + MNE_FEAT, live_rows, lane);
+                    MNE_WAVE_SYNC();
+                }
+                if (EARLY_DHC) {
+#pragma unroll
+                    for (int t = 0; t < NTC; ++t) acc_to_row(frow, 32 * t, dhc[t], hf);
+                    MNE_WAVE_SYNC();
+                    store_rows<HIDC>(feat, tape0, D::ROW, D::T_DHC, valid_rows, lane);
+                    MNE_WAVE_SYNC();
+                }
+                mlp_backward_sdf<HID, HIDC, CP, BIAS, !ALDS>(mk2.x, atab, lane, dh, dout, frow);
             } else {
-                mlp_backward_mfma<HID, HIDC, CP>(mk2.x, mk2.y, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
+                mlp_backward_mfma<HID, HIDC, CP, BIAS, !ALDS>(mk2.x, mk2.y, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
             }
 #endif
             RAY_STAMP(7 + 6 * c);
@@ -769,7 +815,7 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
                 // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates; every
                 // point of the tile belongs to this ray: summed over the wave, stored once at the end
                 float* dprow = dposL + pt * 64;
-                mlp_backward_dpos<HID, HIDC, CP>(dh, dhc, atab, lane, dprow);
+                mlp_backward_dpos<HID, HIDC, CP, !ALDS>(dh, dhc, atab, lane, dprow);
                 MNE_WAVE_SYNC();
                 gather_coord_grad<NSETS, TILE>(a.sc, pn, feat, dpnL, lane);
                 MNE_WAVE_SYNC();
@@ -789,21 +835,19 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
             }
             MNE_WAVE_SYNC();
 #ifdef ABL_NO_BWD_TAPE
-            const unsigned long long tape_rows_mask = 0ull;
+            const unsigned tape_rows_mask = 0u;
 #else
-            const unsigned long long tape_rows_mask = valid_rows;
+            const unsigned tape_rows_mask = valid_rows;
 #endif
             // ---- backward half of the tape rows, staged through the LDS rows (full-line stores, see store_rows)
             if (a.ext_feat) {                                     // caller-owned encoding: d(feature) rows of every valid sample
 #pragma unroll                                                    // (all-zero rows for samples without gradient)
                 for (int set = 0; set < LSETS; ++set)
                     store_rows<MNE_FEAT>(feat + set * TILE * MNE_FS, tape0, D::ROW, D::T_DFEAT + set * MNE_FEAT, valid_rows, lane);
-            } else if (a.bins.lists) {                            // d(feature) rows: read by the binned plane update
-#pragma unroll
-                for (int set = 0; set < LSETS; ++set)
+            } else if (a.plane_grads) {                           // d(feature) rows of the samples that receive gradient: read by the
+#pragma unroll                                                    // binned plane update (tile_adam.hip) or by scatter_kernel (atomics);
+                for (int set = 0; set < LSETS; ++set)             // 0 = the caller wants no plane gradients (pose-only loops)
                     store_rows<MNE_FEAT>(feat + set * TILE * MNE_FS, tape0, D::ROW, D::T_DFEAT + set * MNE_FEAT, live_rows, lane);
-            } else if (a.sc.plane[0][0][0].grad) {                // NULL: the caller wants no plane gradients (pose-only loops)
-                scatter_chunk<NSETS, TILE>(a.sc, pn, feat, live_rows, lane, 0, LSETS);
             }
             MNE_WAVE_SYNC();
             if (HID == 32 && HIDC == 32) {
@@ -816,17 +860,19 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
                 for (int t = 0; t < NT; ++t) acc_to_row(frow, 32 * t, dh[t], hf);
                 MNE_WAVE_SYNC();
                 store_rows<HID>(feat, tape0, D::ROW, D::T_DH, tape_rows_mask, lane);
-                MNE_WAVE_SYNC();
+                if (!EARLY_DHC) {
+                    MNE_WAVE_SYNC();
 #pragma unroll
-                for (int t = 0; t < NTC; ++t) acc_to_row(frow, 32 * t, dhc[t], hf);
-                MNE_WAVE_SYNC();
-                store_rows<HIDC>(feat, tape0, D::ROW, D::T_DHC, tape_rows_mask, lane);
+                    for (int t = 0; t < NTC; ++t) acc_to_row(frow, 32 * t, dhc[t], hf);
+                    MNE_WAVE_SYNC();
+                    store_rows<HIDC>(feat, tape0, D::ROW, D::T_DHC, tape_rows_mask, lane);
+                }
             }
             MNE_WAVE_SYNC();
             acc_to_row(frow, 0, dout, hf, 8);                     // [dout 16 | dc 4 | pn 4 | pad 8]
             if (hf == 0) {
                 *(float4*)(frow + 16) = make_float4(dc[0], dc[1], dc[2], 0.0f);
-                *(float4*)(frow + 20) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+                *(float4*)(frow + 20) = make_float4(pnv[0], pnv[1], pnv[2], live ? 1.0f : 0.0f);   // pn.w: the sample receives gradient (bin_kernel)
             } else {
                 *(float4*)(frow + 24) = make_float4(0.f, 0.f, 0.f, 0.f);
                 *(float4*)(frow + 28) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -834,69 +880,7 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
             MNE_WAVE_SYNC();
             store_rows<32>(feat, tape0, D::ROW, D::T_DOUT, tape_rows_mask, lane);
             RAY_STAMP(8 + 6 * c);
-            if (a.bins.lists) {
-                // The sample is appended to the list of every plane tile its 2x2 footprints touch (tile_adam.hip): one
-                // returning atomic per RUN of lanes with the same list (run_meta), issued back to back for all 12 (24)
-                // (plane, corner-tile) slots of the lane before any result is consumed; then one 32-byte entry per append.
-                constexpr int NJ = NSETS * 3;
-                int want[NJ * 4];
-                unsigned meta[NJ * 4];                             // leader lane | rank << 8 | run length << 16
-                int cix[NJ], ciy[NJ];                              // NW corner of the footprint in each of the lane's planes
-                float wq[NJ][4];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int pidx = 2 * j + hf;                   // planes in [set][orient][level] order
-                    const int ori = (pidx % 6) / 2;
-                    const mne_plane_t& pl = a.sc.plane[pidx / 6][ori][pidx % 2];
-                    float gx, gy;
-                    orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
-                    Bilin b;
-                    bilin_setup(gx, gy, pl.h, pl.w, b);
-                    wq[j][0] = b.w00; wq[j][1] = b.w01; wq[j][2] = b.w10; wq[j][3] = b.w11;
-                    const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
-                    const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
-                    const int base = a.bins.tile_base[pidx], ntx = a.bins.ntx[pidx];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
-                        const bool dup = ((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0);   // same tile again
-                        const int w_ = (live && !dup) ? base + ty * ntx + tx : -1;
-                        want[j * 4 + q] = w_;
-                        meta[j * 4 + q] = run_meta(w_, lane);
-                    }
-                    cix[j] = b.ix0; ciy[j] = b.iy0;
-                }
-                RAY_STAMP(9 + 6 * c);
-                int first_slot[NJ * 4];
-#pragma unroll
-                for (int q = 0; q < NJ * 4; ++q) {
-                    first_slot[q] = 0;
-                    if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q], (int)(meta[q] >> 16));
-                }
-                const unsigned trow = (unsigned)e;                 // tape row of this sample
-#pragma unroll
-                for (int eq = 0; eq < NJ * 4; ++eq) {
-                    const int f0 = __shfl(first_slot[eq], (int)(meta[eq] & 255u));
-                    if (want[eq] >= 0) {
-                        const int slot = f0 + (int)((meta[eq] >> 8) & 255u);
-                        unsigned* dst = nullptr;
-                        if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[eq] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
-                        else {
-                            const int sp = atomicAdd(a.bins.spill_count, 1);
-                            if (sp < a.bins.spill_cap) dst = a.bins.spill + (size_t)sp * MNE_ENTRY_WORDS;
-                            else atomicAdd(a.bins.dropped, 1);              // caller-sized spill area too small: reported, never silent
-                        }
-                        if (dst) {
-                            const int j = eq >> 2, q = eq & 3;
-                            // corner relative to the tile this entry goes to (+1: 0 = one cell before the tile)
-                            const int tx = (cix[j] + (q & 1)) / MNE_TILE, ty = (ciy[j] + (q >> 1)) / MNE_TILE;
-                            const unsigned corner = (unsigned)(cix[j] - tx * MNE_TILE + 1) | ((unsigned)(ciy[j] - ty * MNE_TILE + 1) << 8);
-                            *(uint4*)dst = make_uint4(trow, corner, __float_as_uint(wq[j][0]), __float_as_uint(wq[j][1]));
-                            *(uint4*)(dst + 4) = make_uint4(__float_as_uint(wq[j][2]), __float_as_uint(wq[j][3]), (unsigned)want[eq], 0u);
-                        }
-                    }
-                }
-            }
+            // (the list appends of the binned plane update are bin_kernel's: it reads pn and the `live` flag written above)
             RAY_STAMP(10 + 6 * c);
         }
 #ifdef RENDER_PROFILE
@@ -914,6 +898,130 @@ __global__ __launch_bounds__(64 * (MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY)) void 
                 }
             }
         }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------
+// bin_kernel: the list appends of the binned plane update (tile_adam.hip).  One wave per (ray, 32-sample tile) of the
+// tiles the ray kernels back-propagated (ray_tiles[r]); a lane = (sample, plane level), like the backward tile code.
+// Reads what ray_kernel left in the sample's tape row: the normalised point pn and the flag pn.w = "receives gradient".
+// Until round 3 this was the tail of ray_kernel's tile loop; there its 100+ live registers (24 list slots x {list, run
+// meta, reservation} + corners + weights) sat on top of the MFMA backward state and forced spills in every training
+// instantiation (profiles/r02 spill table), and every ray's first tile paid 17 us for it in sequence.  On its own it is
+// a latency-tolerant kernel at full occupancy over all (ray, tile) pairs at once.
+// -----------------------------------------------------------------------------------------------
+template <bool CP>
+__global__ __launch_bounds__(256) void bin_kernel(RenderArgs a, int ntile) {
+    constexpr int NSETS = CP ? 2 : 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pt = lane & 31, hf = lane >> 5;
+    const int S = a.S;
+    const long long ntask = (long long)a.R * ntile;
+    for (long long task = (long long)blockIdx.x * 4 + wv; task < ntask; task += (long long)gridDim.x * 4) {
+        const int c = (int)(task / a.R), r = (int)(task % a.R);        // tile-major: the skipped tasks cluster at the end
+        if (c >= a.ray_tiles[r]) continue;                             // whole wave together
+        const int i = c * TILE + pt;
+        const bool valid = i < S;
+        const size_t e = (size_t)r * S + (valid ? i : S - 1);
+        const float4 pn4 = *(const float4*)(a.tape + e * a.tape_row + a.tape_tpn);
+        const bool live = valid && pn4.w != 0.0f;
+        const float pnv[3] = {pn4.x, pn4.y, pn4.z};
+#pragma unroll 1
+        for (int set = 0; set < NSETS; ++set) {
+            // The sample is appended to the list of every plane tile its 2x2 footprints touch (tile_adam.hip): one
+            // returning atomic per RUN of lanes with the same list (run_meta), issued back to back for all 12 (24)
+            // (plane, corner-tile) slots of the lane before any result is consumed; then one 32-byte entry per append.
+            constexpr int NJ = 3;                              // the three orientations of one plane set, this lane's level
+            int want[NJ * 4];
+            unsigned meta[NJ * 4];                             // leader lane | rank << 8 | run length << 16
+            int cix[NJ], ciy[NJ];                              // NW corner of the footprint in each of the lane's planes
+            float wq[NJ][4];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int pidx = set * 6 + 2 * j + hf;         // planes in [set][orient][level] order
+                const int ori = (pidx % 6) / 2;
+                const mne_plane_t& pl = a.sc.plane[pidx / 6][ori][pidx % 2];
+                float gx, gy;
+                orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
+                Bilin b;
+                bilin_setup(gx, gy, pl.h, pl.w, b);
+                wq[j][0] = b.w00; wq[j][1] = b.w01; wq[j][2] = b.w10; wq[j][3] = b.w11;
+                const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
+                const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
+                const int base = a.bins.tile_base[pidx], ntx = a.bins.ntx[pidx];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
+                    const bool dup = ((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0);   // same tile again
+                    const int w_ = (live && !dup) ? base + ty * ntx + tx : -1;
+                    want[j * 4 + q] = w_;
+                    meta[j * 4 + q] = run_meta(w_, lane);
+                }
+                cix[j] = b.ix0; ciy[j] = b.iy0;
+            }
+            int first_slot[NJ * 4];
+#pragma unroll
+            for (int q = 0; q < NJ * 4; ++q) {
+                first_slot[q] = 0;
+                if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q], (int)(meta[q] >> 16));
+            }
+            const unsigned trow = (unsigned)e;                 // tape row of this sample
+#pragma unroll
+            for (int eq = 0; eq < NJ * 4; ++eq) {
+                const int f0 = __shfl(first_slot[eq], (int)(meta[eq] & 255u));
+                if (want[eq] >= 0) {
+                    const int slot = f0 + (int)((meta[eq] >> 8) & 255u);
+                    unsigned* dst = nullptr;
+                    if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[eq] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
+                    else {
+                        const int sp = atomicAdd(a.bins.spill_count, 1);
+                        if (sp < a.bins.spill_cap) dst = a.bins.spill + (size_t)sp * MNE_ENTRY_WORDS;
+                        else atomicAdd(a.bins.dropped, 1);              // caller-sized spill area too small: reported, never silent
+                    }
+                    if (dst) {
+                        const int j = eq >> 2, q = eq & 3;
+                        // corner relative to the tile this entry goes to (+1: 0 = one cell before the tile)
+                        const int tx = (cix[j] + (q & 1)) / MNE_TILE, ty = (ciy[j] + (q >> 1)) / MNE_TILE;
+                        const unsigned corner = (unsigned)(cix[j] - tx * MNE_TILE + 1) | ((unsigned)(ciy[j] - ty * MNE_TILE + 1) << 8);
+                        *(uint4*)dst = make_uint4(trow, corner, __float_as_uint(wq[j][0]), __float_as_uint(wq[j][1]));
+                        *(uint4*)(dst + 4) = make_uint4(__float_as_uint(wq[j][2]), __float_as_uint(wq[j][3]), (unsigned)want[eq], 0u);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------
+// scatter_kernel: plane gradients by global atomics (scatter="atomics" and the autograd path), the counterpart of
+// bin_kernel + tile_adam_kernel: one wave per back-propagated (ray, tile); the d(feature) rows ray_kernel left in the tape
+// and the normalised points go through the wave's LDS rows into scatter_chunk (one 128-B line of atomics per half-wave).
+// -----------------------------------------------------------------------------------------------
+template <bool CP>
+__global__ __launch_bounds__(256) void scatter_kernel(RenderArgs a, int ntile) {
+    constexpr int NSETS = CP ? 2 : 1;
+    MNE_DYN_LDS(lds_raw);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pt = lane & 31, hf = lane >> 5;
+    const int S = a.S;
+    float* pn = (float*)(lds_raw + (size_t)wv * tile_wave_lds_bytes(NSETS));
+    float* feat = pn + TILE * 4;
+    const long long ntask = (long long)a.R * ntile;
+    for (long long task = (long long)blockIdx.x * 4 + wv; task < ntask; task += (long long)gridDim.x * 4) {
+        const int c = (int)(task / a.R), r = (int)(task % a.R);
+        if (c >= a.ray_tiles[r]) continue;                             // whole wave together
+        const int i = c * TILE + pt;
+        const bool valid = i < S;
+        const float* tape0 = a.tape + ((size_t)r * S + (size_t)c * TILE) * a.tape_row;
+        const float4 pn4 = *(const float4*)(tape0 + (size_t)(valid ? pt : 0) * a.tape_row + a.tape_tpn);
+        const unsigned live_rows = (unsigned)__ballot(valid && pn4.w != 0.0f && hf == 0);
+        MNE_WAVE_SYNC();                                               // the previous task's LDS reads are done
+        if (hf == 0) *(float4*)(pn + pt * 4) = pn4;
+#pragma unroll
+        for (int set = 0; set < NSETS; ++set)
+            load_rows<MNE_FEAT>(feat + set * TILE * MNE_FS, tape0, a.tape_row, a.tape_tdfeat + set * MNE_FEAT, live_rows, lane);
+        MNE_WAVE_SYNC();
+        scatter_chunk<NSETS, TILE>(a.sc, pn, feat, live_rows, lane);
     }
 }
 
@@ -1120,8 +1228,11 @@ template <int HID, int HIDC, bool CP, int MODE>
 static int launch_ray(RenderArgs a, hipStream_t st, int max_blocks = MNE_NUM_CU) {
     typedef WgShape<HID, HIDC, CP> W;
     typedef ATab<HID, HIDC, CP> T;
+    // A tables in LDS: always for the training kernel (backward steps only: at most 46 KiB); the other modes of the
+    // largest decoder (2x64 + colour planes: 124 KiB of tables) read them through L2
+    constexpr bool ALDS = W::ALDS || MODE == 4;
     size_t tab = table_bytes<HID, HIDC, CP>(MODE);
-    if (MODE == 4 && W::ALDS) tab = (size_t)(T::TOTAL - T::FWD_STEPS) * 64 * sizeof(float);
+    if (MODE == 4) tab = (size_t)(T::TOTAL - T::FWD_STEPS) * 64 * sizeof(float);
     // Training kernel, first pass: LDS for MNE_HOT_LDS_SAMPLES samples per ray instead of S (INS Indoor: S = 1045 would
     // leave room for 4 waves per CU, i.e. 1024 of 2150 rays at a time); the few rays whose decoded prefix is longer
     // go to the second pass, which is sized for S.
@@ -1129,31 +1240,25 @@ static int launch_ray(RenderArgs a, hipStream_t st, int max_blocks = MNE_NUM_CU)
     a.lds_samples = (MODE == 4 && !a.ray_list && a.S > cap) ? cap : 0;
     const int L = a.lds_samples ? a.lds_samples : a.S;
     const size_t per_wave = (size_t)((L + 3) & ~3) * 5 * sizeof(float) + tile_wave_lds_bytes((CP && MODE != 4) ? 2 : 1, MODE == 3);
-    const int wpb = fit_waves<HID, HIDC, CP>(tab, per_wave, MODE == 4 ? MAX_WPB_HOT : MAX_WPB_RAY);
+    const int wpb = fit_waves<HID, HIDC, CP>(tab, per_wave, RAY_WPB(HID, CP, MODE));
     if (wpb < 1) return -4;
     const size_t lds = tab + (size_t)wpb * per_wave;
-    if (lds > 64 * 1024) MNE_SET_MAX_LDS((ray_kernel<HID, HIDC, CP, W::ALDS, MODE>), MNE_LDS_MAX);
+    if (lds > 64 * 1024) MNE_SET_MAX_LDS((ray_kernel<HID, HIDC, CP, ALDS, MODE>), MNE_LDS_MAX);
     long long grid = ((long long)a.R + wpb - 1) / wpb;
     if (grid > max_blocks) grid = max_blocks;
-    MNE_LAUNCH((ray_kernel<HID, HIDC, CP, W::ALDS, MODE>), (unsigned)grid, 64 * wpb, lds, st, a);
+    MNE_LAUNCH((ray_kernel<HID, HIDC, CP, ALDS, MODE>), (unsigned)grid, 64 * wpb, lds, st, a);
     return 0;
 }
 
-// Timing marks (mne_profile_marks): events the next training render records between its kernels, so that a benchmark
-// can time gather / decode / ray / deferred pass live without a profiler.  Consumed by one call; not thread-safe.
-static hipEvent_t g_marks[5];
-static int g_n_marks = 0;
-void mne_set_render_marks(void* const* events, int n) {
-    g_n_marks = n < 0 ? 0 : n > 5 ? 5 : n;
-    for (int i = 0; i < g_n_marks; ++i) g_marks[i] = (hipEvent_t)events[i];
-}
-static inline void mark(int i, hipStream_t st) {
-    if (i < g_n_marks && g_marks[i]) (void)hipEventRecord(g_marks[i], st);
+// Timing marks (mne_fused_opts_t::timing_events): events a training render records between its kernels, so that a benchmark
+// can time gather / decode / ray / deferred pass / binning live without a profiler.  Per-call state, owned by the caller.
+static inline void mark(const RenderHost& h, int i, hipStream_t st) {
+    if (i < h.n_marks && h.marks && h.marks[i]) (void)hipEventRecord((hipEvent_t)h.marks[i], st);
 }
 
 // pre = true: the a-priori tiles' plane features are gathered by gather_kernel first (needs the tape)
 template <int HID, int HIDC, bool CP>
-static int launch_decode(RenderArgs d, hipStream_t st, bool pre = false) {
+static int launch_decode(RenderArgs d, hipStream_t st, const RenderHost& host, bool pre = false) {
     typedef DecDims<HID, HIDC, CP> D;
     typedef WgShape<HID, HIDC, CP> W;
     pre = pre && d.tape && !d.ray_list;
@@ -1161,30 +1266,47 @@ static int launch_decode(RenderArgs d, hipStream_t st, bool pre = false) {
         d.tape_row = D::ROW; d.tape_tx = D::T_X; d.tape_tcf = D::T_CF;
         const int chunks = (d.S + 7) / 8;
         const long long waves = (long long)d.R * chunks;
-        mark(0, st);
+        mark(host, 0, st);
         MNE_LAUNCH((gather_kernel<CP>), (unsigned)((waves + 3) / 4), 256, 0, st, d, chunks);
-        mark(1, st);
+        mark(host, 1, st);
     }
     const size_t tab = table_bytes<HID, HIDC, CP>(0);
-    const int wpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(CP ? 2 : 1), pre ? 8 : MAX_WPB);
+    const int wpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(CP ? 2 : 1), DECODE_WPB);
     if (wpb < 1) return -4;
     const size_t lds = tab + (size_t)wpb * tile_wave_lds_bytes(CP ? 2 : 1);
     const long long ntask = (long long)d.R * ((d.S + TILE - 1) / TILE);
     long long grid = (ntask + wpb - 1) / wpb;
     if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
     // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
-    if (pre) {
-        if (lds > 64 * 1024) MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS, 8>), MNE_LDS_MAX);
-        MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS, 8>), (unsigned)grid, 64 * wpb, lds, st, d, 1);
-    } else {
-        if (lds > 64 * 1024) MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS, MAX_WPB>), MNE_LDS_MAX);
-        MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS, MAX_WPB>), (unsigned)grid, 64 * wpb, lds, st, d, 0);
-    }
+    if (lds > 64 * 1024) MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB>), MNE_LDS_MAX);
+    MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB>), (unsigned)grid, 64 * wpb, lds, st, d, pre ? 1 : 0);
     return 0;
 }
 
+// After the ray kernels of a backward call: what happens to the d(feature) rows they left in the tape -- list appends
+// for the binned plane update, or global atomics into plane[].grad; nothing when no plane gradient is wanted or the
+// encoding is the caller's (ext_feat).
 template <int HID, int HIDC, bool CP>
-static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st) {
+static void launch_plane_pass(const RenderArgs& a, hipStream_t st) {
+    typedef DecDims<HID, HIDC, CP> D;
+    if (!a.plane_grads || a.ext_feat) return;
+    RenderArgs b = a;
+    b.tape_row = D::ROW; b.tape_tpn = D::T_PN; b.tape_tdfeat = D::T_DFEAT;
+    const int ntile = (a.S + TILE - 1) / TILE;
+    long long grid = ((long long)a.R * ntile + 3) / 4;
+    if (grid > MNE_NUM_CU * 8) grid = MNE_NUM_CU * 8;
+    if (a.bins.lists) {
+        MNE_LAUNCH((bin_kernel<CP>), (unsigned)grid, 256, 0, st, b, ntile);
+    } else {
+        const size_t lds = 4 * tile_wave_lds_bytes(CP ? 2 : 1);
+        if (lds > 64 * 1024) MNE_SET_MAX_LDS((scatter_kernel<CP>), MNE_LDS_MAX);
+        MNE_LAUNCH((scatter_kernel<CP>), (unsigned)grid, 256, lds, st, b, ntile);
+    }
+}
+
+template <int HID, int HIDC, bool CP>
+static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHost& host, hipStream_t st) {
+    a.plane_grads = (a.bins.lists != nullptr || a.sc.plane[0][0][0].grad != nullptr) ? 1 : 0;
     typedef WgShape<HID, HIDC, CP> W;
     const bool raygrad = a.d_rays_o != nullptr || a.d_rays_d != nullptr;
     if (raygrad && mode != 3) return -5;
@@ -1192,18 +1314,18 @@ static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st
         if (!workspace) return -6;
         carve_workspace(a, workspace);
     }
-    if (mode == 2 && a.ext_feat && a.ext_grid) {          // hash-grid rows of the tiles the first pass can decode
-        GridArgs g = *a.ext_grid;
+    if (mode == 2 && a.ext_feat && host.ext_grid) {       // hash-grid rows of the tiles the first pass can decode
+        GridArgs g = *host.ext_grid;
         g.ray_counts = a.ray_counts; g.ray_list = nullptr; g.ray_list_count = nullptr;
-        mark(0, st);
+        mark(host, 0, st);
         mne_launch_hash_rows(g, 0, st);
-        mark(1, st);
+        mark(host, 1, st);
     }
     {   // decode: every tile (mode 0), or the a-priori prefix of every ray
         RenderArgs d = a;
         if (mode == 0) { d.ray_counts = nullptr; d.prefix_default = 1 << 30; }
         if (mode == 3) d.raw = nullptr;                    // raw of the forward call stays untouched
-        if (int rc = launch_decode<HID, HIDC, CP>(d, st, mode >= 2)) return rc;
+        if (int rc = launch_decode<HID, HIDC, CP>(d, st, host, mode >= 2)) return rc;
     }
     if (mode == 0) {
         const size_t clds = (size_t)4 * ((a.S + 3) & ~3) * 4 * sizeof(float);
@@ -1217,29 +1339,35 @@ static int launch_render(RenderArgs a, int mode, void* workspace, hipStream_t st
     if (mode == 2) {
         // training: every ray in the lean kernel; the few it cannot resolve from the decoded prefix are finished by the
         // full kernel, driven by the deferred list (a handful of workgroups that leave at once when the list is empty)
-        mark(2, st);
+        mark(host, 2, st);
         if (int rc = launch_ray<HID, HIDC, CP, 4>(a, st)) return rc;
         if (ray_lds_cap(a) < a.S) {        // long rays: those whose decoded prefix exceeded the first pass's LDS, same kernel sized for S
             RenderArgs l = a;
             l.ray_list = a.long_list; l.ray_list_count = a.long_count; l.list_keeps_prefix = 1;
             if (int rc = launch_ray<HID, HIDC, CP, 4>(l, st)) return rc;
         }
-        mark(3, st);
+        mark(host, 3, st);
         RenderArgs d = a;
         d.ray_list = a.defer_list; d.ray_list_count = a.defer_count;
-        if (a.ext_feat && a.ext_grid && a.ray_counts) {    // the deferred rays' remaining hash-grid rows
-            GridArgs g = *a.ext_grid;
+        if (a.ext_feat && host.ext_grid && a.ray_counts) {    // the deferred rays' remaining hash-grid rows
+            GridArgs g = *host.ext_grid;
             g.ray_counts = a.ray_counts; g.ray_list = a.defer_list; g.ray_list_count = a.defer_count;
             mne_launch_hash_rows(g, 0, st);
         }
-        launch_decode<HID, HIDC, CP>(d, st);               // their remaining tiles, tile-parallel
-        const int rc = launch_ray<HID, HIDC, CP, 4>(d, st);    // the same lean kernel: now every listed ray resolves
-        mark(4, st);
-        g_n_marks = 0;
-        return rc;
+        launch_decode<HID, HIDC, CP>(d, st, host);         // their remaining tiles, tile-parallel
+        d.adapt_update = 1;                                // the last ray launch of the call decides the next call's schedule
+        if (int rc = launch_ray<HID, HIDC, CP, 4>(d, st)) return rc;    // the same lean kernel: now every listed ray resolves
+        mark(host, 4, st);
+        launch_plane_pass<HID, HIDC, CP>(a, st);           // list appends (binned) or atomics, all rays at once
+        mark(host, 5, st);
+        return 0;
     }
-    if (raygrad) return launch_ray<HID, HIDC, CP, 3>(a, st);
-    return launch_ray<HID, HIDC, CP, 2>(a, st);
+    {
+        const int rc = raygrad ? launch_ray<HID, HIDC, CP, 3>(a, st) : launch_ray<HID, HIDC, CP, 2>(a, st);
+        if (rc) return rc;
+        launch_plane_pass<HID, HIDC, CP>(a, st);
+        return 0;
+    }
 }
 
 template <int HID, int HIDC, bool CP>
@@ -1250,6 +1378,9 @@ static int launch_query(const QueryArgs& a, hipStream_t st) {
     return 0;
 }
 
+#ifdef MNE_ONLY_SHAPE      // development builds (profiles/resource_usage.py --shape): ONE decoder shape = 2 * hidden + colour planes
+#define MNE_DISPATCH(sc, CALL, BAD) do { CALL((MNE_ONLY_SHAPE / 2), (MNE_ONLY_SHAPE / 2), ((MNE_ONLY_SHAPE & 1) != 0)); } while (0)
+#else
 #define MNE_DISPATCH(sc, CALL, BAD)                                                           \
     do {                                                                                   \
         const bool cp_ = (sc).n_sets == 2;                                                 \
@@ -1257,6 +1388,7 @@ static int launch_query(const QueryArgs& a, hipStream_t st) {
         else if ((sc).hidden == 64 && (sc).hidden_color == 64) { if (cp_) { CALL(64, 64, true); } else { CALL(64, 64, false); } } \
         else return BAD;                                                                   \
     } while (0)
+#endif
 
 int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
 #define CALL(H, HC, CPV) return launch_pack<H, HC, CPV>(sc, pk, st)
@@ -1265,8 +1397,8 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
     return -2;
 }
 
-int mne_launch_render(const RenderArgs& a, int mode, void* workspace, hipStream_t st) {
-#define CALL(H, HC, CPV) return launch_render<H, HC, CPV>(a, mode, workspace, st)
+int mne_launch_render(const RenderArgs& a, int mode, void* workspace, const RenderHost& host, hipStream_t st) {
+#define CALL(H, HC, CPV) return launch_render<H, HC, CPV>(a, mode, workspace, host, st)
     MNE_DISPATCH(a.sc, CALL, -2);
 #undef CALL
     return -2;

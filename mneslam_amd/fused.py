@@ -174,15 +174,11 @@ class FusedStep:
         self.events = None          # set to {} to record HIP events around the dominant launches
         self.overlap = overlap
         self._side, self._ev, self._prefetched, self._planes_pending = None, None, None, False
-        # EXPERIMENT, off by default (MNE_ONE_CRITICAL_STREAM=1): critical kernels of an iteration on ONE stream (render ->
-        # tile_order -> tile_adam -> next render), the decoder chain and the next batch on the side stream, handed back
-        # through a device flag (csrc/adam.hip, flag kernels) instead of an event wait behind the long plane update.
-        # Parity-tested, but measured SLOWER: 0.560 vs 0.540 ms -- tile_adam_kernel takes 277 instead of 258 us in that
-        # arrangement and the event record between ray kernel and tile_order still costs 8 us
-        # (profiles/r02_one_critical_stream_negative.txt).
-        self.one_critical_stream = os.environ.get("MNE_ONE_CRITICAL_STREAM", "0") == "1"
-        self._flag = self._flag_timeout = None
-        self._side_pending = False
+        # Adaptive a-priori prefix (mne_fused_opts_t::adapt_state): 4 device words that carry the schedule decision from
+        # one iteration to the next (mode 0: prefix + deferred pass; mode 1: decode everything a priori while most rays are
+        # unresolved, i.e. while the SDF is untrained).  Exact either way.  MNE_NO_ADAPT=1 pins mode 0 (A/B).
+        self.adapt_state = (torch.zeros(4, device=self.device, dtype=torch.int32)
+                            if os.environ.get("MNE_NO_ADAPT", "0") != "1" else None)
         self.iteration = 0
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
 
@@ -306,7 +302,7 @@ class FusedStep:
                                             P(self.ray_counts) if self.early_termination else None, P(self.packed),
                                             P(self.coef), P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums),
                                             P(self.tape), R * S, P(self.tape_rows), P(self.ray_tiles), C.byref(self.bins),
-                                            P(self.ws), self.ws_bytes, st), "mne_render_fused")
+                                            P(self.ws), self.ws_bytes, C.byref(self._render_opts(None)[0]), st), "mne_render_fused")
             side.wait_stream(cap)
             for k in range(len(self.planes)):
                 self.plane_opt[k].step = t0 + 1
@@ -389,10 +385,6 @@ class FusedStep:
         # caller's stream has long parked on that wait when the plane update finishes, so the next decode starts
         # ~2 us later; joining the other way round (the decoder chain on the side stream) put an event wait
         # BEHIND the long kernel on the same queue and cost 18-20 us per iteration (profiles/r01_gap_analysis.txt).
-        if (self.one_critical_stream and self.bins is not None and side is not None and not self.shared_decoder
-                and not self.use_graph):
-            return self._step_one_critical_stream(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global,
-                                                  idx_cur, u, prefetch, host_batch, key, main, st, side, st2)
         if host_batch or self._prefetched != key:
             self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st)
         self._prefetched = None
@@ -401,18 +393,18 @@ class FusedStep:
             main.wait_event(ev[1])
             self._planes_pending = False
         e0 = self._mark("render")
-        marks = self._render_marks(main)
+        opts, marks = self._render_opts(main)
         _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
                                         P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals),
                                         P(self.ray_counts) if self.early_termination else None, P(self.packed),
                                         P(self.coef), P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape),
                                         R * S, P(self.tape_rows), P(self.ray_tiles),
                                         C.byref(self.bins) if self.bins is not None else None,
-                                        P(self.ws), self.ws_bytes, st),
+                                        P(self.ws), self.ws_bytes, C.byref(opts), st),
                    "mne_render_fused")
         self._mark("render", e0)
         if marks:
-            for name, a, b in (("gather_kernel", 0, 1), ("decode_kernel", 1, 2), ("ray_kernel", 2, 3), ("deferred_pass", 3, 4)):
+            for name, a, b in self.MARK_NAMES:
                 self.events.setdefault(name, []).append((marks[a], marks[b]))
         if self.bins is not None:
             # ---- plane update on the side stream
@@ -459,69 +451,6 @@ class FusedStep:
             main.wait_event(ev[1])
             self._planes_pending = False
 
-    def _step_one_critical_stream(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u,
-                                  prefetch, host_batch, key, main, st, side, st2):
-        """Stream roles (binned plane update, the default):
-          caller's stream  [flag wait] -> render (gather .. deferred pass) -> tile_order -> tile_adam       (the critical chain)
-          side stream      wait "render done" -> wgrad -> decoder Adam -> loss scalars -> NEXT batch + decoder tables -> flag set
-        The only cross-stream edge on the critical chain is the device flag, which has long been set when tile_adam ends."""
-        lib, P = self.lib, _lib.ptr
-        R, S = int(n_global + n_cur), self.S
-        if self._flag is None:
-            self._flag = torch.zeros(2, device=self.device, dtype=torch.int32)       # [0] hand-off word, [1] timeout marker
-            self._ev = self._ev or [torch.cuda.Event() for _ in range(4)]
-        ready = not host_batch and self._prefetched == key and self._side_pending
-        if ready:                                            # batch + decoder tables of this iteration were prepared by the side stream
-            _lib.check(lib.mne_flag_wait(P(self._flag), self.iteration, P(self._flag[1:]), st), "mne_flag_wait")
-        else:
-            self._join_side(main)
-            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st)
-            _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
-        self._prefetched = None
-        e0 = self._mark("render")
-        marks = self._render_marks(main)
-        _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
-                                        P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals),
-                                        P(self.ray_counts) if self.early_termination else None, P(self.packed),
-                                        P(self.coef), P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape),
-                                        R * S, P(self.tape_rows), P(self.ray_tiles), C.byref(self.bins),
-                                        P(self.ws), self.ws_bytes, st), "mne_render_fused")
-        self._mark("render", e0)
-        if marks:
-            for name, a, b in (("gather_kernel", 0, 1), ("decode_kernel", 1, 2), ("ray_kernel", 2, 3), ("deferred_pass", 3, 4)):
-                self.events.setdefault(name, []).append((marks[a], marks[b]))
-        self._after(side, self._ev[0], main)                 # side: everything below waits for "render done"
-        # ---- plane update: stays on the caller's stream, right behind the render
-        for k, p in enumerate(self.planes):
-            stt = self.opt._state(p)
-            stt["step"] += 1
-            self.plane_opt[k].step = stt["step"]
-        _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st), "mne_tile_order")
-        e0 = self._mark("adam")
-        _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), None, st), "mne_tile_adam")
-        self._mark("adam", e0)
-        # ---- decoder chain + next batch on the side stream
-        with torch.cuda.stream(side):
-            _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.ray_tiles), R, S, P(self.partials),
-                                             P(self.dec_grad), self.model.wgrad_impl, st2), "mne_decoder_wgrad")
-            self.opt.step(zero_grad=False, grad_buffers=self.grad_map)      # decoder tensors
-            _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st2), "mne_loss_finalize")
-            self.iteration += 1
-            if prefetch and not host_batch:
-                self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st2)
-                _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st2), "mne_pack_decoder")
-                _lib.check(lib.mne_flag_set(P(self._flag), self.iteration, st2), "mne_flag_set")
-                self._prefetched = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
-            self._ev[1].record(side)
-        self._side_pending = True
-        if not (prefetch and not host_batch):
-            self._join_side(main)                             # whatever the caller enqueues next sees a finished iteration
-
-    def _join_side(self, main):
-        if self._side_pending:
-            main.wait_event(self._ev[1])
-            self._side_pending = False
-
     def refresh_half_planes(self):
         """Re-derive the half-precision copies from the fp32 planes (after planes were modified in place by anything
         other than this step, e.g. a peer's map copied in with ``p.data.copy_``)."""
@@ -534,8 +463,6 @@ class FusedStep:
         """Host-synchronising sanity check (call once per mapping_optimize, not per step): raises if list entries
         were lost because a caller-chosen spill_capacity was too small."""
         self.synchronize()
-        if self._flag is not None and int(self._flag[1].item()) != 0:
-            raise RuntimeError("the caller's stream gave up waiting for the side stream's hand-off flag (mne_flag_wait timeout)")
         if self.bins is not None and int(self.dropped.item()) != 0:
             raise RuntimeError(f"binned scatter lost {int(self.dropped.item())} list entries: spill_capacity too small")
 
@@ -545,20 +472,26 @@ class FusedStep:
         if self._planes_pending:
             torch.cuda.current_stream(self.device).wait_event(self._ev[1])
             self._planes_pending = False
-        if self._side_pending:
-            self._join_side(torch.cuda.current_stream(self.device))
 
-    def _render_marks(self, stream, force=False):
-        """Five events the next mne_render_fused records between its kernels (mne_profile_marks); each is recorded
-        once here so that the handle exists."""
-        if self.events is None or not self.rays_o.is_cuda or (self.bins is None and not force):
-            return None
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-        for e in marks:
-            e.record(stream)
-        arr = (C.c_void_p * 5)(*[e.cuda_event for e in marks])
-        _lib.check(self.lib.mne_profile_marks(arr, 5), "mne_profile_marks")
-        return marks
+    N_MARKS = 6
+
+    def _render_opts(self, stream, force=False):
+        """(mne_fused_opts_t, marks): the per-call extras of the fused render -- the adaptive-schedule words and, when
+        ``events`` is set (bench.py's live kernel timing), six HIP events the call records between its kernels."""
+        o = _lib.FusedOpts()
+        if self.adapt_state is not None:
+            o.adapt_state = self.adapt_state.data_ptr()
+        marks = None
+        if self.events is not None and self.rays_o.is_cuda and (self.bins is not None or force):
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(self.N_MARKS)]
+            for e in marks:
+                e.record(stream)                     # recorded once here so that the handle exists
+            self._mark_arr = (C.c_void_p * self.N_MARKS)(*[e.cuda_event for e in marks])
+            o.timing_events, o.n_timing_events = self._mark_arr, self.N_MARKS
+        return o, marks
+
+    MARK_NAMES = (("gather_kernel", 0, 1), ("decode_kernel", 1, 2), ("ray_kernel", 2, 3), ("deferred_pass", 3, 4),
+                  ("bin_kernel", 4, 5))
 
     def _mark(self, name, start=None, stream=None):
         """HIP events on the launch stream around one launch (bench.py's live kernel timing)."""
@@ -675,13 +608,15 @@ class HashFusedStep(FusedStep):
                                            P(self.tape), st), "mne_hash_gather")
             self._mark("hash_gather", e0)
         e0 = self._mark("render")
-        marks = self._render_marks(torch.cuda.current_stream(self.device) if self.rays_o.is_cuda else None, force=True)
+        opts, marks = self._render_opts(torch.cuda.current_stream(self.device) if self.rays_o.is_cuda else None, force=True)
+        opts.adapt_state = None                           # (the hash gather sizes its row set from the a-priori prefix)
         _lib.check(lib.mne_render_fused_features(sc, C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb),
                                                  P(self.tgt_d), P(self.z_vals),
                                                  P(self.ray_counts) if self.early_termination else None, P(self.packed), P(self.coef), P(self.rgb),
                                                  P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape), R * S,
                                                  P(self.tape_rows), P(self.ray_tiles), P(self.ws), self.ws_bytes,
-                                                 gc if inline_gather else None, P(self.table.data) if inline_gather else None, st),
+                                                 gc if inline_gather else None, P(self.table.data) if inline_gather else None,
+                                                 C.byref(opts), st),
                    "mne_render_fused_features")
         self._mark("render", e0)
         if marks:

@@ -649,7 +649,7 @@ def out_contrib(fs):
 
 
 def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0, small=False, impl="grid_sample",
-                               scatter="binned", plane_storage="fp32"):
+                               scatter="binned", plane_storage="fp32", poison_tape=True):
     """The BENCH path -- bench.Agent: device Feistel ray sampler, Philox jitter, FusedStep on two streams --
     against ONE oracle iteration on the SAME device-drawn batch: the batch (ray indices, rays, targets, z samples)
     is copied back from the device, the oracle (CPU autograd) evaluates forward, the seven losses, backward and
@@ -679,6 +679,12 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
                   for lst in m.all_planes for p in lst]
     dec_params = list(m.decoder.parameters())
     dec_state0 = [{k: (cpu(v) if torch.is_tensor(v) else v) for k, v in ag.opt._state(p).items()} for p in dec_params]
+    if poison_tape:
+        # every tape row the weight-gradient pass, the plane update or the hash scatter reads must have been written by
+        # THIS iteration: a row left over from an earlier one (or from a zero-filled allocation, which is what the host
+        # emulator sees) would go unnoticed otherwise -- the failure mode of the round-2 layout-sensitive kernel
+        # (DESIGN.md 9.3).  NaN x 0 = NaN: one stale row poisons a whole gradient matrix.
+        fs.tape.fill_(float("nan"))
     ag.step()                                            # the iteration under test
     fs.synchronize()
     if dev.type == "cuda":

@@ -1,0 +1,49 @@
+"""Layout fuzz: the 2x64 + colour-plane cases against builds of the library whose kernel
+argument block carries N dummy bytes in its middle (``mneslam_amd.build.FUZZ_VARIANTS``: -DMNE_ARGS_PAD=8 / 16).  No
+kernel reads the padding, so nothing may depend on it.  In round 2 exactly this perturbation turned a latent compiler
+defect (a VGPR spill store placed in front of an exec restore, see mneslam_amd/isa_check.py) into stale tape rows and 10-40 %
+errors in the decoder gradients; the tape is therefore poisoned with NaN before the iteration under test."""
+import os
+
+import pytest
+import torch
+
+import parity_cases as pc
+from mneslam_amd import _lib, build, configs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(params=sorted(build.FUZZ_VARIANTS))
+def fuzz_library(request):
+    if not torch.cuda.is_available():
+        pytest.skip("these tests need an MI355X")
+    path = build.variant_path(request.param)
+    assert os.path.exists(path), f"{path} missing: __graft_entry__.build() builds the layout-fuzz variants"
+    _lib.unload()
+    lib = _lib.load(path)
+    assert os.path.samefile(lib._name, path)
+    yield request.param
+    torch.cuda.synchronize()
+    _lib.unload()
+    _lib.load()                              # back to the shipped library for whatever runs next
+
+
+@pytest.mark.parametrize("hidden", [64, 32])
+def test_scannet_colour_planes_step_vs_oracle(fuzz_library, hidden):
+    """BASELINE configs[3] shape (ScanNet, colour planes) at full plane size, 2x64 as BASELINE words it and 2x32 as
+    configured: one fused iteration after two warm-up steps against the oracle, NaN-poisoned tape."""
+    cfg = configs.WORKLOADS["scannet"][0](hidden)
+    cfg["mapping"]["sample"] = 1024
+    out = pc.check_fused_step_vs_oracle(DEV, cfg, n_keyframes=4, seed=7, warm_steps=2, poison_tape=True)
+    assert out["contributing"] > 0
+
+
+def test_fused_matches_autograd_2x64_colour_planes(fuzz_library):
+    pc.check_fused_vs_autograd(DEV, hidden=64, one_grid=False, co=True)
+
+
+def test_office0_headline_step_vs_oracle(fuzz_library):
+    out = pc.check_fused_step_vs_oracle(DEV, configs.bench_office0(), n_keyframes=4, seed=3, warm_steps=3, poison_tape=True)
+    assert out["contributing"] > 10000
