@@ -16,7 +16,7 @@ INC = os.path.join(HERE, "..", "include")
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout
         return out.split("\n")
     except Exception:
         return names
