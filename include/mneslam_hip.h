@@ -273,6 +273,13 @@ typedef struct mne_fused_opts {
      * the call from the fraction of rays the prefix did not (mode 0) / would not (mode 1) resolve: > 1/8 switches to mode
      * 1, < 1/16 back to mode 0.  word 1 = that count (scratch); words 2, 3 reserved.  NULL = always mode 0. */
     int32_t* adapt_state;
+    /* The list appends of the binned plane update only need the decode's outputs, not the backward: with external_bin != 0
+     * mne_render_fused leaves them to the caller, who runs mne_tile_bin(pass 0) on a SECOND stream once
+     * event_after_decode (a hipEvent_t this call records behind its prefix decode) has fired, and mne_tile_bin(pass 1)
+     * after this call -- both before mne_tile_order / mne_tile_adam.  0 / NULL: the call does the appends itself. */
+    int32_t external_bin;
+    int32_t reserved;
+    void* event_after_decode;
 } mne_fused_opts_t;
 
 /* Fused training form of the two calls above (what Mapper.mapping_optimize runs per iteration), with early ray
@@ -287,6 +294,17 @@ int mne_render_fused(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int 
                      float* ray_sums, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows, int32_t* ray_tiles,
                      const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes, const mne_fused_opts_t* opts,
                      void* stream);
+
+/* The list appends of the binned plane update as a call of its own (see mne_fused_opts_t::external_bin): every sample of
+ * the batch that receives gradient -- derived from the decode's outputs with the rules of the training kernel: render
+ * window behind the first SDF sign change, active loss masks -- is appended to the lists of the plane tiles its bilinear
+ * footprints touch.  pass 0: the rays whose a-priori prefix (+ the resolver's extension) resolves them; pass 1: the rays of
+ * the deferred list, after mne_render_fused returned.  Arguments as given to that mne_render_fused call (same workspace:
+ * it holds the decoded-tile counts and the deferred list); opts->adapt_state must be the same pointer. */
+int mne_tile_bin(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples, const float* rays_o,
+                 const float* rays_d, const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                 const float* coef, const float* raw, const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes,
+                 int pass, const mne_fused_opts_t* opts, void* stream);
 
 /* Binned scatter + Adam for the planes (see csrc/tile_adam.hip): with `bins` given, mne_render_fused
  * does not touch plane[].grad; it appends every contributing sample to the lists of the 16x16-cell

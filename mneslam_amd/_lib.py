@@ -68,7 +68,8 @@ class Clock(C.Structure):
 class FusedOpts(C.Structure):
     """mne_fused_opts_t: per-call extras of mne_render_fused / mne_render_fused_features."""
     _fields_ = [("timing_events", C.POINTER(C.c_void_p)), ("n_timing_events", C.c_int32), ("lds_samples_cap", C.c_int32),
-                ("adapt_state", C.c_void_p)]
+                ("adapt_state", C.c_void_p), ("external_bin", C.c_int32), ("reserved", C.c_int32),
+                ("event_after_decode", C.c_void_p)]
 
 
 class GridCfg(C.Structure):
@@ -107,6 +108,8 @@ _PROTOS = {
     "mne_render_fused": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 13
                          + [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.POINTER(FusedOpts),
                             C.c_void_p]),
+    "mne_tile_bin": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 7
+                     + [C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_int, C.POINTER(FusedOpts), C.c_void_p]),
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_tile_order": (C.c_int, [C.POINTER(Scene), C.POINTER(TileBins), C.c_void_p]),
     "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.POINTER(Clock),

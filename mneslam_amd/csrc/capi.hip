@@ -276,6 +276,7 @@ static int render_fused(bool ext_feat, const GridArgs* ext_grid, const mne_scene
         host.marks = opts->timing_events; host.n_marks = opts->n_timing_events;
         if (opts->lds_samples_cap > 0) a.lds_samples = opts->lds_samples_cap;
         a.adapt = ray_counts ? opts->adapt_state : nullptr;       // without per-ray counts everything is decoded a priori anyway
+        host.external_bin = opts->external_bin; host.ev_after_decode = opts->event_after_decode;
     }
     if (bins)
         if (int rc = fill_bins(scene, bins, a.bins)) return rc;
@@ -311,6 +312,28 @@ int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* 
     return render_fused(true, grid_cfg ? &g : nullptr, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals,
                         ray_counts, packed_decoder, coef, rgb, depth, raw, ray_sums, tape, tape_capacity_rows, tape_rows, ray_tiles,
                         nullptr, workspace, workspace_bytes, opts, stream);
+}
+
+int mne_tile_bin(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples, const float* rays_o,
+                 const float* rays_d, const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                 const float* coef, const float* raw, const mne_tile_bins_t* bins, void* workspace, size_t workspace_bytes,
+                 int pass, const mne_fused_opts_t* opts, void* stream) {
+    if (int rc = check_scene(scene, false)) return rc;
+    if (!cfg || !rays_o || !rays_d || !target_d || !z_vals || !coef || !raw || !bins || !workspace) return fail(-1, "mne_tile_bin: NULL argument");
+    if (pass != 0 && pass != 1) return fail(-1, "mne_tile_bin: pass is 0 or 1");
+    if (n_rays <= 0) return 0;
+    if (workspace_bytes < mne_render_workspace(n_rays, n_samples)) return fail(-1, "mne_tile_bin: workspace too small");
+    RenderArgs a = {};
+    a.sc = *scene;
+    a.R = n_rays; a.S = n_samples;
+    fill_render_consts(a, cfg);
+    a.rays_o = rays_o; a.rays_d = rays_d; a.target_d = target_d; a.z_vals = z_vals; a.coef = coef; a.raw = (float*)raw;
+    a.ray_counts = ray_counts;
+    a.prefix_default = 1 << 30;
+    a.adapt = (opts && ray_counts) ? opts->adapt_state : nullptr;
+    if (int rc = fill_bins(scene, bins, a.bins)) return rc;
+    mne_launch_bin(a, pass, workspace, (hipStream_t)stream);
+    return check_launch("tile_bin");
 }
 
 size_t mne_tile_count(const mne_scene_t* scene) {

@@ -97,6 +97,8 @@ struct RenderHost {
     const struct GridArgs* ext_grid = nullptr;   // ext_feat: hash grid whose rows the call gathers itself (NULL = the caller filled the tape)
     void* const* marks = nullptr;                // hipEvent_t handles recorded between the kernels (mne_fused_opts_t::timing_events)
     int n_marks = 0;
+    int external_bin = 0;                        // the caller runs the list appends itself (mne_tile_bin)
+    void* ev_after_decode = nullptr;             // hipEvent_t recorded once the prefix decode is enqueued
 };
 
 struct LossArgs {
@@ -212,6 +214,7 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
 // mode: 0 = forward, every sample decoded (raw complete);  1 = forward with early ray termination (maps only);
 //       2 = training iteration (decode + backward);  3 = backward of an earlier forward call (raw_in given)
 int mne_launch_render(const RenderArgs& a, int mode, void* workspace, const RenderHost& host, hipStream_t st);
+int mne_launch_bin(RenderArgs a, int pass, void* workspace, hipStream_t st);
 int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st);
 int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st);
 int mne_hash_slice_count(const GridArgs& a);

@@ -428,6 +428,17 @@ __device__ __forceinline__ int first_crossing(const float* raws, int from, int D
     return -1;
 }
 
+// The two rules the training ray kernel and bin_kernel must agree on, sample for sample:
+// (1) the decoded prefix [0, Dn) RESOLVES a ray when the first sign change is known and the render window behind it ends
+//     inside the prefix (z sorted), or when everything is decoded;
+__device__ __forceinline__ bool ray_resolved(const float* zr, int first, int Dn, int S, float win_f) {
+    return Dn >= S || (first >= 0 && !(zr[Dn] < zr[first] + win_f));
+}
+// (2) a sample receives gradient when it lies inside the render window or an active loss mask selects it (exact).
+__device__ __forceinline__ bool sample_contrib(float z, float z_lim, const SampleMasks& mk, bool use_e, bool use_co) {
+    return (z < z_lim) || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) || (use_co && (mk.co_fs || mk.co_sdf));
+}
+
 // Maps, loss partial sums and (WITH_GRAD) the per-ray constants of the gradient.  `first` = index of the first sign
 // change (0 when the whole ray has none, scene_rep.py:195-199); all samples with z < z_lim are among the first D.
 template <bool WITH_GRAD>
@@ -670,8 +681,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
         bool deferred = false;
         while (true) {
             if (first < 0) first = first_crossing(raws, from, Dn, lane);
-            if (Dn >= S) break;
-            if (first >= 0 && !(zr[Dn] < zr[first] + a.win_f)) break;       // z sorted: the window ends before sample Dn
+            if (ray_resolved(zr, first, Dn, S, a.win_f)) break;
             if (HOT) { deferred = true; break; }
             if (!HOT) {
                 // decode the next tile on demand (Dn is a multiple of TILE here)
@@ -710,8 +720,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             bool f = false;
             if (i < Dn) {
                 const float z = zr[i];
-                const SampleMasks mk = sample_masks(z, td, has_t, a);
-                f = (z < G.z_lim) || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) || (use_co && (mk.co_fs || mk.co_sdf));
+                f = sample_contrib(z, G.z_lim, sample_masks(z, td, has_t, a), use_e, use_co);
             }
             const unsigned long long m = __ballot(f);
             if (m) last = base + 63 - __clzll(m);
@@ -766,7 +775,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
                 if (mk.e_tail) ds += cf[MNE_L_E_TAIL] * e_res;
                 if (mk.co_fs) ds += cf[MNE_L_CO_FS] * (s - 1.0f);
                 if (mk.co_sdf) ds += cf[MNE_L_CO_SDF] * c_res;
-                contrib = contrib || (use_e && (mk.e_front || mk.e_center || mk.e_tail)) || (use_co && (mk.co_fs || mk.co_sdf));
+                contrib = sample_contrib(z, G.z_lim, mk, use_e, use_co);
             }
             MNE_WAVE_SYNC();                                      // feat rows are about to be overwritten
             RAY_STAMP(6 + 6 * c);
@@ -902,92 +911,135 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
 }
 
 // -----------------------------------------------------------------------------------------------
-// bin_kernel: the list appends of the binned plane update (tile_adam.hip).  One wave per (ray, 32-sample tile) of the
-// tiles the ray kernels back-propagated (ray_tiles[r]); a lane = (sample, plane level), like the backward tile code.
-// Reads what ray_kernel left in the sample's tape row: the normalised point pn and the flag pn.w = "receives gradient".
-// Until round 3 this was the tail of ray_kernel's tile loop; there its 100+ live registers (24 list slots x {list, run
-// meta, reservation} + corners + weights) sat on top of the MFMA backward state and forced spills in every training
-// instantiation (profiles/r02 spill table), and every ray's first tile paid 17 us for it in sequence.  On its own it is
-// a latency-tolerant kernel at full occupancy over all (ray, tile) pairs at once.
+// List appends of the binned plane update (tile_adam.hip).
+// append_tile: the 32 samples of one (ray, tile) held by a wave, lane = (sample, plane level): every sample that receives
+// gradient (`live`) is appended to the list of every 16x16-cell plane tile its 2x2 footprints touch.
+// bin_kernel: one wave per ray, SELF-SUFFICIENT: it derives "which samples receive gradient" from the decode's outputs alone
+// (raw sdf of the decoded prefix, z, target depth, loss coefficients) with the same rules as the training ray kernel
+// (first_crossing_g / ray_resolved / sample_contrib are shared), so it does not depend on ray_kernel and the host can run
+// it on a second stream BESIDE the backward kernels (mne_tile_bin).  Until round 3 the appends were the tail of
+// ray_kernel's tile loop: their 100+ live registers forced spills in every training instantiation and the returning
+// atomics (one per run of samples in the same list; ~60 us of same-address serialisation on the tiles around the camera
+// centres, profiles/r03_bin_ablation.txt) sat on the critical path of every ray.
 // -----------------------------------------------------------------------------------------------
+template <int NSETS>
+__device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&pnv)[3], bool live, size_t e, int lane, int hf) {
+#pragma unroll 1
+    for (int set = 0; set < NSETS; ++set) {
+        // The sample is appended to the list of every plane tile its 2x2 footprints touch (tile_adam.hip): one
+        // returning atomic per RUN of lanes with the same list (run_meta), issued back to back for all 12 (24)
+        // (plane, corner-tile) slots of the lane before any result is consumed; then one 32-byte entry per append.
+        constexpr int NJ = 3;                              // the three orientations of one plane set, this lane's level
+        int want[NJ * 4];
+        unsigned meta[NJ * 4];                             // leader lane | rank << 8 | run length << 16
+        int cix[NJ], ciy[NJ];                              // NW corner of the footprint in each of the lane's planes
+        float wq[NJ][4];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int pidx = set * 6 + 2 * j + hf;         // planes in [set][orient][level] order
+            const int ori = (pidx % 6) / 2;
+            const mne_plane_t& pl = a.sc.plane[pidx / 6][ori][pidx % 2];
+            float gx, gy;
+            orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
+            Bilin b;
+            bilin_setup(gx, gy, pl.h, pl.w, b);
+            wq[j][0] = b.w00; wq[j][1] = b.w01; wq[j][2] = b.w10; wq[j][3] = b.w11;
+            const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
+            const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
+            const int base = a.bins.tile_base[pidx], ntx = a.bins.ntx[pidx];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
+                const bool dup = ((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0);   // same tile again
+                const int w_ = (live && !dup) ? base + ty * ntx + tx : -1;
+                want[j * 4 + q] = w_;
+                meta[j * 4 + q] = run_meta(w_, lane);
+            }
+            cix[j] = b.ix0; ciy[j] = b.iy0;
+        }
+        int first_slot[NJ * 4];
+#pragma unroll
+        for (int q = 0; q < NJ * 4; ++q) {
+            first_slot[q] = 0;
+            if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q], (int)(meta[q] >> 16));
+        }
+        const unsigned trow = (unsigned)e;                 // tape row of this sample
+#pragma unroll
+        for (int eq = 0; eq < NJ * 4; ++eq) {
+            const int f0 = __shfl(first_slot[eq], (int)(meta[eq] & 255u));
+            if (want[eq] >= 0) {
+                const int slot = f0 + (int)((meta[eq] >> 8) & 255u);
+                unsigned* dst = nullptr;
+                if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[eq] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
+                else {
+                    const int sp = atomicAdd(a.bins.spill_count, 1);
+                    if (sp < a.bins.spill_cap) dst = a.bins.spill + (size_t)sp * MNE_ENTRY_WORDS;
+                    else atomicAdd(a.bins.dropped, 1);              // caller-sized spill area too small: reported, never silent
+                }
+                if (dst) {
+                    const int j = eq >> 2, q = eq & 3;
+                    // corner relative to the tile this entry goes to (+1: 0 = one cell before the tile)
+                    const int tx = (cix[j] + (q & 1)) / MNE_TILE, ty = (ciy[j] + (q >> 1)) / MNE_TILE;
+                    const unsigned corner = (unsigned)(cix[j] - tx * MNE_TILE + 1) | ((unsigned)(ciy[j] - ty * MNE_TILE + 1) << 8);
+                    *(uint4*)dst = make_uint4(trow, corner, __float_as_uint(wq[j][0]), __float_as_uint(wq[j][1]));
+                    *(uint4*)(dst + 4) = make_uint4(__float_as_uint(wq[j][2]), __float_as_uint(wq[j][3]), (unsigned)want[eq], 0u);
+                }
+            }
+        }
+    }
+}
+
+// first adjacent sign change among samples [0, D) of a ray whose raw (r,g,b,sdf) rows start at `raw_ray` (global memory)
+__device__ __forceinline__ int first_crossing_g(const float* raw_ray, int D, int lane) {
+    for (int base = 0; base < D - 1; base += MNE_WAVE) {
+        const int i = base + lane;
+        const bool in = i < D - 1;
+        const float s0 = raw_ray[4 * (in ? i : 0) + 3], s1 = raw_ray[4 * (in ? i + 1 : 0) + 3];
+        const unsigned long long m = __ballot(in && (s1 * s0 < 0.0f));
+        if (m) return base + __ffsll(m) - 1;
+    }
+    return -1;
+}
+
 template <bool CP>
-__global__ __launch_bounds__(256) void bin_kernel(RenderArgs a, int ntile) {
+__global__ __launch_bounds__(256) void bin_kernel(RenderArgs a) {
     constexpr int NSETS = CP ? 2 : 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int pt = lane & 31, hf = lane >> 5;
-    const int S = a.S;
-    const long long ntask = (long long)a.R * ntile;
-    for (long long task = (long long)blockIdx.x * 4 + wv; task < ntask; task += (long long)gridDim.x * 4) {
-        const int c = (int)(task / a.R), r = (int)(task % a.R);        // tile-major: the skipped tasks cluster at the end
-        if (c >= a.ray_tiles[r]) continue;                             // whole wave together
-        const int i = c * TILE + pt;
-        const bool valid = i < S;
-        const size_t e = (size_t)r * S + (valid ? i : S - 1);
-        const float4 pn4 = *(const float4*)(a.tape + e * a.tape_row + a.tape_tpn);
-        const bool live = valid && pn4.w != 0.0f;
-        const float pnv[3] = {pn4.x, pn4.y, pn4.z};
-#pragma unroll 1
-        for (int set = 0; set < NSETS; ++set) {
-            // The sample is appended to the list of every plane tile its 2x2 footprints touch (tile_adam.hip): one
-            // returning atomic per RUN of lanes with the same list (run_meta), issued back to back for all 12 (24)
-            // (plane, corner-tile) slots of the lane before any result is consumed; then one 32-byte entry per append.
-            constexpr int NJ = 3;                              // the three orientations of one plane set, this lane's level
-            int want[NJ * 4];
-            unsigned meta[NJ * 4];                             // leader lane | rank << 8 | run length << 16
-            int cix[NJ], ciy[NJ];                              // NW corner of the footprint in each of the lane's planes
-            float wq[NJ][4];
+    const int S = a.S, ntile = (S + TILE - 1) / TILE;
+    if (a.ray_list && *a.ray_list_count == 0) return;      // deferred-ray pass with nothing deferred (the usual case)
+    const bool has_t = a.target_d != nullptr;
+    float cf[MNE_N_LOSS];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int pidx = set * 6 + 2 * j + hf;         // planes in [set][orient][level] order
-                const int ori = (pidx % 6) / 2;
-                const mne_plane_t& pl = a.sc.plane[pidx / 6][ori][pidx % 2];
-                float gx, gy;
-                orient_coords(ori, pnv[0], pnv[1], pnv[2], gx, gy);
-                Bilin b;
-                bilin_setup(gx, gy, pl.h, pl.w, b);
-                wq[j][0] = b.w00; wq[j][1] = b.w01; wq[j][2] = b.w10; wq[j][3] = b.w11;
-                const int ix1 = b.ix0 + 1 < pl.w ? b.ix0 + 1 : b.ix0, iy1 = b.iy0 + 1 < pl.h ? b.iy0 + 1 : b.iy0;
-                const int tx0 = b.ix0 / MNE_TILE, tx1 = ix1 / MNE_TILE, ty0 = b.iy0 / MNE_TILE, ty1 = iy1 / MNE_TILE;
-                const int base = a.bins.tile_base[pidx], ntx = a.bins.ntx[pidx];
+    for (int q = 0; q < MNE_N_LOSS; ++q) cf[q] = a.coef ? a.coef[q] : 0.0f;
+    const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
+    const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
+    const int n_items = a.ray_list ? *a.ray_list_count : a.R;
+    for (int item = blockIdx.x * 4 + wv; item < n_items; item += gridDim.x * 4) {
+        const int r = a.ray_list ? a.ray_list[item] : item;
+        const float td = has_t ? a.target_d[r] : 0.0f;
+        const float* zr = a.z_vals + (size_t)r * S;
+        const float* raw_ray = a.raw + (size_t)r * S * 4;
+        const int t_dec = (a.dec_tiles && !a.ray_list && a.ray_counts) ? a.dec_tiles[r] : prefix_tiles(a, r, ntile, a.ray_list != nullptr);
+        const int Dn = t_dec * TILE < S ? t_dec * TILE : S;
+        const int first = first_crossing_g(raw_ray, Dn, lane);
+        if (!ray_resolved(zr, first, Dn, S, a.win_f)) continue;       // the deferred pass finishes this ray; its appends come with it
+        const float z_lim = zr[first < 0 ? 0 : first] + a.win_f;
+        float ro[3], rd[3];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int tx = (q & 1) ? tx1 : tx0, ty = (q & 2) ? ty1 : ty0;
-                    const bool dup = ((q & 1) && tx1 == tx0) || ((q & 2) && ty1 == ty0);   // same tile again
-                    const int w_ = (live && !dup) ? base + ty * ntx + tx : -1;
-                    want[j * 4 + q] = w_;
-                    meta[j * 4 + q] = run_meta(w_, lane);
-                }
-                cix[j] = b.ix0; ciy[j] = b.iy0;
-            }
-            int first_slot[NJ * 4];
+        for (int q = 0; q < 3; ++q) { ro[q] = a.rays_o[r * 3 + q]; rd[q] = a.rays_d[r * 3 + q]; }
+        for (int c = 0; c < t_dec; ++c) {
+            const int i = c * TILE + pt;
+            const bool valid = i < Dn;
+            const int ii = valid ? i : Dn - 1;
+            const float z = zr[ii];
+            const bool live = valid && sample_contrib(z, z_lim, sample_masks(z, td, has_t, a), use_e, use_co);
+            if (__ballot(live) == 0ull) continue;                       // nothing of this tile receives gradient
+            float p[3], pnv[3], u[3];
 #pragma unroll
-            for (int q = 0; q < NJ * 4; ++q) {
-                first_slot[q] = 0;
-                if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q], (int)(meta[q] >> 16));
-            }
-            const unsigned trow = (unsigned)e;                 // tape row of this sample
-#pragma unroll
-            for (int eq = 0; eq < NJ * 4; ++eq) {
-                const int f0 = __shfl(first_slot[eq], (int)(meta[eq] & 255u));
-                if (want[eq] >= 0) {
-                    const int slot = f0 + (int)((meta[eq] >> 8) & 255u);
-                    unsigned* dst = nullptr;
-                    if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[eq] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
-                    else {
-                        const int sp = atomicAdd(a.bins.spill_count, 1);
-                        if (sp < a.bins.spill_cap) dst = a.bins.spill + (size_t)sp * MNE_ENTRY_WORDS;
-                        else atomicAdd(a.bins.dropped, 1);              // caller-sized spill area too small: reported, never silent
-                    }
-                    if (dst) {
-                        const int j = eq >> 2, q = eq & 3;
-                        // corner relative to the tile this entry goes to (+1: 0 = one cell before the tile)
-                        const int tx = (cix[j] + (q & 1)) / MNE_TILE, ty = (ciy[j] + (q >> 1)) / MNE_TILE;
-                        const unsigned corner = (unsigned)(cix[j] - tx * MNE_TILE + 1) | ((unsigned)(ciy[j] - ty * MNE_TILE + 1) << 8);
-                        *(uint4*)dst = make_uint4(trow, corner, __float_as_uint(wq[j][0]), __float_as_uint(wq[j][1]));
-                        *(uint4*)(dst + 4) = make_uint4(__float_as_uint(wq[j][2]), __float_as_uint(wq[j][3]), (unsigned)want[eq], 0u);
-                    }
-                }
-            }
+            for (int q = 0; q < 3; ++q) p[q] = ro[q] + rd[q] * z;
+            point_coords(a.sc, p, pnv, u);
+            append_tile<NSETS>(a, pnv, live, (size_t)r * S + ii, lane, hf);
         }
     }
 }
@@ -1283,25 +1335,38 @@ static int launch_decode(RenderArgs d, hipStream_t st, const RenderHost& host, b
     return 0;
 }
 
-// After the ray kernels of a backward call: what happens to the d(feature) rows they left in the tape -- list appends
-// for the binned plane update, or global atomics into plane[].grad; nothing when no plane gradient is wanted or the
-// encoding is the caller's (ext_feat).
+// List appends of the binned plane update for the rays of `pass`: 0 = every ray the decoded prefix resolves (needs the
+// decode's outputs only), 1 = the rays of the deferred list (after the deferred pass decoded their remaining tiles).
+template <bool CP>
+static int launch_bin(RenderArgs b, int pass, hipStream_t st) {
+    if (pass) { b.ray_list = b.defer_list; b.ray_list_count = b.defer_count; }
+    else { b.ray_list = nullptr; b.ray_list_count = nullptr; }
+    long long grid = ((long long)b.R + 3) / 4;
+    if (grid > MNE_NUM_CU * 8) grid = MNE_NUM_CU * 8;
+    MNE_LAUNCH((bin_kernel<CP>), (unsigned)grid, 256, 0, st, b);
+    return 0;
+}
+
+int mne_launch_bin(RenderArgs a, int pass, void* workspace, hipStream_t st) {
+    carve_workspace(a, workspace);
+    return a.sc.n_sets == 2 ? launch_bin<true>(a, pass, st) : launch_bin<false>(a, pass, st);
+}
+
+// After the ray kernels of a backward call: global atomics into plane[].grad from the d(feature) rows they left in the
+// tape (scatter="atomics" and the autograd path); nothing when no plane gradient is wanted, the encoding is the caller's
+// (ext_feat) or the plane update is binned (bin_kernel + tile_adam_kernel).
 template <int HID, int HIDC, bool CP>
 static void launch_plane_pass(const RenderArgs& a, hipStream_t st) {
     typedef DecDims<HID, HIDC, CP> D;
-    if (!a.plane_grads || a.ext_feat) return;
+    if (!a.plane_grads || a.ext_feat || a.bins.lists) return;
     RenderArgs b = a;
     b.tape_row = D::ROW; b.tape_tpn = D::T_PN; b.tape_tdfeat = D::T_DFEAT;
     const int ntile = (a.S + TILE - 1) / TILE;
     long long grid = ((long long)a.R * ntile + 3) / 4;
     if (grid > MNE_NUM_CU * 8) grid = MNE_NUM_CU * 8;
-    if (a.bins.lists) {
-        MNE_LAUNCH((bin_kernel<CP>), (unsigned)grid, 256, 0, st, b, ntile);
-    } else {
-        const size_t lds = 4 * tile_wave_lds_bytes(CP ? 2 : 1);
-        if (lds > 64 * 1024) MNE_SET_MAX_LDS((scatter_kernel<CP>), MNE_LDS_MAX);
-        MNE_LAUNCH((scatter_kernel<CP>), (unsigned)grid, 256, lds, st, b, ntile);
-    }
+    const size_t lds = 4 * tile_wave_lds_bytes(CP ? 2 : 1);
+    if (lds > 64 * 1024) MNE_SET_MAX_LDS((scatter_kernel<CP>), MNE_LDS_MAX);
+    MNE_LAUNCH((scatter_kernel<CP>), (unsigned)grid, 256, lds, st, b, ntile);
 }
 
 template <int HID, int HIDC, bool CP>
@@ -1340,6 +1405,7 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         // training: every ray in the lean kernel; the few it cannot resolve from the decoded prefix are finished by the
         // full kernel, driven by the deferred list (a handful of workgroups that leave at once when the list is empty)
         mark(host, 2, st);
+        if (host.ev_after_decode) (void)hipEventRecord((hipEvent_t)host.ev_after_decode, st);      // the caller's bin pass 0 may start
         if (int rc = launch_ray<HID, HIDC, CP, 4>(a, st)) return rc;
         if (ray_lds_cap(a) < a.S) {        // long rays: those whose decoded prefix exceeded the first pass's LDS, same kernel sized for S
             RenderArgs l = a;
@@ -1358,7 +1424,11 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         d.adapt_update = 1;                                // the last ray launch of the call decides the next call's schedule
         if (int rc = launch_ray<HID, HIDC, CP, 4>(d, st)) return rc;    // the same lean kernel: now every listed ray resolves
         mark(host, 4, st);
-        launch_plane_pass<HID, HIDC, CP>(a, st);           // list appends (binned) or atomics, all rays at once
+        if (a.bins.lists && !host.external_bin) {          // list appends on this stream (the host may run them beside the
+            launch_bin<CP>(a, 0, st);                      // backward instead: mne_tile_bin on a second stream)
+            launch_bin<CP>(a, 1, st);
+        }
+        launch_plane_pass<HID, HIDC, CP>(a, st);           // scatter="atomics"
         mark(host, 5, st);
         return 0;
     }

@@ -174,6 +174,9 @@ class FusedStep:
         self.events = None          # set to {} to record HIP events around the dominant launches
         self.overlap = overlap
         self._side, self._ev, self._prefetched, self._planes_pending = None, None, None, False
+        self._ev_decode = None       # event "prefix decode enqueued" (two-stream runs with the binned plane update)
+        self._bin_pending = False
+        self.concurrent_bin = os.environ.get("MNE_SERIAL_BIN", "0") != "1"
         # Adaptive a-priori prefix (mne_fused_opts_t::adapt_state): 4 device words that carry the schedule decision from
         # one iteration to the next (mode 0: prefix + deferred pass; mode 1: decode everything a priori while most rays are
         # unresolved, i.e. while the SDF is untrained).  Exact either way.  MNE_NO_ADAPT=1 pins mode 0 (A/B).
@@ -195,6 +198,9 @@ class FusedStep:
             # (a high-priority side stream was measured: no effect, 0.522 vs 0.521 ms -- profiles/r02_variants.txt)
             self._side = torch.cuda.Stream(self.device)
             self._ev = [torch.cuda.Event() for _ in range(4)]
+            if self.concurrent_bin:
+                self._ev_decode = torch.cuda.Event()
+                self._ev_decode.record(torch.cuda.current_stream(self.device))      # (recorded once so that the handle exists)
         return (torch.cuda.current_stream(self.device), main_h), (self._side, C.c_void_p(self._side.cuda_stream))
 
     @staticmethod
@@ -224,6 +230,13 @@ class FusedStep:
                                     P(self.ray_counts), ck, st), "mne_sample_z")
         _lib.check(lib.mne_loss_coef(C.byref(self.rc), R, S, P(self.counts), P(self.loss_w), P(self.coef), st),
                    "mne_loss_coef")
+
+    def _tile_bin(self, pass_, opts, st):
+        R, S, P = self.n_active, self.S, _lib.ptr
+        _lib.check(self.lib.mne_tile_bin(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
+                                         P(self.tgt_d), P(self.z_vals),
+                                         P(self.ray_counts) if self.early_termination else None, P(self.coef), P(self.raw),
+                                         C.byref(self.bins), P(self.ws), self.ws_bytes, pass_, C.byref(opts), st), "mne_tile_bin")
 
     def _refresh_pointers(self):
         """Planes, decoder weights and Adam moments are ordinary tensors owned by Python: their storage may be
@@ -297,13 +310,21 @@ class FusedStep:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=cap):
             st, st2 = C.c_void_p(cap.cuda_stream), C.c_void_p(side.cuda_stream)
+            opts = self._render_opts(None)[0]
+            self.n_active = R
             _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
                                             P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals),
                                             P(self.ray_counts) if self.early_termination else None, P(self.packed),
                                             P(self.coef), P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums),
                                             P(self.tape), R * S, P(self.tape_rows), P(self.ray_tiles), C.byref(self.bins),
-                                            P(self.ws), self.ws_bytes, C.byref(self._render_opts(None)[0]), st), "mne_render_fused")
+                                            P(self.ws), self.ws_bytes, C.byref(opts), st), "mne_render_fused")
+            if self._ev_decode is not None:
+                side.wait_event(self._ev_decode)
+                self._tile_bin(0, opts, st2)
             side.wait_stream(cap)
+            if self._ev_decode is not None:
+                self._tile_bin(1, opts, st2)
+                self._ev[2].record(side)
             for k in range(len(self.planes)):
                 self.plane_opt[k].step = t0 + 1
             _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
@@ -316,6 +337,8 @@ class FusedStep:
             _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
             _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
             _lib.check(lib.mne_clock_advance(P(self.clk_iter), None, st), "mne_clock_advance")
+            if self._ev_decode is not None:
+                cap.wait_event(self._ev[2])               # the appends have read this batch: its buffers may be overwritten
             self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st, clock=clock)
             cap.wait_stream(side)
             _lib.check(lib.mne_clock_advance(None, P(self.clk_step), st), "mne_clock_advance")
@@ -405,10 +428,21 @@ class FusedStep:
         self._mark("render", e0)
         if marks:
             for name, a, b in self.MARK_NAMES:
-                self.events.setdefault(name, []).append((marks[a], marks[b]))
+                if name != "bin_kernel" or self._ev_decode is None:      # (timed on the side stream when it runs there)
+                    self.events.setdefault(name, []).append((marks[a], marks[b]))
         if self.bins is not None:
-            # ---- plane update on the side stream
+            # ---- plane update on the side stream; with _ev_decode the list appends (mne_tile_bin) are there too, pass 0
+            # beside the backward kernels (it waits for the decode only), pass 1 (deferred rays) behind them
+            if self._ev_decode is not None and side is not None:
+                side.wait_event(self._ev_decode)
+                e0 = self._mark("bin_kernel", stream=side)
+                self._tile_bin(0, opts, st2)
+                self._mark("bin_kernel", e0, stream=side)
             self._after(side, ev[0], main)
+            if self._ev_decode is not None and side is not None:
+                self._tile_bin(1, opts, st2)
+                ev[2].record(side)                      # "appends done": the batch buffers (rays, z, targets, coefficients)
+                self._bin_pending = True                # may be overwritten by the next batch only after this
             for k, p in enumerate(self.planes):
                 stt = self.opt._state(p)
                 stt["step"] += 1
@@ -444,6 +478,9 @@ class FusedStep:
             self._mark("adam", e0)
         _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
         self.iteration += 1
+        if self._bin_pending:                                     # the side stream's appends read this batch's buffers
+            main.wait_event(ev[2])
+            self._bin_pending = False
         if prefetch and not host_batch and side is not None:
             self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st)
             self._prefetched = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
@@ -481,6 +518,8 @@ class FusedStep:
         o = _lib.FusedOpts()
         if self.adapt_state is not None:
             o.adapt_state = self.adapt_state.data_ptr()
+        if self._ev_decode is not None:                # the list appends run on the side stream beside the backward kernels
+            o.external_bin, o.event_after_decode = 1, self._ev_decode.cuda_event
         marks = None
         if self.events is not None and self.rays_o.is_cuda and (self.bins is not None or force):
             marks = [torch.cuda.Event(enable_timing=True) for _ in range(self.N_MARKS)]
@@ -562,6 +601,13 @@ class HashFusedStep(FusedStep):
             o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
         self._finish_init(overlap=os.environ.get("MNE_NO_OVERLAP", "0") != "1")
         self._decoder_pending = False
+
+    def _tile_bin(self, pass_, opts, st):
+        R, S, P = self.n_active, self.S, _lib.ptr
+        _lib.check(self.lib.mne_tile_bin(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
+                                         P(self.tgt_d), P(self.z_vals),
+                                         P(self.ray_counts) if self.early_termination else None, P(self.coef), P(self.raw),
+                                         C.byref(self.bins), P(self.ws), self.ws_bytes, pass_, C.byref(opts), st), "mne_tile_bin")
 
     def _refresh_pointers(self):
         w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
