@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--scatter", default="binned", choices=["binned", "atomics"],
                     help="fused path: tile-binned LDS scatter fused with Adam (default) or global atomics + streaming Adam")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane update and the decoder chain on ONE stream (ablation)")
-    ap.add_argument("--event-every", type=int, default=8, help="bracket the dominant launches with HIP events on every N-th timed step")
+    ap.add_argument("--event-every", type=int, default=10, help="bracket the dominant launches with HIP events on every N-th timed step")
     ap.add_argument("--share-decoder", action="store_true",
                     help="EXTENSION: all-reduce (mean) the decoder gradient over agents each iteration (RCCL)")
     ap.add_argument("--small", action="store_true", help="tiny planes/frames (functional check, not a benchmark)")

@@ -295,7 +295,9 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
 // Waves per workgroup decode_kernel is compiled for: 8 = 256 registers per lane, no spills in any decoder shape (a
 // 12-wave build for the inline-gather form hid a little more latency and spilled 16-376 B per lane: dropped in round 3,
 // see DESIGN.md 9.3 for why spills are treated as defects here).
+#ifndef DECODE_WPB
 #define DECODE_WPB 8
+#endif
 // -----------------------------------------------------------------------------------------------
 // gather_kernel: tri-plane features of the a-priori samples straight into their tape rows.  The gather is a chain of
 // dependent load rounds; inside decode_kernel (12 waves per CU, LDS- and register-bound) it took 21 of the 34 us a tile

@@ -120,18 +120,23 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
 #ifndef WG_FUSED_BLOCKS
 #define WG_FUSED_BLOCKS 256          // x 4 waves; one partial result per workgroup
 #endif
-template <int HID, int HIDC, bool CP>
-__global__ __launch_bounds__(256) void wgrad_fused_kernel(WgradArgs a) {
+// PART: the four GEMMs are split over TWO kinds of workgroups that share a ray range and a partial-result slot --
+// part 0 accumulates dW1 = DH x X (4 tiles: reads dh and x), part 1 dW2, dV1, dV2 (4-5 tiles: reads dout, h, dhc, the colour
+// input, dc, hc).  One wave holding all 8-10 accumulator tiles needed 200 registers: a single such wave per SIMD and,
+// worse, no room beside it for a second workgroup of the plane update that runs concurrently on the other stream
+// (tile_adam_kernel 198 us alone, 249 us next to it; profiles/r03_tile_adam_ablation.txt).  Each part reads about half
+// of a tape row, so the tape is still read once.
+template <int HID, int HIDC, bool CP, int PART>
+__device__ __forceinline__ void wgrad_fused_part(const WgradArgs& a, float (*red)[64 * 16]) {
     typedef DecDims<HID, HIDC, CP> D;
-    static_assert(HID == 32 && HIDC == 32, "fused weight-gradient kernel is built for the 2x32 decoders");
     constexpr int TNC = D::CINP / 32;
     constexpr int KS = WG_KS;
-    constexpr int NTILE = 4 + 1 + TNC + 1;
-    __shared__ float red[3][64 * 16];                            // one 32x32 tile of waves 1..3
+    constexpr int NTILE = PART == 0 ? 4 : 1 + TNC + 1;           // w1[0..3]  |  w2, v1[0..TNC), v2
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x >> 1, n_slots = gridDim.x >> 1;
     int r0, r1;
-    ray_range(a.R, blockIdx.x * 4 + wv, gridDim.x * 4, r0, r1);
-    f32x16 acc[NTILE];                                           // w1[0..3] | w2 | v1[0..TNC) | v2
+    ray_range(a.R, slot * 4 + wv, n_slots * 4, r0, r1);
+    f32x16 acc[NTILE];
 #pragma unroll
     for (int q = 0; q < NTILE; ++q)
 #pragma unroll
@@ -144,31 +149,43 @@ __global__ __launch_bounds__(256) void wgrad_fused_kernel(WgradArgs a) {
         const int n = ray_rows(a, r);
         const float* base = a.tape + (size_t)r * a.S * D::ROW;
         for (int t = 0; t < n; t += 2 * KS) {
-            float adh[KS], ado[KS], adc[KS], adq[KS], bx[KS][4], bh[KS], bc[KS][TNC], bhc[KS];
+            if (PART == 0) {
+                float adh[KS], bx[KS][4];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int tt = t + 2 * ks + kk;
-                const bool ok = tt < n;
-                const float* row = base + (size_t)(ok ? tt : 0) * D::ROW;
-                adh[ks] = ok ? row[D::T_DH + col] : 0.f;
-                ado[ks] = (ok && col < MNE_OUT1) ? row[D::T_DOUT + col] : 0.f;
-                adc[ks] = ok ? row[D::T_DHC + col] : 0.f;
-                adq[ks] = (ok && col < 3) ? row[D::T_DC + col] : 0.f;
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int tt = t + 2 * ks + kk;
+                    const bool ok = tt < n;
+                    const float* row = base + (size_t)(ok ? tt : 0) * D::ROW;
+                    adh[ks] = ok ? row[D::T_DH + col] : 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bx[ks][q] = (ok && 32 * q + col < MNE_IN1) ? row[D::T_X + 32 * q + col] : 0.f;
-                bh[ks] = ok ? row[D::T_H + col] : 0.f;
+                    for (int q = 0; q < 4; ++q) bx[ks][q] = (ok && 32 * q + col < MNE_IN1) ? row[D::T_X + 32 * q + col] : 0.f;
+                }
 #pragma unroll
-                for (int q = 0; q < TNC; ++q) bc[ks][q] = ok ? row[ccol[q]] : 0.f;
-                bhc[ks] = ok ? row[D::T_HC + col] : 0.f;
-            }
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adh[ks], bx[ks][q], acc[q], 0, 0, 0);
+            } else {
+                float ado[KS], adc[KS], adq[KS], bh[KS], bc[KS][TNC], bhc[KS];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adh[ks], bx[ks][q], acc[q], 0, 0, 0);
-                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(ado[ks], bh[ks], acc[4], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int tt = t + 2 * ks + kk;
+                    const bool ok = tt < n;
+                    const float* row = base + (size_t)(ok ? tt : 0) * D::ROW;
+                    ado[ks] = (ok && col < MNE_OUT1) ? row[D::T_DOUT + col] : 0.f;
+                    adc[ks] = ok ? row[D::T_DHC + col] : 0.f;
+                    adq[ks] = (ok && col < 3) ? row[D::T_DC + col] : 0.f;
+                    bh[ks] = ok ? row[D::T_H + col] : 0.f;
 #pragma unroll
-                for (int q = 0; q < TNC; ++q) acc[5 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adc[ks], bc[ks][q], acc[5 + q], 0, 0, 0);
-                acc[5 + TNC] = __builtin_amdgcn_mfma_f32_32x32x2f32(adq[ks], bhc[ks], acc[5 + TNC], 0, 0, 0);
+                    for (int q = 0; q < TNC; ++q) bc[ks][q] = ok ? row[ccol[q]] : 0.f;
+                    bhc[ks] = ok ? row[D::T_HC + col] : 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ado[ks], bh[ks], acc[0], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < TNC; ++q) acc[1 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adc[ks], bc[ks][q], acc[1 + q], 0, 0, 0);
+                    acc[1 + TNC] = __builtin_amdgcn_mfma_f32_32x32x2f32(adq[ks], bhc[ks], acc[1 + TNC], 0, 0, 0);
+                }
             }
         }
     }
@@ -189,21 +206,34 @@ __global__ __launch_bounds__(256) void wgrad_fused_kernel(WgradArgs a) {
         __syncthreads();
     }
     if (wv != 0) return;
-    float* out = a.partials + (size_t)blockIdx.x * D::NPARAM;
+    float* out = a.partials + (size_t)slot * D::NPARAM;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int o = (e & 3) + 8 * (e >> 2) + 4 * kk;
+        if (PART == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (32 * q + col < MNE_IN1) out[D::P_SDF0 + o * MNE_IN1 + 32 * q + col] = acc[q][e];
-        if (o < MNE_OUT1) out[D::P_SDF1 + o * HID + col] = acc[4][e];
+            for (int q = 0; q < 4; ++q)
+                if (32 * q + col < MNE_IN1) out[D::P_SDF0 + o * MNE_IN1 + 32 * q + col] = acc[q][e];
+        } else {
+            if (o < MNE_OUT1) out[D::P_SDF1 + o * HID + col] = acc[0][e];
 #pragma unroll
-        for (int q = 0; q < TNC; ++q) {
-            const int i = 32 * q + col;                      // element of the colour-net input [pos|(cf)|out16]
-            if (i != D::CINB) out[D::P_COL0 + o * D::CIN + (i > D::CINB ? i - 1 : i)] = acc[5 + q][e];
+            for (int q = 0; q < TNC; ++q) {
+                const int i = 32 * q + col;                      // element of the colour-net input [pos|(cf)|out16]
+                if (i != D::CINB) out[D::P_COL0 + o * D::CIN + (i > D::CINB ? i - 1 : i)] = acc[1 + q][e];
+            }
+            if (o < 3) out[D::P_COL1 + o * HIDC + col] = acc[1 + TNC][e];
         }
-        if (o < 3) out[D::P_COL1 + o * HIDC + col] = acc[5 + TNC][e];
     }
+}
+
+// (second launch bound = workgroups per CU the register allocation must allow: 4 -> 128 registers per lane, with colour planes
+// 3 -> 168: the concurrent plane update keeps its two workgroups per CU (2 x 2 waves x 88 registers per SIMD))
+template <int HID, int HIDC, bool CP>
+__global__ __launch_bounds__(256, CP ? 3 : 4) void wgrad_fused_kernel(WgradArgs a) {
+    static_assert(HID == 32 && HIDC == 32, "fused weight-gradient kernel is built for the 2x32 decoders");
+    __shared__ float red[3][64 * 16];                            // one 32x32 tile of waves 1..3
+    if (blockIdx.x & 1) wgrad_fused_part<HID, HIDC, CP, 1>(a, red);
+    else wgrad_fused_part<HID, HIDC, CP, 0>(a, red);
 }
 
 // The same single pass for the 2x64 decoders: the 64 hidden rows of dW1 / dV1 need 8 + 2*TNC accumulator tiles,
@@ -358,7 +388,7 @@ static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
         int blocks = (a.R + ranges_per_block - 1) / ranges_per_block;
         blocks = blocks < 1 ? 1 : (blocks > WG_FUSED_BLOCKS ? WG_FUSED_BLOCKS : blocks);
         a.n_waves = blocks;
-        if constexpr (HID == 32 && HIDC == 32) MNE_LAUNCH((wgrad_fused_kernel<HID, HIDC, CP>), blocks, 256, 0, st, a);
+        if constexpr (HID == 32 && HIDC == 32) MNE_LAUNCH((wgrad_fused_kernel<HID, HIDC, CP>), 2 * blocks, 256, 0, st, a);   // two parts per slot
         else MNE_LAUNCH((wgrad_fused64_kernel<CP>), blocks, 256, 0, st, a);
         MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
         return 0;

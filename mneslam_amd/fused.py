@@ -321,13 +321,15 @@ class FusedStep:
             if self._ev_decode is not None:
                 side.wait_event(self._ev_decode)
                 self._tile_bin(0, opts, st2)
+                _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             side.wait_stream(cap)
             if self._ev_decode is not None:
                 self._tile_bin(1, opts, st2)
                 self._ev[2].record(side)
+            else:
+                _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             for k in range(len(self.planes)):
                 self.plane_opt[k].step = t0 + 1
-            _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins),
                                          C.byref(clock), st2), "mne_tile_adam")
             _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.ray_tiles), R, S, P(self.partials),
@@ -438,16 +440,24 @@ class FusedStep:
                 e0 = self._mark("bin_kernel", stream=side)
                 self._tile_bin(0, opts, st2)
                 self._mark("bin_kernel", e0, stream=side)
+                # processing order of the tiles from the list lengths as they are now -- the deferred rays' appends (a
+                # handful in steady state) come later and do not change which lists are the heavy ones; tile_adam_kernel
+                # reads the final lengths itself.  Keeps tile_order_kernel (12 us + a launch gap) off the critical path.
+                _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             self._after(side, ev[0], main)
             if self._ev_decode is not None and side is not None:
                 self._tile_bin(1, opts, st2)
                 ev[2].record(side)                      # "appends done": the batch buffers (rays, z, targets, coefficients)
                 self._bin_pending = True                # may be overwritten by the next batch only after this
+            else:
+                _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             for k, p in enumerate(self.planes):
                 stt = self.opt._state(p)
                 stt["step"] += 1
                 self.plane_opt[k].step = stt["step"]
-            _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
+            if os.environ.get("MNE_ABL_EMPTY_LISTS", "0") == "1":      # timing ablation: the plane update as a pure Adam sweep
+                with torch.cuda.stream(side) if side is not None else _null_ctx():
+                    self.tile_counts.zero_()
             e0 = self._mark("adam", stream=side)
             _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), None, st2),
                        "mne_tile_adam")
