@@ -178,6 +178,18 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
                     uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
                     float* target_d, int64_t* out_idx, const mne_clock_t* clock, void* stream);
 
+/* mne_sample_rays + mne_sample_z + mne_loss_coef for one training batch as ONE call of two launches (the per-iteration
+ * batch preparation of the fused mapping step; separately they are four): same arguments and results as the three
+ * calls (see below).  target_d of the z sampling is the depth of the rays just drawn; coef / grad_losses NULL = no
+ * coefficients. */
+int mne_sample_batch(const float* kf_rays, int64_t n_kf_rays, int n_save, const int32_t* kf_pose_ids,
+                     const float* cur_rays, int64_t n_cur_rays, const float* poses, int n_poses,
+                     int n_global, int n_cur, const int64_t* idx_global, const int64_t* idx_cur,
+                     uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
+                     float* target_d, int64_t* out_idx, const struct mne_render_cfg* cfg, const float* u,
+                     const float* lin_tables, uint64_t z_offset, float* z_vals, int32_t* counts, int32_t* ray_counts,
+                     const float* grad_losses, float* coef, const mne_clock_t* clock, void* stream);
+
 /* ---- R3: z sampling -------------------------------------------------------------------- */
 /* Replaces render_rays' sampling block, model/scene_rep.py:362-381: near-surface linspace around
  * target_d (rays with d<=0 get linspace(near,far)), merged with the uniform samples, sorted, then
@@ -325,11 +337,27 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
  * model/decoder.py:150-159) into grad_out.  Rows = for every ray r, the first ray_tiles[r] * 32 samples (as left by
  * mne_render_backward / mne_render_fused); summed ray by ray in a fixed order.  `partials` is scratch of
  * mne_wgrad_partial_floats() floats.  impl: 0 = MFMA (v_mfma_f32_32x32x2_f32), one fused pass over the tape,
- * 1 = scalar check, 2 = MFMA with one launch per matrix. */
+ * 1 = scalar check, 2 = MFMA with one launch per matrix, 3 = the pass of 0 without the final reduction (grad_out is not
+ * written: mne_decoder_update sums the partials and applies Adam in the same launch). */
 size_t mne_decoder_param_floats(const mne_scene_t* scene);
 size_t mne_wgrad_partial_floats(const mne_scene_t* scene);
 int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* ray_tiles, int n_rays, int n_samples,
                       float* partials, float* grad_out, int impl, void* stream);
+
+/* The decoder's optimizer step in ONE launch: the fixed-order sum of the partial weight gradients left by
+ * mne_decoder_wgrad(impl = 3) -> grad_out, torch.optim.Adam on the four decoder tensors (in place; opt->m / opt->v in
+ * decoder.parameters() order: w_col0, w_col1, w_sdf0, w_sdf1; one param group) and the loss scalars of the iteration
+ * (mne_loss_finalize; losses NULL = skip).  Follow with mne_pack_decoder for the next render. */
+typedef struct mne_decoder_opt {
+    float* m[4]; float* v[4];
+    double lr, beta1, beta2, eps, weight_decay;
+    int32_t step;          /* 1-based */
+    int32_t reserved;
+} mne_decoder_opt_t;
+size_t mne_sizeof_decoder_opt(void);
+int mne_decoder_update(const mne_scene_t* scene, const float* partials, int n_rays, float* grad_out,
+                       const mne_decoder_opt_t* opt, int n_samples, const float* ray_sums,
+                       const int32_t* counts, float* losses, const mne_clock_t* clock, void* stream);
 
 /* ---- R12: fused dense Adam --------------------------------------------------------------- */
 /* Replaces torch.optim.Adam.step() + zero_grad() over the groups of MNESLAM.create_optimizer

@@ -72,6 +72,11 @@ class FusedOpts(C.Structure):
                 ("event_after_decode", C.c_void_p)]
 
 
+class DecoderOpt(C.Structure):
+    _fields_ = [("m", C.c_void_p * 4), ("v", C.c_void_p * 4), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
+
+
 class GridCfg(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("n_features", C.c_int32), ("base_resolution", C.c_int32),
                 ("log2_hashmap_size", C.c_int32), ("grid_type", C.c_int32), ("reserved", C.c_int32),
@@ -90,6 +95,12 @@ _PROTOS = {
     "mne_sizeof_plane_opt": (C.c_size_t, []),
     "mne_sizeof_clock": (C.c_size_t, []),
     "mne_sizeof_fused_opts": (C.c_size_t, []),
+    "mne_sizeof_decoder_opt": (C.c_size_t, []),
+    "mne_sample_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5
+                         + [C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 5 + [C.POINTER(Clock), C.c_void_p]),
+    "mne_decoder_update": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(DecoderOpt), C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Clock), C.c_void_p]),
     "mne_clock_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_num_samples": (C.c_int, [C.POINTER(RenderCfg), C.c_int]),
     "mne_sample_z": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -166,7 +177,7 @@ def load(path=None):
         for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
                        (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),
                        (lib.mne_sizeof_plane_opt, PlaneOpt), (lib.mne_sizeof_clock, Clock),
-                       (lib.mne_sizeof_fused_opts, FusedOpts)):
+                       (lib.mne_sizeof_fused_opts, FusedOpts), (lib.mne_sizeof_decoder_opt, DecoderOpt)):
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"struct layout mismatch for {st.__name__}: C {fn()} vs ctypes {C.sizeof(st)}")
         _lib = lib

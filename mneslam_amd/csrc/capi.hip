@@ -81,6 +81,7 @@ size_t mne_sizeof_tile_bins(void) { return sizeof(mne_tile_bins_t); }
 size_t mne_sizeof_plane_opt(void) { return sizeof(mne_plane_opt_t); }
 size_t mne_sizeof_clock(void) { return sizeof(mne_clock_t); }
 size_t mne_sizeof_fused_opts(void) { return sizeof(mne_fused_opts_t); }
+size_t mne_sizeof_decoder_opt(void) { return sizeof(mne_decoder_opt_t); }
 
 int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream) {
     if (!iteration && !step_offset) return fail(-1, "mne_clock_advance: NULL argument");
@@ -410,10 +411,87 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
     return check_launch("sample_rays");
 }
 
+static void fill_zargs(ZArgs& a, const mne_render_cfg_t* cfg, int n_rays, bool has_d) {
+    a.R = n_rays;
+    a.has_d = has_d;
+    a.n_a = has_d ? cfg->n_samples_d : 0;
+    a.n_b = has_d ? cfg->n_range_d : 0;
+    a.S = has_d ? a.n_a + a.n_b : cfg->n_samples;
+    a.perturb = (float)cfg->perturb;
+    a.e_T = (float)cfg->truncation;
+    a.e_T04 = (float)(0.4 * cfg->truncation);
+    a.co_T = (float)(cfg->trunc * cfg->sc_factor);
+    a.depth_trunc = (float)cfg->depth_trunc;
+}
+
+int mne_sample_batch(const float* kf_rays, int64_t n_kf_rays, int n_save, const int32_t* kf_pose_ids,
+                     const float* cur_rays, int64_t n_cur_rays, const float* poses, int n_poses,
+                     int n_global, int n_cur, const int64_t* idx_global, const int64_t* idx_cur,
+                     uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
+                     float* target_d, int64_t* out_idx, const mne_render_cfg_t* cfg, const float* u,
+                     const float* lin_tables, uint64_t z_offset, float* z_vals, int32_t* counts, int32_t* ray_counts,
+                     const float* grad_losses, float* coef, const mne_clock_t* clock, void* stream) {
+    if (!poses || !rays_o || !rays_d || !target_rgb || !target_d || n_poses < 1 || !cfg || !lin_tables || !z_vals || !counts ||
+        !ray_counts)
+        return fail(-1, "mne_sample_batch: NULL argument");
+    if ((coef == nullptr) != (grad_losses == nullptr)) return fail(-1, "mne_sample_batch: coef and grad_losses go together");
+    if (n_global < 0 || n_cur < 0) return fail(-1, "mne_sample_batch: negative count");
+    if (n_global > 0 && (!kf_rays || n_save < 1 || n_kf_rays < n_global)) return fail(-1, "mne_sample_batch: cannot draw n_global distinct keyframe rays");
+    if (n_cur > 0 && (!cur_rays || n_cur_rays < n_cur)) return fail(-1, "mne_sample_batch: cannot draw n_cur distinct current-frame rays");
+    const int R = n_global + n_cur;
+    if (R == 0) return 0;
+    SampleRaysArgs sr = {};
+    sr.kf_rays = kf_rays; sr.n_kf_rays = n_kf_rays; sr.n_save = n_save; sr.kf_pose_ids = kf_pose_ids;
+    sr.cur_rays = cur_rays; sr.n_cur_rays = n_cur_rays; sr.poses = poses; sr.n_poses = n_poses;
+    sr.n_global = n_global; sr.n_cur = n_cur;
+    sr.idx_global = (const long long*)idx_global; sr.idx_cur = (const long long*)idx_cur; sr.out_idx = (long long*)out_idx;
+    sr.rays_o = rays_o; sr.rays_d = rays_d; sr.target_rgb = target_rgb; sr.target_d = target_d;
+    if (fill_clock(clock, sr.clk, 0, 0, false)) return fail(-1, "mne_sample_batch: incomplete clock");
+    ZArgs a = {};
+    fill_zargs(a, cfg, R, true);
+    if (a.S < 1 || a.S > 16384) return fail(-1, "mne_sample_batch: samples per ray out of range [1,16384]");
+    a.target_d = target_d; a.u = u; a.tables = lin_tables; a.seed = seed; a.offset = z_offset;
+    a.z_vals = z_vals; a.counts = counts; a.ray_counts = ray_counts;
+    a.clk = sr.clk;
+    LossArgs lc = {};
+    lc.R = R; lc.S = a.S; lc.counts = counts; lc.grad_losses = grad_losses; lc.coef = coef;
+    lc.e_T = (float)cfg->truncation;
+    lc.co_T = (float)(cfg->trunc * cfg->sc_factor);
+    mne_launch_batch(sr, seed, iteration, a, lc, (hipStream_t)stream);
+    return check_launch("sample_batch");
+}
+
+int mne_decoder_update(const mne_scene_t* scene, const float* partials, int n_rays, float* grad_out,
+                       const mne_decoder_opt_t* opt, int n_samples, const float* ray_sums,
+                       const int32_t* counts, float* losses, const mne_clock_t* clock, void* stream) {
+    if (int rc = check_scene(scene, false, false)) return rc;
+    if (!partials || !grad_out || !opt || n_rays < 1) return fail(-1, "mne_decoder_update: NULL argument");
+    if (losses && (!ray_sums || !counts || n_samples < 1)) return fail(-1, "mne_decoder_update: the loss scalars need ray_sums and counts");
+    if (opt->step < 1) return fail(-1, "mne_decoder_update: bad optimizer state");
+    DecUpdateArgs a = {};
+    a.sc = *scene;
+    a.partials = partials; a.n_partials = mne_wgrad_partial_count(*scene, n_rays); a.grad_out = grad_out;
+    for (int k = 0; k < 4; ++k) {
+        if (!opt->m[k] || !opt->v[k]) return fail(-1, "mne_decoder_update: bad optimizer state");
+        a.m[k] = opt->m[k]; a.v[k] = opt->v[k];
+    }
+    PlaneOpt& o = a.opt;
+    o.omb1 = (float)(1.0 - opt->beta1); o.b2 = (float)opt->beta2; o.omb2 = (float)(1.0 - opt->beta2);
+    o.eps = (float)opt->eps; o.wd = (float)opt->weight_decay;
+    o.step_size = (float)(opt->lr / (1.0 - std::pow(opt->beta1, (double)opt->step)));
+    o.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(opt->beta2, (double)opt->step));
+    o.lr = opt->lr; o.step = opt->step;
+    if (clock && fill_clock(clock, a.clk, opt->beta1, opt->beta2, true))
+        return fail(-1, "mne_decoder_update: clock incomplete or made for other betas");
+    a.fin.R = n_rays; a.fin.S = n_samples; a.fin.ray_sums = ray_sums; a.fin.counts = counts; a.fin.losses = losses;
+    if (int rc = mne_launch_decoder_update(a, (hipStream_t)stream)) return fail(rc, "unsupported decoder shape");
+    return check_launch("decoder_update");
+}
+
 int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t* ray_tiles, int n_rays, int n_samples,
                       float* partials, float* grad_out, int impl, void* stream) {
     if (int rc = check_scene(scene, false, false)) return rc;
-    if (!tape || !ray_tiles || !grad_out || (impl != 1 && !partials)) return fail(-1, "mne_decoder_wgrad: NULL argument");
+    if (!tape || !ray_tiles || (!grad_out && impl != 3) || (impl != 1 && !partials)) return fail(-1, "mne_decoder_wgrad: NULL argument");
     if (n_rays < 1 || n_samples < 1) return fail(-1, "mne_decoder_wgrad: empty batch");
     WgradArgs a = {};
     a.tape = tape; a.ray_tiles = ray_tiles; a.R = n_rays; a.S = n_samples; a.partials = partials; a.grad_out = grad_out;

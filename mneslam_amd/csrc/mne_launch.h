@@ -189,6 +189,18 @@ struct WgradArgs {
 };
 
 
+// wgrad reduce + decoder Adam + loss scalars in one launch (render.hip, decoder_update_kernel)
+struct DecUpdateArgs {
+    mne_scene_t sc;              // decoder weights (updated in place) and dims
+    const float* partials;       // [n_partials][NPARAM] from the fused weight-gradient pass
+    int n_partials;
+    float* grad_out;             // [NPARAM] the summed gradient (kept: tests and callers read it)
+    float* m[4]; float* v[4];    // Adam moments in decoder.parameters() order: col0, col1, sdf0, sdf1
+    PlaneOpt opt;
+    LossArgs fin;                // loss scalars of the iteration (fin.losses NULL: not wanted)
+    Clock clk;
+};
+
 struct TileAdamArgs {
     mne_scene_t sc;
     TileBins bins;
@@ -225,12 +237,16 @@ int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStr
 int mne_launch_loss_finalize(const LossArgs& a, hipStream_t st);
 int mne_launch_loss_coef(const LossArgs& a, hipStream_t st);
 int mne_launch_wgrad(const mne_scene_t& sc, WgradArgs a, int impl, hipStream_t st);
+int mne_wgrad_partial_count(const mne_scene_t& sc, int n_rays);
+int mne_launch_decoder_update(const DecUpdateArgs& a, hipStream_t st);
 int mne_launch_adam(const AdamArgs& a, hipStream_t st);
 int mne_launch_grid(const GridArgs& a, int bwd, hipStream_t st);
 int mne_launch_tile_order(const TileAdamArgs& a, hipStream_t st);
 int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st);
 void mne_tile_geometry(const mne_scene_t& sc, TileBins& b);
 int mne_launch_sample_rays(SampleRaysArgs a, unsigned long long seed, unsigned long long iteration, hipStream_t st);
+int mne_launch_batch(SampleRaysArgs sr, unsigned long long seed, unsigned long long iteration, const ZArgs& a, const LossArgs& lc,
+                     hipStream_t st);
 size_t mne_dims_packed(const mne_scene_t& sc);
 size_t mne_dims_tape_row(const mne_scene_t& sc);
 size_t mne_dims_nparam(const mne_scene_t& sc);

@@ -22,6 +22,7 @@
 // model/utils.py:27-41,117-185 (include/mneslam_hip.h maps each entry point).
 #include "mlp_mfma.h"
 #include "mne_launch.h"
+#include "mne_sampler.h"
 
 #define RAYS_PER_WG 4
 #define TILE 32
@@ -29,20 +30,12 @@
 // -----------------------------------------------------------------------------------------------
 // z sampling + mask counts: one wave per ray, linspace tables staged in LDS once per workgroup
 // -----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
-    MNE_DYN_LDS(lds_raw);
-    const int S = a.S, n_tab = a.has_d ? a.n_a + 2 * a.n_b : S;
-    float* tab = (float*)lds_raw;                                   // [n_tab]
-    for (int i = threadIdx.x; i < n_tab; i += blockDim.x) tab[i] = a.tables[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = blockIdx.x * RAYS_PER_WG + w;
-    if (r >= a.R) return;                                           // whole wave leaves together
+// z samples (+ per-ray mask counts) of ray r by one wave; d = its target depth (unused without depth guidance); tab =
+// the staged linspace tables, `vals` = S floats of this wave's LDS
+__device__ __forceinline__ void sample_z_ray(const ZArgs& a, int r, float d, int lane, const float* tab, float* vals) {
+    const int S = a.S;
     const uint64_t z_offset = a.offset + (a.clk.iteration ? *a.clk.iteration * a.clk.z_offset_stride : 0ull);
-    float* vals = tab + ((n_tab + 3) & ~3) + w * ((S + 3) & ~3);    // [S] sorted samples of this ray
-    float d = 0.0f;
     if (a.has_d) {
-        d = a.target_d[r];
         const float* uni = tab;
         const float* surf = tab + a.n_a;
         const float* inval = tab + a.n_a + a.n_b;
@@ -116,8 +109,22 @@ __global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void counts_reduce_kernel(ZArgs a) {
-    __shared__ int part[256][MNE_N_COUNT];
+__device__ __forceinline__ int z_tab_entries(const ZArgs& a) { return a.has_d ? a.n_a + 2 * a.n_b : a.S; }
+
+__global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
+    MNE_DYN_LDS(lds_raw);
+    const int S = a.S, n_tab = z_tab_entries(a);
+    float* tab = (float*)lds_raw;                                   // [n_tab]
+    for (int i = threadIdx.x; i < n_tab; i += blockDim.x) tab[i] = a.tables[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * RAYS_PER_WG + w;
+    if (r >= a.R) return;                                           // whole wave leaves together
+    sample_z_ray(a, r, a.has_d ? a.target_d[r] : 0.0f, lane, tab, tab + ((n_tab + 3) & ~3) + w * ((S + 3) & ~3));
+}
+
+// sum of the per-ray mask counts: all 256 threads of ONE workgroup
+__device__ __forceinline__ void counts_reduce_block(const ZArgs& a, int (*part)[MNE_N_COUNT]) {
     const int t = threadIdx.x;
     int acc[MNE_N_COUNT];
     for (int k = 0; k < MNE_N_COUNT; ++k) acc[k] = 0;
@@ -131,6 +138,41 @@ __global__ __launch_bounds__(256) void counts_reduce_kernel(ZArgs a) {
         __syncthreads();
     }
     if (t < MNE_N_COUNT) a.counts[t] = part[0][t];
+}
+
+__global__ __launch_bounds__(256) void counts_reduce_kernel(ZArgs a) {
+    __shared__ int part[256][MNE_N_COUNT];
+    counts_reduce_block(a, part);
+}
+
+__device__ __forceinline__ void loss_coef_thread(const LossArgs& a);
+
+// batch_kernel + counts_coef_kernel: the per-iteration batch preparation (R1-R3 + the loss coefficients) in TWO launches
+// instead of four (sample_rays, sample_z, counts_reduce, loss_coef: ~70 us of launch latency in the decoder's dependency
+// chain, profiles/r03_timeline_mid.txt) -- ray draw and pose rotation (sampler.hip) + z samples + per-ray mask counts;
+// then the sum of the counts and the d(total)/d(sample) coefficients.  (One launch with a "last workgroup" epilogue was
+// measured and is WORSE: its agent-scope release fences write back the L2 under the concurrent plane update, which lost
+// 20 us -- profiles/r03_fused_small_kernels.txt.)
+__global__ __launch_bounds__(256) void batch_kernel(SampleRaysArgs sr, ZArgs a) {
+    MNE_DYN_LDS(lds_raw);
+    const int S = a.S, n_tab = z_tab_entries(a);
+    float* tab = (float*)lds_raw;                                   // [n_tab]
+    for (int i = threadIdx.x; i < n_tab; i += blockDim.x) tab[i] = a.tables[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * RAYS_PER_WG + w;
+    if (r < a.R) {
+        const float d = sample_ray(sr, r, lane == 0);              // every lane draws the (same) ray, lane 0 stores it
+        sample_z_ray(a, r, d, lane, tab, tab + ((n_tab + 3) & ~3) + w * ((S + 3) & ~3));
+    }
+}
+
+// sum of the per-ray counts + the loss coefficients: the second (one-workgroup) launch of the batch preparation
+__global__ __launch_bounds__(256) void counts_coef_kernel(ZArgs a, LossArgs lc) {
+    __shared__ int part[256][MNE_N_COUNT];
+    counts_reduce_block(a, part);
+    __syncthreads();
+    if (threadIdx.x == 0 && lc.coef) loss_coef_thread(lc);
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -1030,7 +1072,17 @@ __global__ __launch_bounds__(256) void bin_kernel(RenderArgs a) {
         float ro[3], rd[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) { ro[q] = a.rays_o[r * 3 + q]; rd[q] = a.rays_d[r * 3 + q]; }
-        for (int c = 0; c < t_dec; ++c) {
+        // The rays of one keyframe start at one point: every ray's first tile lands in the lists of the same few plane
+        // tiles, and reservations on one counter are served one after the other (profiles/r03_bin_ablation.txt).  Each ray
+        // therefore starts at a different tile of its own and wraps around, which spreads those reservations over the
+        // kernel's run time instead of queueing them all at its start.
+#ifdef BIN_NO_ROTATE
+        const int c0 = 0;
+#else
+        const int c0 = (int)((unsigned)r % (unsigned)t_dec);
+#endif
+        for (int k = 0; k < t_dec; ++k) {
+            const int c = c0 + k < t_dec ? c0 + k : c0 + k - t_dec;
             const int i = c * TILE + pt;
             const bool valid = i < Dn;
             const int ii = valid ? i : Dn - 1;
@@ -1082,8 +1134,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(RenderArgs a, int ntile) {
 // -----------------------------------------------------------------------------------------------
 // loss scalars / coefficients (single small block; deterministic summation order)
 // -----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_finalize_kernel(LossArgs a) {
-    __shared__ double part[256][MNE_N_LOSS];
+// body of the loss scalars: all 256 threads of ONE workgroup
+__device__ __forceinline__ void loss_finalize_block(const LossArgs& a, double (*part)[MNE_N_LOSS]) {
     const int t = threadIdx.x;
     double acc[MNE_N_LOSS];
     for (int k = 0; k < MNE_N_LOSS; ++k) acc[k] = 0.0;
@@ -1114,8 +1166,13 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(LossArgs a) {
     }
 }
 
-__global__ void loss_coef_kernel(LossArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void loss_finalize_kernel(LossArgs a) {
+    __shared__ double part[256][MNE_N_LOSS];
+    loss_finalize_block(a, part);
+}
+
+// d(total)/d(sample) coefficients: ONE thread
+__device__ __forceinline__ void loss_coef_thread(const LossArgs& a) {
     const float n_valid = (float)a.counts[MNE_C_VALID], n_ef = (float)a.counts[MNE_C_E_FRONT];
     const float n_ec = (float)a.counts[MNE_C_E_CENTER], n_et = (float)a.counts[MNE_C_E_TAIL];
     const float n_cf = (float)a.counts[MNE_C_CO_FS], n_cs = (float)a.counts[MNE_C_CO_SDF];
@@ -1131,6 +1188,56 @@ __global__ void loss_coef_kernel(LossArgs a) {
     a.coef[MNE_L_E_CENTER] = n_ec > 0.f ? g[MNE_L_E_CENTER] * 2.0f * a.e_T / n_ec : 0.0f;
     a.coef[MNE_L_E_TAIL] = n_et > 0.f ? g[MNE_L_E_TAIL] * 2.0f * a.e_T / n_et : 0.0f;
     a.coef[MNE_L_PSNR] = 0.0f;
+}
+
+__global__ void loss_coef_kernel(LossArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    loss_coef_thread(a);
+}
+
+// -----------------------------------------------------------------------------------------------
+// decoder_update_kernel: fixed-order sum of the partial weight gradients (wgrad.hip), torch.optim.Adam on the 6 k decoder
+// parameters and the loss scalars of the iteration in ONE launch (were three: wgrad_reduce, adam, loss_finalize -- 45 us of
+// launch latency in the decoder's dependency chain beside the plane update, profiles/r03_timeline_mid.txt); the caller
+// follows with pack_decoder_kernel for the next render's tables.
+// -----------------------------------------------------------------------------------------------
+template <int HID, int HIDC, bool CP>
+__global__ __launch_bounds__(256) void decoder_update_kernel(DecUpdateArgs a) {
+    typedef DecDims<HID, HIDC, CP> D;
+    __shared__ float part[8][32];
+    __shared__ double lpart[256][MNE_N_LOSS];
+    const int tid = threadIdx.x;
+    const int e = blockIdx.x * 32 + (tid & 31), grp = tid >> 5;
+    float s = 0.0f;
+    if (e < D::NPARAM) {
+#pragma unroll 8
+        for (int w = grp; w < a.n_partials; w += 8) s += a.partials[(size_t)w * D::NPARAM + e];
+    }
+    part[grp][tid & 31] = s;
+    __syncthreads();
+    if (grp == 0 && e < D::NPARAM) {
+        float g = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g += part[k][tid];
+        a.grad_out[e] = g;
+        // decoder.parameters() order: col0 | col1 | sdf0 | sdf1
+        const int t = e < D::P_COL1 ? 0 : e < D::P_SDF0 ? 1 : e < D::P_SDF1 ? 2 : 3;
+        const int off = e - (t == 0 ? D::P_COL0 : t == 1 ? D::P_COL1 : t == 2 ? D::P_SDF0 : D::P_SDF1);
+        float* P = (float*)(t == 0 ? a.sc.w_col0 : t == 1 ? a.sc.w_col1 : t == 2 ? a.sc.w_sdf0 : a.sc.w_sdf1);
+        PlaneOpt o = a.opt;
+        if (a.clk.bias_table) clock_bias(a.clk, o.lr, o.step, o.step_size, o.bc2_sqrt);
+        float p = P[off], m = a.m[t][off], v = a.v[t][off];
+        adam_elem(p, g, m, v, o);
+        P[off] = p; a.m[t][off] = m; a.v[t][off] = v;
+    }
+    if (blockIdx.x == 0 && a.fin.losses) loss_finalize_block(a.fin, lpart);
+}
+
+template <int HID, int HIDC, bool CP>
+static int launch_decoder_update(const DecUpdateArgs& a, hipStream_t st) {
+    typedef DecDims<HID, HIDC, CP> D;
+    MNE_LAUNCH((decoder_update_kernel<HID, HIDC, CP>), (D::NPARAM + 31) / 32, 256, 0, st, a);
+    return 0;
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -1259,6 +1366,19 @@ static void carve_workspace(RenderArgs& a, void* ws) {
     a.long_list = (int*)p; p += align16((size_t)a.R * sizeof(int));
     a.defer_count = (int*)p;
     a.long_count = (int*)(p + 16);
+}
+
+int mne_half_bits_for(long long n);
+int mne_launch_batch(SampleRaysArgs sr, unsigned long long seed, unsigned long long iteration, const ZArgs& a, const LossArgs& lc,
+                     hipStream_t st) {
+    sr.half_bits_kf = mne_half_bits_for(sr.n_kf_rays);
+    sr.half_bits_cur = mne_half_bits_for(sr.n_cur_rays);
+    sr.seed = seed; sr.iteration = iteration;
+    const int n_tab = a.has_d ? a.n_a + 2 * a.n_b : a.S;
+    const size_t lds = (size_t)(((n_tab + 3) & ~3) + RAYS_PER_WG * ((a.S + 3) & ~3)) * sizeof(float);
+    MNE_LAUNCH(batch_kernel, (a.R + RAYS_PER_WG - 1) / RAYS_PER_WG, 256, lds, st, sr, a);
+    MNE_LAUNCH(counts_coef_kernel, 1, 256, 0, st, a, lc);
+    return 0;
 }
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
@@ -1478,6 +1598,13 @@ int mne_launch_render(const RenderArgs& a, int mode, void* workspace, const Rend
 
 int mne_launch_query(const QueryArgs& a, hipStream_t st) {
 #define CALL(H, HC, CPV) return launch_query<H, HC, CPV>(a, st)
+    MNE_DISPATCH(a.sc, CALL, -2);
+#undef CALL
+    return -2;
+}
+
+int mne_launch_decoder_update(const DecUpdateArgs& a, hipStream_t st) {
+#define CALL(H, HC, CPV) return launch_decoder_update<H, HC, CPV>(a, st)
     MNE_DISPATCH(a.sc, CALL, -2);
 #undef CALL
     return -2;

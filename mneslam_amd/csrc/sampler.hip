@@ -9,86 +9,23 @@
 // on [0, 2^k); cycle-walking restricts it to a bijection on [0, N), so the images of 0..n-1 are n
 // distinct uniformly scrambled indices.  Explicit index arrays (e.g. the host RNG's draws) can be
 // supplied instead, which makes the assembly bit-comparable with the reference.
-#include "mne_device.h"
-#include "mne_launch.h"
-
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
-}
-
-__device__ __forceinline__ uint64_t feistel_index(uint64_t i, uint64_t n, int half_bits, uint64_t key) {
-    const uint32_t mask = (1u << half_bits) - 1u;
-    uint64_t x = i;
-    do {
-        uint32_t l = (uint32_t)(x >> half_bits) & mask, r = (uint32_t)x & mask;
-#pragma unroll
-        for (int round = 0; round < 4; ++round) {
-            const uint32_t f = mix32(r ^ (uint32_t)(key >> (16 * round)) ^ (0x9E3779B9u * (round + 1)) ^ (uint32_t)(key >> 32)) & mask;
-            const uint32_t nl = r;
-            r = l ^ f;
-            l = nl;
-        }
-        x = ((uint64_t)l << half_bits) | r;
-    } while (x >= n);
-    return x;
-}
-
-// two independent 64-bit keys from (seed, iteration) -- splitmix64; host and device run the same integer arithmetic
-__host__ __device__ inline void ray_keys(unsigned long long seed, unsigned long long iteration, unsigned long long& key_kf,
-                                         unsigned long long& key_cur) {
-    unsigned long long z = seed * 0x9E3779B97F4A7C15ull + iteration * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
-    unsigned long long k[2];
-    for (int i = 0; i < 2; ++i) {
-        z += 0x9E3779B97F4A7C15ull;
-        unsigned long long x = z;
-        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-        k[i] = x ^ (x >> 31);
-    }
-    key_kf = k[0]; key_cur = k[1];
-}
+#include "mne_sampler.h"
 
 __global__ __launch_bounds__(256) void sample_rays_kernel(SampleRaysArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int R = a.n_global + a.n_cur;
-    if (t >= R) return;
-    unsigned long long key_kf, key_cur;
-    ray_keys(a.seed, a.iteration + (a.clk.iteration ? *a.clk.iteration : 0ull), key_kf, key_cur);
-    const float* src;
-    int pose_id;
-    long long idx;
-    if (t < a.n_global) {
-        idx = a.idx_global ? a.idx_global[t] : (long long)feistel_index((uint64_t)t, (uint64_t)a.n_kf_rays, a.half_bits_kf, key_kf);
-        src = a.kf_rays + idx * 7;
-        pose_id = a.kf_pose_ids ? a.kf_pose_ids[idx / a.n_save] : (int)(idx / a.n_save);
-    } else {
-        const int j = t - a.n_global;
-        idx = a.idx_cur ? a.idx_cur[j] : (long long)feistel_index((uint64_t)j, (uint64_t)a.n_cur_rays, a.half_bits_cur, key_cur);
-        src = a.cur_rays + idx * 7;
-        pose_id = a.n_poses - 1;                      // id -1 in the reference: poses[-1]
-    }
-    if (a.out_idx) a.out_idx[t] = idx;
-    const float* P = a.poses + (size_t)pose_id * 16;  // row-major 4x4 c2w
-    const float d0 = src[0], d1 = src[1], d2 = src[2];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        a.rays_d[t * 3 + j] = (d0 * P[j * 4 + 0] + d1 * P[j * 4 + 1]) + d2 * P[j * 4 + 2];
-        a.rays_o[t * 3 + j] = P[j * 4 + 3];
-    }
-    a.target_rgb[t * 3 + 0] = src[3]; a.target_rgb[t * 3 + 1] = src[4]; a.target_rgb[t * 3 + 2] = src[5];
-    a.target_d[t] = src[6];
+    if (t >= a.n_global + a.n_cur) return;
+    sample_ray(a, t, true);
 }
 
-static int half_bits_for(long long n) {
+int mne_half_bits_for(long long n) {
     int bits = 2;
     while ((1ll << bits) < n) ++bits;
     return (bits + 1) / 2;          // even total width >= bits
 }
 
 int mne_launch_sample_rays(SampleRaysArgs a, unsigned long long seed, unsigned long long iteration, hipStream_t st) {
-    a.half_bits_kf = half_bits_for(a.n_kf_rays);
-    a.half_bits_cur = half_bits_for(a.n_cur_rays);
+    a.half_bits_kf = mne_half_bits_for(a.n_kf_rays);
+    a.half_bits_cur = mne_half_bits_for(a.n_cur_rays);
     a.seed = seed; a.iteration = iteration;
     const int R = a.n_global + a.n_cur;
     MNE_LAUNCH(sample_rays_kernel, (R + 255) / 256, 256, 0, st, a);

@@ -372,6 +372,14 @@ __global__ __launch_bounds__(256) void wgrad_scalar_kernel(WgradArgs a) {
 
 int mne_wgrad_waves(void) { return MNE_WGRAD_BLOCKS * 4; }
 
+// partial results the fused pass leaves for n_rays rays
+static int fused_partials(int hid, int n_rays) {
+    const int ranges_per_block = (hid == 32) ? 4 : 2;
+    const int blocks = (n_rays + ranges_per_block - 1) / ranges_per_block;
+    return blocks < 1 ? 1 : (blocks > WG_FUSED_BLOCKS ? WG_FUSED_BLOCKS : blocks);
+}
+int mne_wgrad_partial_count(const mne_scene_t& sc, int n_rays) { return fused_partials(sc.hidden, n_rays); }
+
 template <int HID, int HIDC, bool CP>
 static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
     typedef DecDims<HID, HIDC, CP> D;
@@ -383,14 +391,12 @@ static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
         return 0;
     }
     // one partial per WORKGROUP (fused kernels) or per wave (impl 2); never more waves than rays
-    if (impl == 0) {
-        const int ranges_per_block = (HID == 32) ? 4 : 2;
-        int blocks = (a.R + ranges_per_block - 1) / ranges_per_block;
-        blocks = blocks < 1 ? 1 : (blocks > WG_FUSED_BLOCKS ? WG_FUSED_BLOCKS : blocks);
+    if (impl == 0 || impl == 3) {          // 3: without the reduction (the caller continues with mne_decoder_update)
+        const int blocks = fused_partials(HID, a.R);
         a.n_waves = blocks;
         if constexpr (HID == 32 && HIDC == 32) MNE_LAUNCH((wgrad_fused_kernel<HID, HIDC, CP>), 2 * blocks, 256, 0, st, a);   // two parts per slot
         else MNE_LAUNCH((wgrad_fused64_kernel<CP>), blocks, 256, 0, st, a);
-        MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
+        if (impl == 0) MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
         return 0;
     }
     int blocks = (a.R + 3) / 4;

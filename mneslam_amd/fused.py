@@ -64,6 +64,9 @@ class FusedStep:
                 raise ValueError("fused step needs channels_last planes on the compute device")
         self.dec_w = model.decoder.hip_weights()
         self.group_of = {p: g for g in optimizer.param_groups for p in g["params"]}
+        self.group_of_dec = self.group_of[self.dec_w[0]]
+        if any(self.group_of[w] is not self.group_of_dec for w in self.dec_w):
+            raise ValueError("the decoder tensors must be in one param group (slam_glue.create_optimizer builds it that way)")
         self.grads = None
         if scatter == "atomics":
             # persistent gradient accumulators (zeroed by the Adam kernel itself after each use)
@@ -174,6 +177,7 @@ class FusedStep:
         self.events = None          # set to {} to record HIP events around the dominant launches
         self.overlap = overlap
         self._side, self._ev, self._prefetched, self._planes_pending = None, None, None, False
+        self._packed_key = None
         self._ev_decode = None       # event "prefix decode enqueued" (two-stream runs with the binned plane update)
         self._bin_pending = False
         self.concurrent_bin = os.environ.get("MNE_SERIAL_BIN", "0") != "1"
@@ -221,15 +225,61 @@ class FusedStep:
         lib, P, R, S = self.lib, _lib.ptr, int(n_global + n_cur), self.S
         it = self.iteration if clock is None else 0
         ck = C.byref(clock) if clock is not None else None
-        _lib.check(lib.mne_sample_rays(P(kf_rays), int(n_kf_rays), int(n_save), None, P(cur_rays), cur_rays.shape[0],
-                                       P(poses), poses.shape[0], n_global, n_cur, P(idx_global), P(idx_cur),
-                                       self.seed, it, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb),
-                                       P(self.tgt_d), P(self.idx), ck, st), "mne_sample_rays")
-        _lib.check(lib.mne_sample_z(C.byref(self.rc), R, P(self.tgt_d), P(u), P(self.tables), self.seed,
-                                    it * ((R * S + 3) // 4), P(self.z_vals), P(self.counts),
-                                    P(self.ray_counts), ck, st), "mne_sample_z")
-        _lib.check(lib.mne_loss_coef(C.byref(self.rc), R, S, P(self.counts), P(self.loss_w), P(self.coef), st),
-                   "mne_loss_coef")
+        # one launch: ray draw + z samples + mask counts + loss coefficients (csrc/render.hip, batch_kernel)
+        _lib.check(lib.mne_sample_batch(P(kf_rays), int(n_kf_rays), int(n_save), None, P(cur_rays), cur_rays.shape[0],
+                                        P(poses), poses.shape[0], n_global, n_cur, P(idx_global), P(idx_cur),
+                                        self.seed, it, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb), P(self.tgt_d),
+                                        P(self.idx), C.byref(self.rc), P(u), P(self.tables), it * ((R * S + 3) // 4),
+                                        P(self.z_vals), P(self.counts), P(self.ray_counts), P(self.loss_w), P(self.coef),
+                                        ck, st), "mne_sample_batch")
+
+    def _decoder_chain(self, R, S, st, clock=None):
+        """wgrad -> (all-reduce) -> decoder Adam -> loss scalars -> decoder tables of the NEXT render.  Two launches
+        (weight-gradient pass; decoder_update_kernel) unless the decoder gradient is shared between agents or a
+        cross-check implementation of the weight gradients is selected."""
+        lib, P = self.lib, _lib.ptr
+        fused = not self.shared_decoder and self.model.wgrad_impl == 0
+        _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.ray_tiles), R, S, P(self.partials),
+                                         P(self.dec_grad), 3 if fused else self.model.wgrad_impl, st), "mne_decoder_wgrad")
+        if not fused:
+            if self.shared_decoder:
+                from . import dist as mdist
+                mdist.allreduce_mean_(self.dec_grad)
+            self.opt.step(zero_grad=False, grad_buffers=self.dec_grad_views, clock=clock)      # decoder tensors
+            _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
+            self._packed_key = None
+            return
+        w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
+        grp = self.group_of_dec
+        o = _lib.DecoderOpt()
+        steps = set()
+        for k, w in enumerate((w_col0, w_col1, w_sdf0, w_sdf1)):       # decoder.parameters() order
+            stt = self.opt._state(w)
+            if clock is None:
+                stt["step"] += 1
+            steps.add(stt["step"])
+            o.m[k], o.v[k] = stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr()
+        if len(steps) != 1:
+            raise RuntimeError("the decoder tensors must share one Adam step count")
+        o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
+        o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
+        o.step = steps.pop() + (1 if clock is not None else 0)
+        _lib.check(lib.mne_decoder_update(C.byref(self.scene), P(self.partials), R, P(self.dec_grad), C.byref(o),
+                                          S, P(self.ray_sums), P(self.counts), P(self.losses),
+                                          C.byref(clock) if clock is not None else None, st), "mne_decoder_update")
+        # the NEXT render's decoder tables, here in the decoder chain (beside the plane update), not in front of that render
+        _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
+        self._packed_key = self._decoder_key()              # self.packed now holds the tables of these weights
+
+    def _decoder_key(self):
+        return tuple((w.data_ptr(), w._version) for w in self.dec_w)
+
+    def _pack_if_stale(self, st):
+        """Decoder tables for the render: repacked only when the weights are not the ones the last decoder update packed
+        (first step, re-bound or externally modified weights)."""
+        if self._packed_key is None or self._packed_key != self._decoder_key():
+            _lib.check(self.lib.mne_pack_decoder(C.byref(self.scene), _lib.ptr(self.packed), st), "mne_pack_decoder")
+            self._packed_key = self._decoder_key()
 
     def _tile_bin(self, pass_, opts, st):
         R, S, P = self.n_active, self.S, _lib.ptr
@@ -332,12 +382,7 @@ class FusedStep:
                 self.plane_opt[k].step = t0 + 1
             _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins),
                                          C.byref(clock), st2), "mne_tile_adam")
-            _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.ray_tiles), R, S, P(self.partials),
-                                             P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
-            self.opt.step(zero_grad=False, grad_buffers=self.grad_map, clock=clock)
-            # the NEXT iteration's decoder tables (this iteration's render is done with them): off the critical path
-            _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
-            _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
+            self._decoder_chain(R, S, st, clock=clock)      # leaves the NEXT iteration's decoder tables in self.packed
             _lib.check(lib.mne_clock_advance(P(self.clk_iter), None, st), "mne_clock_advance")
             if self._ev_decode is not None:
                 cap.wait_event(self._ev[2])               # the appends have read this batch: its buffers may be overwritten
@@ -413,7 +458,7 @@ class FusedStep:
         if host_batch or self._prefetched != key:
             self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st)
         self._prefetched = None
-        _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
+        self._pack_if_stale(st)
         if self._planes_pending:                                  # previous step's plane update (side stream)
             main.wait_event(ev[1])
             self._planes_pending = False
@@ -466,12 +511,7 @@ class FusedStep:
                 ev[1].record(side)                      # "planes updated": what the next decode waits for
                 self._planes_pending = True
             # ---- decoder chain on the caller's stream, concurrent with the plane update
-            _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.ray_tiles), R, S, P(self.partials),
-                                             P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
-            if self.shared_decoder:
-                from . import dist as mdist
-                mdist.allreduce_mean_(self.dec_grad)
-            self.opt.step(zero_grad=False, grad_buffers=self.grad_map)      # decoder tensors
+            self._decoder_chain(R, S, st)
         else:
             _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(self.tape), P(self.ray_tiles), R, S, P(self.partials),
                                              P(self.dec_grad), self.model.wgrad_impl, st), "mne_decoder_wgrad")
@@ -486,7 +526,8 @@ class FusedStep:
             e0 = self._mark("adam")
             self.opt.step(zero_grad=True, grad_buffers=self.grad_map)
             self._mark("adam", e0)
-        _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
+            self._packed_key = None
+            _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
         self.iteration += 1
         if self._bin_pending:                                     # the side stream's appends read this batch's buffers
             main.wait_event(ev[2])
@@ -611,13 +652,6 @@ class HashFusedStep(FusedStep):
             o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
         self._finish_init(overlap=os.environ.get("MNE_NO_OVERLAP", "0") != "1")
         self._decoder_pending = False
-
-    def _tile_bin(self, pass_, opts, st):
-        R, S, P = self.n_active, self.S, _lib.ptr
-        _lib.check(self.lib.mne_tile_bin(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
-                                         P(self.tgt_d), P(self.z_vals),
-                                         P(self.ray_counts) if self.early_termination else None, P(self.coef), P(self.raw),
-                                         C.byref(self.bins), P(self.ws), self.ws_bytes, pass_, C.byref(opts), st), "mne_tile_bin")
 
     def _refresh_pointers(self):
         w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
