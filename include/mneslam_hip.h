@@ -286,9 +286,10 @@ typedef struct mne_fused_opts {
      * 1, < 1/16 back to mode 0.  word 1 = that count (scratch); words 2, 3 reserved.  NULL = always mode 0. */
     int32_t* adapt_state;
     /* The list appends of the binned plane update only need the decode's outputs, not the backward: with external_bin != 0
-     * mne_render_fused leaves them to the caller, who runs mne_tile_bin(pass 0) on a SECOND stream once
-     * event_after_decode (a hipEvent_t this call records behind its prefix decode) has fired, and mne_tile_bin(pass 1)
-     * after this call -- both before mne_tile_order / mne_tile_adam.  0 / NULL: the call does the appends itself. */
+     * mne_render_fused leaves those of the rays its a-priori prefix resolves to the caller, who runs mne_tile_bin(pass 0)
+     * on a SECOND stream once event_after_decode (a hipEvent_t this call records behind its prefix decode) has fired --
+     * before mne_tile_adam.  The deferred rays' appends stay in this call (behind its deferred pass).  0 / NULL: the call
+     * does all appends itself. */
     int32_t external_bin;
     int32_t reserved;
     void* event_after_decode;

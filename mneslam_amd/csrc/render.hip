@@ -1546,9 +1546,9 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         d.adapt_update = 1;                                // the last ray launch of the call decides the next call's schedule
         if (int rc = launch_ray<HID, HIDC, CP, 4>(d, st)) return rc;    // the same lean kernel: now every listed ray resolves
         mark(host, 4, st);
-        if (a.bins.lists && !host.external_bin) {          // list appends on this stream (the host may run them beside the
-            launch_bin<CP>(a, 0, st);                      // backward instead: mne_tile_bin on a second stream)
-            launch_bin<CP>(a, 1, st);
+        if (a.bins.lists) {                                // list appends: the resolved rays' (pass 0) here unless the host runs
+            if (!host.external_bin) launch_bin<CP>(a, 0, st);   // them beside the backward (mne_tile_bin on a second stream);
+            launch_bin<CP>(a, 1, st);                      // the deferred rays' always here, right behind their ray pass
         }
         launch_plane_pass<HID, HIDC, CP>(a, st);           // scatter="atomics"
         mark(host, 5, st);

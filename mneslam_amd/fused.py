@@ -201,6 +201,8 @@ class FusedStep:
         if self._side is None:
             # (a high-priority side stream was measured: no effect, 0.522 vs 0.521 ms -- profiles/r02_variants.txt)
             self._side = torch.cuda.Stream(self.device)
+            # (events created with hipEventReleaseToDevice were measured: 1.5 % slower than the runtime's default events,
+            # profiles/r03_events_negative.txt)
             self._ev = [torch.cuda.Event() for _ in range(4)]
             if self.concurrent_bin:
                 self._ev_decode = torch.cuda.Event()
@@ -372,11 +374,9 @@ class FusedStep:
                 side.wait_event(self._ev_decode)
                 self._tile_bin(0, opts, st2)
                 _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
-            side.wait_stream(cap)
-            if self._ev_decode is not None:
-                self._tile_bin(1, opts, st2)
                 self._ev[2].record(side)
-            else:
+            side.wait_stream(cap)
+            if self._ev_decode is None:
                 _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             for k in range(len(self.planes)):
                 self.plane_opt[k].step = t0 + 1
@@ -397,7 +397,7 @@ class FusedStep:
         eager steps ran in between."""
         main = torch.cuda.current_stream(self.device)
         if self._planes_pending:
-            main.wait_event(self._ev[1])
+            self._main.wait_event(ev[1])
             self._planes_pending = False
         step_now = self.opt._state(self.planes[0])["step"]
         clk_iter, clk_step, _ = rec["keep"]
@@ -489,12 +489,10 @@ class FusedStep:
                 # handful in steady state) come later and do not change which lists are the heavy ones; tile_adam_kernel
                 # reads the final lengths itself.  Keeps tile_order_kernel (12 us + a launch gap) off the critical path.
                 _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
-            self._after(side, ev[0], main)
-            if self._ev_decode is not None and side is not None:
-                self._tile_bin(1, opts, st2)
                 ev[2].record(side)                      # "appends done": the batch buffers (rays, z, targets, coefficients)
                 self._bin_pending = True                # may be overwritten by the next batch only after this
-            else:
+            self._after(side, ev[0], main)              # the deferred rays' appends are part of the render call (caller's stream)
+            if self._ev_decode is None or side is None:
                 _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             for k, p in enumerate(self.planes):
                 stt = self.opt._state(p)
