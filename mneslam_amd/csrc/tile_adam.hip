@@ -224,8 +224,10 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     // passes over the list, then over the spill area (spill entries of other tiles contribute nothing)
     const int n_total = n_list + n_spill;
     // this part's share of the list; the last part also scans the spill area
+    // (every bound is clamped to the list: with a tiny split threshold the part count is capped and part * chunk can pass
+    // the list's end -- the last part must then still start at the FIRST spill entry)
     const int chunk = (n_list + n_parts - 1) / n_parts;
-    const int e_lo = part * chunk;
+    const int e_lo = part * chunk < n_list ? part * chunk : n_list;
     const int e_hi = part == n_parts - 1 ? n_total : ((part + 1) * chunk < n_list ? (part + 1) * chunk : n_list);
     TILE_STAMP(1);
     for (int p0 = e_lo; p0 < e_hi; p0 += PASS_ENTRIES) {

@@ -27,6 +27,8 @@ class _null_ctx:
 
 
 class FusedStep:
+    LIST_BUDGET_BYTES = 4 << 30          # upper bound for the tile lists of the binned plane update (all tiles together)
+
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
                  tile_capacity=None, spill_capacity=None, shared_decoder=False, overlap=True, overlap_peers=None,
                  plane_storage="fp32"):
@@ -97,17 +99,21 @@ class FusedStep:
             n_tiles = self.lib.mne_tile_count(C.byref(self.scene))
             if tile_capacity is None:
                 # 4x the mean list length of the plane with the fewest tiles if every sample contributed (a sample
-                # touches ~1.3 tiles of a plane); office0: 5,020 entries (longest list observed: 2,840).  Overflow is
-                # still correct (spill area), only slower.
+                # touches ~1.3 tiles of a plane); office0: 5,020 entries (longest list observed: 2,840) -- but never more
+                # than LIST_BUDGET_BYTES for all lists together: one global capacity serves every tile of every plane, so
+                # a scene with few coarse tiles and many samples per ray (INS Indoor: S = 1045) would otherwise reserve tens
+                # of GB.  Overflow is still correct (spill area, sized for the worst case), only slower.
                 tiles_min = min(((p.shape[2] + 15) // 16) * ((p.shape[3] + 15) // 16) for p in self.planes)
-                tile_capacity = int(min(max(4096, 4 * 1.3 * R * S / tiles_min), 1 << 20))
-            self.tile_lists = torch.zeros(n_tiles, tile_capacity, 8, device=dev, dtype=torch.int32)
+                tile_capacity = int(max(4096, 4 * 1.3 * R * S / tiles_min))
+                tile_capacity = max(256, min(tile_capacity, self.LIST_BUDGET_BYTES // (32 * max(n_tiles, 1))))
+            # (only the counters need to start at zero: an entry is read after it was written)
+            self.tile_lists = torch.empty(n_tiles, tile_capacity, 8, device=dev, dtype=torch.int32)
             self.tile_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
             if spill_capacity is None:
                 # worst case: every sample appends to 4 tiles of every plane and every entry overflows its list --
                 # then nothing can ever be dropped (small scenes put >4096 samples into most tiles; office0 none)
                 spill_capacity = R * S * len(self.planes) * 4
-            self.spill = torch.zeros(spill_capacity, 8, device=dev, dtype=torch.int32)
+            self.spill = torch.empty(spill_capacity, 8, device=dev, dtype=torch.int32)
             self.spill_count = torch.zeros(1, device=dev, dtype=torch.int32)
             self.dropped = torch.zeros(1, device=dev, dtype=torch.int32)
             b = _lib.TileBins()

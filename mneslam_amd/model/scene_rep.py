@@ -119,12 +119,13 @@ class JointEncoding(nn.Module):
         """Host copy of ``bounding_box`` / ``bound`` (device tensors in the live system): fetched once per distinct
         tensor / in-place version instead of one device synchronisation per render call."""
         t = getattr(self, attr)
-        key = (id(t), getattr(t, "_version", None), getattr(t, "dtype", None))
         caches = self.__dict__.setdefault("_host_cache", {})
         hit = caches.get(attr)
-        if hit is None or hit[0] != key:
-            hit = caches[attr] = (key, torch.as_tensor(t).detach().cpu())
-        return hit[1]
+        # the cache entry HOLDS the tensor it was made from: `is` cannot be fooled by a freed tensor's recycled id()
+        # (load_foreign_model re-binds bound / bounding_box to fresh tensors on every peer checkpoint, ADVICE r02)
+        if hit is None or hit[0] is not t or hit[1] != getattr(t, "_version", None):
+            hit = caches[attr] = (t, getattr(t, "_version", None), torch.as_tensor(t).detach().cpu())
+        return hit[2]
 
     def _flat_planes(self):
         planes = [p for lst in self.all_planes for p in lst]
