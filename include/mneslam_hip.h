@@ -229,6 +229,15 @@ int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, in
                        float* rgb, float* depth, float* disp, float* acc, float* depth_var,
                        float* raw, float* ray_sums, const int32_t* ray_counts, int flags, void* stream);
 
+/* mne_render_forward for a scene encoding that is the caller's (NS-a: hash / dense grid): `features` [R*S][64] holds the
+ * decoder's feature input of every sample (row = ray * n_samples + sample; e.g. filled by mne_hash_features); the plane
+ * descriptors of `scene` are ignored.  Everything else as mne_render_forward. */
+int mne_render_forward_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                                const float* rays_o, const float* rays_d, const float* target_rgb,
+                                const float* target_d, const float* z_vals, const float* packed_decoder,
+                                const float* features, float* rgb, float* depth, float* disp, float* acc, float* depth_var,
+                                float* raw, float* ray_sums, const int32_t* ray_counts, int flags, void* stream);
+
 /* ---- R10: loss scalars ------------------------------------------------------------------- */
 /* losses[MNE_N_LOSS] = rgb, depth, co_sdf, co_fs, e_fs, e_center, e_tail, psnr with the reference's
  * normalisations (means over selections; empty selection -> NaN; Co-SLAM count weights). */
@@ -294,6 +303,17 @@ typedef struct mne_fused_opts {
     int32_t reserved;
     void* event_after_decode;
 } mne_fused_opts_t;
+
+/* mne_render_backward for a caller-owned encoding: the feature columns of every tape row ([64] floats at column 0 of row
+ * ray * n_samples + sample) are filled by the caller before the call (mne_hash_gather); no plane gradients and no ray
+ * gradients -- the d(feature) rows of every sample of the first ray_tiles[r] tiles of ray r are left in the tape (column
+ * mne_tape_dfeat_offset) for the caller's scatter (mne_hash_scatter); tape rows for mne_decoder_wgrad as usual. */
+int mne_render_backward_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                                 const float* rays_o, const float* rays_d, const float* target_rgb,
+                                 const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                                 const float* packed_decoder, const float* raw, const float* coef, const float* g_rgb,
+                                 const float* g_depth, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                                 int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused training form of the two calls above (what Mapper.mapping_optimize runs per iteration), with early ray
  * termination: decodes every ray up to the last sample it needs (tile-parallel for the samples ray_counts marks,
@@ -380,6 +400,11 @@ int mne_query_points(const mne_scene_t* scene, int64_t n_pts, const float* pts,
                      const float* packed_decoder, float* raw, float* geo, float* feat,
                      int32_t* corner_idx, int flags, void* stream);
 
+/* mne_query_points for a caller-owned encoding: `features` [N][64] = the decoder's feature input of every point (e.g.
+ * mne_grid_encode_box with out_stride 64 into a zero-initialised buffer). */
+int mne_query_features(const mne_scene_t* scene, int64_t n_pts, const float* pts, const float* features,
+                       const float* packed_decoder, float* raw, float* geo, void* stream);
+
 /* ---- R7: OneBlob encoding as a stand-alone op -------------------------------------------- */
 /* Replaces tcnn.Encoding(otype="OneBlob", n_bins=16) (model/encodings.py:61-71):
  * x [N][dims] in [0,1] -> out [N][dims*16], layout [dim0 bins | dim1 bins | ...]. */
@@ -401,6 +426,10 @@ size_t mne_grid_param_count(const mne_grid_cfg_t* cfg);
  * indices within each level (the "integer hash indices" of this encoding) */
 int mne_grid_encode(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, const float* params,
                     float* out, uint32_t* idx, void* stream);
+/* the same for WORLD points: x = (p - bb_lo) / (bb_hi - bb_lo) with scene's raw bounding box, exactly the OneBlob input
+ * of the render kernels; out rows are out_stride floats apart (>= n_levels*n_features; the rest of a row is untouched) */
+int mne_grid_encode_box(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int64_t n_pts, const float* pts,
+                        const float* params, float* out, int out_stride, void* stream);
 /* d(params) += scatter of dout [N][n_levels*n_features] (dparams pre-zeroed by the caller) */
 int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, const float* dout,
                              float* dparams, void* stream);
@@ -436,6 +465,10 @@ int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int
                         const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
 int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                     const float* rays_d, const float* z_vals, const float* table, float* tape, void* stream);
+/* the grid features of every sample as compact rows: features [R*S][64], columns [0, n_levels*2) written, the rest
+ * untouched (zero-initialise once): the input of mne_render_forward_features */
+int mne_hash_features(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                      const float* rays_d, const float* z_vals, const float* table, float* features, void* stream);
 int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                               const float* rays_o, const float* rays_d, const float* target_rgb, const float* target_d,
                               const float* z_vals, const int32_t* ray_counts, const float* packed_decoder, const float* coef,

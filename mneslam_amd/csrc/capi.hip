@@ -141,12 +141,13 @@ int mne_pack_decoder(const mne_scene_t* scene, float* packed, void* stream) {
     return check_launch("pack_decoder");
 }
 
-int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+static int render_forward(const float* features, const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                        const float* rays_o, const float* rays_d, const float* target_rgb,
                        const float* target_d, const float* z_vals, const float* packed_decoder,
                        float* rgb, float* depth, float* disp, float* acc, float* depth_var,
                        float* raw, float* ray_sums, const int32_t* ray_counts, int flags, void* stream) {
-    if (int rc = check_scene(scene, false)) return rc;
+    if (int rc = check_scene(scene, false, features == nullptr)) return rc;
+    if (features && scene->n_sets != 1) return fail(-2, "caller-supplied features replace ONE plane set (no colour planes)");
     if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw) return fail(-1, "mne_render_forward: NULL argument");
     if (n_rays <= 0) return 0;
     if (n_samples < 1 || n_samples > 16384) return fail(-1, "samples per ray out of range");
@@ -164,8 +165,28 @@ int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, in
     const bool early = (flags & MNE_RENDER_EARLY_TERMINATION) != 0;
     a.ray_counts = early ? ray_counts : nullptr;
     a.prefix_default = early ? 1 : (1 << 30);
+    if (features) { a.ext_feat = 1; a.ext_rows = features; a.ext_stride = 64; }
     if (int rc = mne_launch_render(a, early ? 1 : 0, nullptr, RenderHost{}, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_forward");
+}
+
+int mne_render_forward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                       const float* rays_o, const float* rays_d, const float* target_rgb,
+                       const float* target_d, const float* z_vals, const float* packed_decoder,
+                       float* rgb, float* depth, float* disp, float* acc, float* depth_var,
+                       float* raw, float* ray_sums, const int32_t* ray_counts, int flags, void* stream) {
+    return render_forward(nullptr, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, packed_decoder, rgb,
+                          depth, disp, acc, depth_var, raw, ray_sums, ray_counts, flags, stream);
+}
+
+int mne_render_forward_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                                const float* rays_o, const float* rays_d, const float* target_rgb,
+                                const float* target_d, const float* z_vals, const float* packed_decoder,
+                                const float* features, float* rgb, float* depth, float* disp, float* acc, float* depth_var,
+                                float* raw, float* ray_sums, const int32_t* ray_counts, int flags, void* stream) {
+    if (!features) return fail(-1, "mne_render_forward_features: features is NULL");
+    return render_forward(features, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, packed_decoder, rgb,
+                          depth, disp, acc, depth_var, raw, ray_sums, ray_counts, flags, stream);
 }
 
 int mne_loss_finalize(int n_rays, int n_samples, const float* ray_sums, const int32_t* counts, float* losses,
@@ -206,7 +227,7 @@ static int fill_bins(const mne_scene_t* scene, const mne_tile_bins_t* bins, Tile
     return 0;
 }
 
-int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+static int render_backward(bool ext_feat, const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                         const float* rays_o, const float* rays_d, const float* target_rgb,
                         const float* target_d, const float* z_vals, const int32_t* ray_counts,
                         const float* packed_decoder, const float* raw, const float* coef, const float* g_rgb,
@@ -214,7 +235,9 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
                         int32_t* ray_tiles, float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
                         void* stream) {
     // plane gradients are optional as a whole: all plane[].grad NULL = ray / decoder gradients only
-    if (int rc = check_scene(scene, scene && scene->plane[0][0][0].grad != nullptr)) return rc;
+    if (int rc = check_scene(scene, !ext_feat && scene && scene->plane[0][0][0].grad != nullptr, !ext_feat)) return rc;
+    if (ext_feat && (d_rays_o || d_rays_d)) return fail(-2, "ray gradients need the plane encoding (not provided for caller-supplied features)");
+    if (ext_feat && scene->n_sets != 1) return fail(-2, "caller-supplied features replace ONE plane set (no colour planes)");
     if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows || !ray_tiles || !workspace)
         return fail(-1, "mne_render_backward: NULL argument");
     if (n_rays <= 0) return 0;
@@ -234,9 +257,36 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
     a.coef = coef; a.g_rgb = g_rgb; a.g_depth = g_depth;
     a.tape = tape; a.tape_rows = tape_rows; a.ray_tiles = ray_tiles;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d;
+    a.ext_feat = ext_feat ? 1 : 0;
     if (int rc = mne_launch_render(a, 3, workspace, RenderHost{}, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_backward");
 }
+
+extern "C" {
+int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                        const float* rays_o, const float* rays_d, const float* target_rgb,
+                        const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                        const float* packed_decoder, const float* raw, const float* coef, const float* g_rgb,
+                        const float* g_depth, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                        int32_t* ray_tiles, float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    return render_backward(false, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, ray_counts, packed_decoder,
+                           raw, coef, g_rgb, g_depth, tape, tape_capacity_rows, tape_rows, ray_tiles, d_rays_o, d_rays_d, workspace,
+                           workspace_bytes, stream);
+}
+
+int mne_render_backward_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
+                                 const float* rays_o, const float* rays_d, const float* target_rgb,
+                                 const float* target_d, const float* z_vals, const int32_t* ray_counts,
+                                 const float* packed_decoder, const float* raw, const float* coef, const float* g_rgb,
+                                 const float* g_depth, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
+                                 int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream) {
+    return render_backward(true, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, ray_counts, packed_decoder,
+                           raw, coef, g_rgb, g_depth, tape, tape_capacity_rows, tape_rows, ray_tiles, nullptr, nullptr, workspace,
+                           workspace_bytes, stream);
+}
+}   // extern "C"
+
 
 }   // extern "C"
 
@@ -530,6 +580,18 @@ int mne_encode_oneblob(int64_t n_pts, int dims, const float* x, float* out, void
     return check_launch("encode_oneblob");
 }
 
+int mne_query_features(const mne_scene_t* scene, int64_t n_pts, const float* pts, const float* features,
+                       const float* packed_decoder, float* raw, float* geo, void* stream) {
+    if (int rc = check_scene(scene, false, false)) return rc;
+    if (!pts || !features || !packed_decoder || (!raw && !geo)) return fail(-1, "mne_query_features: NULL argument");
+    if (scene->n_sets != 1) return fail(-2, "caller-supplied features replace ONE plane set (no colour planes)");
+    if (n_pts <= 0) return 0;
+    QueryArgs a = {};
+    a.sc = *scene; a.n = n_pts; a.pts = pts; a.packed = packed_decoder; a.raw = raw; a.geo = geo; a.ext_rows = features;
+    if (int rc = mne_launch_query(a, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
+    return check_launch("query_features");
+}
+
 int mne_query_points(const mne_scene_t* scene, int64_t n_pts, const float* pts, const float* packed_decoder,
                      float* raw, float* geo, float* feat, int32_t* corner_idx, int flags, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
@@ -593,6 +655,19 @@ int mne_grid_encode(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, co
     return check_launch("grid_encode");
 }
 
+int mne_grid_encode_box(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int64_t n_pts, const float* pts,
+                        const float* params, float* out, int out_stride, void* stream) {
+    GridArgs a = {};
+    if (int rc = fill_grid(cfg, a)) return rc;
+    if (!scene || !pts || !params || !out || out_stride < a.out_dim) return fail(-1, "mne_grid_encode_box: bad argument");
+    if (n_pts <= 0) return 0;
+    a.n = n_pts; a.x = pts; a.params = params; a.out = out; a.out_stride = out_stride; a.x_is_world = 1;
+    for (int k = 0; k < 3; ++k) { a.bb_lo[k] = scene->bb_lo[k]; a.bb_hi[k] = scene->bb_hi[k]; }
+    a.bb_is_f64 = scene->bb_is_f64;
+    mne_launch_grid(a, 0, (hipStream_t)stream);
+    return check_launch("grid_encode_box");
+}
+
 int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const float* x, const float* dout,
                              float* dparams, void* stream) {
     GridArgs a = {};
@@ -632,6 +707,18 @@ int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_r
     a.params = table;
     mne_launch_hash_rows(a, 0, (hipStream_t)stream);
     return check_launch("hash_gather");
+}
+
+int mne_hash_features(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                      const float* rays_d, const float* z_vals, const float* table, float* features, void* stream) {
+    GridArgs a = {};
+    if (int rc = fill_hash_rows(cfg, scene, n_rays, n_samples, rays_o, rays_d, z_vals, features, a)) return rc;
+    if (!table) return fail(-1, "mne_hash_features: NULL argument");
+    if (n_rays <= 0) return 0;
+    a.params = table;
+    a.row_stride = 64; a.col_x = 0;            // compact [R*S][64] rows (the decoder's feature slot), not tape rows
+    mne_launch_hash_rows(a, 0, (hipStream_t)stream);
+    return check_launch("hash_features");
 }
 
 size_t mne_hash_workspace_bytes(int n_rays, int n_samples) {

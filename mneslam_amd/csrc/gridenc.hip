@@ -27,15 +27,18 @@ __global__ __launch_bounds__(256) void grid_kernel(GridArgs a) {
     uint32_t cell[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const float pos = fmaf(scale, a.x[t * 3 + d], 0.5f);
+        float x = a.x[t * 3 + d];
+        if (a.x_is_world) x = unit_coord(x, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
+        const float pos = fmaf(scale, x, 0.5f);
         const float fl = floorf(pos);
         cell[d] = (uint32_t)(int)fl;
         frac[d] = pos - fl;
     }
     const int F = a.n_features;
+    const long long ostr = a.out_stride ? a.out_stride : a.out_dim;
     float acc[MNE_GRID_MAX_F];
 #pragma unroll
-    for (int f = 0; f < MNE_GRID_MAX_F; ++f) acc[f] = BWD ? a.dout[t * a.out_dim + level * F + (f < F ? f : 0)] : 0.0f;
+    for (int f = 0; f < MNE_GRID_MAX_F; ++f) acc[f] = BWD ? a.dout[t * ostr + level * F + (f < F ? f : 0)] : 0.0f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float w = 1.0f;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void grid_kernel(GridArgs a) {
         }
     }
     if (!BWD)
-        for (int f = 0; f < F; ++f) a.out[t * a.out_dim + level * F + f] = acc[f];
+        for (int f = 0; f < F; ++f) a.out[t * ostr + level * F + f] = acc[f];
 }
 
 // ---- fused form: the encoding of a ray batch's samples, written as (read from) rows of the render tape ----------

@@ -67,6 +67,8 @@ struct RenderArgs {
     char args_pad[MNE_ARGS_PAD];
 #endif
     int ext_feat;                // feature rows come from the caller (tape columns T_X..): no plane gather, no plane scatter
+    const float* ext_rows;       // forward-only calls with caller-supplied features: [R*S][ext_stride] rows, 64 floats used
+    int ext_stride;
     const int* ray_counts;      // [R][MNE_N_COUNT] from sample_z (slot MNE_C_NEED = a-priori sample count)
     int prefix_default;         // ray_counts == NULL: a-priori tiles of every ray (ntile = decode everything, 1 = on demand only)
     const float *coef, *g_rgb, *g_depth;
@@ -117,6 +119,7 @@ struct QueryArgs {
     const float* pts;
     const float* packed;
     float *raw, *geo, *feat_out;
+    const float* ext_rows;   // optional [n][64]: the points' feature rows come from the caller (hash / dense grid) instead of the planes
     int* corner_idx;     // optional [n][3*n_sets][2][2]: (ix0, iy0) per plane
     int flags;
 };
@@ -152,11 +155,13 @@ struct GridArgs {
     long long n;                 // points
     const float* x;              // [n][3] in [0,1]
     const float* params;         // flat table, level after level, F floats per entry
-    float* out;                  // [n][n_levels*F]
+    float* out;                  // [n][out_stride] (n_levels*F used)
     unsigned* idx_out;           // optional [n][n_levels][8] table indices (within the level)
     const float* dout;           // backward: [n][n_levels*F]
     float* dparams;              // backward: same layout as params, accumulated into
     int n_levels, n_features, out_dim;
+    int out_stride;              // row length of `out` / `dout` (0 = out_dim)
+    int x_is_world;              // x holds world points: the grid input is (p - bb_lo) / (bb_hi - bb_lo), as the OneBlob input
     float scale[MNE_GRID_MAX_LEVELS];
     unsigned res[MNE_GRID_MAX_LEVELS], size[MNE_GRID_MAX_LEVELS], offset[MNE_GRID_MAX_LEVELS];
     // fused form (hash_rows_kernel): the points are the samples of a ray batch, the outputs rows of the tape

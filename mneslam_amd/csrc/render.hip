@@ -270,7 +270,8 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     MNE_WAVE_SYNC();                                       // earlier LDS reads of this wave are done
     if (PRE) {
         DEC_STAMP(1);
-        load_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
+        if (a.ext_rows) load_rows<MNE_FEAT>(feat, a.ext_rows + ((size_t)r * S + (size_t)c * TILE) * a.ext_stride, a.ext_stride, 0, live, lane);
+        else load_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
         if (CP) load_rows<MNE_FEAT>(feat + TILE * MNE_FS, tape0, D::ROW, D::T_CF, live, lane);
         MNE_WAVE_SYNC();
         DEC_STAMP(2);
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
         // is still unresolved.)  dec_tiles[r] = tiles decoded in the end.  One decode_tile call site for both uses.
         const bool resolver = a.dec_tiles && a.ray_counts && !a.ray_list && c == prefix_tiles(a, r, ntile) - 1;
         int cc = c;
-        bool found = false, have_carry = false, pre_now = pre != 0 || a.ext_feat != 0;   // ext_feat: every row's features are in the tape
+        bool found = false, have_carry = false, pre_now = pre != 0 || a.ext_feat != 0;   // ext_feat: every row's features are the caller's
         float z_lim = 0.0f, s_carry = 0.0f;
         const float* zr = a.z_vals + (size_t)r * a.S;
         while (true) {
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
                 // decode the next tile on demand (Dn is a multiple of TILE here)
                 float pnv[3], u[3];
                 uint2 relu;
-                const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu);
+                const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu, -1, a.ext_feat != 0);
                 const int i = t_dec * TILE + pt;
                 if (i < S && hf == 0) *(float4*)(raws + 4 * i) = rw;
                 MNE_WAVE_SYNC();
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             const size_t e = (size_t)r * S + ii;
             uint2 mk2;
             if (LATE_DECODE && c >= t_dec) {                      // tape rows of this tile are missing: decode it now
-                decode_tile<HID, HIDC, CP, !ALDS>(a, r, c, lane, pn, feat, atab, pnv, u, mk2);
+                decode_tile<HID, HIDC, CP, !ALDS>(a, r, c, lane, pn, feat, atab, pnv, u, mk2, -1, a.ext_feat != 0);
                 t_dec = c + 1;
             } else {
 #pragma unroll
@@ -1279,7 +1280,12 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a) {
                 dst[0] = b.ix0; dst[1] = b.iy0;
             }
     }
-    gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+    if (a.ext_rows) {                                       // caller-supplied feature rows (hash / dense grid model)
+        const unsigned live = (unsigned)__ballot(valid && hf == 0);
+        load_rows<MNE_FEAT>(feat, a.ext_rows + (size_t)tile * TILE * MNE_FEAT, MNE_FEAT, 0, live, lane);
+    } else {
+        gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+    }
     MNE_WAVE_SYNC();
     if (a.feat_out && valid) {
 #pragma unroll

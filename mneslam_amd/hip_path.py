@@ -262,3 +262,155 @@ def query_points(info, planes, dec_w, pts, want_raw=True, want_geo=False, want_f
     if want_corner_idx:
         return raw, geo, feat, cidx
     return raw, geo, feat
+
+
+# --------------------------------------------------------------------------------------------------
+# NS-a: the same surface for a scene model whose encoding is a multiresolution hash / dense grid
+# (model/scene_rep_hash.py; EXTENSION, parity unpinned).  The grid features are the caller-supplied feature rows of the
+# *_features entry points; everything behind them (OneBlob, decoder, compositing, losses) is the tri-plane path's.
+# --------------------------------------------------------------------------------------------------
+def _hash_scene(info, dec_w):
+    sc = scene_struct(info, [], [w.detach() for w in dec_w])
+    sc.n_sets = 1
+    return sc
+
+
+def _hash_forward(lib, info, grid_cfg, tables, rays_o, rays_d, tgt_rgb, tgt_d, u, seed_offset, table, dec_w, early, want_losses):
+    """sample_z + pack + grid features of every sample + forward render.  Returns everything a caller may need."""
+    dev, st = rays_o.device, _lib.stream_for(rays_o)
+    rc = info["render_cfg"]
+    R = rays_o.shape[0]
+    has_d = tgt_d is not None
+    S = lib.mne_num_samples(C.byref(rc), 1 if has_d else 0)
+    opts = dict(device=dev, dtype=torch.float32)
+    z_vals = torch.empty(R, S, **opts)
+    counts = torch.empty(_lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
+    ray_counts = torch.empty(R, _lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
+    seed, offset = seed_offset
+    _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u), _lib.ptr(tables), seed, offset,
+                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), None, st), "mne_sample_z")
+    sc = _hash_scene(info, dec_w)
+    packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
+    _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
+    feats = torch.zeros(R * S, 64, **opts)               # the grid fills the first n_levels*2 columns of the 64-wide slot
+    _lib.check(lib.mne_hash_features(C.byref(grid_cfg), C.byref(sc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals),
+                                     _lib.ptr(table.detach()), _lib.ptr(feats), st), "mne_hash_features")
+    rgb, depth = torch.empty(R, 3, **opts), torch.empty(R, **opts)
+    disp, acc, var = torch.empty(R, **opts), torch.empty(R, **opts), torch.empty(R, **opts)
+    raw = torch.empty(R, S, 4, **opts)
+    ray_sums = torch.empty(R, _lib.N_LOSS, **opts) if want_losses else None
+    _lib.check(lib.mne_render_forward_features(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                                               _lib.ptr(tgt_rgb) if want_losses else None, _lib.ptr(tgt_d), _lib.ptr(z_vals),
+                                               _lib.ptr(packed), _lib.ptr(feats), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(disp),
+                                               _lib.ptr(acc), _lib.ptr(var), _lib.ptr(raw), _lib.ptr(ray_sums),
+                                               _lib.ptr(ray_counts) if early else None,
+                                               _lib.RENDER_EARLY_TERMINATION if early else 0, st), "mne_render_forward_features")
+    return dict(S=S, sc=sc, z_vals=z_vals, counts=counts, ray_counts=ray_counts, packed=packed, rgb=rgb, depth=depth, disp=disp,
+                acc=acc, var=var, raw=raw, ray_sums=ray_sums)
+
+
+class HashRenderFunction(torch.autograd.Function):
+    """RenderFunction for a hash / dense grid scene model:
+       (rays, targets, jitter, table, decoder weights...) -> rgb, depth, disp, acc, depth_var, z_vals, raw, losses[8].
+    forward  = mne_sample_z + mne_pack_decoder + mne_hash_features + mne_render_forward_features (+ mne_loss_finalize)
+    backward = mne_loss_coef + mne_hash_gather + mne_render_backward_features + mne_hash_scatter + mne_decoder_wgrad.
+    Differentiable w.r.t. the table and the decoder; ray gradients need the plane encoding and raise."""
+
+    @staticmethod
+    def forward(ctx, info, grid_cfg, tables, rays_o, rays_d, target_rgb, target_d, u, seed_offset, table, *dec_w):
+        lib = _lib.load()
+        rays_o_c, rays_d_c = _f32c(rays_o.detach(), "rays_o"), _f32c(rays_d.detach(), "rays_d")
+        tgt_rgb = _f32c(target_rgb, "target_rgb")
+        tgt_d = _f32c(target_d.reshape(-1), "target_d") if target_d is not None else None
+        want_losses = tgt_d is not None and target_rgb is not None
+        f = _hash_forward(lib, info, grid_cfg, tables, rays_o_c, rays_d_c, tgt_rgb, tgt_d, _f32c(u, "u"), seed_offset, table, dec_w,
+                          early=False, want_losses=want_losses)
+        losses = torch.zeros(_lib.N_LOSS, device=rays_o.device, dtype=torch.float32)
+        if want_losses:
+            _lib.check(lib.mne_loss_finalize(rays_o.shape[0], f["S"], _lib.ptr(f["ray_sums"]), _lib.ptr(f["counts"]), _lib.ptr(losses),
+                                             _lib.stream_for(rays_o)), "mne_loss_finalize")
+        ctx.info, ctx.grid_cfg, ctx.S, ctx.want_losses = info, grid_cfg, f["S"], want_losses
+        ctx.save_for_backward(rays_o_c, rays_d_c, tgt_rgb, tgt_d, f["z_vals"], f["raw"], f["counts"], f["ray_counts"], f["packed"],
+                              table, *dec_w)
+        ctx.mark_non_differentiable(f["disp"], f["acc"], f["var"], f["z_vals"], f["raw"])
+        return f["rgb"], f["depth"], f["disp"], f["acc"], f["var"], f["z_vals"], f["raw"], losses
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_disp, g_acc, g_var, g_z, g_raw, g_losses):
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            raise NotImplementedError("ray gradients (pose optimisation) are provided for the tri-plane encoding only")
+        lib = _lib.load()
+        info, S, gc = ctx.info, ctx.S, ctx.grid_cfg
+        rays_o, rays_d, tgt_rgb, tgt_d, z_vals, raw, counts, ray_counts, packed, table, *dec_w = ctx.saved_tensors
+        dev, st = rays_o.device, _lib.stream_for(rays_o)
+        rc = info["render_cfg"]
+        R = rays_o.shape[0]
+        opts = dict(device=dev, dtype=torch.float32)
+        sc = _hash_scene(info, dec_w)
+        coef = None
+        if ctx.want_losses and g_losses is not None:
+            coef = torch.empty(_lib.N_LOSS, **opts)
+            _lib.check(lib.mne_loss_coef(C.byref(rc), R, S, _lib.ptr(counts), _lib.ptr(_f32c(g_losses, "g")), _lib.ptr(coef), st),
+                       "mne_loss_coef")
+        row = lib.mne_tape_row_floats(C.byref(sc))
+        tape = torch.empty(R * S, row, **opts)
+        tape[:, :64].zero_()                               # feature columns the grid does not fill must read as zero
+        _lib.check(lib.mne_hash_gather(C.byref(gc), C.byref(sc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals),
+                                       _lib.ptr(table.detach()), _lib.ptr(tape), st), "mne_hash_gather")
+        tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        ray_tiles = torch.empty(R, device=dev, dtype=torch.int32)
+        ws_bytes = lib.mne_render_workspace_bytes(R, S)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        _lib.check(lib.mne_render_backward_features(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                                                    _lib.ptr(tgt_rgb) if coef is not None else None, _lib.ptr(tgt_d),
+                                                    _lib.ptr(z_vals), _lib.ptr(ray_counts), _lib.ptr(packed), _lib.ptr(raw),
+                                                    _lib.ptr(coef), _lib.ptr(_f32c(g_rgb, "g_rgb")), _lib.ptr(_f32c(g_depth, "g_depth")),
+                                                    _lib.ptr(tape), R * S, _lib.ptr(tape_rows), _lib.ptr(ray_tiles), _lib.ptr(ws),
+                                                    ws_bytes, st), "mne_render_backward_features")
+        g_table = None
+        if ctx.needs_input_grad[9]:
+            g_table = torch.zeros_like(table)
+            _lib.check(lib.mne_hash_scatter(C.byref(gc), C.byref(sc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals),
+                                            _lib.ptr(tape), _lib.ptr(ray_tiles), _lib.ptr(g_table), st), "mne_hash_scatter")
+        partials = torch.empty(lib.mne_wgrad_partial_floats(C.byref(sc)), **opts)
+        dgrad = torch.empty(lib.mne_decoder_param_floats(C.byref(sc)), **opts)
+        _lib.check(lib.mne_decoder_wgrad(C.byref(sc), _lib.ptr(tape), _lib.ptr(ray_tiles), R, S, _lib.ptr(partials),
+                                         _lib.ptr(dgrad), info.get("wgrad_impl", 0), st), "mne_decoder_wgrad")
+        w_sdf0, w_sdf1, w_col0, w_col1 = dec_w
+        n0, n1, n2 = w_col0.numel(), w_col1.numel(), w_sdf0.numel()
+        return (None, None, None, None, None, None, None, None, None, g_table,
+                dgrad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0), dgrad[n0 + n1 + n2:].view_as(w_sdf1),
+                dgrad[:n0].view_as(w_col0), dgrad[n0:n0 + n1].view_as(w_col1))
+
+
+@torch.no_grad()
+def hash_render_maps(info, grid_cfg, tables, rays_o, rays_d, target_d, u, seed_offset, table, dec_w):
+    """No-grad rendering with exact early ray termination for the hash / dense grid model (the counterpart of render_maps)."""
+    lib = _lib.load()
+    tgt_d = _f32c(target_d.reshape(-1), "target_d") if target_d is not None else None
+    f = _hash_forward(lib, info, grid_cfg, tables, _f32c(rays_o.detach(), "rays_o"), _f32c(rays_d.detach(), "rays_d"), None, tgt_d,
+                      _f32c(u, "u"), seed_offset, table, dec_w, early=True, want_losses=False)
+    return f["rgb"], f["depth"], f["disp"], f["acc"], f["var"]
+
+
+@torch.no_grad()
+def hash_query_points(info, grid_cfg, table, dec_w, pts, want_raw=True, want_geo=False, want_feat=False):
+    """Forward-only point query of the hash / dense grid model: raw [N,4], geo [N,15], feat [N, n_levels*2]."""
+    lib = _lib.load()
+    flat = _f32c(pts.reshape(-1, 3).detach(), "pts")
+    n = flat.shape[0]
+    opts = dict(device=flat.device, dtype=torch.float32)
+    st = _lib.stream_for(flat)
+    sc = _hash_scene(info, dec_w)
+    feats = torch.zeros(n, 64, **opts)
+    _lib.check(lib.mne_grid_encode_box(C.byref(grid_cfg), C.byref(sc), n, _lib.ptr(flat), _lib.ptr(table.detach()),
+                                       _lib.ptr(feats), 64, st), "mne_grid_encode_box")
+    raw = geo = None
+    if want_raw or want_geo:
+        packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
+        _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
+        raw = torch.empty(n, 4, **opts)
+        geo = torch.empty(n, info["geo_feat_dim"], **opts) if want_geo else None
+        _lib.check(lib.mne_query_features(C.byref(sc), n, _lib.ptr(flat), _lib.ptr(feats), _lib.ptr(packed), _lib.ptr(raw),
+                                          _lib.ptr(geo), st), "mne_query_features")
+    return raw, geo, (feats[:, :grid_cfg.n_levels * grid_cfg.n_features] if want_feat else None)

@@ -13,14 +13,17 @@ Layout choice: the decoder keeps a 64-wide feature slot (``input_ch`` 64, as wit
 gradients -- mathematically the [hidden, 32 + 48] first layer of the commented-out wiring, and the same HIP decoder
 kernels serve both encodings.
 
-Only the mapping iteration is provided for this model (``mneslam_amd.fused.HashFusedStep``, bench workload
-``replica_office0_hashT19_2x64_2048x128``): there is no reference behaviour to mirror for the other entry points.
+The mapping iteration is ``mneslam_amd.fused.HashFusedStep`` (bench workload ``replica_office0_hashT19_2x64_2048x128``);
+``render_rays`` / ``forward`` / ``render_img`` / ``render_maps`` / ``query_*`` / ``run_network*`` keep JointEncoding's
+signatures and run the same kernels with the grid features as caller-supplied feature rows (``hip_path.Hash*``); ray
+gradients (pose loops) need the plane encoding and raise.  ``grid.enc: dense`` gives BASELINE configs[0]'s 16^3 grid.
 """
 import torch
 
 from .decoder import ColorSDFNet_v2
 from .encodings import get_encoder
 from .scene_rep import JointEncoding
+from .. import hip_path
 from .utils import batchify
 
 
@@ -53,9 +56,45 @@ class HashJointEncoding(JointEncoding):
         info["n_planes"] = 0
         return info
 
-    def _no_planes(self, *a, **k):
-        raise NotImplementedError("HashJointEncoding provides the fused mapping iteration only (fused.HashFusedStep); "
-                                  "render_rays / forward / queries exist for the tri-plane model the reference runs")
+    # ------------------------------------------------------------------ rendering / queries (HIP, hip_path.Hash*)
+    def _render(self, rays_o, rays_d, target_rgb, target_d, u=None):
+        dev = rays_o.device
+        has_d = target_d is not None
+        if not has_d and not self.config["training"].get("n_samples"):
+            raise KeyError("n_samples")            # the reference raises the same
+        tables = hip_path.linspace_tables(self.config, has_d, dev)
+        seed_offset = (0, 0)
+        if u is None:
+            tr = self.config["training"]
+            S = (tr["n_range_d"] + tr["n_samples_d"]) if has_d else tr["n_samples"]
+            u, seed_offset = self._jitter(rays_o.shape[0], S, rays_o)
+        return hip_path.HashRenderFunction.apply(self._info(), self.embed_fn.cfg, tables, rays_o, rays_d, target_rgb, target_d, u,
+                                                 seed_offset, self.embed_fn.params, *self.decoder.hip_weights())
 
-    _render = render_rays = forward = render_img = render_maps = query_sdf = query_color = query_color_sdf = _no_planes
-    run_network = run_network_flat = render_surface_color = _no_planes
+    def render_maps(self, rays_o, rays_d, target_d=None, u=None):
+        dev = rays_o.device
+        has_d = target_d is not None
+        if not has_d and not self.config["training"].get("n_samples"):
+            raise KeyError("n_samples")
+        tr = self.config["training"]
+        S = (tr["n_range_d"] + tr["n_samples_d"]) if has_d else tr["n_samples"]
+        seed_offset = (0, 0)
+        if u is None:
+            u, seed_offset = self._jitter(rays_o.shape[0], S, rays_o)
+        rgb, depth, disp, acc, var = hip_path.hash_render_maps(self._info(), self.embed_fn.cfg, hip_path.linspace_tables(self.config, has_d, dev),
+                                                               rays_o, rays_d, target_d, u, seed_offset, self.embed_fn.params,
+                                                               self.decoder.hip_weights())
+        return {"rgb": rgb, "depth": depth, "disp_map": disp, "acc_map": acc, "depth_var": var}
+
+    # render_rays / forward / render_img / query_color / run_network(_flat) / render_surface_color are JointEncoding's: they
+    # go through _render, render_maps and _query.  Whole-frame renders hold one 256-byte feature row per sample:
+    render_chunk_rays = 1 << 16
+
+    def _query(self, pts, want_raw=True, want_geo=False, want_feat=False, **unsupported):
+        if unsupported.get("normalised") or unsupported.get("want_corner_idx"):
+            raise NotImplementedError("plane coordinates / corner indices belong to the tri-plane encoding")
+        return hip_path.hash_query_points(self._info(), self.embed_fn.cfg, self.embed_fn.params, self.decoder.hip_weights(), pts,
+                                          want_raw=want_raw, want_geo=want_geo, want_feat=want_feat)
+
+    def sample_plane_feature(self, *a, **k):
+        raise NotImplementedError("HashJointEncoding has no planes (model/scene_rep.py:28-53 belongs to the tri-plane wiring)")

@@ -41,6 +41,7 @@ def fixture_inputs(g, requires_grad=False):
 
 
 def assert_close(a, b, rtol=1e-5, atol=1e-6, what=""):
+    a, b = [t.detach().cpu() if torch.is_tensor(t) else t for t in (a, b)]
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"

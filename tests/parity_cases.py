@@ -2,10 +2,12 @@
 two backends: the real library on an MI355X (tests/test_hip_parity_gpu.py, ``-m gpu``) and the
 test-only host emulation of the same kernel sources (tests/test_kernels_hostemu.py, CPU).
 Every function takes the torch device to run on."""
+import copy
 import random
 import types
 
 import numpy as np
+import pytest
 import torch
 
 from mneslam_amd import configs, slam_glue
@@ -1047,3 +1049,148 @@ def check_quality_trajectory(device, n_iters=30):
         assert abs(p_h - p_o) < 0.05 + 0.01 * abs(p_o) and abs(d_h - d_o) < 0.02 * max(d_o, 0.05), (it, p_h, p_o, d_h, d_o)
     assert rows[-1][1] > rows[0][1] + 1.0, "PSNR did not improve"
     return rows
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NS-a: the full JointEncoding surface of the hash / dense grid model against oracle.scene_rep.OracleHashScene
+# ---------------------------------------------------------------------------------------------------------------------
+def _hash_model_and_oracle(device, cfg, seed=4, table_scale=200.0):
+    from oracle.scene_rep import OracleHashScene
+    from mneslam_amd.model.scene_rep_hash import HashJointEncoding
+    torch.manual_seed(seed)
+    bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
+    m = HashJointEncoding(cfg, bb.to(device)).to(device)
+    with torch.no_grad():
+        m.embed_fn.params.mul_(table_scale)                 # U(-1e-4, 1e-4) features would leave the decoder blind
+    gc = m.embed_fn.cfg
+    scales, _, _, _ = m.embed_fn.level_table()
+    grid = dict(n_levels=gc.n_levels, n_features=gc.n_features, base_resolution=gc.base_resolution,
+                per_level_scale=gc.per_level_scale, log2_hashmap_size=gc.log2_hashmap_size)
+    if gc.grid_type == 1:
+        grid["grid_type"] = "dense"
+    sc = OracleHashScene(cfg, bb, m.embed_fn.params.detach().cpu().clone(), grid, scales=scales)
+    sd = {k: v.detach().cpu().clone() for k, v in m.decoder.state_dict().items()}
+    sc.col_w = [sd["color_net.model.0.weight"], sd["color_net.model.2.weight"]]
+    sc.sdf_w = [sd["sdf_net.model.0.weight"], sd["sdf_net.model.2.weight"]]
+    return m, sc
+
+
+def _synthetic_rays(cfg, n_rays, seed=0, img=(34, 60)):
+    """Rays of a synthetic frame inside the config's bound (camera rays, rgb, depth with a few invalid pixels)."""
+    from mneslam_amd import synthetic
+    H, W = img
+    fr = synthetic.make_frames(1, H, W, W / 2.0, W / 2.0, (W - 1) / 2.0, (H - 1) / 2.0, synthetic.room_from_config(cfg), seed=seed)[0]
+    g = torch.Generator().manual_seed(seed + 1)
+    idx = torch.randperm(H * W, generator=g)[:n_rays]
+    d_cam = fr["direction"].reshape(-1, 3)[idx]
+    rays_d = torch.sum(d_cam[:, None, :] * fr["c2w"][:3, :3], -1)
+    rays_o = fr["c2w"][None, :3, 3].repeat(n_rays, 1)
+    return rays_o, rays_d, fr["rgb"].reshape(-1, 3)[idx], fr["depth"].reshape(-1, 1)[idx], fr
+
+
+def check_hash_scene_api(device, cfg, n_rays=48, co=False, img=(34, 60)):
+    """HashJointEncoding.render_rays / forward (+ backward) / render_maps / render_img / query_* against the oracle."""
+    cfg = copy.deepcopy(cfg)
+    cfg["is_co_sdf"] = co
+    m, sc = _hash_model_and_oracle(device, cfg)
+    m.train()
+    H, W = img
+    cam = dict(H=H, W=W, fx=W / 2.0, fy=W / 2.0, cx=(W - 1) / 2.0, cy=(H - 1) / 2.0)
+    rays_o, rays_d, rgb, dep, fr = _synthetic_rays(cfg, n_rays, img=img)
+    dev = torch.device(device)
+    ro, rd, tr_, td = rays_o.to(dev), rays_d.to(dev), rgb.to(dev), dep.to(dev)
+    tr = cfg["training"]
+    S = tr["n_range_d"] + tr["n_samples_d"]
+    U = torch.rand(n_rays, S, generator=torch.Generator().manual_seed(3))
+    # ---- render_rays with depth guidance: maps and raw of EVERY sample
+    out = m._render(ro, rd, None, td, u=U.to(dev))
+    z = out[5].cpu()
+    ref = sc.render_rays(rays_o, rays_d, target_d=dep, z_vals=z)
+    assert_close(out[0].cpu(), ref["rgb"], rtol=1e-4, atol=2e-5, what="hash render_rays rgb")
+    assert_close(out[1].cpu(), ref["depth"], rtol=1e-4, atol=2e-5, what="hash render_rays depth")
+    assert_close(out[6].cpu(), ref["raw"], rtol=1e-4, atol=2e-5, what="hash render_rays raw")
+    assert float((out[0].detach().cpu() - ref["rgb"]).abs().mean()) < 1e-4 and float((out[1].detach().cpu() - ref["depth"]).abs().mean()) < 1e-4
+    # ---- forward: seven losses + psnr, then the gradients of the table and the decoder through autograd
+    sc.requires_grad_(True)
+    # (forward() draws its own jitter; the comparison needs a fixed U: _render is what forward() calls)
+    res = m._render(ro, rd, tr_, td, u=U.to(dev))
+    L = res[7]
+    ref = sc.forward(rays_o, rays_d, rgb, dep, z_vals=z)
+    for k, key in enumerate(LOSS_KEYS):
+        assert_close(L[k].detach().cpu(), ref[key].detach().reshape(()), rtol=1e-4, atol=1e-7, what="hash " + key)
+    ret_hip = {"rgb_loss": L[0], "depth_loss": L[1], "co_sdf_loss": L[2], "co_fs_loss": L[3], "e_fs_loss": L[4],
+               "e_center_loss": L[5], "e_tail_loss": L[6]}
+    slam_glue.get_loss_from_ret(cfg, ret_hip, is_co_sdf=co).backward()
+    omap.loss_from_ret(cfg, ref, is_co_sdf=co).backward()
+    g_t = m.embed_fn.params.grad.cpu()
+    assert float(sc.table.grad.abs().max()) > 0
+    assert_close(g_t, sc.table.grad, rtol=2e-3, atol=2e-5 * float(sc.table.grad.abs().max()), what="hash table grad (autograd path)")
+    for w, w_ref, nm in zip([m.decoder.color_net.model[0].weight, m.decoder.color_net.model[2].weight,
+                             m.decoder.sdf_net.model[0].weight, m.decoder.sdf_net.model[2].weight], sc.decoder_list(), DEC_KEYS):
+        assert_close(w.grad.cpu(), w_ref.grad, rtol=2e-3, atol=2e-5 * max(1.0, float(w_ref.grad.abs().max())), what=f"hash decoder grad {nm}")
+    # ---- the public entry points with their own jitter: shapes / finiteness, eval-mode forward == render_rays dict
+    d1 = m.render_rays(ro, rd, target_d=td)
+    assert set(d1) == {"rgb", "depth", "disp_map", "acc_map", "depth_var", "z_vals", "raw"} and d1["raw"].shape == (n_rays, S, 4)
+    d2 = m.forward(ro, rd, tr_, td)
+    assert set(d2) >= {"rgb", "depth", "rgb_loss", "psnr"} and torch.isfinite(d2["rgb_loss"])
+    # ---- without depth guidance (training.n_samples uniform samples)
+    if tr.get("n_samples"):
+        U2 = torch.rand(n_rays, tr["n_samples"], generator=torch.Generator().manual_seed(5))
+        o2 = m._render(ro, rd, None, None, u=U2.to(dev))
+        ref2 = sc.render_rays(rays_o, rays_d, target_d=None, z_vals=o2[5].cpu())
+        assert_close(o2[0].cpu(), ref2["rgb"].detach(), rtol=1e-4, atol=2e-5, what="hash render_rays rgb (no depth)")
+        assert_close(o2[1].cpu(), ref2["depth"].detach(), rtol=1e-4, atol=2e-5, what="hash render_rays depth (no depth)")
+    # ---- render_maps (no-grad, exact early termination) == render_rays on the same jitter
+    mp = m.render_maps(ro, rd, target_d=td, u=U.to(dev))
+    assert_close(mp["rgb"].cpu(), out[0].detach().cpu(), rtol=1e-5, atol=1e-6, what="hash render_maps rgb")
+    assert_close(mp["depth"].cpu(), out[1].detach().cpu(), rtol=1e-5, atol=1e-6, what="hash render_maps depth")
+    # ---- render_img: whole frame == render_maps over its rays, chunked or not
+    m.eval()
+    m.config["training"]["perturb"] = 0.0
+    cam_backup = dict(cfg["cam"])
+    m.config["cam"].update(cam, crop_edge=0)
+    depth_img, color_img = m.render_img(fr["c2w"], dev, gt_depth=fr["depth"])
+    m.render_chunk_rays = max(H * W // 3, 1)
+    depth_img2, color_img2 = m.render_img(fr["c2w"], dev, gt_depth=fr["depth"])
+    del m.render_chunk_rays
+    assert depth_img.shape == (H, W) and depth_img.dtype == torch.float64 and color_img.shape == (H, W, 3)
+    assert_close(depth_img2.cpu(), depth_img.cpu(), rtol=1e-6, atol=1e-7, what="hash render_img depth (chunked)")
+    assert_close(color_img2.cpu(), color_img.cpu(), rtol=1e-6, atol=1e-7, what="hash render_img colour (chunked)")
+    sc.requires_grad_(False)
+    from mneslam_amd.model.utils import get_rays
+    io, id_ = get_rays(H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"], fr["c2w"], "cpu")
+    zi = m.render_rays(io.reshape(-1, 3).to(dev), id_.reshape(-1, 3).to(dev), target_d=fr["depth"].reshape(-1, 1).to(dev))["z_vals"].cpu()
+    refi = sc.render_rays(io.reshape(-1, 3), id_.reshape(-1, 3), target_d=fr["depth"].reshape(-1, 1), z_vals=zi)    # perturb = 0: no jitter
+    assert_close(depth_img.float().cpu().reshape(-1), refi["depth"], rtol=1e-4, atol=2e-5, what="hash render_img depth vs oracle")
+    assert_close(color_img.cpu().reshape(-1, 3), refi["rgb"], rtol=1e-4, atol=2e-5, what="hash render_img colour vs oracle")
+    m.config["cam"].update(cam_backup)
+    # ---- point queries
+    g = torch.Generator().manual_seed(9)
+    lo, hi = sc.bounding_box[:, 0].float(), sc.bounding_box[:, 1].float()
+    pts = lo + (hi - lo) * torch.rand(5, 37, 3, generator=g)
+    raw_ref = sc.query_color_sdf(pts).reshape(5, 37, 4)
+    assert_close(m.query_color_sdf(pts.to(dev)).cpu().reshape(5, 37, 4), raw_ref, rtol=1e-4, atol=2e-5, what="hash query_color_sdf")
+    assert_close(m.query_sdf(pts.to(dev)).cpu(), raw_ref[..., 3], rtol=1e-4, atol=2e-5, what="hash query_sdf")
+    sdf, geo = m.query_sdf(pts.to(dev), return_geo=True)
+    assert geo.shape == (5, 37, 15)
+    assert_close(m.query_color(pts.to(dev)).cpu().reshape(5, 37, 3), torch.sigmoid(raw_ref[..., :3]), rtol=1e-4, atol=2e-5, what="hash query_color")
+    emb = m.query_sdf(pts.to(dev), embed=True)
+    feat_ref = sc.grid_features(pts.reshape(-1, 3))[:, :emb.shape[-1]].reshape(5, 37, -1)
+    assert_close(emb.cpu(), feat_ref, rtol=1e-5, atol=1e-7, what="hash query_sdf(embed=True)")
+    assert_close(m.run_network(pts.to(dev)).cpu(), raw_ref, rtol=1e-4, atol=2e-5, what="hash run_network")
+    with pytest.raises(NotImplementedError):
+        ro_g = ro.clone().requires_grad_(True)
+        m.train()
+        m.render_rays(ro_g, rd, target_d=td)["depth"].sum().backward()
+    return {"S": S}
+
+
+def dense_grid_config():
+    """BASELINE.json configs[0] in its as-north-star form: 16^3 dense grid (get_encoder('dense',
+    base_resolution=16, desired_resolution=16): 4 levels x 16^3 x 2 features) + 2x32 MLPs, 512 rays x 64 samples
+    (n_range_d 21 + n_samples_d 43), office0 bound."""
+    cfg = configs.bench_office0_hash(hidden=32, hash_size=19, desired_resolution=16)
+    cfg["grid"]["enc"] = "dense"
+    cfg["training"]["n_range_d"], cfg["training"]["n_samples_d"] = 21, 43
+    cfg["mapping"]["sample"] = 512
+    return cfg

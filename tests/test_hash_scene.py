@@ -1,5 +1,5 @@
-"""HashJointEncoding (NS-a, EXTENSION): host-side construction only -- no kernel runs here (the iteration itself is
-covered by tests/test_kernels_hostemu.py::test_hash_grid_fused_step_vs_oracle and the -m gpu tests)."""
+"""HashJointEncoding (NS-a, EXTENSION): host-side construction -- no kernel runs here (the iteration and the full
+render / query surface are covered by tests/test_kernels_hostemu.py and the -m gpu tests)."""
 import pytest
 import torch
 
@@ -29,7 +29,7 @@ def test_construction_matches_the_factory_defaults_and_the_spec():
     keys = set(m.state_dict().keys())
     assert {"embed_fn.params", "embedpos_fn.params", "decoder.sdf_net.model.0.weight", "decoder.color_net.model.2.weight"} <= keys
     with pytest.raises(NotImplementedError):
-        m.render_rays(torch.zeros(1, 3), torch.zeros(1, 3))
+        m.sample_plane_feature(torch.zeros(1, 3), [], [], [])
 
 
 def test_headline_table_size_and_optimizer_groups():

@@ -418,6 +418,30 @@ def test_hash_grid_headline_config_vs_oracle():
     assert out["R"] == 2048 + 512 and out["S"] == 128
 
 
+@pytest.mark.parametrize("hidden,co", [(32, False), (64, True)])
+def test_hash_scene_api_vs_oracle(hidden, co):
+    """The whole JointEncoding surface of the hash-grid model -- render_rays (with / without depth), forward + autograd
+    backward (table and decoder gradients), render_maps, render_img (chunked and whole), query_sdf / query_color /
+    query_color_sdf / run_network -- against oracle.scene_rep.OracleHashScene."""
+    cfg = pc.hash_test_config(hash_size=14, hidden=hidden)
+    cfg["training"]["n_samples"] = 64
+    pc.check_hash_scene_api(DEV, cfg, n_rays=300, co=co)
+
+
+@pytest.mark.parametrize("warm", [0, 2])
+def test_dense_grid_configs0_fused_step_vs_oracle(warm):
+    """BASELINE.json configs[0] in its as-north-star form on the HIP path: 16^3 dense grid (4 levels x 2 features) + 2x32
+    MLPs, 512 rays x 64 samples: one fused mapping iteration against the oracle on the device-drawn batch."""
+    out = pc.check_hash_fused_step_vs_oracle(DEV, pc.dense_grid_config(), n_keyframes=4, seed=3, warm_steps=warm, small=False)
+    assert out["S"] == 64 and out["R"] >= 512
+
+
+def test_dense_grid_scene_api_vs_oracle():
+    cfg = pc.dense_grid_config()
+    cfg["training"]["n_samples"] = 48
+    pc.check_hash_scene_api(DEV, cfg, n_rays=200)
+
+
 def test_hash_grid_training_learns():
     """The hash-grid iteration trains: PSNR rises and depth L1 falls over 150 prefetching iterations at full size."""
     import bench

@@ -199,6 +199,27 @@ def test_hash_grid_fused_step_vs_oracle():
     assert out["touched_entries"] > 0
 
 
+def test_hash_scene_api_vs_oracle():
+    """NS-a: render_rays / forward + backward / render_maps / render_img / query_* of the hash-grid scene model"""
+    cfg = pc.hash_test_config(hash_size=9, hidden=32, desired_resolution=64)
+    cfg["training"]["n_range_d"], cfg["training"]["n_samples_d"], cfg["training"]["n_samples"] = 9, 20, 24
+    cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["cam"]["far"] = 4.0
+    pc.check_hash_scene_api(DEV, cfg, n_rays=12, img=(6, 10))
+
+
+@full
+def test_dense_grid_fused_step_vs_oracle():
+    """BASELINE configs[0] as north-star: 16^3 dense grid + 2x32 (tiny batch for the emulator)"""
+    cfg = pc.dense_grid_config()
+    cfg["training"]["n_range_d"], cfg["training"]["n_samples_d"] = 9, 20
+    cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["mapping"]["sample"], cfg["mapping"]["min_pixels_cur"] = 24, 8
+    cfg["cam"]["far"] = 4.0
+    out = pc.check_hash_fused_step_vs_oracle(DEV, cfg, n_keyframes=3, seed=2, small=True)
+    assert out["touched_entries"] > 0
+
+
 @full
 def test_bench_path_step_fp16_plane_storage_vs_oracle():
     """NS-b: lookups read half-precision copies of the planes (EXTENSION); the oracle sees the same rounded values,
