@@ -34,6 +34,7 @@ from mneslam_amd.fused import FusedStep, HashFusedStep  # noqa: E402
 from mneslam_amd.model.scene_rep import JointEncoding  # noqa: E402
 from mneslam_amd.model.scene_rep_hash import HashJointEncoding  # noqa: E402
 
+PMC_JSON = "r03_pmc_traffic.json"      # committed counter passes of this round's kernels (profiles/r03_pmc.sh)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -59,6 +60,8 @@ def parse_args():
     ap.add_argument("--event-every", type=int, default=10, help="bracket the dominant launches with HIP events on every N-th timed step")
     ap.add_argument("--share-decoder", action="store_true",
                     help="EXTENSION: all-reduce (mean) the decoder gradient over agents each iteration (RCCL)")
+    ap.add_argument("--no-variants", dest="variants", action="store_false",
+                    help="skip the short runs of the other section-8d workloads reported in the line's `variants` object")
     ap.add_argument("--small", action="store_true", help="tiny planes/frames (functional check, not a benchmark)")
     ap.add_argument("--mode", default="mapping", choices=["mapping", "render_img"],
                     help="mapping = the metric (default); render_img = SURVEY 8f row N1: full-frame no-grad renders, the "
@@ -161,9 +164,10 @@ class Agent:
         return float(ret["psnr"].detach()[0]), float(l1)
 
 
-def cpu_baseline(cfg, n_keyframes, iters, seed=0):
+def cpu_baseline(cfg, n_keyframes, iters, seed=0, batch=None):
     """The oracle (CPU restatement of the reference's PyTorch path; checker code, reported baseline
-    only) timed on this box's host cores on the same workload shape."""
+    only) timed on this box's host cores on the same workload shape -- with ``batch`` = (rays_o, rays_d, rgb, depth, z_vals)
+    on the very batch the device drew in its last timed iteration."""
     from oracle import mapping as omap
     from oracle.scene_rep import OracleScene
     cores = min(os.cpu_count() or 1, 32)      # more threads only add contention on the scatter-heavy backward
@@ -184,13 +188,18 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0):
         sc = OracleScene(cfg, bb, generator=gen).requires_grad_(True)
     opt = omap.OracleAdam(sc, cfg)
     n = cfg["mapping"]["sample"] + max(cfg["mapping"]["sample"] // n_keyframes, cfg["mapping"]["min_pixels_cur"])
-    frames = synthetic.make_frames(1, 68, 120, 60.0, 60.0, 59.0, 33.0, synthetic.OFFICE0_ROOM, seed=seed)
-    fr = frames[0]
-    idx = torch.randint(0, 68 * 120, (n,), generator=gen)
-    d_cam = fr["direction"].reshape(-1, 3)[idx]
-    rays_d = torch.sum(d_cam[:, None, :] * fr["c2w"][:3, :3], -1)
-    rays_o = fr["c2w"][None, :3, 3].repeat(n, 1)
-    rgb, dep = fr["rgb"].reshape(-1, 3)[idx], fr["depth"].reshape(-1, 1)[idx]
+    z_vals = None
+    if batch is not None:
+        rays_o, rays_d, rgb, dep, z_vals = [t.detach().to("cpu", torch.float32) for t in batch]
+        dep, n = dep.reshape(-1, 1), rays_o.shape[0]
+    else:
+        frames = synthetic.make_frames(1, 68, 120, 60.0, 60.0, 59.0, 33.0, synthetic.OFFICE0_ROOM, seed=seed)
+        fr = frames[0]
+        idx = torch.randint(0, 68 * 120, (n,), generator=gen)
+        d_cam = fr["direction"].reshape(-1, 3)[idx]
+        rays_d = torch.sum(d_cam[:, None, :] * fr["c2w"][:3, :3], -1)
+        rays_o = fr["c2w"][None, :3, 3].repeat(n, 1)
+        rgb, dep = fr["rgb"].reshape(-1, 3)[idx], fr["depth"].reshape(-1, 1)[idx]
     times = []
     t_start = time.perf_counter()
     for it in range(iters + 1):
@@ -198,13 +207,16 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0):
             break
         t0 = time.perf_counter()
         opt.zero_grad()
-        ret = sc.forward(rays_o, rays_d, rgb, dep, impl="grid_sample")
+        ret = sc.forward(rays_o, rays_d, rgb, dep, impl="grid_sample", z_vals=z_vals) if z_vals is not None \
+            else sc.forward(rays_o, rays_d, rgb, dep, impl="grid_sample")
         omap.loss_from_ret(cfg, ret, is_co_sdf=cfg["is_co_sdf"]).backward()
         opt.step()
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / max(len(times) - 1, 1)
     return {"value": 1.0 / t, "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times) - 1} mapping iterations (1 warm-up) of the same workload ({n} rays x "
+            "sample": f"{len(times) - 1} mapping iterations (1 warm-up) "
+                      + ("on the batch the device drew in its last timed iteration " if batch is not None else "of the same workload ")
+                      + f"({n} rays x "
                       f"{cfg['training']['n_range_d'] + cfg['training']['n_samples_d']} samples, "
                       f"{sum(p.numel() for p in sc.plane_list())} plane params) with the CPU oracle, torch "
                       f"{torch.__version__}, {cores} threads"}
@@ -257,6 +269,99 @@ def bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, m
             "depth_l1_vs_gt": float((d1.float() - gt)[gt > 0].abs().mean())}), flush=True)
 
 
+def account(cfg, agent, plane_storage, avg_ms):
+    """Algorithmic bytes per launch of the path's kernels and the dominant one among the live-measured launches."""
+    S = cfg["training"]["n_range_d"] + cfg["training"]["n_samples_d"]
+    R = cfg["mapping"]["sample"] + agent.n_cur
+    n_par = agent.n_plane_params + agent.n_dec_params
+    # Algorithmic bytes per launch = SURVEY.md section 8d's per-unit figures x the units the launch processes (both stated
+    # in DESIGN.md):  G = planes x 4 corners x 32 ch x 4 B per point per gather or scatter pass; 32 B per parameter
+    # per optimiser sweep (the reference's read p,g,m,v + write p,m,v + zero g).
+    #   tile_adam_kernel : scatter of the P' contributing samples + the sweep over every parameter
+    #   gather_kernel    : gather of the D samples the exact early termination decodes; D is counted from below as
+    #                      the samples of the tiles the backward walks (ray_tiles, read back live), D <= R*S
+    #   decode_kernel, ray_kernel : the MLP forward / composite+backward; no algorithmic HBM bytes (latency-bound)
+    #   atomics variant  : adam_kernel = the sweep; the render call gathers and scatters (atomics)
+    G = 3072.0 * (1 if cfg["grid"]["oneGrid"] else 2)
+    G_gather = G / 2 if plane_storage == "fp16" else G        # 64-byte corner rows
+    binned = agent.fused is not None and agent.fused.bins is not None
+    p_contrib = float(agent.fused.tape_rows.item()) if agent.fused is not None else float(R * S)
+    decoded = float((agent.fused.ray_tiles[:R].long() * 32).clamp(max=S).sum().item()) if agent.fused is not None else float(R * S)
+    if agent.hash:
+        # hash grid: 16 levels x 8 corners x 2 features x 4 B = 1,024 B per point per gather or scatter pass (SURVEY 8d)
+        Gh = agent.model.embed_fn.cfg.n_levels * 8 * agent.model.embed_fn.cfg.n_features * 4.0
+        n_gather = decoded if agent.fused.early_termination else float(R * S)       # rows the gather fills (counted from below)
+        alg = {"hash_gather": n_gather * Gh, "hash_scatter": p_contrib * Gh, "adam": 32.0 * n_par, "render": 0.0}
+        slices = agent.fused.table_update != "atomics"
+        if slices:       # the table update = scatter + Adam sweep of the table in one call
+            alg["hash_scatter"] += 32.0 * agent.n_plane_params
+            alg["adam"] = 32.0 * agent.n_dec_params
+        kern = {"hash_gather": "hash_rows_kernel<false> (grid gather into the tape)",
+                "hash_scatter": ("hash_offsets + hash_pack + hash_slice_adam + hash_dense_adam kernels (LDS slices, Adam fused; one mne_hash_slice_adam call)"
+                                 if slices else "hash_scatter_runs_kernel (run-reduced global atomics)"),
+                "adam": "adam_kernel (decoder)" if slices else "adam_kernel (table + decoder, one launch)", "wgrad": "wgrad kernels",
+                "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
+                "deferred_pass": "hash gather + decode_kernel + ray_kernel over the deferred-ray list",
+                "render": "whole mne_render_fused_features call (decode + ray kernels; MFMA / latency, no algorithmic HBM bytes)"}
+        alg["iteration"] = alg["hash_gather"] + alg["hash_scatter"] + alg["adam"]
+    elif binned:
+        alg = {"adam": p_contrib * G + 32.0 * n_par + (2.0 * agent.n_plane_params if plane_storage == "fp16" else 0.0),
+               "gather_kernel": decoded * G_gather, "render": decoded * G_gather}
+        kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)", "gather_kernel": "gather_kernel",
+                "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
+                "deferred_pass": "decode_kernel + ray_kernel over the deferred-ray list",
+                "bin_kernel": "bin_kernel (list appends of the binned plane update)",
+                "render": "whole mne_render_fused call (gather + decode + ray + deferred pass + bin)"}
+    else:
+        alg = {"adam": 32.0 * n_par, "render": (decoded + p_contrib) * G}
+        kern = {"adam": "adam_kernel (planes + decoder, one launch)",
+                "render": "whole mne_render_fused call (gather + decode + ray kernels, atomic scatter)"}
+    # the dominant KERNEL = the longest live-measured single launch (the bracket around the whole render call is
+    # reported beside it, not as a kernel, when its kernels are timed individually)
+    single = {k: v for k, v in avg_ms.items() if not (k == "render" and ("gather_kernel" in avg_ms or agent.hash))}
+    dom = max(single, key=single.get) if single else "adam"
+    dom_ms = avg_ms.get(dom, 0.0)
+    achieved = alg.get(dom, 0.0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    return {"alg": alg, "kern": kern, "dom": dom, "dom_ms": dom_ms, "achieved": achieved, "p_contrib": p_contrib,
+            "decoded": decoded, "R": R, "S": S}
+
+
+VARIANTS = (("office0_2x64", "office0", 64), ("office0_hash", "office0_hash", None), ("scannet", "scannet", None),
+            ("indoor", "indoor", None))
+
+
+def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, block=50):
+    """A short (<= ~2 s of device time) run of another workload of SURVEY.md section 8d through the same step: the other
+    decoder width, the hash-grid headline encoding, the ScanNet / indoor-scale plane sets.  Reported beside the metric,
+    never as it."""
+    make_cfg, workload = configs.WORKLOADS[config]
+    cfg = make_cfg(hidden) if hidden else make_cfg()
+    agent = Agent(cfg, device, seed=0, n_keyframes=keyframes)
+    for _ in range(warmup):
+        agent.step()
+    timers, steps = {}, 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while True:
+        for i in range(block):
+            agent.step(timers if i % 10 == 0 else None, prefetch=True)
+        steps += block
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if elapsed > budget_s or steps >= 2000:
+            break
+    avg_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timers.items()}
+    acc = account(cfg, agent, "fp32", avg_ms)
+    out = {"workload": workload, "mlp_hidden": cfg["decoder"]["hidden_dim"], "value": steps / elapsed, "unit": "it/s",
+           "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
+           "plane_params": agent.n_plane_params, "rays_per_iter": acc["R"], "samples_per_ray": acc["S"],
+           "dominant_kernel": acc["kern"][acc["dom"]], "avg_launch_ms": acc["dom_ms"],
+           "achieved_GBs": acc["achieved"], "frac": acc["achieved"] / HBM_PEAK_GBS}
+    del agent
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     if not torch.cuda.is_available():
@@ -296,61 +401,13 @@ def main():
     avg_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timers.items()}
     psnr, depth_l1 = agent.quality()
     if rank == 0:
-        S = cfg["training"]["n_range_d"] + cfg["training"]["n_samples_d"]
-        R = cfg["mapping"]["sample"] + agent.n_cur
-        n_par = agent.n_plane_params + agent.n_dec_params
-        # Algorithmic bytes per launch = SURVEY.md section 8d's per-unit figures x the units the launch processes (both stated
-        # in DESIGN.md):  G = planes x 4 corners x 32 ch x 4 B per point per gather or scatter pass; 32 B per parameter
-        # per optimiser sweep (the reference's read p,g,m,v + write p,m,v + zero g).
-        #   tile_adam_kernel : scatter of the P' contributing samples + the sweep over every parameter
-        #   gather_kernel    : gather of the D samples the exact early termination decodes; D is counted from below as
-        #                      the samples of the tiles the backward walks (ray_tiles, read back live), D <= R*S
-        #   decode_kernel, ray_kernel : the MLP forward / composite+backward; no algorithmic HBM bytes (latency-bound)
-        #   atomics variant  : adam_kernel = the sweep; the render call gathers and scatters (atomics)
-        G = 3072.0 * (1 if cfg["grid"]["oneGrid"] else 2)
-        G_gather = G / 2 if args.plane_storage == "fp16" else G        # 64-byte corner rows
-        binned = agent.fused is not None and agent.fused.bins is not None
-        p_contrib = float(agent.fused.tape_rows.item()) if agent.fused is not None else float(R * S)
-        decoded = float((agent.fused.ray_tiles[:R].long() * 32).clamp(max=S).sum().item()) if agent.fused is not None else float(R * S)
-        if agent.hash:
-            # hash grid: 16 levels x 8 corners x 2 features x 4 B = 1,024 B per point per gather or scatter pass
-            Gh = agent.model.embed_fn.cfg.n_levels * 8 * agent.model.embed_fn.cfg.n_features * 4.0
-            n_gather = decoded if agent.fused.early_termination else float(R * S)       # rows the gather fills (counted from below)
-            alg = {"hash_gather": n_gather * Gh, "hash_scatter": p_contrib * Gh, "adam": 32.0 * n_par, "render": 0.0}
-            slices = agent.fused.table_update != "atomics"
-            if slices:       # the table update = scatter + Adam sweep of the table in one call
-                alg["hash_scatter"] += 32.0 * agent.n_plane_params
-                alg["adam"] = 32.0 * agent.n_dec_params
-            kern = {"hash_gather": "hash_rows_kernel<false> (grid gather into the tape)",
-                    "hash_scatter": ("hash_offsets + hash_pack + hash_slice_adam + hash_dense_adam kernels (LDS slices, Adam fused; one mne_hash_slice_adam call)"
-                                     if slices else "hash_scatter_runs_kernel (run-reduced global atomics)"),
-                    "adam": "adam_kernel (decoder)" if slices else "adam_kernel (table + decoder, one launch)", "wgrad": "wgrad kernels",
-                    "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
-                    "deferred_pass": "hash gather + decode_kernel + ray_kernel over the deferred-ray list",
-                    "render": "whole mne_render_fused_features call (decode + ray kernels; MFMA / latency, no algorithmic HBM bytes)"}
-            alg["iteration"] = alg["hash_gather"] + alg["hash_scatter"] + alg["adam"]
-        elif binned:
-            alg = {"adam": p_contrib * G + 32.0 * n_par + (2.0 * agent.n_plane_params if args.plane_storage == "fp16" else 0.0),
-                   "gather_kernel": decoded * G_gather, "render": decoded * G_gather}
-            kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)", "gather_kernel": "gather_kernel",
-                    "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
-                    "deferred_pass": "decode_kernel + ray_kernel over the deferred-ray list",
-                    "bin_kernel": "bin_kernel (list appends of the binned plane update)",
-                    "render": "whole mne_render_fused call (gather + decode + ray + deferred pass + bin)"}
-        else:
-            alg = {"adam": 32.0 * n_par, "render": (decoded + p_contrib) * G}
-            kern = {"adam": "adam_kernel (planes + decoder, one launch)",
-                    "render": "whole mne_render_fused call (gather + decode + ray kernels, atomic scatter)"}
-        # the dominant KERNEL = the longest live-measured single launch (the bracket around the whole render call is
-        # reported beside it, not as a kernel, when its kernels are timed individually)
-        single = {k: v for k, v in avg_ms.items() if not (k == "render" and ("gather_kernel" in avg_ms or agent.hash))}
-        dom = max(single, key=single.get) if single else "adam"
-        dom_ms = avg_ms.get(dom, 0.0)
-        achieved = alg.get(dom, 0.0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        acc = account(cfg, agent, args.plane_storage, avg_ms)
+        alg, kern, dom, dom_ms, achieved = acc["alg"], acc["kern"], acc["dom"], acc["dom_ms"], acc["achieved"]
+        p_contrib, decoded, R, S = acc["p_contrib"], acc["decoded"], acc["R"], acc["S"]
         # HBM traffic and matrix-pipe busy cycles from committed PMC passes (rocprofv3 cannot run inside the timed loop)
         traffic, mfma_busy = None, None
         try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(REPO, "profiles", PMC_JSON)))
             if (pmc["workload"] == workload and not args.small and args.path == "fused"
                     and pmc["scatter"] == args.scatter and args.hidden == 32 and args.plane_storage == "fp32"):
                 per_k = pmc["per_kernel_hbm_bytes_per_iteration"]
@@ -389,7 +446,16 @@ def main():
                          "iteration_hbm_frac": alg.get("iteration", alg["adam"] + alg["render"]) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and args.cpu_iters > 0:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.keyframes, args.cpu_iters)
+            batch = None
+            if agent.fused is not None and not agent.hash:       # the batch the device drew in its last timed iteration
+                f = agent.fused
+                batch = (f.rays_o[:R], f.rays_d[:R], f.tgt_rgb[:R], f.tgt_d[:R], f.z_vals[:R])
+            out["cpu_baseline"] = cpu_baseline(cfg, args.keyframes, args.cpu_iters, batch=batch)
+        if world == 1 and args.variants and not args.small:
+            del agent
+            torch.cuda.empty_cache()
+            out["variants"] = {name: run_variant(c, h, device, args.keyframes) for name, c, h in VARIANTS
+                               if not (c == args.config and (h or args.hidden) == args.hidden)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

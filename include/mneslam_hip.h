@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MNE_ABI_VERSION 4
+#define MNE_ABI_VERSION 5
 
 /* orientation index of a plane triple, as in JointEncoding.all_planes (scene_rep.py:117) */
 enum { MNE_XY = 0, MNE_XZ = 1, MNE_YZ = 2 };
@@ -93,7 +93,7 @@ typedef struct mne_render_cfg {
  * caller-owned device memory; counts and *spill_count must be zero before the first use (each
  * mne_tile_adam call leaves counts zeroed again; mne_render_fused zeroes *spill_count itself). */
 typedef struct mne_tile_bins {
-    uint32_t* lists;       /* [mne_tile_count()][cap][8]: tape row, packed local corner, 4 weights, tile id, 0 (32-byte entries) */
+    uint32_t* lists;       /* [mne_tile_list_entries()][8] = [mne_tile_count()][cap][8] with one capacity: tape row, packed local corner, 4 weights, tile id, 0 (32-byte entries) */
     int32_t* counts;       /* [mne_tile_count()] */
     uint32_t* spill;       /* [spill_cap][8] overflow entries (same layout) */
     int32_t* spill_count;  /* [1] */
@@ -107,6 +107,16 @@ typedef struct mne_tile_bins {
      * mne_tile_count() + MNE_TILE_SPLIT_PARTS entries. */
     float* split_scratch;  /* [MNE_TILE_SPLIT_PARTS][16*16*c_dim] */
     int32_t* split_state;  /* [mne_tile_count() + 1], zero-initialised by the caller, left zeroed by mne_tile_adam */
+    /* Optional: [mne_tile_count()], zero-initialised by the caller.  mne_tile_adam leaves every list's final length here
+     * and mne_tile_order balances on max(length now, length of the previous call): it may then run BEFORE the lists are
+     * complete (beside the deferred rays' second pass) without mis-judging scenes where many rays are deferred. */
+    int32_t* prev_counts;
+    /* Optional per-plane list capacities in JointEncoding.all_planes order ([set][xy,xz,yz][coarse,fine]); an entry of 0
+     * means `cap`.  One capacity for all tiles reserves tens of GB on scenes whose coarse planes have a few dozen tiles
+     * taking 10^4-10^5 entries each next to thousands of fine tiles taking a few hundred (ScanNet with colour planes, INS
+     * Indoor); per plane, 4x the mean list length costs 0.6-2.3 GB on every workload of BASELINE.json.  `lists` then holds
+     * mne_tile_list_entries() entries: plane after plane, each plane's tiles back to back. */
+    int32_t plane_cap[12];
 } mne_tile_bins_t;
 #define MNE_TILE_SPLIT_PARTS 2048
 
@@ -347,6 +357,8 @@ int mne_tile_bin(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_ra
  * (mneslam_mp.py:459-469) with no gradient buffer and no global atomics.  opt[] has 6*n_sets entries.
  * Entries reference tape rows (ray * n_samples + sample). */
 size_t mne_tile_count(const mne_scene_t* scene);
+/* Entries `bins->lists` must hold for this scene with bins->cap / bins->plane_cap (0 on invalid arguments). */
+size_t mne_tile_list_entries(const mne_scene_t* scene, const mne_tile_bins_t* bins);
 /* Processing order of the tiles for the next mne_tile_adam call (bins->order): longest lists first, so the
  * few very long lists do not form the tail of the launch.  Call after mne_render_fused, before mne_tile_adam. */
 int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* stream);

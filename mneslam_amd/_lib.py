@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmneslam_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 N_LOSS = 8
 N_COUNT = 8
 C_NEED = 6
@@ -49,7 +49,7 @@ class AdamSeg(C.Structure):
 class TileBins(C.Structure):
     _fields_ = [("lists", C.c_void_p), ("counts", C.c_void_p), ("spill", C.c_void_p), ("spill_count", C.c_void_p),
                 ("order", C.c_void_p), ("cap", C.c_int32), ("spill_cap", C.c_int32), ("dropped", C.c_void_p),
-                ("split_scratch", C.c_void_p), ("split_state", C.c_void_p)]
+                ("split_scratch", C.c_void_p), ("split_state", C.c_void_p), ("prev_counts", C.c_void_p), ("plane_cap", C.c_int32 * 12)]
 
 
 TILE_SPLIT_PARTS = 2048
@@ -130,6 +130,7 @@ _PROTOS = {
     "mne_tile_bin": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 7
                      + [C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_int, C.POINTER(FusedOpts), C.c_void_p]),
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
+    "mne_tile_list_entries": (C.c_size_t, [C.POINTER(Scene), C.POINTER(TileBins)]),
     "mne_tile_order": (C.c_int, [C.POINTER(Scene), C.POINTER(TileBins), C.c_void_p]),
     "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.POINTER(Clock),
                                 C.c_void_p]),

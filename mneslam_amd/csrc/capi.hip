@@ -214,6 +214,18 @@ size_t mne_render_workspace_bytes(int n_rays, int n_samples) {
     return mne_render_workspace(n_rays, n_samples);
 }
 
+// per-plane capacities and list offsets (tile_base / ntx must be filled); returns the total number of entries
+static size_t list_layout(const mne_scene_t& sc, const mne_tile_bins_t* bins, TileBins& out) {
+    long long off = 0;
+    for (int p = 0; p < MNE_MAX_PLANES; ++p) {
+        const int cap = (p < sc.n_sets * 6 && bins->plane_cap[p] > 0) ? bins->plane_cap[p] : bins->cap;
+        out.pcap[p] = cap;
+        out.list_off[p] = off - (long long)out.tile_base[p] * cap;
+        off += (long long)(out.tile_base[p + 1] - out.tile_base[p]) * cap;
+    }
+    return (size_t)off;
+}
+
 static int fill_bins(const mne_scene_t* scene, const mne_tile_bins_t* bins, TileBins& out) {
     if (!bins->lists || !bins->counts || !bins->spill || !bins->spill_count || !bins->order || !bins->dropped || bins->cap < 1 ||
         bins->spill_cap < 1)
@@ -224,6 +236,7 @@ static int fill_bins(const mne_scene_t* scene, const mne_tile_bins_t* bins, Tile
     if ((bins->split_scratch != nullptr) != (bins->split_state != nullptr)) return fail(-1, "tile bins: split_scratch and split_state go together");
     out.split_scratch = bins->split_scratch; out.split_state = bins->split_state;
     mne_tile_geometry(*scene, out);
+    list_layout(*scene, bins, out);
     return 0;
 }
 
@@ -394,6 +407,14 @@ size_t mne_tile_count(const mne_scene_t* scene) {
     return (size_t)b.tile_base[scene->n_sets * 6];
 }
 
+size_t mne_tile_list_entries(const mne_scene_t* scene, const mne_tile_bins_t* bins) {
+    if (!scene || !bins || bins->cap < 1 || (scene->n_sets != 1 && scene->n_sets != 2)) return 0;
+    for (int p = 0; p < 12; ++p) if (bins->plane_cap[p] < 0) return 0;
+    TileBins b = {};
+    mne_tile_geometry(*scene, b);
+    return list_layout(*scene, bins, b);
+}
+
 int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
     if (!bins || !bins->counts || !bins->order) return fail(-1, "mne_tile_order: NULL argument");
@@ -401,11 +422,12 @@ int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* 
     a.sc = *scene;
     a.n_planes = scene->n_sets * 6;
     a.bins.counts = bins->counts; a.bins.order = bins->order; a.bins.cap = bins->cap;
-    a.bins.split_scratch = bins->split_scratch; a.bins.split_state = bins->split_state;
+    a.bins.split_scratch = bins->split_scratch; a.bins.split_state = bins->split_state; a.prev_counts = bins->prev_counts;
     const char* sm = std::getenv("MNE_TILE_SPLIT_MIN");                   // tests force splitting on tiny scenes
     const int split_min = sm ? std::atoi(sm) : MNE_TILE_SPLIT_MIN_DEFAULT;
     a.bins.split_min = split_min < 1 ? 1 : split_min;
     mne_tile_geometry(*scene, a.bins);
+    list_layout(*scene, bins, a.bins);
     mne_launch_tile_order(a, (hipStream_t)stream);
     return check_launch("tile_order");
 }
@@ -418,6 +440,7 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
     a.sc = *scene;
     a.n_planes = scene->n_sets * 6;
     if (int rc = fill_bins(scene, bins, a.bins)) return rc;
+    a.prev_counts = bins->prev_counts;
     for (int k = 0; k < a.n_planes; ++k) {
         const mne_plane_opt_t& g = opt[k];
         if (!g.m || !g.v || g.step < 1) return fail(-1, "mne_tile_adam: bad plane optimizer state");

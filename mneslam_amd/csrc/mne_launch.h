@@ -38,7 +38,7 @@ struct TileBins {
     unsigned* spill;          // [spill_cap][MNE_SPILL_WORDS] overflow entries
     int* spill_count;
     int* order;               // [n_tiles] processing order of tile_adam_kernel (heaviest lists first)
-    int cap, spill_cap;
+    int cap, spill_cap;       // cap: capacity of every list when the caller gives no per-plane capacities
     int* dropped;             // sticky count of entries lost to a full spill area
     float* split_scratch;     // [MNE_TILE_SPLIT_PARTS][16*16*32] partial gradient tiles of split lists (NULL: never split)
     int* split_state;         // [n_tiles + 1]: arrival counters per tile (zero between calls), [n_tiles] = number of work items
@@ -47,6 +47,11 @@ struct TileBins {
                                           // 8192 costs Indoor 3 % (profiles/r02_tile_split_min.txt)
     int tile_base[MNE_MAX_PLANES + 1];   // first tile id of each plane ([set][orient][level] order)
     int ntx[MNE_MAX_PLANES];             // tiles per plane row
+    // list capacity per plane (a coarse plane's few tiles take thousands of entries each, a fine plane's many tiles a few
+    // hundred): list of tile t of plane p = lists + (list_off[p] + (long long)t * pcap[p]) entries  (t = GLOBAL tile id;
+    // list_off already has tile_base[p] * pcap[p] taken off)
+    int pcap[MNE_MAX_PLANES];
+    long long list_off[MNE_MAX_PLANES];
 };
 
 struct GridArgs;
@@ -214,6 +219,7 @@ struct TileAdamArgs {
     int row_stride, t_dfeat, t_pn;
     int n_planes, n_tiles;
     Clock clk;
+    int* prev_counts;         // [n_tiles] final list lengths of the previous tile_adam launch (NULL: none) -- balance hint of tile_order
 };
 
 struct AdamArgs {

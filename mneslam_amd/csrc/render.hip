@@ -270,7 +270,7 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     MNE_WAVE_SYNC();                                       // earlier LDS reads of this wave are done
     if (PRE) {
         DEC_STAMP(1);
-        if (a.ext_rows) load_rows<MNE_FEAT>(feat, a.ext_rows + ((size_t)r * S + (size_t)c * TILE) * a.ext_stride, a.ext_stride, 0, live, lane);
+        if (!CP && a.ext_rows) load_rows<MNE_FEAT>(feat, a.ext_rows + ((size_t)r * S + (size_t)c * TILE) * a.ext_stride, a.ext_stride, 0, live, lane);
         else load_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
         if (CP) load_rows<MNE_FEAT>(feat + TILE * MNE_FS, tape0, D::ROW, D::T_CF, live, lane);
         MNE_WAVE_SYNC();
@@ -978,6 +978,8 @@ __device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&p
         int want[NJ * 4];
         unsigned meta[NJ * 4];                             // leader lane | rank << 8 | run length << 16
         int cix[NJ], ciy[NJ];                              // NW corner of the footprint in each of the lane's planes
+        int pcap[NJ];                                      // list capacity / list offset of the lane's planes
+        long long loff[NJ];
         float wq[NJ][4];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -1001,6 +1003,7 @@ __device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&p
                 meta[j * 4 + q] = run_meta(w_, lane);
             }
             cix[j] = b.ix0; ciy[j] = b.iy0;
+            pcap[j] = a.bins.pcap[pidx]; loff[j] = a.bins.list_off[pidx];
         }
         int first_slot[NJ * 4];
 #pragma unroll
@@ -1015,7 +1018,7 @@ __device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&p
             if (want[eq] >= 0) {
                 const int slot = f0 + (int)((meta[eq] >> 8) & 255u);
                 unsigned* dst = nullptr;
-                if (slot < a.bins.cap) dst = a.bins.lists + ((size_t)want[eq] * a.bins.cap + slot) * MNE_ENTRY_WORDS;
+                if (slot < pcap[eq >> 2]) dst = a.bins.lists + (size_t)(loff[eq >> 2] + (long long)want[eq] * pcap[eq >> 2] + slot) * MNE_ENTRY_WORDS;
                 else {
                     const int sp = atomicAdd(a.bins.spill_count, 1);
                     if (sp < a.bins.spill_cap) dst = a.bins.spill + (size_t)sp * MNE_ENTRY_WORDS;

@@ -96,15 +96,27 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
     // counts are read ONCE (this kernel is a latency chain on the critical path): up to ORDER_REGS tiles per thread stay
     // in registers for all three passes, the rest (more than 8192 tiles) is re-read
     constexpr int ORDER_REGS = 8;
+    // With prev_counts a list counts as max(length now, final length of the previous launch): the kernel may run while the
+    // deferred rays' appends are still to come (scenes with many deferred rays would otherwise get yesterday's heavy lists
+    // unsplit: ScanNet 1.16 ms instead of 0.44 ms).
+    // (a list holds at most its plane's capacity; what is beyond sits in the spill area, scanned by the last part)
+    auto length = [&](int t) {
+        int c = a.bins.counts[t];
+        if (a.prev_counts) { const int p = a.prev_counts[t]; c = c > p ? c : p; }
+        int pidx = 0;
+        while (pidx + 1 < a.n_planes && t >= a.bins.tile_base[pidx + 1]) ++pidx;
+        const int cap = a.bins.pcap[pidx];
+        return c < cap ? c : cap;
+    };
     int cnt[ORDER_REGS];
     int mine = 0;
 #pragma unroll
     for (int q = 0; q < ORDER_REGS; ++q) {
         const int t = tid + q * 1024;
-        cnt[q] = t < n_tiles ? a.bins.counts[t] : 0;
-        mine += cnt[q] < a.bins.cap ? cnt[q] : a.bins.cap;
+        cnt[q] = t < n_tiles ? length(t) : 0;
+        mine += cnt[q];
     }
-    for (int t = tid + ORDER_REGS * 1024; t < n_tiles; t += 1024) { const int c = a.bins.counts[t]; mine += c < a.bins.cap ? c : a.bins.cap; }
+    for (int t = tid + ORDER_REGS * 1024; t < n_tiles; t += 1024) mine += length(t);
     for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
     if ((tid & 63) == 0 && mine) atomicAdd(&total, mine);
     __syncthreads();
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
     }
     // split items first, whole tiles into their length buckets
     auto classify = [&](int t, int c0) {
-        const int c = c0 < a.bins.cap ? c0 : a.bins.cap;
+        const int c = c0;
         if (c > split) {
             int np = (c + split - 1) / split;
             np = np > 63 ? 63 : np;
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
 #pragma unroll
     for (int q = 0; q < ORDER_REGS; ++q)
         if (tid + q * 1024 < n_tiles) classify(tid + q * 1024, cnt[q]);
-    for (int t = tid + ORDER_REGS * 1024; t < n_tiles; t += 1024) classify(t, a.bins.counts[t]);
+    for (int t = tid + ORDER_REGS * 1024; t < n_tiles; t += 1024) classify(t, length(t));
     __syncthreads();
     if (tid < 64) {                                   // exclusive scan over the 32 buckets, heaviest first, by one wave
         const int b = 31 - (tid & 31);
@@ -140,13 +152,13 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
     }
     __syncthreads();
     auto place = [&](int t, int c0) {
-        const int c = c0 < a.bins.cap ? c0 : a.bins.cap;
+        const int c = c0;
         if (c <= split) a.bins.order[atomicAdd(&start[31 - __clz(c0 + 1)], 1)] = t;
     };
 #pragma unroll
     for (int q = 0; q < ORDER_REGS; ++q)
         if (tid + q * 1024 < n_tiles) place(tid + q * 1024, cnt[q]);
-    for (int t = tid + ORDER_REGS * 1024; t < n_tiles; t += 1024) place(t, a.bins.counts[t]);
+    for (int t = tid + ORDER_REGS * 1024; t < n_tiles; t += 1024) place(t, length(t));
 }
 // (A ballot-ranked counting sort without same-address atomics was measured at 14.5 us against 12 us for this one.)
 
@@ -174,13 +186,14 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     const bool empty = TILE_EMPTY_FAST && cnt == 0;            // no contribution: the sweep runs with g = 0, LDS untouched
     if (!empty)
         for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int n_list = cnt < a.bins.cap ? cnt : a.bins.cap;
+    const int cap = a.bins.pcap[pidx];
+    const int n_list = cnt < cap ? cnt : cap;
     int n_spill = 0;
-    if (cnt > a.bins.cap) {                     // only a tile whose list overflowed has entries in the spill area
+    if (cnt > cap) {                     // only a tile whose list overflowed has entries in the spill area
         const int ns = *a.bins.spill_count;
         n_spill = ns < a.bins.spill_cap ? ns : a.bins.spill_cap;
     }
-    const unsigned* lst = a.bins.lists + (size_t)tile * a.bins.cap * MNE_ENTRY_WORDS;
+    const unsigned* lst = a.bins.lists + (size_t)(a.bins.list_off[pidx] + (long long)tile * cap) * MNE_ENTRY_WORDS;
     // Adam operands of this thread's elements, requested BEFORE the list passes so that the HBM stream of the
     // sweep (24 B/param) overlaps the LDS accumulation instead of following it (TILE_PREFETCH: 0 none, 1 p+m, 2 p+m+v)
     constexpr int NIT = (TILE_CELLS * MNE_C / 4) / TILE_THREADS;
@@ -428,7 +441,10 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     if (tid == 0 && blockIdx.x < 4096)
         ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 8192) * MNE_SPILL_WORDS))[blockIdx.x * 8 + 7] = (unsigned long long)cnt;
 #endif
-    if (tid == 0) a.bins.counts[tile] = 0;                                     // ready for the next iteration
+    if (tid == 0) {
+        if (a.prev_counts) a.prev_counts[tile] = cnt;
+        a.bins.counts[tile] = 0;                                               // ready for the next iteration
+    }
 }
 
 void mne_tile_geometry(const mne_scene_t& sc, TileBins& b) {

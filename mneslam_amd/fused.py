@@ -97,17 +97,27 @@ class FusedStep:
             self.grad_map.update({p: g for p, g in zip(self.planes, self.grads)})
         else:
             n_tiles = self.lib.mne_tile_count(C.byref(self.scene))
+            b = _lib.TileBins()
             if tile_capacity is None:
-                # 4x the mean list length of the plane with the fewest tiles if every sample contributed (a sample
-                # touches ~1.3 tiles of a plane); office0: 5,020 entries (longest list observed: 2,840) -- but never more
-                # than LIST_BUDGET_BYTES for all lists together: one global capacity serves every tile of every plane, so
-                # a scene with few coarse tiles and many samples per ray (INS Indoor: S = 1045) would otherwise reserve tens
-                # of GB.  Overflow is still correct (spill area, sized for the worst case), only slower.
-                tiles_min = min(((p.shape[2] + 15) // 16) * ((p.shape[3] + 15) // 16) for p in self.planes)
-                tile_capacity = int(max(4096, 4 * 1.3 * R * S / tiles_min))
-                tile_capacity = max(256, min(tile_capacity, self.LIST_BUDGET_BYTES // (32 * max(n_tiles, 1))))
+                # One capacity PER PLANE: 4x its mean list length if every sample contributed (a sample touches ~1.3 tiles of
+                # a plane), at least 4096 entries.  A coarse plane's few tiles take 10^4-10^5 entries each, a fine plane's
+                # thousands of tiles a few hundred: one capacity for all reserved 17.5 GB on ScanNet with colour planes and
+                # 30 GB on INS Indoor, and capping THAT sent ScanNet's coarse lists into the spill area (every
+                # overflowing tile scans all of it: 0.44 -> 1.16 ms).  Per plane: office0 0.65 GB, ScanNet 1.27, Indoor 2.24.
+                # LIST_BUDGET_BYTES still bounds the sum (capacities scaled down together); overflow stays correct (spill
+                # area sized for the worst case), only slower.
+                tiles = [((p.shape[2] + 15) // 16) * ((p.shape[3] + 15) // 16) for p in self.planes]
+                caps = [int(max(4096, 4 * 1.3 * R * S / t)) for t in tiles]
+                need = 32 * sum(t * c for t, c in zip(tiles, caps))
+                if need > self.LIST_BUDGET_BYTES:
+                    caps = [max(256, int(c * self.LIST_BUDGET_BYTES / need)) for c in caps]
+                tile_capacity = max(caps)
+                for k, c in enumerate(caps):
+                    b.plane_cap[k] = c
+            b.cap = tile_capacity
+            n_entries = self.lib.mne_tile_list_entries(C.byref(self.scene), C.byref(b))
             # (only the counters need to start at zero: an entry is read after it was written)
-            self.tile_lists = torch.empty(n_tiles, tile_capacity, 8, device=dev, dtype=torch.int32)
+            self.tile_lists = torch.empty(n_entries, 8, device=dev, dtype=torch.int32)
             self.tile_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
             if spill_capacity is None:
                 # worst case: every sample appends to 4 tiles of every plane and every entry overflows its list --
@@ -116,7 +126,6 @@ class FusedStep:
             self.spill = torch.empty(spill_capacity, 8, device=dev, dtype=torch.int32)
             self.spill_count = torch.zeros(1, device=dev, dtype=torch.int32)
             self.dropped = torch.zeros(1, device=dev, dtype=torch.int32)
-            b = _lib.TileBins()
             b.lists, b.counts = self.tile_lists.data_ptr(), self.tile_counts.data_ptr()
             b.spill, b.spill_count = self.spill.data_ptr(), self.spill_count.data_ptr()
             # processing order of the tiles (heaviest lists first), recomputed every iteration from that iteration's list
@@ -131,6 +140,8 @@ class FusedStep:
                 self.split_scratch = torch.empty(_lib.TILE_SPLIT_PARTS, 16 * 16 * 32, device=dev)
                 self.split_state = torch.zeros(n_tiles + 1, device=dev, dtype=torch.int32)
                 b.split_scratch, b.split_state = self.split_scratch.data_ptr(), self.split_state.data_ptr()
+            self.prev_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
+            b.prev_counts = self.prev_counts.data_ptr()
             b.cap, b.spill_cap = tile_capacity, spill_capacity
             b.dropped = self.dropped.data_ptr()
             self.bins = b
