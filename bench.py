@@ -62,6 +62,7 @@ def parse_args():
                     help="EXTENSION: all-reduce (mean) the decoder gradient over agents each iteration (RCCL)")
     ap.add_argument("--no-variants", dest="variants", action="store_false",
                     help="skip the short runs of the other section-8d workloads reported in the line's `variants` object")
+    ap.add_argument("--rays", type=int, default=None, help="with --small: global rays per iteration (functional runs)")
     ap.add_argument("--small", action="store_true", help="tiny planes/frames (functional check, not a benchmark)")
     ap.add_argument("--mode", default="mapping", choices=["mapping", "render_img"],
                     help="mapping = the metric (default); render_img = SURVEY 8f row N1: full-frame no-grad renders, the "
@@ -364,14 +365,27 @@ def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, bloc
 
 def main():
     args = parse_args()
-    if not torch.cuda.is_available():
+    # Launcher dry run (tests/test_dist_gloo.py): with MNE_EMULATED_LIBRARY = a host-emulator build of the kernels (test
+    # infrastructure, tests/hostemu) and no GPU, the same code path runs over gloo so that the multi-process logic has been
+    # executed before an 8-GPU node sees it.  Its line is marked as such and is not a measurement.
+    dry = os.environ.get("MNE_EMULATED_LIBRARY") if not torch.cuda.is_available() else None
+    if not torch.cuda.is_available() and not dry:
         raise SystemExit("bench.py needs an MI355X (the HIP library is the only backend)")
+    if dry:
+        from mneslam_amd import _lib
+        _lib.load(dry)
+        args.event_every, args.cpu_iters, args.variants = 1 << 30, 0, False
     from mneslam_amd import dist as mdist
     rank, world, device = mdist.init_agents()          # one process per GPU; RCCL when WORLD_SIZE > 1
     import torch.distributed as dist
     make_cfg, workload = configs.WORKLOADS[args.config]
     cfg = make_cfg(args.hidden) if args.hidden else make_cfg()
     args.hidden = cfg["decoder"]["hidden_dim"]
+    if args.rays:
+        if not args.small:
+            raise SystemExit("--rays changes the workload: functional runs (--small) only")
+        cfg["mapping"]["sample"] = args.rays
+        cfg["mapping"]["min_pixels_cur"] = min(cfg["mapping"]["min_pixels_cur"], max(args.rays // 4, 1))
     if args.small:
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
@@ -381,7 +395,8 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
 
     if args.mode == "render_img":
         return bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, mdist)
@@ -424,7 +439,7 @@ def main():
             "metric": f"mapping iters/sec ({cfg['mapping']['sample']} rays x {S} samples)", "value": world * args.steps / elapsed,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (HOST-EMULATOR DRY RUN of the launcher logic: not a measurement)" if dry else ""),
             "config": {"workload": workload + ("_SMALL" if args.small else "") + ("_fp16planes" if args.plane_storage == "fp16" else ""),
                        "rays_per_iter": R, "samples_per_ray": S, "plane_params": agent.n_plane_params,
                        "decoder_params": agent.n_dec_params, "mlp_hidden": args.hidden, "keyframes": args.keyframes,

@@ -365,6 +365,29 @@ int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* 
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
                   const mne_tile_bins_t* bins, const mne_clock_t* clock, void* stream);
 
+/* EXTENSION (multi-agent; the reference's agents exchange maps through files only, mp_slam/mapper.py:491-509 just tests
+ * which overlap box a point is in): plane gradients of the cells two agents both map, on the binned path -- no dense
+ * gradient tensor on either side.  The agents' planes sit on one lattice; the cells shared with peer k are, per plane, a
+ * rectangle of nodes [x0,x1) x [y0,y1) in THIS agent's indices (x1 <= x0: the plane shares nothing).  A buffer holds the
+ * rectangles of all planes back to back in all_planes order, each as [y1-y0][x1-x0][c_dim] floats
+ * (mne_tile_overlap_floats() in total).
+ *   mne_tile_order -> mne_tile_grad_export (send[k] filled) -> exchange with the peers (one message each way per peer)
+ *   -> mne_tile_adam_shared (= mne_tile_adam where a shared cell's gradient is send[k] + recv[k]: the agents add the same
+ *      two numbers, so cells that start equal stay bit-equal on both). */
+#define MNE_MAX_OVERLAP_PEERS 2
+typedef struct mne_tile_overlap {
+    int32_t n_peers, reserved;
+    struct { int32_t x0, y0, x1, y1; } rect[MNE_MAX_OVERLAP_PEERS][12];
+    float* send[MNE_MAX_OVERLAP_PEERS];
+    const float* recv[MNE_MAX_OVERLAP_PEERS];
+} mne_tile_overlap_t;
+size_t mne_sizeof_tile_overlap(void);
+size_t mne_tile_overlap_floats(const mne_scene_t* scene, const mne_tile_overlap_t* overlap, int peer);
+int mne_tile_grad_export(const mne_scene_t* scene, const float* tape, const mne_tile_bins_t* bins,
+                         const mne_tile_overlap_t* overlap, void* stream);
+int mne_tile_adam_shared(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
+                         const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, const mne_clock_t* clock, void* stream);
+
 /* Decoder weight gradients from the tape: dW = sum_rows outer(d_out, in) for the four matrices,
  * written as [w_col0 | w_col1 | w_sdf0 | w_sdf1] (the order of decoder.parameters(),
  * model/decoder.py:150-159) into grad_out.  Rows = for every ray r, the first ray_tiles[r] * 32 samples (as left by

@@ -53,6 +53,16 @@ class TileBins(C.Structure):
 
 
 TILE_SPLIT_PARTS = 2048
+MAX_OVERLAP_PEERS = 2
+
+
+class OverlapRect(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
+
+
+class TileOverlap(C.Structure):
+    _fields_ = [("n_peers", C.c_int32), ("reserved", C.c_int32), ("rect", (OverlapRect * 12) * MAX_OVERLAP_PEERS),
+                ("send", C.c_void_p * MAX_OVERLAP_PEERS), ("recv", C.c_void_p * MAX_OVERLAP_PEERS)]
 
 
 class PlaneOpt(C.Structure):
@@ -131,6 +141,11 @@ _PROTOS = {
                      + [C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_int, C.POINTER(FusedOpts), C.c_void_p]),
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_tile_list_entries": (C.c_size_t, [C.POINTER(Scene), C.POINTER(TileBins)]),
+    "mne_sizeof_tile_overlap": (C.c_size_t, []),
+    "mne_tile_overlap_floats": (C.c_size_t, [C.POINTER(Scene), C.POINTER(TileOverlap), C.c_int]),
+    "mne_tile_grad_export": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.POINTER(TileBins), C.POINTER(TileOverlap), C.c_void_p]),
+    "mne_tile_adam_shared": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins),
+                                       C.POINTER(TileOverlap), C.POINTER(Clock), C.c_void_p]),
     "mne_tile_order": (C.c_int, [C.POINTER(Scene), C.POINTER(TileBins), C.c_void_p]),
     "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.POINTER(Clock),
                                 C.c_void_p]),
@@ -186,7 +201,8 @@ def load(path=None):
         for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
                        (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),
                        (lib.mne_sizeof_plane_opt, PlaneOpt), (lib.mne_sizeof_clock, Clock),
-                       (lib.mne_sizeof_fused_opts, FusedOpts), (lib.mne_sizeof_decoder_opt, DecoderOpt)):
+                       (lib.mne_sizeof_fused_opts, FusedOpts), (lib.mne_sizeof_decoder_opt, DecoderOpt),
+                       (lib.mne_sizeof_tile_overlap, TileOverlap)):
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"struct layout mismatch for {st.__name__}: C {fn()} vs ctypes {C.sizeof(st)}")
         _lib = lib

@@ -432,16 +432,54 @@ int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* 
     return check_launch("tile_order");
 }
 
-int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
-                  const mne_tile_bins_t* bins, const mne_clock_t* clock, void* stream) {
+// overlap descriptor -> kernel form (rectangles clipped to nothing are refused: the caller's geometry is wrong then)
+static int fill_overlap(const mne_scene_t* scene, const mne_tile_overlap_t* ov, TileOverlap& out, bool need_send, bool need_recv) {
+    if (!ov || ov->n_peers < 1 || ov->n_peers > MNE_MAX_OVERLAP_PEERS) return fail(-1, "tile overlap: 1..MNE_MAX_OVERLAP_PEERS peers");
+    out.n_peers = ov->n_peers;
+    for (int k = 0; k < ov->n_peers; ++k) {
+        long long off = 0;
+        for (int p = 0; p < MNE_MAX_PLANES; ++p) {
+            OverlapRect& r = out.rect[k][p];
+            r = OverlapRect{0, 0, 0, 0, 0};
+            if (p >= scene->n_sets * 6) continue;
+            const mne_plane_t& pl = scene->plane[p / 6][(p % 6) / 2][p % 2];
+            const auto& q = ov->rect[k][p];
+            if (q.x1 <= q.x0 || q.y1 <= q.y0) continue;
+            if (q.x0 < 0 || q.y0 < 0 || q.x1 > pl.w || q.y1 > pl.h) return fail(-1, "tile overlap: rectangle outside its plane");
+            r = OverlapRect{q.x0, q.y0, q.x1, q.y1, off};
+            off += (long long)(q.x1 - q.x0) * (q.y1 - q.y0) * scene->c_dim;
+        }
+        if ((need_send && !ov->send[k]) || (need_recv && !ov->recv[k])) return fail(-1, "tile overlap: NULL exchange buffer");
+        out.send[k] = ov->send[k]; out.recv[k] = ov->recv[k];
+    }
+    return 0;
+}
+
+size_t mne_sizeof_tile_overlap(void) { return sizeof(mne_tile_overlap_t); }
+
+size_t mne_tile_overlap_floats(const mne_scene_t* scene, const mne_tile_overlap_t* ov, int peer) {
+    if (!scene || !ov || peer < 0 || peer >= ov->n_peers || peer >= MNE_MAX_OVERLAP_PEERS) return 0;
+    size_t n = 0;
+    for (int p = 0; p < scene->n_sets * 6 && p < 12; ++p) {
+        const auto& q = ov->rect[peer][p];
+        if (q.x1 > q.x0 && q.y1 > q.y0) n += (size_t)(q.x1 - q.x0) * (q.y1 - q.y0) * scene->c_dim;
+    }
+    return n;
+}
+
+static int tile_adam_impl(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
+                          const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, int form, const mne_clock_t* clock, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
-    if (!opt || !tape || !bins) return fail(-1, "mne_tile_adam: NULL argument");
+    if ((!opt && form != 1) || !tape || !bins) return fail(-1, "mne_tile_adam: NULL argument");
     TileAdamArgs a = {};
     a.sc = *scene;
     a.n_planes = scene->n_sets * 6;
     if (int rc = fill_bins(scene, bins, a.bins)) return rc;
     a.prev_counts = bins->prev_counts;
-    for (int k = 0; k < a.n_planes; ++k) {
+    TileOverlap ov = {};
+    if (form != 0)
+        if (int rc = fill_overlap(scene, overlap, ov, true, form == 2)) return rc;
+    for (int k = 0; form != 1 && k < a.n_planes; ++k) {
         const mne_plane_opt_t& g = opt[k];
         if (!g.m || !g.v || g.step < 1) return fail(-1, "mne_tile_adam: bad plane optimizer state");
         PlaneOpt& o = a.opt[k];
@@ -459,8 +497,23 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
     a.row_stride = (int)mne_dims_tape_row(*scene);
     a.t_dfeat = (int)mne_dims_tape_dfeat(*scene);
     a.t_pn = (int)mne_dims_tape_pn(*scene);
-    mne_launch_tile_adam(a, (hipStream_t)stream);
+    mne_launch_tile_adam(a, (hipStream_t)stream, form ? &ov : nullptr, form);
     return check_launch("tile_adam");
+}
+
+int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
+                  const mne_tile_bins_t* bins, const mne_clock_t* clock, void* stream) {
+    return tile_adam_impl(scene, opt, tape, bins, nullptr, 0, clock, stream);
+}
+
+int mne_tile_grad_export(const mne_scene_t* scene, const float* tape, const mne_tile_bins_t* bins,
+                         const mne_tile_overlap_t* overlap, void* stream) {
+    return tile_adam_impl(scene, nullptr, tape, bins, overlap, 1, nullptr, stream);
+}
+
+int mne_tile_adam_shared(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
+                         const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, const mne_clock_t* clock, void* stream) {
+    return tile_adam_impl(scene, opt, tape, bins, overlap, 2, clock, stream);
 }
 
 int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const int32_t* kf_pose_ids,

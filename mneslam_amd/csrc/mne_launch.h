@@ -222,6 +222,16 @@ struct TileAdamArgs {
     int* prev_counts;         // [n_tiles] final list lengths of the previous tile_adam launch (NULL: none) -- balance hint of tile_order
 };
 
+// EXTENSION (multi-agent): node rectangles of this agent's planes that a peer maps as well, with the exchange buffers
+// (mne_tile_overlap_t of the C ABI + the float offset of each plane's rectangle inside a buffer).
+struct OverlapRect { int x0, y0, x1, y1; long long off; };
+struct TileOverlap {
+    int n_peers;
+    OverlapRect rect[MNE_MAX_OVERLAP_PEERS][MNE_MAX_PLANES];
+    float* send[MNE_MAX_OVERLAP_PEERS];
+    const float* recv[MNE_MAX_OVERLAP_PEERS];
+};
+
 struct AdamArgs {
     mne_adam_seg_t seg[32];
     float step_size[32];      // lr / (1 - beta1^t)
@@ -253,7 +263,7 @@ int mne_launch_decoder_update(const DecUpdateArgs& a, hipStream_t st);
 int mne_launch_adam(const AdamArgs& a, hipStream_t st);
 int mne_launch_grid(const GridArgs& a, int bwd, hipStream_t st);
 int mne_launch_tile_order(const TileAdamArgs& a, hipStream_t st);
-int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st);
+int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st, const TileOverlap* ov = nullptr, int form = 0);
 void mne_tile_geometry(const mne_scene_t& sc, TileBins& b);
 int mne_launch_sample_rays(SampleRaysArgs a, unsigned long long seed, unsigned long long iteration, hipStream_t st);
 int mne_launch_batch(SampleRaysArgs sr, unsigned long long seed, unsigned long long iteration, const ZArgs& a, const LossArgs& lc,

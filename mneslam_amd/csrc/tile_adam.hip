@@ -162,7 +162,19 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
 }
 // (A ballot-ranked counting sort without same-address atomics was measured at 14.5 us against 12 us for this one.)
 
-__global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel(TileAdamArgs a) {
+// OV (EXTENSION, multi-agent: gradients of the plane cells two agents both map, mne_tile_overlap_t) --
+//   0  the mapping iteration of one agent (the only form the reference has);
+//   1  EXPORT: the tiles that meet a shared rectangle accumulate their lists as usual and write the gradient of the shared
+//      cells into the send buffers; no Adam, list counters untouched (the same lists are walked again by form 2);
+//   2  form 0 with the peers' gradients of the shared cells (recv buffers) added before the Adam update.
+// The shared cells of a plane are a rectangle of NODES in this agent's indices (the agents sit on one lattice,
+// mneslam_amd/dist.py::overlap_slices); buffers hold them plane after plane as [rows][cols][32].
+struct NoOverlap {};
+template <int OV> struct OvArg { typedef TileOverlap type; };
+template <> struct OvArg<0> { typedef NoOverlap type; };
+
+template <int OV>
+__global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel(TileAdamArgs a, typename OvArg<OV>::type ov) {
     MNE_DYN_LDS(lds_raw);
     float* g = (float*)lds_raw;                                   // [16][16][32] gradient tile, 32 KiB
     float* stage = g + TILE_CELLS * MNE_C;                        // [PASS_ENTRIES][32] gradient rows of this pass
@@ -183,6 +195,15 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     const int local = tile - a.bins.tile_base[pidx];
     const int tx0 = local % a.bins.ntx[pidx], ty0 = local / a.bins.ntx[pidx];
     const int cnt = a.bins.counts[tile];
+    bool shared_tile = false;                                  // does this tile hold cells of a shared rectangle?
+    if constexpr (OV != 0) {
+        for (int k = 0; k < ov.n_peers; ++k) {
+            const OverlapRect& r = ov.rect[k][pidx];
+            shared_tile = shared_tile || (r.x1 > r.x0 && tx0 * MNE_TILE < r.x1 && (tx0 + 1) * MNE_TILE > r.x0 &&
+                                          ty0 * MNE_TILE < r.y1 && (ty0 + 1) * MNE_TILE > r.y0);
+        }
+        if (OV == 1 && !shared_tile) return;                   // export: only the shared tiles have anything to say
+    }
     const bool empty = TILE_EMPTY_FAST && cnt == 0;            // no contribution: the sweep runs with g = 0, LDS untouched
     if (!empty)
         for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -408,6 +429,20 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         if (tid == 0) a.bins.split_state[tile] = 0;                                  // arrival counter ready for the next call
     }
     TILE_STAMP(5);
+    if constexpr (OV == 1) {                                   // ---- export the shared cells' gradient, nothing else
+        for (int it = 0; it < NIT; ++it) {
+            const int i4 = it * TILE_THREADS + tid;
+            const int y = i4 / (MNE_TILE * MNE_C / 4), x4 = i4 % (MNE_TILE * MNE_C / 4);
+            const int gy = ty0 * MNE_TILE + y, gx = tx0 * MNE_TILE + x4 / (MNE_C / 4);
+            const float4 gg = empty ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)g)[i4];
+            for (int k = 0; k < ov.n_peers; ++k) {
+                const OverlapRect& r = ov.rect[k][pidx];
+                if (gx >= r.x0 && gx < r.x1 && gy >= r.y0 && gy < r.y1)
+                    *(float4*)(ov.send[k] + r.off + ((size_t)(gy - r.y0) * (r.x1 - r.x0) + (gx - r.x0)) * MNE_C + (x4 % (MNE_C / 4)) * 4) = gg;
+            }
+        }
+        return;
+    }
     // ---- Adam on the tile: 16 rows x (16 cells x 32 ch) = 2048 float4
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -425,7 +460,24 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
 #else
             float4 p = *(float4*)(P + off), m = *(float4*)(o.m + offmv), v = *(float4*)(o.v + offmv);
 #endif
-            const float4 gg = empty ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)g)[i4];
+            float4 gg = empty ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)g)[i4];
+            if constexpr (OV == 2) {
+                if (shared_tile) {
+                    // A shared cell takes its OWN share from the send buffer, i.e. exactly the value the peer received, not
+                    // from this launch's LDS sum (same lists, but the summation order inside a cell is not fixed): both
+                    // agents then add the same two numbers and their shared cells stay bit-equal.
+                    bool own_taken = false;
+                    for (int k = 0; k < ov.n_peers; ++k) {
+                        const OverlapRect& r = ov.rect[k][pidx];
+                        if (gx >= r.x0 && gx < r.x1 && gy >= r.y0 && gy < r.y1) {
+                            const size_t at = r.off + ((size_t)(gy - r.y0) * (r.x1 - r.x0) + (gx - r.x0)) * MNE_C + ch4 * 4;
+                            if (!own_taken) { gg = *(const float4*)(ov.send[k] + at); own_taken = true; }
+                            const float4 t = *(const float4*)(ov.recv[k] + at);
+                            gg.x += t.x; gg.y += t.y; gg.z += t.z; gg.w += t.w;
+                        }
+                    }
+                }
+            }
             adam_elem(p.x, gg.x, m.x, v.x, o); adam_elem(p.y, gg.y, m.y, v.y, o);
             adam_elem(p.z, gg.z, m.z, v.z, o); adam_elem(p.w, gg.w, m.w, v.w, o);
             *(float4*)(P + off) = p; *(float4*)(o.m + offmv) = m; *(float4*)(o.v + offmv) = v;
@@ -468,12 +520,16 @@ int mne_launch_tile_order(const TileAdamArgs& a, hipStream_t st) {
     return 0;
 }
 
-int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st) {
+int mne_launch_tile_adam(const TileAdamArgs& a, hipStream_t st, const TileOverlap* ov, int form) {
     const int n_tiles = a.bins.tile_base[a.n_planes];
     if (n_tiles <= 0) return 0;
     const size_t lds = (size_t)(TILE_CELLS + PASS_ENTRIES) * MNE_C * sizeof(float);
-    if (lds > 32 * 1024) MNE_SET_MAX_LDS(tile_adam_kernel, lds);        // static LDS (keys, weights, counters) comes on top
+    if (lds > 32 * 1024) {
+        MNE_SET_MAX_LDS((tile_adam_kernel<0>), lds); MNE_SET_MAX_LDS((tile_adam_kernel<1>), lds); MNE_SET_MAX_LDS((tile_adam_kernel<2>), lds);
+    }        // static LDS (keys, weights, counters) comes on top
     const int grid = n_tiles + (a.bins.split_scratch ? MNE_TILE_SPLIT_PARTS : 0);          // item capacity; surplus workgroups leave at once
-    MNE_LAUNCH(tile_adam_kernel, grid, TILE_THREADS, lds, st, a);
+    if (!ov) MNE_LAUNCH((tile_adam_kernel<0>), grid, TILE_THREADS, lds, st, a, NoOverlap{});
+    else if (form == 1) MNE_LAUNCH((tile_adam_kernel<1>), grid, TILE_THREADS, lds, st, a, *ov);
+    else MNE_LAUNCH((tile_adam_kernel<2>), grid, TILE_THREADS, lds, st, a, *ov);
     return 0;
 }

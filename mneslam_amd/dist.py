@@ -187,6 +187,18 @@ def exchange_overlap_gradients(grads, shapes_bounds, peer, peer_shapes_bounds):
         g[:, :, ys, xs] += theirs
 
 
+def exchange_buffers(peers, send, recv):
+    """One message each way per peer, all posted together (the binned path's overlap exchange: ``send[k]`` holds this agent's
+    gradients of the cells shared with ``peers[k]``, ``recv[k]`` receives the peer's; RCCL point-to-point over xGMI on
+    GPUs, stream-ordered with the caller's current stream)."""
+    ops = []
+    for peer, s, r in zip(peers, send, recv):
+        ops.append(dist.P2POp(dist.isend, s, peer))
+        ops.append(dist.P2POp(dist.irecv, r, peer))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
 def plane_geometry(model):
     """((H, W), extended bound as [3][2] floats, plane axes) for every plane of ``model`` in all_planes order."""
     bound = [[float(lo), float(hi)] for lo, hi in torch.as_tensor(model.bound).cpu()]

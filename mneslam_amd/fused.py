@@ -43,9 +43,12 @@ class FusedStep:
         self.shared_decoder = shared_decoder
         # EXTENSION: [(peer rank, peer plane geometry)] of agents on the same global lattice whose bounds overlap ours:
         # the plane gradients of the shared region are summed pairwise before Adam (dist.exchange_overlap_gradients)
+        # (binned path: the shared cells' gradients travel as rectangles cut out of the tiles' LDS sums, one message each
+        # way per peer -- mne_tile_grad_export / mne_tile_adam_shared; atomics path: slices of the gradient buffers)
         self.overlap_peers = list(overlap_peers or [])
-        if self.overlap_peers and scatter != "atomics":
-            raise ValueError("the overlap-region gradient exchange works on gradient buffers: scatter='atomics'")
+        self.tile_overlap = None
+        if len(self.overlap_peers) > _lib.MAX_OVERLAP_PEERS and scatter != "atomics":
+            raise ValueError(f"the binned plane update exchanges with at most {_lib.MAX_OVERLAP_PEERS} peers (slabs along one axis)")
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("the fused mapping step needs mneslam_amd.optim.FusedAdam "
                             "(slam_glue.create_optimizer builds it with the reference's groups)")
@@ -143,6 +146,25 @@ class FusedStep:
             self.prev_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
             b.prev_counts = self.prev_counts.data_ptr()
             b.cap, b.spill_cap = tile_capacity, spill_capacity
+            if self.overlap_peers:
+                from . import dist as mdist
+                ov = _lib.TileOverlap()
+                ov.n_peers = len(self.overlap_peers)
+                geo = mdist.plane_geometry(model)
+                for k, (peer, peer_geo) in enumerate(self.overlap_peers):
+                    for pi, ((shape, bound, axes), (pshape, pbound, _)) in enumerate(zip(geo, peer_geo)):
+                        sl = mdist.overlap_slices(bound, pbound, shape, pshape, axes)
+                        if sl is not None:
+                            (ys, xs), _ = sl
+                            r = ov.rect[k][pi]
+                            r.x0, r.x1, r.y0, r.y1 = xs.start, xs.stop, ys.start, ys.stop
+                self.ov_send, self.ov_recv = [], []
+                for k in range(ov.n_peers):
+                    n = self.lib.mne_tile_overlap_floats(C.byref(self.scene), C.byref(ov), k)
+                    self.ov_send.append(torch.zeros(max(n, 1), device=dev))
+                    self.ov_recv.append(torch.zeros(max(n, 1), device=dev))
+                    ov.send[k], ov.recv[k] = self.ov_send[k].data_ptr(), self.ov_recv[k].data_ptr()
+                self.tile_overlap = ov
             b.dropped = self.dropped.data_ptr()
             self.bins = b
             self.plane_opt = (_lib.PlaneOpt * len(self.planes))()
@@ -519,8 +541,19 @@ class FusedStep:
                 with torch.cuda.stream(side) if side is not None else _null_ctx():
                     self.tile_counts.zero_()
             e0 = self._mark("adam", stream=side)
-            _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), None, st2),
-                       "mne_tile_adam")
+            if self.tile_overlap is not None:
+                # EXTENSION: the peers' gradients of the shared cells join ours before the update.  Export -> one batched
+                # exchange per peer (RCCL point-to-point on the side stream; gloo on the host) -> update.
+                from . import dist as mdist
+                _lib.check(lib.mne_tile_grad_export(C.byref(self.scene), P(self.tape), C.byref(self.bins),
+                                                    C.byref(self.tile_overlap), st2), "mne_tile_grad_export")
+                with torch.cuda.stream(side) if side is not None else _null_ctx():
+                    mdist.exchange_buffers([peer for peer, _ in self.overlap_peers], self.ov_send, self.ov_recv)
+                _lib.check(lib.mne_tile_adam_shared(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins),
+                                                    C.byref(self.tile_overlap), None, st2), "mne_tile_adam_shared")
+            else:
+                _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), None, st2),
+                           "mne_tile_adam")
             self._mark("adam", e0, stream=side)
             if side is not None:
                 ev[1].record(side)                      # "planes updated": what the next decode waits for
