@@ -184,6 +184,8 @@ class FusedMappingMixin:
         n, floor = cfg["mapping"]["sample"], cfg["mapping"]["min_pixels_cur"]
         per_kf = max(n // num_expanded_kfs, floor) if num_expanded_kfs > 0 else n
         pool = self.dataset.rays_d.reshape(-1, 3)
+        if self.compute == "fused" and expanded_foreign_kfs_for_distill:
+            return self._distillation_fused(expanded_foreign_kfs_for_distill, per_kf, pool)
         for _ in range(cfg["mapping"]["distill_iters"]):
             pieces = []
             for kf in expanded_foreign_kfs_for_distill:
@@ -200,6 +202,40 @@ class FusedMappingMixin:
             ret = self.model.forward(*[torch.cat(col, 0) for col in zip(*pieces)])
             self.slam.get_loss_from_ret(ret, is_co_sdf=cfg["is_co_sdf"]).backward()
             self.map_optimizer.step()
+
+
+    def _distillation_fused(self, kfs, per_kf, pool):
+        """The same loop as device work only: per iteration ONE no-grad teacher launch sequence over the rays of all foreign
+        keyframes (``render_maps``) and ONE fused student iteration (FusedStep: no autograd graph, no gradient tensors,
+        no torch.optim step).  The batch reaches the fused step in the keyframe-database form it already understands:
+        rows [camera direction, teacher rgb, teacher depth], ``per_kf`` rows per keyframe, row k belongs to pose k // per_kf.
+        Host RNG draws (ray picks, jitter with ``jitter_rng == "torch_cpu"``) keep the reference's order."""
+        cfg, dev, K = self.config, self.device, len(kfs)
+        R = K * per_kf
+        fs = self._fused_step(R)
+        poses = torch.stack([kf["pose"].to(dev, torch.float32) for kf in kfs]).contiguous()          # [K,4,4]
+        pool_dev = pool.to(dev, torch.float32)
+        rows = torch.arange(R, device=dev)
+        teacher, S_t = self.model_shared, cfg["training"]["n_samples"]
+        host_u = cfg["training"]["perturb"] > 0.0 and getattr(teacher, "jitter_rng", None) == "torch_cpu"
+        host_u_student = cfg["training"]["perturb"] > 0.0 and getattr(self.model, "jitter_rng", None) == "torch_cpu"
+        rot, org = poses[:, None, :3, :3], poses[:, None, :3, 3]
+        for it in range(cfg["mapping"]["distill_iters"]):
+            picks, us = [], []
+            for _ in range(K):                          # (reference order: pick, teacher jitter, next keyframe)
+                picks.append(torch.randint(0, len(pool), (per_kf,)))
+                if host_u:
+                    us.append(torch.rand(per_kf, S_t))
+            dirs = pool_dev[torch.stack(picks).to(dev)]                                            # [K,per_kf,3]
+            rays_d = torch.sum(dirs[..., None, :] * rot, dim=-1).reshape(R, 3)
+            rays_o = org.expand(K, per_kf, 3).reshape(R, 3)
+            with torch.no_grad():
+                t = teacher.render_maps(rays_o, rays_d, target_d=None, u=torch.cat(us).to(dev) if host_u else None)
+            db = torch.cat([dirs.reshape(R, 3), t["rgb"], t["depth"].reshape(R, 1)], -1).contiguous()
+            fs.step(db, R, per_kf, db, poses, R, 0, idx_global=rows,
+                    u=torch.rand(R, fs.S).to(dev) if host_u_student else None)
+        fs.check()
+        self.last_losses = fs.loss_dict()
 
 
 def bind(host_mapper_cls, compute="fused", sampler="host", scatter="binned", **fused_kwargs):

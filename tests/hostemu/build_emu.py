@@ -36,7 +36,7 @@ def build(force=False):
         obj = os.path.join(OUT, s[:-4] + ".o")
         cmd = [_cxx(), "-x", "c++", "-std=c++20", "-O1", "-g", "-fPIC", "-pthread", "-DMNE_HOST_EMU",
                "-ffp-contract=off", "-Wno-unknown-pragmas", "-Wno-pass-failed",
-               *((["-fsanitize=" + SAN, "-fno-omit-frame-pointer"]) if SAN else []),
+               *((["-fsanitize=" + SAN, "-fno-omit-frame-pointer", "-DMNE_EMU_OS_THREADS"]) if SAN else []),
                "-I", HERE, "-I", CSRC, "-I", os.path.join(REPO, "include"),
                "-c", os.path.join(CSRC, s), "-o", obj]
         subprocess.check_call(cmd)

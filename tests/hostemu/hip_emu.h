@@ -2,14 +2,18 @@
 //
 // Purpose: the build container has no GPU, and GPU time is scarce.  Compiling the *same* kernel
 // sources with g++ -DMNE_HOST_EMU against this header lets tests/ run them on CPU tensors (slowly):
-// one workgroup at a time, one OS thread per work-item, wave64 collectives (__shfl*, __ballot,
-// MFMA) and __syncthreads implemented with barriers.  It is never part of the shipped library:
+// one workgroup at a time, one OS thread per wave with its work-items as fibers (or, for sanitizer builds,
+// -DMNE_EMU_OS_THREADS: one OS thread per work-item), wave64 collectives (__shfl*, __ballot, MFMA) and
+// __syncthreads as barriers.  It is never part of the shipped library:
 // mneslam_amd/ loads only the hipcc-built libmneslam_hip.so and fails loudly without it.
 //
 // Emulated semantics follow /opt/skills/guides (wave = 64 lanes; MFMA f32 32x32x2 fragment layout:
 // A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D col=l&31,row=(reg&3)+8*(reg>>2)+4*(l>>5)).
 #pragma once
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <sys/mman.h>
 #include <barrier>
 #include <cmath>
 #include <cstdint>
@@ -56,7 +60,7 @@ struct BlockCtx {
     unsigned nthreads;
     std::unique_ptr<std::barrier<>> block_bar;
     std::unique_ptr<std::barrier<>> end_bar;
-    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
+    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;      // (OS-thread model only)
     std::vector<uint64_t> xchg;      // one 8-byte slot per work-item
     std::vector<uint64_t> xchg2;
     std::vector<unsigned char> dyn_lds;
@@ -70,21 +74,11 @@ inline int wave_lanes() {           // live lanes in this (possibly partial) wav
     int n = (int)g_ctx->nthreads - base;
     return n > WAVE ? WAVE : n;
 }
+
+#ifdef MNE_EMU_OS_THREADS
+// ---- model A (sanitizer builds): one OS thread per work-item, std::barrier per wave and per block
 inline void wave_sync() { g_ctx->wave_bar[wave()]->arrive_and_wait(); }
-
-template <class T> inline uint64_t to_bits(T v) { uint64_t b = 0; std::memcpy(&b, &v, sizeof(T)); return b; }
-template <class T> inline T from_bits(uint64_t b) { T v; std::memcpy(&v, &b, sizeof(T)); return v; }
-
-template <class T> inline T shfl_idx(T v, int src) {
-    static_assert(sizeof(T) <= 8, "shuffle payload");
-    int base = wave() * WAVE;
-    g_ctx->xchg[threadIdx.x] = to_bits(v);
-    wave_sync();
-    int s = src & 63;
-    T r = (s < wave_lanes()) ? from_bits<T>(g_ctx->xchg[base + s]) : v;
-    wave_sync();
-    return r;
-}
+inline void block_sync() { g_ctx->block_bar->arrive_and_wait(); }
 
 template <class K, class... A>
 void launch(K kern, unsigned grid, unsigned block, size_t lds, A... args) {
@@ -118,6 +112,146 @@ void launch(K kern, unsigned grid, unsigned block, size_t lds, A... args) {
     for (auto& th : pool) th.join();
     g_ctx = nullptr;
 }
+#else
+// ---- model B (default): one OS thread per WAVE, its work-items are fibers on that thread (user-space context switch).
+// A wave collective is a turn of the round robin instead of a futex barrier among 64 oversubscribed threads: the same
+// kernels run 10-30x faster.  Lanes of a wave still execute independently between collectives, exactly as far as the
+// kernels are allowed to assume (they mark every cross-lane dependency with MNE_WAVE_SYNC / a shuffle / __syncthreads).
+constexpr size_t FIBER_STACK = 1u << 20;
+struct WaveCtx {
+    int n = 0, cur = 0, wave = 0, n_done = 0;
+    void* sp[WAVE];
+    bool done[WAVE];
+    void* sched_sp = nullptr;
+    int arrived = 0, arrived_b = 0;
+    unsigned gen = 0, gen_b = 0;
+    char* stacks = nullptr;
+    std::function<void()> body;
+};
+inline thread_local WaveCtx* t_wave = nullptr;
+
+// save callee-saved registers + stack pointer of the running fiber, continue the other one (System V x86-64)
+__attribute__((naked, noinline)) static void emu_switch(void** /*save_sp: rdi*/, void* /*load_sp: rsi*/) {
+    __asm__ volatile(
+        "pushq %rbp\n pushq %rbx\n pushq %r12\n pushq %r13\n pushq %r14\n pushq %r15\n"
+        "movq %rsp, (%rdi)\n movq %rsi, %rsp\n"
+        "popq %r15\n popq %r14\n popq %r13\n popq %r12\n popq %rbx\n popq %rbp\n ret\n");
+}
+inline void fiber_resume_from(WaveCtx& w, int from, int to) {
+    w.cur = to;
+    threadIdx.x = (unsigned)(w.wave * WAVE + to);
+    emu_switch(&w.sp[from], w.sp[to]);
+}
+inline void fiber_yield() {
+    WaveCtx& w = *t_wave;
+    int nxt = w.cur;
+    for (int k = 1; k <= w.n; ++k) { nxt = (w.cur + k) % w.n; if (!w.done[nxt]) break; }
+    if (nxt == w.cur) {       // every other lane of the wave has left the kernel while this one waits in a collective
+        std::fprintf(stderr, "hip_emu: lane %d of wave %d waits in a collective its wave has abandoned\n", w.cur, w.wave);
+        std::abort();
+    }
+    fiber_resume_from(w, w.cur, nxt);
+}
+inline void wave_sync() {
+    WaveCtx& w = *t_wave;
+    if (w.n == 1) return;
+    const unsigned g = w.gen;
+    if (++w.arrived == w.n) { w.arrived = 0; ++w.gen; return; }
+    while (*(volatile unsigned*)&w.gen == g) fiber_yield();
+}
+inline void block_sync() {
+    WaveCtx& w = *t_wave;
+    const unsigned g = w.gen_b;
+    if (++w.arrived_b == w.n) {            // the wave's last lane meets the other waves, then releases its own
+        w.arrived_b = 0;
+        g_ctx->block_bar->arrive_and_wait();
+        ++w.gen_b;
+        return;
+    }
+    while (*(volatile unsigned*)&w.gen_b == g) fiber_yield();
+}
+static void fiber_entry() {
+    WaveCtx& w = *t_wave;
+    w.body();
+    WaveCtx& v = *t_wave;
+    v.done[v.cur] = true;
+    void* dead;
+    if (++v.n_done == v.n) emu_switch(&dead, v.sched_sp);          // back to the wave's OS thread: block finished
+    int nxt = v.cur;
+    for (int k = 1; k <= v.n; ++k) { nxt = (v.cur + k) % v.n; if (!v.done[nxt]) break; }
+    v.cur = nxt;
+    threadIdx.x = (unsigned)(v.wave * WAVE + nxt);
+    emu_switch(&dead, v.sp[nxt]);
+    __builtin_unreachable();
+}
+inline void run_wave(WaveCtx& w, unsigned grid, BlockCtx& ctx) {
+    t_wave = &w;
+    w.stacks = (char*)mmap(nullptr, FIBER_STACK * w.n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (w.stacks == (char*)MAP_FAILED) { std::perror("hip_emu: mmap"); std::abort(); }
+    for (unsigned b = 0; b < grid; ++b) {
+        blockIdx.x = b;
+        w.n_done = 0; w.arrived = w.arrived_b = 0;
+        for (int i = 0; i < w.n; ++i) {
+            w.done[i] = false;
+            uintptr_t top = ((uintptr_t)(w.stacks + FIBER_STACK * (size_t)(i + 1))) & ~(uintptr_t)15;
+            void** s = (void**)top;
+            *--s = nullptr;                      // keeps the entry frame 16-byte aligned as after a call
+            *--s = (void*)&fiber_entry;          // `ret` target of the first switch
+            for (int r = 0; r < 6; ++r) *--s = nullptr;
+            w.sp[i] = (void*)s;
+        }
+        w.cur = 0;
+        threadIdx.x = (unsigned)(w.wave * WAVE);
+        emu_switch(&w.sched_sp, w.sp[0]);
+        ctx.end_bar->arrive_and_wait();          // static __shared__ is reused by the next block
+    }
+    munmap(w.stacks, FIBER_STACK * w.n);
+    t_wave = nullptr;
+}
+
+template <class K, class... A>
+void launch(K kern, unsigned grid, unsigned block, size_t lds, A... args) {
+    BlockCtx ctx;
+    ctx.nthreads = block;
+    const unsigned nw = (block + WAVE - 1) / WAVE;
+    ctx.block_bar = std::make_unique<std::barrier<>>(nw);
+    ctx.end_bar = std::make_unique<std::barrier<>>(nw);
+    ctx.xchg.assign(block, 0);
+    ctx.xchg2.assign(block, 0);
+    ctx.dyn_lds.assign(lds + 64, 0);
+    g_ctx = &ctx;
+    blockDim.x = block;
+    gridDim.x = grid;
+    std::vector<std::thread> pool;
+    pool.reserve(nw);
+    for (unsigned wv = 0; wv < nw; ++wv) {
+        pool.emplace_back([&, wv]() {
+            WaveCtx w;
+            w.wave = (int)wv;
+            w.n = (int)std::min<unsigned>(WAVE, block - wv * WAVE);
+            w.body = [&]() { kern(args...); };
+            run_wave(w, grid, ctx);
+        });
+    }
+    for (auto& th : pool) th.join();
+    g_ctx = nullptr;
+}
+#endif
+
+template <class T> inline uint64_t to_bits(T v) { uint64_t b = 0; std::memcpy(&b, &v, sizeof(T)); return b; }
+template <class T> inline T from_bits(uint64_t b) { T v; std::memcpy(&v, &b, sizeof(T)); return v; }
+
+template <class T> inline T shfl_idx(T v, int src) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    int base = wave() * WAVE;
+    g_ctx->xchg[threadIdx.x] = to_bits(v);
+    wave_sync();
+    int s = src & 63;
+    T r = (s < wave_lanes()) ? from_bits<T>(g_ctx->xchg[base + s]) : v;
+    wave_sync();
+    return r;
+}
+
 template <class K, class... A>
 void launch2d(K kern, unsigned gx, unsigned gy, unsigned block, A... args) {
     // collective-free kernels only: run work-items sequentially on the calling thread
@@ -144,7 +278,7 @@ typedef const float* mne_cptr;
 #define MNE_FENCE_RELEASE_AGENT() std::atomic_thread_fence(std::memory_order_seq_cst)
 #define MNE_FENCE_ACQUIRE_AGENT() std::atomic_thread_fence(std::memory_order_seq_cst)
 #define MNE_SET_MAX_LDS(kern, bytes) ((void)0)
-inline void __syncthreads() { hipemu::g_ctx->block_bar->arrive_and_wait(); }
+inline void __syncthreads() { hipemu::block_sync(); }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 template <class T> inline T __shfl(T v, int src, int = 64) { return hipemu::shfl_idx(v, src); }
 template <class T> inline T mne_bcast8(T v, int k) { return __shfl(v, (int)((threadIdx.x & 63u) & ~7u) | k); }

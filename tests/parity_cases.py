@@ -3,6 +3,7 @@ two backends: the real library on an MI355X (tests/test_hip_parity_gpu.py, ``-m 
 test-only host emulation of the same kernel sources (tests/test_kernels_hostemu.py, CPU).
 Every function takes the torch device to run on."""
 import copy
+import os
 import random
 import types
 
@@ -546,9 +547,10 @@ def check_pose_alignment(device):
     assert not torch.allclose(rel_h, base @ torch.inverse(target0))     # the pose moved
 
 
-def check_distillation(device):
+def check_distillation(device, compute="autograd"):
     """Mapper.distillation (reference loop: mp_slam/mapper.py:598-640): teacher = model_shared, student = model; three
-    iterations on the HIP path vs the same loop on the CPU oracle (oracle forward/backward + OracleAdam)."""
+    iterations on the HIP path vs the same loop on the CPU oracle (oracle forward/backward + OracleAdam).
+    compute="fused": the device loop (one teacher render_maps + one FusedStep iteration, no autograd, no torch.optim)."""
     g = load_golden("mapping3_onegrid_esdf")
     cfg = configs.small_test_config(one_grid=True, is_co_sdf=False)
     cfg["mapping"].update(sample=64, min_pixels_cur=10, distill_iters=3)
@@ -566,9 +568,11 @@ def check_distillation(device):
     slam = types.SimpleNamespace(model=student, model_shared=teacher, map_optimizer=opt, device=torch.device(device),
                                  dataset=dataset, video=None,
                                  get_loss_from_ret=lambda ret, is_co_sdf=True: slam_glue.get_loss_from_ret(cfg, ret, is_co_sdf=is_co_sdf))
-    mp = Mapper(cfg, slam)
+    mp = Mapper(cfg, slam, compute=compute)
     torch.manual_seed(5)
     mp.distillation(1, kfs, len(kfs))
+    if compute == "fused":
+        assert all(p.grad is None for lst in student.all_planes for p in lst) and bool(torch.isfinite(mp.last_losses["rgb_loss"]))
     # oracle: the same loop with the CPU restatement
     t_sc = oracle_scene_from_golden(g, cfg, prefix="init.")
     s_sc = oracle_scene_from_golden(g, cfg, prefix="init.")
@@ -1194,3 +1198,36 @@ def dense_grid_config():
     cfg["training"]["n_range_d"], cfg["training"]["n_samples_d"] = 21, 43
     cfg["mapping"]["sample"] = 512
     return cfg
+
+
+def check_checkpoint_handoff(device, tmp_dir):
+    """N4 on the device: an agent publishes its map from a device-resident model (slam_glue.save_latest_checkpoint), a peer
+    reads it into its device-resident ``model_shared`` (slam_glue.load_foreign_model; reference: mneslam_mp.py:294-315,
+    mp_slam/mapper.py:708-726) and uses it as the distillation teacher: ``render_maps`` without depth guidance
+    (mp_slam/mapper.py:617-622) against the oracle holding the publisher's parameters."""
+    g = load_golden("fwd_onegrid")
+    cfg = configs.small_test_config(one_grid=True)
+    cfg["data"].update(output=str(tmp_dir), exp_name="handoff")
+    publisher = model_from_golden(g, cfg, device).train()
+    path = slam_glue.save_latest_checkpoint(publisher, cfg, rank=1)
+    # the reader starts from another map of ANOTHER shape (its own bound) and is replaced wholesale
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["mapping"]["bound"] = [[-0.5, 0.7], [-0.6, 0.6], [-0.4, 0.5]]
+    shared = JointEncoding(cfg2, torch.tensor(cfg2["mapping"]["bound"], dtype=torch.float64)).to(device)
+    ckpt = slam_glue.load_foreign_model(shared, cfg, 1, torch.device(device))
+    assert set(ckpt) == {"model", "all_planes", "bound", "bounding_box"} and os.path.dirname(path) == slam_glue.agent_dir(cfg, 1)
+    assert not shared.training
+    for lst_s, lst_p in zip(shared.all_planes, publisher.all_planes):
+        for p, q in zip(lst_s, lst_p):
+            assert p.device.type == torch.device(device).type and p.is_contiguous(memory_format=torch.channels_last)
+            assert torch.equal(p, q.detach())
+    rays_o, rays_d, *_ = fixture_inputs(g)
+    n = rays_o.shape[0]
+    u = torch.rand(n, cfg["training"]["n_samples"], generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        got = shared.render_maps(rays_o.to(device), rays_d.to(device), target_d=None, u=u.to(device))
+    sc = oracle_scene_from_golden(g, cfg)
+    with torch.no_grad():
+        want = sc.render_rays(rays_o, rays_d, target_d=None, u=u)
+    assert_close(got["rgb"].cpu(), want["rgb"], rtol=1e-4, atol=2e-5, what="teacher rgb after the hand-off")
+    assert_close(got["depth"].cpu(), want["depth"], rtol=1e-4, atol=2e-5, what="teacher depth after the hand-off")

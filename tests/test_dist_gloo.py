@@ -142,7 +142,6 @@ def _shared_decoder_worker(rank, world, port, ret):
     open(ret + f".ok{rank}", "w").write("ok")
 
 
-@pytest.mark.skipif(os.environ.get("MNE_EMU_FULL", "0") != "1", reason="slow emulator case (MNE_EMU_FULL=1)")
 def test_two_agents_shared_decoder_fused_step(tmp_path):
     port = 29900 + (os.getpid() % 90)
     ret = str(tmp_path / "s")

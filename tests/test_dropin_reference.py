@@ -23,10 +23,8 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 
 REF = os.environ.get("MNESLAM_REFERENCE", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
-# the emulator runs one OS thread per work-item: the default CPU run keeps the cheap structural cases; MNE_EMU_FULL=1 runs
-# every case, including the end-to-end ones (the reference's own Mapper driving this repository's model through
-# first_frame_mapping / mapping_optimize against the golden post-step parameters: ~5 minutes each)
-full = pytest.mark.skipif(os.environ.get("MNE_EMU_FULL", "0") != "1", reason="slow emulator case (MNE_EMU_FULL=1)")
+# (every case runs by default, including the end-to-end ones: the reference's own Mapper driving this repository's model
+# through first_frame_mapping / mapping_optimize against the golden post-step parameters)
 
 from helpers import DEC_KEYS, assert_close, load_golden, n_plane_sets  # noqa: E402
 import parity_cases as pc  # noqa: E402
@@ -113,7 +111,7 @@ def _assert_final(g, m):
         assert_close(sd[k].detach().cpu(), g[f"final.dec.{k}"], rtol=1e-3, atol=1e-4, what=f"decoder {k}")
 
 
-@pytest.mark.parametrize("kf_side", [pytest.param("reference", marks=full), pytest.param("repo", marks=full)])   # ~5 min each on the emulator
+@pytest.mark.parametrize("kf_side", ["reference", "repo"])
 def test_reference_mapper_drives_repo_model(ref, tmp_path, kf_side):
     """Integration level 1: the reference's UNMODIFIED Mapper.mapping_optimize (its own loop, its own ray assembly)
     on this repository's JointEncoding + FusedAdam reaches the parameters the reference reached with its own model."""
@@ -141,7 +139,6 @@ def test_bound_mapper_class_structure(ref):
         repo_mapper.bind(ref.Mapper, compute="autograd", sampler="device")
 
 
-@full
 def test_fused_mixin_over_reference_mapper(ref, tmp_path):
     """Integration level 2: bind(reference Mapper) replaces mapping_optimize by the fused iteration (host RNG draws in
     the reference's order); everything else of the class is the reference's."""
@@ -159,7 +156,6 @@ def test_fused_mixin_over_reference_mapper(ref, tmp_path):
     _assert_final(g, m)
 
 
-@full
 def test_first_frame_mapping_keeps_host_bookkeeping(ref, tmp_path):
     """The fused first-frame loop hands over to the reference's own first_frame_mapping (zero iterations) for the
     bookkeeping of mp_slam/mapper.py:91-116: first keyframe, keyframe_dict entry, flag, dumps, pose files."""

@@ -166,8 +166,13 @@ def test_loop_closure_pose_alignment():
     pc.check_pose_alignment(DEV)
 
 
-def test_loop_closure_distillation():
-    pc.check_distillation(DEV)
+def test_checkpoint_handoff_between_device_models(tmp_path):
+    pc.check_checkpoint_handoff(DEV, tmp_path)
+
+
+@pytest.mark.parametrize("compute", ["autograd", "fused"])
+def test_loop_closure_distillation(compute):
+    pc.check_distillation(DEV, compute)
 
 
 def test_full_size_paths_agree_and_learn():

@@ -13,10 +13,8 @@ import parity_cases as pc  # noqa: E402
 from mneslam_amd import _lib  # noqa: E402
 
 DEV = "cpu"
-# The emulator runs one OS thread per work-item, so the heavier cases take minutes each.  The default
-# CPU run keeps a fast core (ABI, OneBlob, Adam, sampler, one forward, one backward, the fused binned
-# iteration); MNE_EMU_FULL=1 runs everything (what the kernels were debugged with).
-full = pytest.mark.skipif(os.environ.get("MNE_EMU_FULL", "0") != "1", reason="slow emulator case (MNE_EMU_FULL=1)")
+# The emulator runs a wave as one OS thread with its 64 work-items as fibers (tests/hostemu/hip_emu.h): every case of this
+# file, end-to-end iterations included, takes seconds, so all of them are in the default CPU run.
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -46,23 +44,19 @@ def test_forward_onegrid():
     pc.check_forward("fwd_onegrid", DEV)
 
 
-@full
 def test_forward_colorplanes():
     pc.check_forward("fwd_colorplanes", DEV)
 
 
-@full
 def test_backward_onegrid_esdf():
     pc.check_backward("fwd_onegrid", False, DEV)
 
 
-@full
 @pytest.mark.parametrize("name,co", [("fwd_onegrid", True), ("fwd_colorplanes", False), ("fwd_colorplanes", True)])
 def test_backward(name, co):
     pc.check_backward(name, co, DEV)
 
 
-@full
 def test_backward_scalar_wgrad_crosscheck():
     pc.check_backward("fwd_onegrid", False, DEV, wgrad_impl=1)
 
@@ -71,22 +65,18 @@ def test_all_invalid():
     pc.check_all_invalid(DEV)
 
 
-@full
 def test_render_nodepth():
     pc.check_render_nodepth(DEV)
 
 
-@full
 def test_queries():
     pc.check_queries(DEV)
 
 
-@full
 def test_device_clock():
     pc.check_device_clock(DEV)
 
 
-@full
 def test_render_maps_fast_path_and_render_img():
     pc.check_render_maps_fast_path(DEV)
 
@@ -95,7 +85,6 @@ def test_corner_indices_bit_exact():
     pc.check_corner_indices(DEV, "fwd_onegrid")
 
 
-@full
 def test_mapping3_onegrid():
     pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV)
 
@@ -104,34 +93,28 @@ def test_device_sampler():
     pc.check_device_sampler(DEV)
 
 
-@full
 @pytest.mark.parametrize("scatter", ["binned", "atomics"])
 def test_mapping3_fused_path(scatter):
     pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV, compute="fused", scatter=scatter)
 
 
-@full
 def test_mapping3_fused_binned_with_list_overflow():
     """tile lists of 8 entries: most contributions go through the spill area"""
     pc.check_mapping3("mapping3_onegrid_esdf", True, False, 21, DEV, compute="fused", scatter="binned", tile_capacity=8)
 
 
-@full
 def test_mapping3_fused_binned_colorplanes():
     pc.check_mapping3("mapping3_colorplanes_cosdf", False, True, 22, DEV, compute="fused", scatter="binned")
 
 
-@full
 def test_ray_gradients_onegrid():
     pc.check_ray_gradients("fwd_onegrid", False, DEV)
 
 
-@full
 def test_ray_gradients_colorplanes_cosdf():
     pc.check_ray_gradients("fwd_colorplanes", True, DEV)
 
 
-@full
 def test_render_nodepth_pose_gradients():
     pc.check_render_nodepth_pose_gradients(DEV)
 
@@ -141,14 +124,17 @@ def test_grid_encoding(kind):
     pc.check_grid_encoding(DEV, kind)
 
 
-@full
 def test_loop_closure_pose_alignment():
     pc.check_pose_alignment(DEV)
 
 
-@full
-def test_loop_closure_distillation():
-    pc.check_distillation(DEV)
+def test_checkpoint_handoff_then_teacher_render(tmp_path):
+    pc.check_checkpoint_handoff(DEV, tmp_path)
+
+
+@pytest.mark.parametrize("compute", ["autograd", "fused"])
+def test_loop_closure_distillation(compute):
+    pc.check_distillation(DEV, compute)
 
 
 @pytest.mark.parametrize("n_rays,S_d,S_r", [(1, 4, 3), (5, 20, 13), (3, 1, 1)])
@@ -157,12 +143,10 @@ def test_ragged_sizes_vs_oracle(n_rays, S_d, S_r):
     pc.check_oracle_random_scene(DEV, n_rays=n_rays, S_d=S_d, S_r=S_r, invalid_every=0)
 
 
-@full
 def test_fused_step_matches_autograd_path_2x64_colorplanes():
     pc.check_fused_vs_autograd(DEV, hidden=64, one_grid=False, co=True, iters=2)
 
 
-@full
 @pytest.mark.parametrize("one_grid", [True, False])
 def test_random_scene_2x64_vs_oracle(one_grid):
     """2x64 decoders (ALDS / global A tables, fused 2x64 weight-gradient kernel) against the oracle's autograd"""
@@ -208,7 +192,6 @@ def test_hash_scene_api_vs_oracle():
     pc.check_hash_scene_api(DEV, cfg, n_rays=12, img=(6, 10))
 
 
-@full
 def test_dense_grid_fused_step_vs_oracle():
     """BASELINE configs[0] as north-star: 16^3 dense grid + 2x32 (tiny batch for the emulator)"""
     cfg = pc.dense_grid_config()
@@ -220,7 +203,6 @@ def test_dense_grid_fused_step_vs_oracle():
     assert out["touched_entries"] > 0
 
 
-@full
 def test_bench_path_step_fp16_plane_storage_vs_oracle():
     """NS-b: lookups read half-precision copies of the planes (EXTENSION); the oracle sees the same rounded values,
     Adam moves the fp32 parameters, tile_adam_kernel keeps the copies equal to the rounded parameters."""
@@ -229,7 +211,6 @@ def test_bench_path_step_fp16_plane_storage_vs_oracle():
     assert out["contributing"] > 0
 
 
-@full
 def test_bench_path_step_with_split_tile_lists(monkeypatch):
     """Long tile lists are cut into parts accumulated by several workgroups and combined by the last arriver
     (tile_adam.hip); forced here on a tiny scene with MNE_TILE_SPLIT_MIN."""
@@ -238,7 +219,6 @@ def test_bench_path_step_with_split_tile_lists(monkeypatch):
     assert out["contributing"] > 0
 
 
-@full
 def test_bench_path_step_with_capped_ray_lds(monkeypatch):
     """The training ray kernel's first pass keeps only MNE_HOT_LDS_SAMPLES samples of a ray in LDS (more waves per CU on
     long rays, INS Indoor: S = 1045); rays whose decoded prefix is longer are finished by the second pass.  Forced here
