@@ -47,9 +47,6 @@ def parse_args():
     ap.add_argument("--config", default="office0", choices=sorted(configs.WORKLOADS),
                     help="workload (mneslam_amd/configs.py::WORKLOADS): office0 = BASELINE configs[1] as wired (the metric's "
                          "configuration, default); apartment / scannet / indoor = the single-agent shapes of configs[2..4]")
-    ap.add_argument("--plane-storage", default="fp32", choices=["fp32", "fp16"],
-                    help="fp16: EXTENSION (BASELINE configs[4]) -- lookups read a half-precision copy of the planes, everything "
-                         "else stays fp32; changes the numerics against the reference")
     ap.add_argument("--hidden", type=int, default=None, choices=[32, 64], help="decoder width (default: the workload's own)")
     ap.add_argument("--path", default="fused", choices=["fused", "autograd"],
                     help="fused = FusedStep + device sampler (default); autograd = the reference's call sequence")
@@ -74,7 +71,7 @@ class Agent:
     """One mapping agent: scene model + optimizer + device-resident keyframe rays."""
 
     def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused", scatter="binned", share_decoder=False,
-                 overlap=True, plane_storage="fp32"):
+                 overlap=True):
         self.cfg, self.device, self.path = cfg, device, path
         cam = synthetic.camera_from_config(cfg)          # office0: 680x1200, fx=fy=600, cx=599, cy=339
         if small:
@@ -114,7 +111,7 @@ class Agent:
             self.fused.seed = seed
         elif path == "fused":
             self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device,
-                                   scatter=scatter, shared_decoder=share_decoder, plane_storage=plane_storage,
+                                   scatter=scatter, shared_decoder=share_decoder,
                                    overlap=overlap and os.environ.get("MNE_NO_OVERLAP", "0") != "1")
             self.fused.seed = seed
 
@@ -270,7 +267,7 @@ def bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, m
             "depth_l1_vs_gt": float((d1.float() - gt)[gt > 0].abs().mean())}), flush=True)
 
 
-def account(cfg, agent, plane_storage, avg_ms):
+def account(cfg, agent, avg_ms):
     """Algorithmic bytes per launch of the path's kernels and the dominant one among the live-measured launches."""
     S = cfg["training"]["n_range_d"] + cfg["training"]["n_samples_d"]
     R = cfg["mapping"]["sample"] + agent.n_cur
@@ -284,7 +281,7 @@ def account(cfg, agent, plane_storage, avg_ms):
     #   decode_kernel, ray_kernel : the MLP forward / composite+backward; no algorithmic HBM bytes (latency-bound)
     #   atomics variant  : adam_kernel = the sweep; the render call gathers and scatters (atomics)
     G = 3072.0 * (1 if cfg["grid"]["oneGrid"] else 2)
-    G_gather = G / 2 if plane_storage == "fp16" else G        # 64-byte corner rows
+    G_gather = G
     binned = agent.fused is not None and agent.fused.bins is not None
     p_contrib = float(agent.fused.tape_rows.item()) if agent.fused is not None else float(R * S)
     decoded = float((agent.fused.ray_tiles[:R].long() * 32).clamp(max=S).sum().item()) if agent.fused is not None else float(R * S)
@@ -306,7 +303,7 @@ def account(cfg, agent, plane_storage, avg_ms):
                 "render": "whole mne_render_fused_features call (decode + ray kernels; MFMA / latency, no algorithmic HBM bytes)"}
         alg["iteration"] = alg["hash_gather"] + alg["hash_scatter"] + alg["adam"]
     elif binned:
-        alg = {"adam": p_contrib * G + 32.0 * n_par + (2.0 * agent.n_plane_params if plane_storage == "fp16" else 0.0),
+        alg = {"adam": p_contrib * G + 32.0 * n_par,
                "gather_kernel": decoded * G_gather, "render": decoded * G_gather}
         kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)", "gather_kernel": "gather_kernel",
                 "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
@@ -352,7 +349,7 @@ def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, bloc
         if elapsed > budget_s or steps >= 2000:
             break
     avg_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timers.items()}
-    acc = account(cfg, agent, "fp32", avg_ms)
+    acc = account(cfg, agent, avg_ms)
     out = {"workload": workload, "mlp_hidden": cfg["decoder"]["hidden_dim"], "value": steps / elapsed, "unit": "it/s",
            "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
            "plane_params": agent.n_plane_params, "rays_per_iter": acc["R"], "samples_per_ray": acc["S"],
@@ -390,7 +387,7 @@ def main():
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
     agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter,
-                  share_decoder=args.share_decoder, overlap=not args.no_overlap, plane_storage=args.plane_storage)
+                  share_decoder=args.share_decoder, overlap=not args.no_overlap)
 
     def barrier():
         if world > 1:
@@ -416,7 +413,7 @@ def main():
     avg_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timers.items()}
     psnr, depth_l1 = agent.quality()
     if rank == 0:
-        acc = account(cfg, agent, args.plane_storage, avg_ms)
+        acc = account(cfg, agent, avg_ms)
         alg, kern, dom, dom_ms, achieved = acc["alg"], acc["kern"], acc["dom"], acc["dom_ms"], acc["achieved"]
         p_contrib, decoded, R, S = acc["p_contrib"], acc["decoded"], acc["R"], acc["S"]
         # HBM traffic and matrix-pipe busy cycles from committed PMC passes (rocprofv3 cannot run inside the timed loop)
@@ -424,7 +421,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", PMC_JSON)))
             if (pmc["workload"] == workload and not args.small and args.path == "fused"
-                    and pmc["scatter"] == args.scatter and args.hidden == 32 and args.plane_storage == "fp32"):
+                    and pmc["scatter"] == args.scatter and args.hidden == 32):
                 per_k = pmc["per_kernel_hbm_bytes_per_iteration"]
                 tag = {"adam": "tile_adam_kernel"}.get(dom, dom)
                 traffic = sum(v for k, v in per_k.items() if tag in k) or None
@@ -440,7 +437,7 @@ def main():
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (HOST-EMULATOR DRY RUN of the launcher logic: not a measurement)" if dry else ""),
-            "config": {"workload": workload + ("_SMALL" if args.small else "") + ("_fp16planes" if args.plane_storage == "fp16" else ""),
+            "config": {"workload": workload + ("_SMALL" if args.small else ""),
                        "rays_per_iter": R, "samples_per_ray": S, "plane_params": agent.n_plane_params,
                        "decoder_params": agent.n_dec_params, "mlp_hidden": args.hidden, "keyframes": args.keyframes,
                        "frame": f"{agent.W}x{agent.H}", "path": args.path, "scatter": ("hash-" + agent.fused.table_update) if agent.hash else args.scatter if args.path == "fused" else "atomics", "agents": world,

@@ -21,7 +21,7 @@ L_RGB, L_DEPTH, L_CO_SDF, L_CO_FS, L_E_FS, L_E_CENTER, L_E_TAIL, L_PSNR = range(
 
 
 class Plane(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("grad", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("half_data", C.c_void_p)]
+    _fields_ = [("data", C.c_void_p), ("grad", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32)]
 
 
 class Scene(C.Structure):
@@ -70,11 +70,6 @@ class PlaneOpt(C.Structure):
                 ("eps", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
 
 
-class Clock(C.Structure):
-    _fields_ = [("iteration", C.c_void_p), ("step_offset", C.c_void_p), ("bias_table", C.c_void_p), ("n_table", C.c_int32),
-                ("reserved", C.c_int32), ("beta1", C.c_double), ("beta2", C.c_double), ("z_offset_stride", C.c_uint64)]
-
-
 class FusedOpts(C.Structure):
     """mne_fused_opts_t: per-call extras of mne_render_fused / mne_render_fused_features."""
     _fields_ = [("timing_events", C.POINTER(C.c_void_p)), ("n_timing_events", C.c_int32), ("lds_samples_cap", C.c_int32),
@@ -103,18 +98,16 @@ _PROTOS = {
     "mne_sizeof_adam_seg": (C.c_size_t, []),
     "mne_sizeof_tile_bins": (C.c_size_t, []),
     "mne_sizeof_plane_opt": (C.c_size_t, []),
-    "mne_sizeof_clock": (C.c_size_t, []),
     "mne_sizeof_fused_opts": (C.c_size_t, []),
     "mne_sizeof_decoder_opt": (C.c_size_t, []),
     "mne_sample_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5
-                         + [C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 5 + [C.POINTER(Clock), C.c_void_p]),
+                         + [C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 5 + [C.c_void_p]),
     "mne_decoder_update": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(DecoderOpt), C.c_int,
-                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Clock), C.c_void_p]),
-    "mne_clock_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_num_samples": (C.c_int, [C.POINTER(RenderCfg), C.c_int]),
     "mne_sample_z": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
-                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Clock), C.c_void_p]),
+                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_packed_decoder_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_pack_decoder": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p]),
     "mne_render_forward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 14
@@ -145,18 +138,17 @@ _PROTOS = {
     "mne_tile_overlap_floats": (C.c_size_t, [C.POINTER(Scene), C.POINTER(TileOverlap), C.c_int]),
     "mne_tile_grad_export": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.POINTER(TileBins), C.POINTER(TileOverlap), C.c_void_p]),
     "mne_tile_adam_shared": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins),
-                                       C.POINTER(TileOverlap), C.POINTER(Clock), C.c_void_p]),
+                                       C.POINTER(TileOverlap), C.c_void_p]),
     "mne_tile_order": (C.c_int, [C.POINTER(Scene), C.POINTER(TileBins), C.c_void_p]),
-    "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.POINTER(Clock),
-                                C.c_void_p]),
+    "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.c_void_p]),
     "mne_sample_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5
-                        + [C.POINTER(Clock), C.c_void_p]),
+                        + [C.c_void_p]),
     "mne_decoder_param_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_wgrad_partial_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_decoder_wgrad": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p]),
-    "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.POINTER(Clock), C.c_void_p]),
+    "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.c_void_p]),
     "mne_query_points": (C.c_int, [C.POINTER(Scene), C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "mne_grid_level_table": (C.c_int, [C.POINTER(GridCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_grid_param_count": (C.c_size_t, [C.POINTER(GridCfg)]),
@@ -200,7 +192,7 @@ def load(path=None):
             raise RuntimeError("libmneslam_hip ABI version mismatch")
         for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
                        (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),
-                       (lib.mne_sizeof_plane_opt, PlaneOpt), (lib.mne_sizeof_clock, Clock),
+                       (lib.mne_sizeof_plane_opt, PlaneOpt),
                        (lib.mne_sizeof_fused_opts, FusedOpts), (lib.mne_sizeof_decoder_opt, DecoderOpt),
                        (lib.mne_sizeof_tile_overlap, TileOverlap)):
             if fn() != C.sizeof(st):

@@ -30,7 +30,6 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(AdamArgs a) {
     const float wd = (float)sg.weight_decay, omb1 = (float)(1.0 - sg.beta1), b2 = (float)sg.beta2;
     const float omb2 = (float)(1.0 - sg.beta2), eps = (float)sg.eps;
     float step_size = a.step_size[s], bc2_sqrt = a.bc2_sqrt[s];
-    if (a.clk.bias_table) clock_bias(a.clk, sg.lr, sg.step, step_size, bc2_sqrt);        // graph replay: step from device memory
     const long long base = (blk - a.blk_start[s]) * ADAM_ELEMS_PER_BLOCK;
 #pragma unroll
     for (int it = 0; it < ADAM_VEC_PER_THREAD; ++it) {
@@ -62,16 +61,5 @@ int mne_launch_adam(const AdamArgs& a, hipStream_t st) {
     return 0;
 }
 
-__global__ void clock_advance_kernel(unsigned long long* iteration, int* step_offset) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (iteration) *iteration += 1ull;
-        if (step_offset) *step_offset += 1;
-    }
-}
-
-int mne_launch_clock_advance(unsigned long long* iteration, int* step_offset, hipStream_t st) {
-    MNE_LAUNCH(clock_advance_kernel, 1, 64, 0, st, iteration, step_offset);
-    return 0;
-}
 
 long long mne_adam_blocks_for(long long n) { return (n + ADAM_ELEMS_PER_BLOCK - 1) / ADAM_ELEMS_PER_BLOCK; }

@@ -44,13 +44,6 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, 
     return (float)(w >> 8) * (1.0f / 16777216.0f);      // [0,1), 24 bits like torch.rand
 }
 
-// ---- Adam bias corrections from the device clock (graph replay): same double arithmetic as the host path --------
-__device__ __forceinline__ void clock_bias(const Clock& clk, double lr, int step, float& step_size, float& bc2_sqrt) {
-    int t = step + *clk.step_offset;
-    t = t < 1 ? 1 : (t > clk.n_table ? clk.n_table : t);
-    step_size = (float)(lr / clk.bias_table[2 * (t - 1)]);
-    bc2_sqrt = (float)sqrt(clk.bias_table[2 * (t - 1) + 1]);
-}
 
 // ---- one Adam element (torch.optim.Adam single-tensor arithmetic; constants prepared on the host in double) ------
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const PlaneOpt& o) {
@@ -151,14 +144,8 @@ __device__ __forceinline__ void oneblob16(float x, float* out /*16*/, bool inter
 #endif
 // Tri-plane features of ONE point for the 8 lanes that share it (cg = lane & 7: float4 chunk of the 128-B rows); the
 // blended rows go to out + set * set_stride + level * 32 + cg * 4 (LDS row or tape row).
-// Four channels of one corner row: from the fp32 parameter, or from its half-precision copy when the scene has one
-// (element offset e is the same in both; the branch is uniform over the launch).
+// Four channels of one corner row
 __device__ __forceinline__ float4 plane_row4(const mne_plane_t& pl, int e) {
-    if (pl.half_data) {
-        union { uint2 u; _Float16 h[4]; } r;
-        r.u = *(const uint2*)((const _Float16*)pl.half_data + e);
-        return make_float4((float)r.h[0], (float)r.h[1], (float)r.h[2], (float)r.h[3]);
-    }
     return *(const float4*)(pl.data + e);
 }
 

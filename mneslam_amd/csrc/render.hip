@@ -34,7 +34,7 @@
 // the staged linspace tables, `vals` = S floats of this wave's LDS
 __device__ __forceinline__ void sample_z_ray(const ZArgs& a, int r, float d, int lane, const float* tab, float* vals) {
     const int S = a.S;
-    const uint64_t z_offset = a.offset + (a.clk.iteration ? *a.clk.iteration * a.clk.z_offset_stride : 0ull);
+    const uint64_t z_offset = a.offset;
     if (a.has_d) {
         const float* uni = tab;
         const float* surf = tab + a.n_a;
@@ -1229,7 +1229,6 @@ __global__ __launch_bounds__(256) void decoder_update_kernel(DecUpdateArgs a) {
         const int off = e - (t == 0 ? D::P_COL0 : t == 1 ? D::P_COL1 : t == 2 ? D::P_SDF0 : D::P_SDF1);
         float* P = (float*)(t == 0 ? a.sc.w_col0 : t == 1 ? a.sc.w_col1 : t == 2 ? a.sc.w_sdf0 : a.sc.w_sdf1);
         PlaneOpt o = a.opt;
-        if (a.clk.bias_table) clock_bias(a.clk, o.lr, o.step, o.step_size, o.bc2_sqrt);
         float p = P[off], m = a.m[t][off], v = a.v[t][off];
         adam_elem(p, g, m, v, o);
         P[off] = p; a.m[t][off] = m; a.v[t][off] = v;

@@ -99,14 +99,14 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
     // With prev_counts a list counts as max(length now, final length of the previous launch): the kernel may run while the
     // deferred rays' appends are still to come (scenes with many deferred rays would otherwise get yesterday's heavy lists
     // unsplit: ScanNet 1.16 ms instead of 0.44 ms).
-    // (a list holds at most its plane's capacity; what is beyond sits in the spill area, scanned by the last part)
+    // (Lengths are NOT clamped to the plane's list capacity: an overflowing list -- rare, a capacity is 4x the mean -- is
+    // then cut into a few more parts than its in-list entries need, which is harmless; finding the plane of every tile
+    // here cost 8 us of this latency-critical kernel.)
     auto length = [&](int t) {
-        int c = a.bins.counts[t];
-        if (a.prev_counts) { const int p = a.prev_counts[t]; c = c > p ? c : p; }
-        int pidx = 0;
-        while (pidx + 1 < a.n_planes && t >= a.bins.tile_base[pidx + 1]) ++pidx;
-        const int cap = a.bins.pcap[pidx];
-        return c < cap ? c : cap;
+        const int c = a.bins.counts[t];
+        if (!a.prev_counts) return c;
+        const int p = a.prev_counts[t];
+        return c > p ? c : p;
     };
     int cnt[ORDER_REGS];
     int mine = 0;
@@ -219,7 +219,6 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     // sweep (24 B/param) overlaps the LDS accumulation instead of following it (TILE_PREFETCH: 0 none, 1 p+m, 2 p+m+v)
     constexpr int NIT = (TILE_CELLS * MNE_C / 4) / TILE_THREADS;
     PlaneOpt o = a.opt[pidx];
-    if (a.clk.bias_table) clock_bias(a.clk, o.lr, o.step, o.step_size, o.bc2_sqrt);       // graph replay: step from device memory
     float* P = (float*)pl.data;
     float4 pre_p[NIT], pre_m[NIT], pre_v[NIT];
 #if TILE_PREFETCH == 3
@@ -481,11 +480,6 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             adam_elem(p.x, gg.x, m.x, v.x, o); adam_elem(p.y, gg.y, m.y, v.y, o);
             adam_elem(p.z, gg.z, m.z, v.z, o); adam_elem(p.w, gg.w, m.w, v.w, o);
             *(float4*)(P + off) = p; *(float4*)(o.m + offmv) = m; *(float4*)(o.v + offmv) = v;
-            if (pl.half_data) {                                   // half-precision copy the lookups read (round to nearest even)
-                union { uint2 u; _Float16 h[4]; } r;
-                r.h[0] = (_Float16)p.x; r.h[1] = (_Float16)p.y; r.h[2] = (_Float16)p.z; r.h[3] = (_Float16)p.w;
-                *(uint2*)((_Float16*)pl.half_data + off) = r.u;
-            }
         }
     }
     TILE_STAMP(6);

@@ -44,7 +44,7 @@ def as_channels_last(plane):
     return plane.contiguous(memory_format=torch.channels_last)
 
 
-def scene_struct(model_info, planes_cl, dec_w, grads=None, halves=None):
+def scene_struct(model_info, planes_cl, dec_w, grads=None):
     """Fill mne_scene_t.  ``planes_cl``: flat list in all_planes order
     (xy[coarse,fine], xz[...], yz[...], then the colour planes); ``grads``: same order or None."""
     sc = _lib.Scene()
@@ -62,7 +62,6 @@ def scene_struct(model_info, planes_cl, dec_w, grads=None, halves=None):
                 pl.data = p.data_ptr()
                 pl.h, pl.w = p.shape[2], p.shape[3]
                 pl.grad = grads[s * 6 + o * 2 + l].data_ptr() if grads is not None else None
-                pl.half_data = halves[s * 6 + o * 2 + l].data_ptr() if halves is not None else None
     for k in range(3):
         sc.bound_lo[k], sc.bound_hi[k] = model_info["bound_lo"][k], model_info["bound_hi"][k]
         sc.bb_lo[k], sc.bb_hi[k] = model_info["bb_lo"][k], model_info["bb_hi"][k]
@@ -126,7 +125,7 @@ class RenderFunction(torch.autograd.Function):
         ray_counts = torch.empty(R, _lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
         seed, offset = seed_offset
         _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u_c), _lib.ptr(tables), seed, offset,
-                                    _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), None, st), "mne_sample_z")
+                                    _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), st), "mne_sample_z")
         sc = scene_struct(info, [p.detach() for p in planes], [w.detach() for w in dec_w])
         packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
         _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
@@ -225,7 +224,7 @@ def render_maps(info, tables, rays_o, rays_d, target_d, u, seed_offset, planes, 
     ray_counts = torch.empty(R, _lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
     seed, offset = seed_offset
     _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u_c), _lib.ptr(tables), seed, offset,
-                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), None, st), "mne_sample_z")
+                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), st), "mne_sample_z")
     sc = scene_struct(info, [as_channels_last(p.detach()) for p in planes], [w.detach() for w in dec_w])
     packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
     _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
@@ -288,7 +287,7 @@ def _hash_forward(lib, info, grid_cfg, tables, rays_o, rays_d, tgt_rgb, tgt_d, u
     ray_counts = torch.empty(R, _lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
     seed, offset = seed_offset
     _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u), _lib.ptr(tables), seed, offset,
-                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), None, st), "mne_sample_z")
+                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), st), "mne_sample_z")
     sc = _hash_scene(info, dec_w)
     packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
     _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")

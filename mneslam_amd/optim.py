@@ -37,8 +37,8 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     def segments(self, zero_grad_buffers=None, advance=True):
-        """ctypes segment array for every parameter that has a gradient (advances the step counts unless
-        ``advance`` is False: a recorded iteration reads its step from the device clock, ``step`` is then the base)."""
+        """ctypes segment array for every parameter that has a gradient (advances the step counts unless ``advance`` is
+        False)."""
         segs = []
         keep = []
         for group in self.param_groups:
@@ -67,21 +67,17 @@ class FusedAdam(torch.optim.Optimizer):
         return segs, keep
 
     @torch.no_grad()
-    def step(self, closure=None, zero_grad=False, grad_buffers=None, clock=None):
-        """``clock`` (mneslam_amd._lib.Clock, graph recording only): the kernel adds the device step offset to the
-        parameters' CURRENT step + 1 and the python step counts are left alone (the caller advances them per replay)."""
+    def step(self, closure=None, zero_grad=False, grad_buffers=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        segs, keep = self.segments(grad_buffers, advance=clock is None)
+        segs, keep = self.segments(grad_buffers)
         if not segs:
             return loss
         lib = _lib.load()
         for i in range(0, len(segs), 32):
             chunk = segs[i:i + 32]
             arr = (_lib.AdamSeg * len(chunk))(*[s for s, _ in chunk])
-            _lib.check(lib.mne_adam_step(arr, len(chunk), 1 if zero_grad else 0,
-                                         C.byref(clock) if clock is not None else None, _lib.stream_for(chunk[0][1])),
-                       "mne_adam_step")
+            _lib.check(lib.mne_adam_step(arr, len(chunk), 1 if zero_grad else 0, _lib.stream_for(chunk[0][1])), "mne_adam_step")
         return loss

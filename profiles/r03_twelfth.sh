@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp; mkdir -p gpurun_out
-for c in "--config scannet" "--config scannet --hidden 64" "--config indoor" "" "--hidden 64" "--config apartment"; do
+for c in "--config scannet" "--config indoor" "" "--hidden 64"; do
   echo "== $c"; timeout 300 python bench.py $c --steps 200 --warmup 20 --no-variants --cpu-iters 0 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().split('\n')[-1]); r=d['roofline']

@@ -223,7 +223,7 @@ def check_device_sampler(device):
     P = _lib.ptr
     _lib.check(lib.mne_sample_rays(P(a[0]), n_kf * n_save, n_save, None, P(a[1]), HW, P(a[2]), n_kf + 1, n_g, n_c,
                                    P(a[3]), P(a[4]), 0, 0, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(oidx),
-                                   None, _lib.stream_for(out[0])))
+                                   _lib.stream_for(out[0])))
     assert_close(out[0].cpu(), ref_o, rtol=0, atol=0, what="rays_o (bit-exact)")
     assert_close(out[1].cpu(), ref_d, rtol=0, atol=0, what="rays_d (bit-exact)")
     assert_close(out[2].cpu(), ref_rgb, rtol=0, atol=0, what="target rgb")
@@ -232,7 +232,7 @@ def check_device_sampler(device):
     for it in range(3):
         _lib.check(lib.mne_sample_rays(P(a[0]), n_kf * n_save, n_save, None, P(a[1]), HW, P(a[2]), n_kf + 1, n_g, n_c,
                                        None, None, 1234, it, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(oidx),
-                                       None, _lib.stream_for(out[0])))
+                                       _lib.stream_for(out[0])))
         ii = oidx.cpu()
         g, c = ii[:n_g], ii[n_g:]
         assert g.unique().numel() == n_g and int(g.min()) >= 0 and int(g.max()) < n_kf * n_save
@@ -242,7 +242,7 @@ def check_device_sampler(device):
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
     _lib.check(lib.mne_sample_rays(P(a[0]), n_kf * n_save, n_save, None, P(a[1]), HW, P(a[2]), n_kf + 1, n_g, n_c,
                                    None, None, 1234, 0, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(oidx),
-                                   None, _lib.stream_for(out[0])))
+                                   _lib.stream_for(out[0])))
     assert torch.equal(oidx.cpu(), seen[0]), "same (seed, iteration) must give the same batch"
     # spread: owners of the global rows cover every keyframe roughly evenly
     own = torch.bincount(torch.div(torch.cat(seen)[: 3 * n_g].reshape(3, -1)[:, :n_g].reshape(-1), n_save, rounding_mode="trunc"),
@@ -655,7 +655,7 @@ def out_contrib(fs):
 
 
 def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0, small=False, impl="grid_sample",
-                               scatter="binned", plane_storage="fp32", poison_tape=True):
+                               scatter="binned", poison_tape=True):
     """The BENCH path -- bench.Agent: device Feistel ray sampler, Philox jitter, FusedStep on two streams --
     against ONE oracle iteration on the SAME device-drawn batch: the batch (ray indices, rays, targets, z samples)
     is copied back from the device, the oracle (CPU autograd) evaluates forward, the seven losses, backward and
@@ -669,10 +669,8 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     Works at any size (full office0: 38.4 M parameters, 2150 x 128 samples; ~2 s of oracle time)."""
     import bench
     dev = torch.device(device)
-    ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, small=small, path="fused", scatter=scatter,
-                     plane_storage=plane_storage)
+    ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, small=small, path="fused", scatter=scatter)
     fs, m = ag.fused, ag.model
-    half = plane_storage == "fp16"         # EXTENSION: the lookups see round-to-nearest-even fp16 copies of the planes
     for _ in range(warm_steps):
         ag.step()
     fs.synchronize()
@@ -714,7 +712,7 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     assert_close(tgt_d, ref_dep[:, 0], rtol=0, atol=0, what="target depth")
     # ---- oracle scene with the pre-step parameters
     sc = OracleScene(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64), build=False)
-    sc.all_planes = tuple([(p.half().float() if half else p).contiguous() for p in lst] for lst in planes0)
+    sc.all_planes = tuple([p.contiguous() for p in lst] for lst in planes0)
     sc.col_w = [dec0["color_net.model.0.weight"], dec0["color_net.model.2.weight"]]
     sc.sdf_w = [dec0["sdf_net.model.0.weight"], dec0["sdf_net.model.2.weight"]]
     sc.requires_grad_(True)
@@ -760,14 +758,7 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
             ref = ref_p.grad
             assert_close(g_hip, ref, rtol=2e-3, atol=2e-5 * max(1e-6, float(ref.abs().max())), what=f"plane grad {k}")
     # ---- Adam
-    if half:                                   # gradients were taken at the rounded values; Adam moves the fp32 parameters
-        with torch.no_grad():
-            for ref_p, p0 in zip(sc.plane_list(), [p for lst in planes0 for p in lst]):
-                ref_p.copy_(p0)
     opt.step()
-    if half:
-        for k, (h, p) in enumerate(zip(fs.halves, flat_planes)):
-            assert torch.equal(cpu(h), cpu(p).half()), f"half-precision copy of plane {k} is not the rounded parameter"
     for k, (p, ref_p, g_m) in enumerate(zip(flat_planes, sc.plane_list(), opt.groups[1].m + (opt.groups[2].m if len(opt.groups) > 2 else []))):
         st = ag.opt._state(p)
         assert_close(cpu(st["exp_avg"]), g_m, rtol=2e-3, atol=2e-6 * max(1e-6, float(g_m.abs().max())), what=f"exp_avg {k}")
@@ -885,76 +876,6 @@ def check_hash_fused_step_vs_oracle(device, cfg, n_keyframes=3, seed=5, warm_ste
         lr = ag.opt.param_groups[0]["lr"]
         assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 5e-3, f"decoder {nm} after Adam"
     return {"R": R, "S": S, "touched_entries": int(touched.sum()), "rgb_l1": float((rgb - ret["rgb"].detach()).abs().mean())}
-
-
-def check_device_clock(device):
-    """mne_clock_t: iteration / Adam step read from device memory (graph replay) give bit-identical results to the same
-    values passed as arguments -- ray sampling keys, the jitter counter offset, the bias corrections of both Adam kernels."""
-    import ctypes as C
-    from mneslam_amd import _lib
-    lib, P = _lib.load(), _lib.ptr
-    dev = torch.device(device)
-    gen = torch.Generator().manual_seed(8)
-    n_kf, n_save, HW, n_g, n_c = 4, 200, 500, 128, 32
-    kf = torch.randn(n_kf * n_save, 7, generator=gen).to(dev)
-    cur = torch.randn(HW, 7, generator=gen).to(dev)
-    poses = torch.randn(n_kf + 1, 4, 4, generator=gen).to(dev)
-    R = n_g + n_c
-    b1, b2, n_table = 0.9, 0.99, 64
-    table = torch.tensor([(1.0 - b1 ** k, 1.0 - b2 ** k) for k in range(1, n_table + 1)], dtype=torch.float64, device=dev)
-    clk_iter = torch.zeros(1, dtype=torch.int64, device=dev)
-    clk_step = torch.zeros(1, dtype=torch.int32, device=dev)
-    ck = _lib.Clock()
-    ck.iteration, ck.step_offset, ck.bias_table = clk_iter.data_ptr(), clk_step.data_ptr(), table.data_ptr()
-    ck.n_table, ck.beta1, ck.beta2 = n_table, b1, b2
-    cfg = configs.small_test_config()
-    from mneslam_amd import hip_path
-    rc = hip_path.render_cfg_struct(cfg)
-    S = lib.mne_num_samples(C.byref(rc), 1)
-    ck.z_offset_stride = (R * S + 3) // 4
-    tables = hip_path.linspace_tables(cfg, True, dev)
-    st = _lib.stream_for(kf)
-
-    def batch(iteration, clock):
-        o = [torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev), torch.empty(R, device=dev)]
-        idx = torch.empty(R, dtype=torch.int64, device=dev)
-        z = torch.empty(R, S, device=dev)
-        cnt, rcnt = torch.empty(8, dtype=torch.int32, device=dev), torch.empty(R, 8, dtype=torch.int32, device=dev)
-        _lib.check(lib.mne_sample_rays(P(kf), n_kf * n_save, n_save, None, P(cur), HW, P(poses), n_kf + 1, n_g, n_c, None, None,
-                                       77, iteration, P(o[0]), P(o[1]), P(o[2]), P(o[3]), P(idx),
-                                       C.byref(clock) if clock else None, st))
-        d = o[3].abs() + 0.5
-        _lib.check(lib.mne_sample_z(C.byref(rc), R, P(d), None, P(tables), 77, iteration * ck.z_offset_stride if not clock else 0,
-                                    P(z), P(cnt), P(rcnt), C.byref(clock) if clock else None, st))
-        return idx.cpu(), z.cpu()
-
-    for it in (0, 3, 11):
-        ref = batch(it, None)
-        clk_iter.fill_(it)
-        got = batch(0, ck)
-        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), f"iteration {it}: clock and argument disagree"
-    assert lib.mne_clock_advance(P(clk_iter), P(clk_step), st) == 0
-    assert int(clk_iter.item()) == 12 and int(clk_step.item()) == 1
-    # Adam: step t as argument vs step 1 + device offset t - 1
-    for t in (1, 2, 17):
-        res = []
-        for use_clock in (False, True):
-            g0 = torch.Generator().manual_seed(t)
-            p = torch.randn(1000, generator=g0).to(dev); g = torch.randn(1000, generator=g0).to(dev)
-            m = (0.1 * torch.randn(1000, generator=g0)).to(dev); v = (0.01 * torch.rand(1000, generator=g0)).to(dev)
-            seg = _lib.AdamSeg()
-            seg.p, seg.g, seg.m, seg.v, seg.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1000
-            seg.lr, seg.beta1, seg.beta2, seg.eps, seg.weight_decay = 0.005, b1, b2, 1e-15, 1e-6
-            seg.step = 1 if use_clock else t
-            clk_step.fill_(t - 1)
-            arr = (_lib.AdamSeg * 1)(seg)
-            _lib.check(lib.mne_adam_step(arr, 1, 0, C.byref(ck) if use_clock else None, st))
-            res.append((p.cpu(), m.cpu(), v.cpu()))
-        for a, b in zip(*res):
-            assert torch.equal(a, b), f"Adam step {t}: clock and argument disagree"
-    bad = _lib.Clock(); bad.iteration = clk_iter.data_ptr(); bad.step_offset = clk_step.data_ptr(); bad.bias_table = table.data_ptr()
-    bad.n_table, bad.beta1, bad.beta2 = n_table, 0.8, b2
-    assert lib.mne_adam_step(arr, 1, 0, C.byref(bad), st) < 0 and b"betas" in lib.mne_last_error()
 
 
 def check_render_maps_fast_path(device):
