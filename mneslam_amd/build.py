@@ -9,7 +9,7 @@ is no CPU fallback (mneslam_amd/_lib.py raises when it is missing).
 
 Variants (``build_variant``): the same sources with extra -D switches, objects and library in their own directory.
 ``FUZZ_VARIANTS`` are the kernel-argument layout perturbations tests/test_layout_fuzz_gpu.py runs the 2x64 + colour-plane
-cases against (DESIGN.md 9.3): a kernel never reads the padding, so its results must not depend on it.
+cases against (DESIGN.md section 9): a kernel never reads the padding, so its results must not depend on it.
 """
 import json
 import os
@@ -96,7 +96,7 @@ def check_isa(obj_dir, lib, strict=True):
         json.dump(report, f, indent=1)
     if report["hazards"] and strict and os.environ.get("MNE_ALLOW_SPILL_HAZARD", "0") != "1":
         msg = "; ".join(f"{h['kernel']} ({h['source']}:{h['line']}: {h['spill']} <before> {h['before']})" for h in report["hazards"])
-        raise RuntimeError("compiler defect in the generated ISA (VGPR spill store in front of an exec restore, DESIGN.md 9.3): " + msg)
+        raise RuntimeError("compiler defect in the generated ISA (VGPR spill store in front of an exec restore, DESIGN.md section 9): " + msg)
     return report
 
 

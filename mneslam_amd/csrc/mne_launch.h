@@ -58,7 +58,7 @@ struct RenderArgs {
     int lds_samples;             // ray_kernel: samples of a ray its LDS arrays hold (0 = all S); rays that need more are deferred
 #if defined(MNE_ARGS_PAD) && MNE_ARGS_PAD > 0
     // LAYOUT FUZZ (tests only, -DMNE_ARGS_PAD=N builds under mneslam_amd/_fuzz/): dummy bytes in the middle of the kernel
-    // argument block.  No kernel reads them; a kernel whose results change with N is miscompiled or racy (DESIGN.md 9.3).
+    // argument block.  No kernel reads them; a kernel whose results change with N is miscompiled or racy (DESIGN.md section 9).
     char args_pad[MNE_ARGS_PAD];
 #endif
     int ext_feat;                // feature rows come from the caller (tape columns T_X..): no plane gather, no plane scatter

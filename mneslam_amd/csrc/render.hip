@@ -337,7 +337,7 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
 
 // Waves per workgroup decode_kernel is compiled for: 8 = 256 registers per lane, no spills in any decoder shape (a
 // 12-wave build for the inline-gather form hid a little more latency and spilled 16-376 B per lane: dropped in round 3,
-// see DESIGN.md 9.3 for why spills are treated as defects here).
+// see DESIGN.md section 9 for why spills are treated as defects here).
 #ifndef DECODE_WPB
 #define DECODE_WPB 8
 #endif

@@ -1,6 +1,6 @@
 """Static checks of the generated gfx950 ISA, run by ``mneslam_amd.build`` on every kernel it compiles.
 
-1. ``scan_asm`` -- the compiler defect behind DESIGN.md 9.3 (ROCm 7.2 / clang-22 AMDGPU backend, found in round 3):
+1. ``scan_asm`` -- the compiler defect behind DESIGN.md section 9 (ROCm 7.2 / clang-22 AMDGPU backend, found in round 3):
    the register allocator may place a VGPR *spill store* (``scratch_store_* ... Folded Spill``) at the top of a
    control-flow JOIN block, in front of the ``s_or_b64 exec, exec, s[..]`` that re-enables the lanes masked off by the
    preceding divergent region.  The store then only saves the lanes that were active inside the region (lane 0 after

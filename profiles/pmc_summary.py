@@ -18,9 +18,9 @@ def per_kernel(path, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 mfma, busy = per_kernel(sys.argv[3], "SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel(sys.argv[3], "SQ_BUSY_CYCLES")
-n_it_f = max(n for k, (n, v) in fetch.items() if k.startswith("tile_adam_kernel"))
-n_it_w = max(n for k, (n, v) in write.items() if k.startswith("tile_adam_kernel"))
-n_it_s = max(n for k, (n, v) in mfma.items() if k.startswith("tile_adam_kernel"))
+n_it_f = max(n for k, (n, v) in fetch.items() if "tile_adam_kernel" in k)
+n_it_w = max(n for k, (n, v) in write.items() if "tile_adam_kernel" in k)
+n_it_s = max(n for k, (n, v) in mfma.items() if "tile_adam_kernel" in k)
 rows = []
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, (0, 0.0))[1] / n_it_f, write.get(k, (0, 0.0))[1] / n_it_w
@@ -44,7 +44,7 @@ def mf(pred):
 
 render = lambda k: any(t in k for t in ("gather_kernel", "decode_kernel", "ray_kernel", "composite_kernel"))
 out = {"workload": "replica_office0_triplane_asWired_2048x128", "path": "fused", "scatter": "binned",
-       "hbm_bytes_per_launch": {"adam": total(lambda k: k.startswith("tile_adam_kernel")), "render": total(render)},
+       "hbm_bytes_per_launch": {"adam": total(lambda k: "tile_adam_kernel" in k), "render": total(render)},
        "mfma_busy_cycles_per_launch": {"adam": 0.0, "render": mf(render)},
        "per_kernel_hbm_bytes_per_iteration": {k[:60]: b for b, k, *_ in rows[:12]},
        "per_kernel_mfma_busy_cycles_per_iteration": {k[:60]: v / n_it_s for k, (n, v) in mfma.items() if v > 0},

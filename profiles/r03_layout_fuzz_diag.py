@@ -1,5 +1,5 @@
 """Round-3 root-cause experiment for the kernel-argument-layout-sensitive 2x64 + colour-plane training kernel
-(DESIGN.md 9.3).  Runs on the GPU box:
+(DESIGN.md section 9).  Runs on the GPU box:
 
     python profiles/r03_layout_fuzz_diag.py <libmneslam_hip.so variant> [--poison]
 

@@ -1,4 +1,4 @@
-"""Static check of the generated gfx950 ISA for the compiler defect behind DESIGN.md 9.3.
+"""Static check of the generated gfx950 ISA for the compiler defect behind DESIGN.md section 9.
 
     python profiles/spill_exec_scan.py [file.hip ...] [-- extra hipcc flags]     (default: every kernel source)
 

@@ -10,7 +10,7 @@ r = json.load(open(os.path.join(REPO, "mneslam_amd", "isa_report.json")))
 names = [k["kernel"] for k in r["kernels"]]
 dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
 print("# every kernel of libmneslam_hip.so (mneslam_amd/isa_report.json, written by the build from the compiler's own kernel info)")
-print("# kernels carrying the compiler defect of DESIGN.md 9.3 (spill store in front of an exec restore): %d" % len(r["hazards"]))
+print("# kernels carrying the compiler defect of DESIGN.md section 9 (spill store in front of an exec restore): %d" % len(r["hazards"]))
 print("%5s %5s %5s %8s %4s %8s %8s  %s" % ("SGPR", "VGPR", "AGPR", "scratchB", "occ", "sgprSpil", "vgprSpil", "kernel"))
 for k, d in sorted(zip(r["kernels"], dem), key=lambda x: (-x[0].get("scratch", 0), x[1])):
     d = re.sub(r"\(.*\)$", "", d.replace("void ", ""))

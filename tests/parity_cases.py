@@ -687,7 +687,7 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
         # every tape row the weight-gradient pass, the plane update or the hash scatter reads must have been written by
         # THIS iteration: a row left over from an earlier one (or from a zero-filled allocation, which is what the host
         # emulator sees) would go unnoticed otherwise -- the failure mode of the round-2 layout-sensitive kernel
-        # (DESIGN.md 9.3).  NaN x 0 = NaN: one stale row poisons a whole gradient matrix.
+        # (DESIGN.md section 9).  NaN x 0 = NaN: one stale row poisons a whole gradient matrix.
         fs.tape.fill_(float("nan"))
     ag.step()                                            # the iteration under test
     fs.synchronize()

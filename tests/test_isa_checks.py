@@ -1,4 +1,4 @@
-"""The ISA checks the build runs on every kernel (mneslam_amd/isa_check.py, DESIGN.md 9.3): unit tests of the scanner on
+"""The ISA checks the build runs on every kernel (mneslam_amd/isa_check.py, DESIGN.md section 9): unit tests of the scanner on
 hand-written assembly, and the report of the shipped build -- no kernel may carry the spill-in-front-of-exec-restore
 defect, and the kernels of the mapping iteration must not use scratch memory at all."""
 import json

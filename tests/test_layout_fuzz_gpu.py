@@ -1,4 +1,4 @@
-"""Layout fuzz (VERDICT r02 #1, DESIGN.md 9.3): the 2x64 + colour-plane cases against builds of the library whose kernel
+"""Layout fuzz (VERDICT r02 #1, DESIGN.md section 9): the 2x64 + colour-plane cases against builds of the library whose kernel
 argument block carries N dummy bytes in its middle (``mneslam_amd.build.FUZZ_VARIANTS``: -DMNE_ARGS_PAD=8 / 16).  No
 kernel reads the padding, so nothing may depend on it.  In round 2 exactly this perturbation turned a latent compiler
 defect (a VGPR spill store placed in front of an exec restore, see mneslam_amd/isa_check.py) into stale tape rows and 10-40 %
