@@ -60,6 +60,13 @@ class OverlapRect(C.Structure):
     _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
 
 
+class PoseState(C.Structure):
+    _fields_ = [("rot", C.c_void_p), ("trans", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p),
+                ("c2w", C.c_void_p), ("best_loss", C.c_void_p), ("best_c2w", C.c_void_p), ("last_loss", C.c_void_p),
+                ("r_base", C.c_float * 9), ("reserved", C.c_float),
+                ("lr_rot", C.c_double), ("lr_trans", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+
+
 class TileOverlap(C.Structure):
     _fields_ = [("n_peers", C.c_int32), ("reserved", C.c_int32), ("rect", (OverlapRect * 12) * MAX_OVERLAP_PEERS),
                 ("send", C.c_void_p * MAX_OVERLAP_PEERS), ("recv", C.c_void_p * MAX_OVERLAP_PEERS)]
@@ -135,6 +142,11 @@ _PROTOS = {
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_tile_list_entries": (C.c_size_t, [C.POINTER(Scene), C.POINTER(TileBins)]),
     "mne_sizeof_tile_overlap": (C.c_size_t, []),
+    "mne_sizeof_pose_state": (C.c_size_t, []),
+    "mne_pose_rays": (C.c_int, [C.POINTER(PoseState), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_pose_loss": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_pose_update": (C.c_int, [C.POINTER(PoseState), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_tile_overlap_floats": (C.c_size_t, [C.POINTER(Scene), C.POINTER(TileOverlap), C.c_int]),
     "mne_tile_grad_export": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.POINTER(TileBins), C.POINTER(TileOverlap), C.c_void_p]),
     "mne_tile_adam_shared": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins),
@@ -194,7 +206,7 @@ def load(path=None):
                        (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),
                        (lib.mne_sizeof_plane_opt, PlaneOpt),
                        (lib.mne_sizeof_fused_opts, FusedOpts), (lib.mne_sizeof_decoder_opt, DecoderOpt),
-                       (lib.mne_sizeof_tile_overlap, TileOverlap)):
+                       (lib.mne_sizeof_tile_overlap, TileOverlap), (lib.mne_sizeof_pose_state, PoseState)):
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"struct layout mismatch for {st.__name__}: C {fn()} vs ctypes {C.sizeof(st)}")
         _lib = lib

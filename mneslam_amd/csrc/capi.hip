@@ -592,6 +592,50 @@ int mne_decoder_wgrad(const mne_scene_t* scene, const float* tape, const int32_t
     return check_launch("decoder_wgrad");
 }
 
+size_t mne_sizeof_pose_state(void) { return sizeof(mne_pose_state_t); }
+
+static int fill_pose(const mne_pose_state_t* ps, PoseArgs& a) {
+    if (!ps || !ps->rot || !ps->trans || !ps->m || !ps->v || !ps->step || !ps->c2w || !ps->best_loss || !ps->best_c2w || !ps->last_loss)
+        return fail(-1, "mne_pose_state: NULL field");
+    a.rot = ps->rot; a.trans = ps->trans; a.m = ps->m; a.v = ps->v; a.step = ps->step; a.c2w = ps->c2w;
+    a.best_loss = ps->best_loss; a.best_c2w = ps->best_c2w; a.last_loss = ps->last_loss;
+    for (int k = 0; k < 9; ++k) a.r_base[k] = ps->r_base[k];
+    a.lr_rot = ps->lr_rot; a.lr_trans = ps->lr_trans; a.beta1 = ps->beta1; a.beta2 = ps->beta2; a.eps = ps->eps;
+    return 0;
+}
+
+int mne_pose_rays(const mne_pose_state_t* pose, int n_rays, const float* dirs_cam, float* rays_o, float* rays_d, void* stream) {
+    PoseArgs a = {};
+    if (int rc = fill_pose(pose, a)) return rc;
+    if (n_rays < 1 || !dirs_cam || !rays_o || !rays_d) return fail(-1, "mne_pose_rays: NULL argument");
+    a.n = n_rays; a.dirs = dirs_cam; a.rays_o = rays_o; a.rays_d = rays_d;
+    mne_launch_pose(a, 0, (hipStream_t)stream);
+    return check_launch("pose_rays");
+}
+
+int mne_pose_loss(int n_rays, const float* rgb, const float* depth, const float* want_rgb, const float* want_depth,
+                  double w_rgb, double w_depth, float* d_rgb, float* d_depth, float* partials, void* stream) {
+    if (n_rays < 1 || !rgb || !depth || !want_rgb || !want_depth || !d_rgb || !d_depth || !partials)
+        return fail(-1, "mne_pose_loss: NULL argument");
+    PoseArgs a = {};
+    a.n = n_rays; a.rgb = rgb; a.depth = depth; a.want_rgb = want_rgb; a.want_depth = want_depth;
+    a.w_rgb = (float)w_rgb; a.w_depth = (float)w_depth; a.d_rgb = d_rgb; a.d_depth = d_depth; a.partials = partials;
+    mne_launch_pose(a, 1, (hipStream_t)stream);
+    return check_launch("pose_loss");
+}
+
+int mne_pose_update(const mne_pose_state_t* pose, int n_rays, const float* dirs_cam, const float* d_rays_o,
+                    const float* d_rays_d, const float* partials, void* stream) {
+    PoseArgs a = {};
+    if (int rc = fill_pose(pose, a)) return rc;
+    if (n_rays < 1 || !dirs_cam || !d_rays_o || !d_rays_d || !partials) return fail(-1, "mne_pose_update: NULL argument");
+    if (!(pose->beta1 >= 0.0 && pose->beta1 < 1.0 && pose->beta2 >= 0.0 && pose->beta2 < 1.0)) return fail(-1, "mne_pose_update: betas out of range");
+    a.n = n_rays; a.dirs = dirs_cam; a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d; a.partials = (float*)partials;
+    a.n_partials = (n_rays + 255) / 256;
+    mne_launch_pose(a, 2, (hipStream_t)stream);
+    return check_launch("pose_update");
+}
+
 int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* stream) {
     if (n_seg < 0 || n_seg > 32) return fail(-1, "mne_adam_step: n_seg must be in [0,32]");
     if (n_seg == 0) return 0;

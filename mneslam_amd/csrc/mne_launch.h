@@ -219,6 +219,35 @@ struct TileOverlap {
     const float* recv[MNE_MAX_OVERLAP_PEERS];
 };
 
+// pose-alignment loop (csrc/pose.hip)
+struct PoseArgs {
+    int n;
+    const float* dirs;          // [n][3] camera-frame directions
+    float* rot;                 // [3] axis-angle
+    float* trans;               // [3]
+    float r_base[9];            // row-major
+    float* c2w;                 // [12] row-major 3x4 of the CURRENT parameters
+    float* rays_o;              // [n][3]
+    float* rays_d;              // [n][3]
+    // loss
+    const float *rgb, *depth, *want_rgb, *want_depth;
+    float w_rgb, w_depth;
+    float* d_rgb;               // [n][3]
+    float* d_depth;             // [n]
+    float* partials;            // [n_partials] loss partial sums (one per workgroup of pose_loss_kernel)
+    int n_partials;
+    // update
+    const float *d_rays_o, *d_rays_d;
+    float* m;                   // [6] exp_avg      (rot 0..2, trans 3..5)
+    float* v;                   // [6] exp_avg_sq
+    int* step;                  // [1] steps taken so far
+    float* best_loss;           // [1]
+    float* best_c2w;            // [12]
+    float* last_loss;           // [1]
+    double lr_rot, lr_trans, beta1, beta2, eps;
+};
+int mne_launch_pose(const PoseArgs& a, int what, hipStream_t st);
+
 struct AdamArgs {
     mne_adam_seg_t seg[32];
     float step_size[32];      // lr / (1 - beta1^t)

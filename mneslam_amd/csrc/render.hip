@@ -656,6 +656,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
         const int n = mode ? a.adapt[1] : *a.ray_list_count;
         a.adapt[0] = mode ? (n * 16 >= a.R ? 1 : 0) : (n * 8 > a.R ? 1 : 0);
         a.adapt[1] = 0;
+        a.adapt[2] = n;                       // (diagnostics: what the decision was taken on)
     }
     if (a.ray_list && *a.ray_list_count == 0) return;      // second pass with nothing deferred (the usual case)
     if (ALDS) {

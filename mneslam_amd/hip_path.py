@@ -413,3 +413,115 @@ def hash_query_points(info, grid_cfg, table, dec_w, pts, want_raw=True, want_geo
         _lib.check(lib.mne_query_features(C.byref(sc), n, _lib.ptr(flat), _lib.ptr(feats), _lib.ptr(packed), _lib.ptr(raw),
                                           _lib.ptr(geo), st), "mne_query_features")
     return raw, geo, (feats[:, :grid_cfg.n_levels * grid_cfg.n_features] if want_feat else None)
+
+
+# --------------------------------------------------------------------------------------------------
+# N2: the pose-alignment loop as device work (csrc/pose.hip)
+# --------------------------------------------------------------------------------------------------
+def _rodrigues_host(rot):
+    """axis-angle [3] -> 3x3, the formula of optimization/utils.py:161-177 (host-side probe only)."""
+    th = torch.sqrt((rot * rot).sum() + 1e-24)
+    o = rot / th
+    K = torch.zeros(3, 3, dtype=rot.dtype)
+    K[0, 1], K[0, 2], K[1, 0], K[1, 2], K[2, 0], K[2, 1] = -o[2], o[1], o[2], -o[0], -o[1], o[0]
+    return torch.eye(3, dtype=rot.dtype) + torch.sin(th) * K + (1.0 - torch.cos(th)) * (K @ K)
+
+
+def probe_axis_angle(matrix_from_tensor, rot0, trans0):
+    """Does the host's ``matrix_from_tensor(rot, trans)`` have the form  R = Rodrigues(rot) @ R_base,  t = trans ?
+    Returns R_base (3x3 float32 on the CPU; identity for the reference's ``rot_rep: 'axis_angle'``) or None (quaternions,
+    anything else): the caller then keeps the host's own autograd loop.  Two evaluations of the host function, once per
+    alignment (not per iteration)."""
+    if rot0.shape[-1] != 3 or trans0.shape[-1] != 3:
+        return None
+    with torch.no_grad():
+        r0, t0 = rot0.detach().reshape(1, 3).float().cpu(), trans0.detach().reshape(1, 3).float().cpu()
+        M0 = matrix_from_tensor(r0.to(rot0.device), t0.to(rot0.device)).detach().float().cpu().reshape(4, 4)
+        base = _rodrigues_host(r0[0]).T @ M0[:3, :3]
+        r1 = r0 + torch.tensor([[0.011, -0.017, 0.013]])
+        t1 = t0 + torch.tensor([[0.02, -0.01, 0.03]])
+        M1 = matrix_from_tensor(r1.to(rot0.device), t1.to(rot0.device)).detach().float().cpu().reshape(4, 4)
+        ok = (torch.allclose(_rodrigues_host(r1[0]) @ base, M1[:3, :3], atol=2e-6) and torch.allclose(M1[:3, 3], t1[0], atol=1e-7)
+              and torch.allclose(base @ base.T, torch.eye(3), atol=1e-5))
+    return base.contiguous() if ok else None
+
+
+class PoseAlignment:
+    """Scratch + state of one alignment (``n`` rays): iterate with ``step(u)``; ``best()`` returns (best c2w 4x4, loss)."""
+
+    def __init__(self, model, dirs, want_rgb, want_depth, rot0, trans0, r_base, lr_rot, lr_trans, betas, eps, w_rgb, w_depth):
+        lib = self.lib = _lib.load()
+        dev = dirs.device
+        self.model, self.n = model, dirs.shape[0]
+        n = self.n
+        f = dict(device=dev, dtype=torch.float32)
+        self.dirs = _f32c(dirs, "dirs")
+        self.want_rgb, self.want_depth = _f32c(want_rgb, "rgb"), _f32c(want_depth.reshape(-1), "depth")
+        self.w = (float(w_rgb), float(w_depth))
+        cfg = model.config
+        if not cfg["training"].get("n_samples"):
+            raise KeyError("n_samples")
+        self.info = model._info()
+        self.rc = self.info["render_cfg"]
+        self.S = lib.mne_num_samples(C.byref(self.rc), 0)
+        S = self.S
+        self.tables = linspace_tables(cfg, False, dev)
+        self.planes = [p.detach() for p in model._flat_planes()]
+        self.dec_w = [w.detach() for w in model.decoder.hip_weights()]
+        self.scene = scene_struct(self.info, self.planes, self.dec_w)
+        self.packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(self.scene)), **f)
+        self.rot, self.trans = rot0.detach().reshape(3).to(**f).clone(), trans0.detach().reshape(3).to(**f).clone()
+        self.m, self.v = torch.zeros(6, **f), torch.zeros(6, **f)
+        self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.c2w, self.best_c2w = torch.zeros(12, **f), torch.zeros(12, **f)
+        self.best_loss, self.last_loss = torch.full((1,), float("inf"), **f), torch.zeros(1, **f)
+        self.rays_o, self.rays_d = torch.empty(n, 3, **f), torch.empty(n, 3, **f)
+        self.z, self.raw = torch.empty(n, S, **f), torch.empty(n, S, 4, **f)
+        self.counts = torch.empty(_lib.N_COUNT, device=dev, dtype=torch.int32)
+        self.rgb, self.depth = torch.empty(n, 3, **f), torch.empty(n, **f)
+        self.aux = torch.empty(3, n, **f)
+        self.d_rgb, self.d_depth = torch.empty(n, 3, **f), torch.empty(n, **f)
+        self.partials = torch.empty((n + 255) // 256, **f)
+        self.d_o, self.d_d = torch.empty(n, 3, **f), torch.empty(n, 3, **f)
+        self.tape = torch.empty(n * S, lib.mne_tape_row_floats(C.byref(self.scene)), **f)
+        self.tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.ray_tiles = torch.empty(n, device=dev, dtype=torch.int32)
+        self.ws_bytes = lib.mne_render_workspace_bytes(n, S)
+        self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
+        ps = self.ps = _lib.PoseState()
+        ps.rot, ps.trans, ps.m, ps.v, ps.step = (t.data_ptr() for t in (self.rot, self.trans, self.m, self.v, self.step_count))
+        ps.c2w, ps.best_loss, ps.best_c2w, ps.last_loss = (t.data_ptr() for t in (self.c2w, self.best_loss, self.best_c2w, self.last_loss))
+        for k, val in enumerate(r_base.reshape(-1).tolist()):
+            ps.r_base[k] = val
+        ps.lr_rot, ps.lr_trans, (ps.beta1, ps.beta2), ps.eps = float(lr_rot), float(lr_trans), map(float, betas), float(eps)
+        st = _lib.stream_for(self.dirs)
+        _lib.check(lib.mne_pack_decoder(C.byref(self.scene), _lib.ptr(self.packed), st), "mne_pack_decoder")   # weights are fixed here
+
+    def step(self, u=None, seed_offset=(0, 0)):
+        """One iteration: rays from the current parameters, render, loss, ray gradients, Adam.  ``u`` [n, S] = the host's
+        jitter draw (reference order) or None (device generator, ``seed_offset``)."""
+        lib, P, n, S = self.lib, _lib.ptr, self.n, self.S
+        st = _lib.stream_for(self.dirs)
+        sc, rc = C.byref(self.scene), C.byref(self.rc)
+        _lib.check(lib.mne_pose_rays(C.byref(self.ps), n, P(self.dirs), P(self.rays_o), P(self.rays_d), st), "mne_pose_rays")
+        u_c = _f32c(u, "u") if u is not None else None
+        _lib.check(lib.mne_sample_z(rc, n, None, P(u_c), P(self.tables), seed_offset[0], seed_offset[1], P(self.z), P(self.counts),
+                                    None, st), "mne_sample_z")
+        _lib.check(lib.mne_render_forward(sc, rc, n, S, P(self.rays_o), P(self.rays_d), None, None, P(self.z), P(self.packed),
+                                          P(self.rgb), P(self.depth), P(self.aux[0]), P(self.aux[1]), P(self.aux[2]), P(self.raw),
+                                          None, None, 0, st), "mne_render_forward")
+        _lib.check(lib.mne_pose_loss(n, P(self.rgb), P(self.depth), P(self.want_rgb), P(self.want_depth), self.w[0], self.w[1],
+                                     P(self.d_rgb), P(self.d_depth), P(self.partials), st), "mne_pose_loss")
+        self.d_o.zero_()
+        self.d_d.zero_()
+        _lib.check(lib.mne_render_backward(sc, rc, n, S, P(self.rays_o), P(self.rays_d), None, None, P(self.z), None,
+                                           P(self.packed), P(self.raw), None, P(self.d_rgb), P(self.d_depth), P(self.tape), n * S,
+                                           P(self.tape_rows), P(self.ray_tiles), P(self.d_o), P(self.d_d), P(self.ws),
+                                           self.ws_bytes, st), "mne_render_backward")
+        _lib.check(lib.mne_pose_update(C.byref(self.ps), n, P(self.dirs), P(self.d_o), P(self.d_d), P(self.partials), st),
+                   "mne_pose_update")
+
+    def best(self):
+        T = torch.eye(4, device=self.dirs.device)
+        T[:3, :4] = self.best_c2w.reshape(3, 4)
+        return T, self.best_loss[0]

@@ -159,6 +159,12 @@ class FusedMappingMixin:
             o_t, d_t, _, _ = world_rays(torch.cat([dirs, dirs.new_zeros(n, 4)], -1), base_c2w.expand(n, 4, 4))
             teacher = model_for_base.render_rays(o_t, d_t, target_d=None)
             want_rgb, want_depth = teacher["rgb"].detach(), teacher["depth"].detach()
+        fused = self._pose_alignment_fused(model_for_target, dirs, want_rgb, want_depth, rot, trans, pose_opt, steps, w_rgb, w_depth) \
+            if self.compute == "fused" else None
+        self.last_pose_loop = "device" if fused is not None else "host"
+        if fused is not None:
+            best_pose, best = fused
+            return base_c2w @ torch.inverse(best_pose), float(best)
         best = torch.full((), float("inf"), device=dev)
         best_pose = start.clone()
         for _ in range(steps):
@@ -175,6 +181,38 @@ class FusedMappingMixin:
             loss.backward()
             pose_opt.step()
         return base_c2w @ torch.inverse(best_pose), float(best)
+
+    def _pose_alignment_fused(self, model, dirs, want_rgb, want_depth, rot, trans, pose_opt, steps, w_rgb, w_depth):
+        """The alignment loop as six launches per iteration (csrc/pose.hip: rays from the parameters, the render forward
+        and backward with ray gradients, loss, analytic axis-angle Jacobian + Adam on the six parameters, best pose tracked
+        on the device): no autograd graph, no torch.optim step, no host synchronisation inside the loop.  Used when the
+        host's ``matrix_from_tensor`` IS an axis-angle map (probed: the reference's ``rot_rep: 'axis_angle'``,
+        optimization/utils.py:161-197, or one relative to a constant rotation) and its optimizer is plain Adam over
+        (rot, trans); returns None otherwise and the caller runs the host's own loop."""
+        from .. import hip_path
+        if not isinstance(pose_opt, torch.optim.Adam) or len(pose_opt.param_groups) != 2:
+            return None
+        g_rot, g_trans = pose_opt.param_groups
+        same = all(g_rot[k] == g_trans[k] for k in ("betas", "eps")) and not any(
+            g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") for g in (g_rot, g_trans))
+        if not same or g_rot["params"][0] is not rot or g_trans["params"][0] is not trans:
+            return None
+        r_base = hip_path.probe_axis_angle(self.slam.matrix_from_tensor, rot, trans)
+        if r_base is None:
+            return None
+        pa = hip_path.PoseAlignment(model, dirs, want_rgb, want_depth, rot, trans, r_base, g_rot["lr"], g_trans["lr"],
+                                    g_rot["betas"], g_rot["eps"], w_rgb, w_depth)
+        host_u = self.config["training"]["perturb"] > 0.0 and getattr(model, "jitter_rng", None) == "torch_cpu"
+        for _ in range(steps):
+            if host_u:
+                pa.step(u=torch.rand(pa.n, pa.S).to(self.device))          # the reference's CPU draw, in its order
+            else:
+                u, so = model._jitter(pa.n, pa.S, dirs)
+                pa.step(u=u, seed_offset=so)
+        with torch.no_grad():                                              # the host's parameters end where the loop ended
+            rot.copy_(pa.rot.reshape(rot.shape))
+            trans.copy_(pa.trans.reshape(trans.shape))
+        return pa.best()
 
     def distillation(self, other_rank, expanded_foreign_kfs_for_distill, num_expanded_kfs):
         """Distil a foreign agent's map (``model_shared`` = teacher) into ``model`` (the training loop of

@@ -509,6 +509,26 @@ class _OracleModel:
         return self.scene.render_rays(rays_o, rays_d, target_d=target_d)
 
 
+class _PoseSLAMAbsolute(_PoseSLAM):
+    """The reference's own parameterisation (rot_rep 'axis_angle', mneslam_mp.py:199-201, :577-584): the rotation
+    vector of the pose itself, c2w = [Rodrigues(rot) | trans]."""
+
+    def get_pose_param_optim(self, poses, mapping=True):
+        R = poses[0, :3, :3].detach().double()
+        ang = torch.acos(torch.clamp((torch.trace(R) - 1.0) / 2.0, -1.0, 1.0))
+        axis = torch.stack([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2.0 * torch.sin(ang))
+        cur_rot = torch.nn.Parameter((axis * ang).to(poses.dtype)[None].clone())
+        cur_trans = torch.nn.Parameter(poses[:, :3, 3].detach().clone())
+        opt = torch.optim.Adam([{"params": cur_rot, "lr": self.lr_rot}, {"params": cur_trans, "lr": self.lr_trans}])
+        return cur_rot, cur_trans, opt
+
+    def matrix_from_tensor(self, rot, trans):
+        T = torch.eye(4, dtype=rot.dtype, device=rot.device)[None].repeat(rot.shape[0], 1, 1)
+        T[:, :3, :3] = _rodrigues(rot)
+        T[:, :3, 3] = trans
+        return T
+
+
 def _alignment_setup(g, device):
     rays_o, rays_d, *_ = fixture_inputs(g)
     cam_dirs = rays_d[:48].clone()                                   # any fixed bundle of camera-frame directions
@@ -520,9 +540,11 @@ def _alignment_setup(g, device):
     return cam_dirs, base, target0
 
 
-def check_pose_alignment(device):
+def check_pose_alignment(device, compute="autograd", absolute=False):
     """Mapper.optimize_relative_pose (reference loop: mp_slam/mapper.py:362-412) on the HIP path vs the same loop
-    driven by the CPU oracle's autograd: same seeds -> same jitter draws -> same pose trajectory."""
+    driven by the CPU oracle's autograd: same seeds -> same jitter draws -> same pose trajectory.
+    compute="fused": the device loop (csrc/pose.hip: no autograd graph, no torch.optim step); ``absolute``: the reference's
+    own axis-angle parameterisation instead of one relative to the initial rotation."""
     g = load_golden("render_nodepth")
     cfg = configs.small_test_config()
     cfg["mapping"]["loop_iters"] = 4
@@ -535,11 +557,13 @@ def check_pose_alignment(device):
             model, dev = _OracleModel(oracle_scene_from_golden(g, cfg)), "cpu"
         slam = types.SimpleNamespace(model=model, model_shared=model, map_optimizer=None, device=torch.device(dev),
                                      dataset=None, video=None, get_pose_param_optim=None, matrix_from_tensor=None)
-        pose = _PoseSLAM()
+        pose = _PoseSLAMAbsolute() if absolute else _PoseSLAM()
         slam.get_pose_param_optim, slam.matrix_from_tensor = pose.get_pose_param_optim, pose.matrix_from_tensor
-        mp = Mapper(cfg, slam)
+        mp = Mapper(cfg, slam, compute=compute if kind == "hip" else "autograd")
         torch.manual_seed(11)
         rel, best = mp.optimize_relative_pose(base.clone(), target0.clone(), model, model, rays_d_cam_batch=cam_dirs.clone())
+        if kind == "hip":
+            assert mp.last_pose_loop == ("device" if compute == "fused" else "host")
         results.append((rel.detach().cpu(), best))
     (rel_h, best_h), (rel_o, best_o) = results
     assert best_h == best_h and abs(best_h - best_o) <= 1e-3 * abs(best_o) + 1e-7, (best_h, best_o)
