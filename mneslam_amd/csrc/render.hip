@@ -1081,11 +1081,7 @@ __global__ __launch_bounds__(256) void bin_kernel(RenderArgs a) {
         // tiles, and reservations on one counter are served one after the other (profiles/r03_bin_ablation.txt).  Each ray
         // therefore starts at a different tile of its own and wraps around, which spreads those reservations over the
         // kernel's run time instead of queueing them all at its start.
-#ifdef BIN_NO_ROTATE
-        const int c0 = 0;
-#else
         const int c0 = (int)((unsigned)r % (unsigned)t_dec);
-#endif
         for (int k = 0; k < t_dec; ++k) {
             const int c = c0 + k < t_dec ? c0 + k : c0 + k - t_dec;
             const int i = c * TILE + pt;

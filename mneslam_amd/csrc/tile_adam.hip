@@ -85,11 +85,6 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
     __shared__ int total, n_split;
     const int tid = threadIdx.x;
     int* n_items = a.bins.split_state ? a.bins.split_state + n_tiles : nullptr;
-#ifdef TILE_ORDER_IDENTITY        // experiment: spatial order (neighbouring tiles run together), no load balancing
-    for (int t = tid; t < n_tiles; t += 1024) a.bins.order[t] = t;
-    if (tid == 0 && n_items) *n_items = n_tiles;
-    return;
-#endif
     if (tid < 32) hist[tid] = 0;
     if (tid == 0) { total = 0; n_split = 0; }
     __syncthreads();

@@ -403,9 +403,6 @@ class FusedStep:
                 stt = self.opt._state(p)
                 stt["step"] += 1
                 self.plane_opt[k].step = stt["step"]
-            if os.environ.get("MNE_ABL_EMPTY_LISTS", "0") == "1":      # timing ablation: the plane update as a pure Adam sweep
-                with torch.cuda.stream(side) if side is not None else _null_ctx():
-                    self.tile_counts.zero_()
             e0 = self._mark("adam", stream=side)
             if self.tile_overlap is not None:
                 # EXTENSION: the peers' gradients of the shared cells join ours before the update.  Export -> one batched
