@@ -2,6 +2,7 @@
 two backends: the real library on an MI355X (tests/test_hip_parity_gpu.py, ``-m gpu``) and the
 test-only host emulation of the same kernel sources (tests/test_kernels_hostemu.py, CPU).
 Every function takes the torch device to run on."""
+import contextlib
 import copy
 import os
 import random
@@ -1176,3 +1177,106 @@ def check_checkpoint_handoff(device, tmp_dir):
         want = sc.render_rays(rays_o, rays_d, target_d=None, u=u)
     assert_close(got["rgb"].cpu(), want["rgb"], rtol=1e-4, atol=2e-5, what="teacher rgb after the hand-off")
     assert_close(got["depth"].cpu(), want["depth"], rtol=1e-4, atol=2e-5, what="teacher depth after the hand-off")
+
+
+# --------------------------------------------------------------------------------------------------------------
+# EXTENSION: two agents on one lattice, binned plane update, shared cells + shared decoder
+# --------------------------------------------------------------------------------------------------------------
+def lattice_config(rank):
+    """Two slabs along x whose planes sit on ONE lattice on both levels: extended x length 2.4 m with 13 / 25 nodes
+    (spacing 0.2 / 0.1 m), agent 1 shifted by 1.4 m = 7 coarse / 14 fine nodes; y and z extents are the agents' common ones."""
+    cfg = configs.small_test_config(one_grid=True, is_co_sdf=False, n_samples_d=21, n_range_d=11)
+    x0 = -1.0 + 1.4 * rank
+    cfg["mapping"]["bound"] = [[x0, x0 + 2.3], [-1.2, 1.1], [-0.8, 0.9]]             # extended by bound_dividable to 2.4 / 2.4 / 1.8
+    cfg["planes_res"] = {"coarse": 0.181, "fine": 0.095, "bound_dividable": 0.2}
+    room = [[x0 + 0.2, x0 + 2.2], [-1.0, 0.9], [-0.6, 0.7]]
+    return cfg, room
+
+
+def run_overlap_agent(rank, device, comm):
+    """One of two agents on one lattice: FusedStep (binned plane update, overlap_peers + shared_decoder) against an oracle
+    agent with the exchange written out in tensor ops -- plane gradients summed over the node rectangles both agents hold,
+    decoder gradient averaged, then Adam.  Equal by construction to ONE model over the union lattice trained on the union
+    batch wherever the cells are shared.  Checks, over two iterations: every plane and decoder parameter against the oracle
+    agent, and the shared cells and the decoder bit-equal between the two HIP agents.  ``comm.all_gather(obj)`` -> the
+    two agents' objects by rank (gloo processes on the CPU, threads of one process on the GPU)."""
+    from mneslam_amd import dist as mdist, synthetic
+    from mneslam_amd.fused import FusedStep
+    cfg, room = lattice_config(rank)
+    bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
+    with getattr(comm, "lock", contextlib.nullcontext()):        # (threads of one process share the global generator)
+        torch.manual_seed(11)                                    # the same decoder on both agents
+        model = JointEncoding(cfg, bb).to(device).train()
+    geo = mdist.plane_geometry(model)
+    peer_geo = comm.all_gather(geo)[1 - rank]
+    # planes = windows of one field over the union lattice (same seed on both ranks), so shared cells start equal
+    flat = [p for lst in model.all_planes for p in lst]
+    rects = []
+    for k, (p, (shape, bnd, axes), (pshape, pbnd, _)) in enumerate(zip(flat, geo, peer_geo)):
+        (ys, xs), (pys, pxs) = mdist.overlap_slices(bnd, pbnd, shape, pshape, axes)
+        rects.append(((ys, xs), (pys, pxs)))
+        off = (xs.start - pxs.start) if rank == 1 else 0        # this agent's first node on the union lattice (x only)
+        if axes[0] != 0:
+            assert xs == slice(0, shape[1]) and ys == slice(0, shape[0])          # yz planes: shared as a whole
+        shift = pxs.start if rank == 0 else 0                    # union width = own + peer - shared
+        width = shape[1] + pshape[1] - (xs.stop - xs.start)
+        field = 0.05 * torch.randn(1, p.shape[1], shape[0], width, generator=torch.Generator().manual_seed(100 + k))
+        start = 0 if (rank == 0 or axes[0] != 0) else width - shape[1]
+        with torch.no_grad():
+            p.copy_(field[..., start:start + shape[1]].to(device))
+        del off, shift
+    opt = slam_glue.create_optimizer(model, cfg)
+    n_rays = 40
+    fs = FusedStep(model, opt, cfg, n_rays, device, scatter="binned", shared_decoder=True, overlap_peers=[(1 - rank, peer_geo)])
+    assert fs.tile_overlap is not None and fs.ov_send[0].numel() > 32 * 25
+    H, W = 34, 60
+    frames = synthetic.make_frames(2, H, W, 30.0, 30.0, 29.5, 16.5, room, seed=3 + rank)
+    fr = frames[1]
+    cur = torch.cat([fr["direction"], fr["rgb"], fr["depth"][..., None]], -1).reshape(-1, 7).contiguous().to(device)
+    poses = fr["c2w"].reshape(1, 4, 4).contiguous().to(device)
+    # ---- oracle agent
+    cpu = lambda t: t.detach().cpu().clone()
+    sc = OracleScene(cfg, bb, build=False)
+    sc.all_planes = tuple([cpu(p).contiguous() for p in lst] for lst in model.all_planes)
+    sd = model.decoder.state_dict()
+    sc.col_w = [cpu(sd["color_net.model.0.weight"]), cpu(sd["color_net.model.2.weight"])]
+    sc.sdf_w = [cpu(sd["sdf_net.model.0.weight"]), cpu(sd["sdf_net.model.2.weight"])]
+    sc.requires_grad_(True)
+    oopt = omap.OracleAdam(sc, cfg)
+    gen = torch.Generator().manual_seed(7 + rank)
+    for it in range(2):
+        idx = torch.randperm(H * W, generator=gen)[:n_rays]
+        fs.step(None, 0, 1, cur, poses, 0, n_rays, idx_cur=idx.to(device), u=torch.rand(n_rays, fs.S, generator=gen).to(device))
+        fs.synchronize()
+        fs.check()
+        oopt.zero_grad()
+        r = sc.forward(cpu(fs.rays_o), cpu(fs.rays_d), cpu(fs.tgt_rgb), cpu(fs.tgt_d)[:, None], impl="grid_sample",
+                       z_vals=cpu(fs.z_vals))
+        omap.loss_from_ret(cfg, r, is_co_sdf=False).backward()
+        mine = [p.grad.clone() for p in sc.plane_list()]
+        theirs = comm.all_gather(mine)
+        with torch.no_grad():
+            for p, g_peer, ((ys, xs), (pys, pxs)) in zip(sc.plane_list(), theirs[1 - rank], rects):
+                p.grad[:, :, ys, xs] += g_peer[:, :, pys, pxs]
+            for w in sc.decoder_list():
+                gs = comm.all_gather(w.grad.clone())
+                w.grad.copy_((gs[0] + gs[1]) / 2)
+        oopt.step()
+        lr = opt.param_groups[1]["lr"]
+        for k, (p, ref) in enumerate(zip(flat, sc.plane_list())):
+            d = (cpu(p) - ref.detach()).abs()
+            assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 2e-3, \
+                f"iteration {it} plane {k}: mean {float(d.mean()):.3e}, outliers {float((d > 0.05 * lr).float().mean()):.3e}"
+        for w_hip, w_ref in zip(model.decoder.parameters(), sc.decoder_list()):
+            d = (cpu(w_hip) - w_ref.detach()).abs()
+            assert float(d.mean()) < 2e-3 * opt.param_groups[0]["lr"], f"iteration {it}: decoder after Adam"
+    # the exchange carried something: the shared cells' first moments hold the peer's share too
+    ex = fs.ov_recv[0]
+    assert float(ex.abs().max()) > 0
+    # shared cells are bit-equal on the two agents (a + b == b + a; same moments, same step), the rest is not
+    for k, (p, ((ys, xs), (pys, pxs))) in enumerate(zip(flat, rects)):
+        both = comm.all_gather(cpu(p)[:, :, ys, xs].clone())
+        assert torch.equal(both[0], both[1]), f"plane {k}: shared cells differ between the agents"
+    dec = torch.cat([cpu(p).reshape(-1) for p in model.decoder.parameters()])
+    both = comm.all_gather(dec)
+    assert torch.equal(both[0], both[1])

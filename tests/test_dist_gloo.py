@@ -155,122 +155,27 @@ def test_two_agents_shared_decoder_fused_step(tmp_path):
 # --------------------------------------------------------------------------------------------------------------
 # EXTENSION: two agents on one lattice, binned plane update, shared cells + shared decoder
 # --------------------------------------------------------------------------------------------------------------
-def _lattice_config(rank):
-    """Two slabs along x whose planes sit on ONE lattice on both levels: extended x length 2.4 m with 13 / 25 nodes
-    (spacing 0.2 / 0.1 m), agent 1 shifted by 1.4 m = 7 coarse / 14 fine nodes; y and z extents are the agents' common ones."""
-    from mneslam_amd import configs
-    cfg = configs.small_test_config(one_grid=True, is_co_sdf=False, n_samples_d=21, n_range_d=11)
-    x0 = -1.0 + 1.4 * rank
-    cfg["mapping"]["bound"] = [[x0, x0 + 2.3], [-1.2, 1.1], [-0.8, 0.9]]             # extended by bound_dividable to 2.4 / 2.4 / 1.8
-    cfg["planes_res"] = {"coarse": 0.181, "fine": 0.095, "bound_dividable": 0.2}
-    room = [[x0 + 0.2, x0 + 2.2], [-1.0, 0.9], [-0.6, 0.7]]
-    return cfg, room
-
-
 def _binned_overlap_worker(rank, world, port, ret):
     """Two FusedSteps (binned plane update, overlap_peers + shared_decoder) against two oracle agents with the exchange
-    written out in tensor ops: plane gradients summed over the node rectangles both agents hold, decoder gradient averaged,
-    then Adam.  Equal by construction to ONE model over the union lattice trained on the union batch wherever the cells are
-    shared.  Checks, over two iterations: every plane and decoder parameter against the oracle agents, and the shared cells
-    bit-equal between the two HIP agents."""
+    written out in tensor ops (parity_cases.run_overlap_agent), over gloo with the kernels in the host emulator."""
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import build_emu
-    from mneslam_amd import _lib, dist as mdist, slam_glue, synthetic
-    from mneslam_amd.fused import FusedStep
-    from mneslam_amd.model.scene_rep import JointEncoding
-    from oracle import mapping as omap
-    from oracle.scene_rep import OracleScene
-    from helpers import assert_close
+    from mneslam_amd import _lib, dist as mdist
+    import parity_cases as pc
     _lib.unload()
     _lib.load(build_emu.build())
     mdist.init_agents(backend="gloo")
-    cfg, room = _lattice_config(rank)
-    bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
-    torch.manual_seed(11)                                        # the same decoder on both agents
-    model = JointEncoding(cfg, bb).train()
-    geo = mdist.plane_geometry(model)
-    geos = [None, None]
-    dist.all_gather_object(geos, geo)
-    peer_geo = geos[1 - rank]
-    # planes = windows of one field over the union lattice (same seed on both ranks), so shared cells start equal
-    flat = [p for lst in model.all_planes for p in lst]
-    rects = []
-    for k, (p, (shape, bnd, axes), (pshape, pbnd, _)) in enumerate(zip(flat, geo, peer_geo)):
-        (ys, xs), (pys, pxs) = mdist.overlap_slices(bnd, pbnd, shape, pshape, axes)
-        rects.append(((ys, xs), (pys, pxs)))
-        off = (xs.start - pxs.start) if rank == 1 else 0        # this agent's first node on the union lattice (x only)
-        if axes[0] != 0:
-            assert xs == slice(0, shape[1]) and ys == slice(0, shape[0])          # yz planes: shared as a whole
-        shift = pxs.start if rank == 0 else 0                    # union width = own + peer - shared
-        width = shape[1] + pshape[1] - (xs.stop - xs.start)
-        field = 0.05 * torch.randn(1, p.shape[1], shape[0], width, generator=torch.Generator().manual_seed(100 + k))
-        start = 0 if (rank == 0 or axes[0] != 0) else width - shape[1]
-        with torch.no_grad():
-            p.copy_(field[..., start:start + shape[1]])
-        del off, shift
-    opt = slam_glue.create_optimizer(model, cfg)
-    n_rays = 40
-    fs = FusedStep(model, opt, cfg, n_rays, "cpu", scatter="binned", shared_decoder=True, overlap_peers=[(1 - rank, peer_geo)])
-    assert fs.tile_overlap is not None and fs.ov_send[0].numel() > 32 * 25
-    H, W = 34, 60
-    frames = synthetic.make_frames(2, H, W, 30.0, 30.0, 29.5, 16.5, room, seed=3 + rank)
-    fr = frames[1]
-    cur = torch.cat([fr["direction"], fr["rgb"], fr["depth"][..., None]], -1).reshape(-1, 7).contiguous()
-    poses = fr["c2w"].reshape(1, 4, 4).contiguous()
-    # ---- oracle agent
-    cpu = lambda t: t.detach().clone()
-    sc = OracleScene(cfg, bb, build=False)
-    sc.all_planes = tuple([cpu(p).contiguous() for p in lst] for lst in model.all_planes)
-    sd = model.decoder.state_dict()
-    sc.col_w = [cpu(sd["color_net.model.0.weight"]), cpu(sd["color_net.model.2.weight"])]
-    sc.sdf_w = [cpu(sd["sdf_net.model.0.weight"]), cpu(sd["sdf_net.model.2.weight"])]
-    sc.requires_grad_(True)
-    oopt = omap.OracleAdam(sc, cfg)
-    gen = torch.Generator().manual_seed(7 + rank)
-    for it in range(2):
-        idx = torch.randperm(H * W, generator=gen)[:n_rays]
-        fs.step(None, 0, 1, cur, poses, 0, n_rays, idx_cur=idx, u=torch.rand(n_rays, fs.S, generator=gen))
-        fs.synchronize()
-        fs.check()
-        oopt.zero_grad()
-        r = sc.forward(fs.rays_o.clone(), fs.rays_d.clone(), fs.tgt_rgb.clone(), fs.tgt_d.clone()[:, None], impl="grid_sample",
-                       z_vals=fs.z_vals.clone())
-        omap.loss_from_ret(cfg, r, is_co_sdf=False).backward()
-        mine = [p.grad.clone() for p in sc.plane_list()]
-        theirs = [None, None]
-        dist.all_gather_object(theirs, mine)
-        with torch.no_grad():
-            for p, g_peer, ((ys, xs), (pys, pxs)) in zip(sc.plane_list(), theirs[1 - rank], rects):
-                p.grad[:, :, ys, xs] += g_peer[:, :, pys, pxs]
-            for w in sc.decoder_list():
-                gs = [None, None]
-                dist.all_gather_object(gs, w.grad.clone())
-                w.grad.copy_((gs[0] + gs[1]) / 2)
-        oopt.step()
-        lr = opt.param_groups[1]["lr"]
-        for k, (p, ref) in enumerate(zip(flat, sc.plane_list())):
-            d = (p.detach() - ref.detach()).abs()
-            assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 2e-3, \
-                f"iteration {it} plane {k}: mean {float(d.mean()):.3e}, outliers {float((d > 0.05 * lr).float().mean()):.3e}"
-        for w_hip, w_ref in zip(model.decoder.parameters(), sc.decoder_list()):
-            d = (w_hip.detach() - w_ref.detach()).abs()
-            assert float(d.mean()) < 2e-3 * opt.param_groups[0]["lr"], f"iteration {it}: decoder after Adam"
-    # the exchange carried something: the shared cells' first moments hold the peer's share too
-    ex = fs.ov_recv[0]
-    assert float(ex.abs().max()) > 0
-    # shared cells are bit-equal on the two agents (a + b == b + a; same moments, same step), the rest is not
-    for k, (p, ((ys, xs), (pys, pxs))) in enumerate(zip(flat, rects)):
-        both = [None, None]
-        dist.all_gather_object(both, p.detach()[:, :, ys, xs].clone())
-        assert torch.equal(both[0], both[1]), f"plane {k}: shared cells differ between the agents"
-    dec = torch.cat([p.detach().reshape(-1) for p in model.decoder.parameters()])
-    both = [None, None]
-    dist.all_gather_object(both, dec)
-    assert torch.equal(both[0], both[1])
+
+    class GlooComm:
+        def all_gather(self, obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+    pc.run_overlap_agent(rank, "cpu", GlooComm())
     dist.destroy_process_group()
     open(ret + f".ok{rank}", "w").write("ok")
 

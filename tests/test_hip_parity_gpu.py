@@ -445,3 +445,62 @@ def test_forced_split_lists_and_capped_ray_lds(monkeypatch):
     cfg["mapping"]["sample"] = 512
     out = pc.check_fused_step_vs_oracle(DEV, cfg, n_keyframes=4, seed=11, warm_steps=2, small=True)
     assert out["contributing"] > 1000
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 8e on real hardware as far as one GPU allows: the multi-agent forms of the plane update (tile_adam_kernel<1>, <2>),
+# two agents = two threads of this process on the same device, the exchange done by device-to-device copies
+# ------------------------------------------------------------------------------------------------------------
+def test_two_agents_binned_overlap_on_one_device(monkeypatch):
+    """parity_cases.run_overlap_agent with both agents on cuda:0: mne_tile_grad_export / mne_tile_adam_shared on the GPU,
+    FusedStep(overlap_peers, shared_decoder) on its two streams; what torch.distributed would carry (the send / recv
+    buffers of the shared cells, the decoder-gradient mean) is copied between the agents' buffers under a barrier."""
+    import threading
+    from mneslam_amd import dist as mdist
+    bar, slots, local = threading.Barrier(2), [None, None], threading.local()
+
+    class ThreadComm:
+        lock = threading.Lock()
+
+        def all_gather(self, obj):
+            slots[local.rank] = obj
+            bar.wait()
+            out = list(slots)
+            bar.wait()
+            return out
+    comm = ThreadComm()
+
+    def exchange(peers, send, recv):
+        torch.cuda.current_stream().synchronize()                 # my export has finished
+        theirs = comm.all_gather(send)[1 - local.rank]
+        for r, s in zip(recv, theirs):
+            r.copy_(s)
+        torch.cuda.current_stream().synchronize()
+        bar.wait()                                                # the peer has read my send buffers
+
+    def allreduce_mean(buf):
+        torch.cuda.current_stream().synchronize()
+        both = comm.all_gather(buf)
+        mean = (both[0] + both[1]) / 2
+        torch.cuda.current_stream().synchronize()
+        bar.wait()
+        buf.copy_(mean)
+        return buf
+    monkeypatch.setattr(mdist, "exchange_buffers", exchange)
+    monkeypatch.setattr(mdist, "allreduce_mean_", allreduce_mean)
+    errors = []
+
+    def agent(rank):
+        local.rank = rank
+        try:
+            with torch.cuda.device(0):
+                pc.run_overlap_agent(rank, DEV, comm)
+        except BaseException as e:          # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, e))
+            bar.abort()
+    threads = [threading.Thread(target=agent, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
