@@ -12,6 +12,7 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 // mode 0: ds_add_f32 (atomicAdd, result unused)   1: plain read-add-write (racy; upper bound of the LDS data path)
+// mode 2: ds_add_u32 on fixed-point values   3: ds_add_u64
 // spread: cells are drawn from [0, spread) -- 256 = whole tile, 16 = one cell row (a wall seen edge-on), 1 = one cell
 template <int MODE>
 __global__ __launch_bounds__(512) void accum_kernel(const unsigned* cells, const float* rows, float* out, int n_entries, int reps) {
@@ -39,7 +40,9 @@ __global__ __launch_bounds__(512) void accum_kernel(const unsigned* cells, const
                     float* p = g + (yy * 16 + xx) * 32 + c;
                     const float w = 0.25f * v[j];
                     if (MODE == 0) atomicAdd(p, w);
-                    else *p += w;
+                    else if (MODE == 1) *p += w;
+                    else if (MODE == 2) atomicAdd((int*)p, (int)(w * 1048576.0f));                      // ds_add_u32, fixed point
+                    else atomicAdd((unsigned long long*)g + ((yy * 16 + xx) * 32 + c) / 2, (unsigned long long)(long long)(w * 1048576.0f));   // ds_add_u64 (half the cells)
                 }
             }
         }
@@ -67,12 +70,14 @@ int main() {
         unsigned s = 12345u;
         for (auto& c : cells) { s = s * 1664525u + 1013904223u; c = (s >> 8) % spread; }
         CHECK(hipMemcpy(d_cells, cells.data(), cells.size() * 4, hipMemcpyHostToDevice));
-        for (int mode = 0; mode < 2; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             float best = 1e9f;
             for (int t = 0; t < 3; ++t) {
                 CHECK(hipEventRecord(e0));
                 if (mode == 0) hipLaunchKernelGGL(accum_kernel<0>, dim3(blocks), dim3(512), 0, 0, d_cells, d_rows, d_out, n_entries, reps);
-                else hipLaunchKernelGGL(accum_kernel<1>, dim3(blocks), dim3(512), 0, 0, d_cells, d_rows, d_out, n_entries, reps);
+                else if (mode == 1) hipLaunchKernelGGL(accum_kernel<1>, dim3(blocks), dim3(512), 0, 0, d_cells, d_rows, d_out, n_entries, reps);
+                else if (mode == 2) hipLaunchKernelGGL(accum_kernel<2>, dim3(blocks), dim3(512), 0, 0, d_cells, d_rows, d_out, n_entries, reps);
+                else hipLaunchKernelGGL(accum_kernel<3>, dim3(blocks), dim3(512), 0, 0, d_cells, d_rows, d_out, n_entries, reps);
                 CHECK(hipEventRecord(e1));
                 CHECK(hipEventSynchronize(e1));
                 float ms;
@@ -81,7 +86,7 @@ int main() {
             }
             const double entries = (double)blocks * n_entries * reps;
             printf("cells spread %3d  %s: %.3f ms  -> %.2f G entry-corners/s chip-wide, %.2f us per 512-entry pass per workgroup (512 workgroups resident), %.1f G lane-ops/s per CU\n",
-                   spread, mode == 0 ? "ds_add_f32      " : "read-add-write  ", best, entries * 4 / best / 1e6,
+                   spread, mode == 0 ? "ds_add_f32      " : mode == 1 ? "read-add-write  " : mode == 2 ? "ds_add_u32 fixed" : "ds_add_u64 fixed", best, entries * 4 / best / 1e6,
                    best * 1e3 / ((double)n_entries * reps / 512.0), entries * 4 * 32 / best / 1e6 / 256.0);
         }
     }
