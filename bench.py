@@ -466,8 +466,14 @@ def main():
         if world == 1 and args.variants and not args.small:
             del agent
             torch.cuda.empty_cache()
-            out["variants"] = {name: run_variant(c, h, device, args.keyframes) for name, c, h in VARIANTS
-                               if not (c == args.config and (h or args.hidden) == args.hidden)}
+            out["variants"] = {}
+            for name, c, h in VARIANTS:
+                if c == args.config and (h or args.hidden) == args.hidden:
+                    continue
+                try:                      # a side record must never cost the metric's line
+                    out["variants"][name] = run_variant(c, h, device, args.keyframes)
+                except Exception as e:    # noqa: BLE001
+                    out["variants"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
