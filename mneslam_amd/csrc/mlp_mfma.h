@@ -163,18 +163,31 @@ struct MlpState {
 
 // OneBlob of this lane's half of the 48 channels: half 0 -> pos[0..23] = dim0 (16) + dim1 bins 0..7,
 // half 1 -> pos[24..47] = dim1 bins 8..15 + dim2 (16).
+// LEAN: the middle dimension's eight bins of this half only (oneblob8: 25 instead of 32 cumulative values per lane, same
+// bits).  Off for the one kernel that has no register to spare for the extra live range (decode of 2x64 + colour planes).
+template <bool LEAN = true>
 __device__ __forceinline__ void oneblob_half(const float u[3], int h, float (&pos)[24]) {
-    float full[MNE_NB], part[MNE_NB];
+    float full[MNE_NB], part[LEAN ? 8 : MNE_NB];
     const float xf = h == 0 ? u[0] : u[2];
     const bool in_f = xf >= 0.125f && xf <= 0.875f, in_p = u[1] >= 0.125f && u[1] <= 0.875f;
     const bool interior = __ballot(!(in_f && in_p)) == 0ull;        // wave-uniform fast path
     oneblob16(xf, full, interior);
-    oneblob16(u[1], part, interior);
+    if constexpr (LEAN) oneblob8(u[1], h * 8, part, interior);
+    else oneblob16(u[1], part, interior);
+    if constexpr (!LEAN) {
+#pragma unroll
+        for (int idx = 0; idx < 24; ++idx) {
+            const float lo = idx < 16 ? full[idx & 15] : part[(idx - 16) & 15];      // half 0: dim0 | dim1[0..7]
+            const float hi = idx < 8 ? part[(8 + idx) & 15] : full[(idx - 8) & 15];   // half 1: dim1[8..15] | dim2
+            pos[idx] = h == 0 ? lo : hi;
+        }
+        return;
+    }
     // static register indices only (a lane-dependent index would put pos[] in scratch)
 #pragma unroll
     for (int idx = 0; idx < 24; ++idx) {
-        const float lo = idx < 16 ? full[idx & 15] : part[(idx - 16) & 15];      // half 0: dim0 | dim1[0..7]
-        const float hi = idx < 8 ? part[(8 + idx) & 15] : full[(idx - 8) & 15];   // half 1: dim1[8..15] | dim2
+        const float lo = idx < 16 ? full[idx & 15] : part[(idx - 16) & 7];       // half 0: dim0 | dim1[0..7]
+        const float hi = idx < 8 ? part[idx & 7] : full[(idx - 8) & 15];          // half 1: dim1[8..15] | dim2
         pos[idx] = h == 0 ? lo : hi;
     }
 }

@@ -128,6 +128,23 @@ __device__ __forceinline__ void oneblob16(float x, float* out /*16*/, bool inter
     out[MNE_NB - 1] = (c[0] + 1.0f) - c[MNE_NB - 1];
 }
 
+// Eight consecutive bins [base, base + 8) of the same encoding, base = 0 or 8 (lane-dependent): the nine cumulative values
+// they need instead of all sixteen -- same expressions on the same inputs, so the values are bit-identical to
+// oneblob16's (the half-wave layout of the MLP kernels needs only half of the middle dimension's bins per lane).
+__device__ __forceinline__ void oneblob8(float x, int base, float* out /*8*/, bool interior = false) {
+    float c[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int b = (base + j) & (MNE_NB - 1);              // base = 8: the ninth value is c[0] (periodic wrap, below)
+        float t = (float)b * 0.0625f - x;
+        c[j] = interior ? (quartic_cdf(t) + 0.0f) + 1.0f
+                        : (quartic_cdf(t) + quartic_cdf(t - 1.0f)) + quartic_cdf(t + 1.0f);
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) out[j] = c[j + 1] - c[j];
+    out[7] = base ? (c[8] + 1.0f) - c[7] : c[8] - c[7];        // bin 15 wraps around: (c[0] + 1) - c[15]
+}
+
 // ---- gather: tri-plane features of the 64 staged points -> LDS rows ---------------------------
 // Lane layout: 8 lanes x float4 cover one 128-B corner row, 8 points per pass (coalesced rows).
 // pn: LDS [NPTS][4] normalised points; feat: LDS [NSETS][NPTS][MNE_FS].

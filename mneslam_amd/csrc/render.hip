@@ -291,7 +291,7 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     const float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
     DEC_STAMP(3);
     float pos[24];
-    oneblob_half(u, hf, pos);
+    oneblob_half<!(HID == 64 && CP)>(u, hf, pos);
     DEC_STAMP(4);
     MlpState<HID, HIDC> st;
     mlp_forward_mfma<HID, HIDC, CP, GTAB>(frow, cfrow, pos, atab, lane, st);
