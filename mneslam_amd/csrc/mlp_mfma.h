@@ -169,7 +169,9 @@ template <bool LEAN = true>
 __device__ __forceinline__ void oneblob_half(const float u[3], int h, float (&pos)[24]) {
     float full[MNE_NB], part[LEAN ? 8 : MNE_NB];
     const float xf = h == 0 ? u[0] : u[2];
-    const bool in_f = xf >= 0.125f && xf <= 0.875f, in_p = u[1] >= 0.125f && u[1] <= 0.875f;
+    // x in [1/64, 59/64]: for every bin the two periodic wrap terms have |16 t| >= 1.25, where the clamped quartic is exactly
+    // 0 and 1 (its value there is 0.023 outside [0, 1]; checked over 2.2 M fp32 values incl. every value next to the bounds)
+    const bool in_f = xf >= 0.015625f && xf <= 0.921875f, in_p = u[1] >= 0.015625f && u[1] <= 0.921875f;
     const bool interior = __ballot(!(in_f && in_p)) == 0ull;        // wave-uniform fast path
     oneblob16(xf, full, interior);
     if constexpr (LEAN) oneblob8(u[1], h * 8, part, interior);

@@ -113,8 +113,8 @@ __device__ __forceinline__ float quartic_cdf(float t) {
     return fminf(1.0f, fmaxf(poly, 0.0f));
 }
 
-// `interior` (wave-uniform): every lane's x lies in [2/16, 14/16], where the two periodic wrap terms are
-// exactly 0 and 1 (|u| >= 2 > 1: the clamp saturates), so only the central kernel is evaluated.
+// `interior` (wave-uniform): every lane's x lies in [1/64, 59/64], where the two periodic wrap terms are
+// exactly 0 and 1 (|u| >= 1.25: the clamp saturates with a margin of 0.023), so only the central kernel is evaluated.
 __device__ __forceinline__ void oneblob16(float x, float* out /*16*/, bool interior = false) {
     float c[MNE_NB];
 #pragma unroll
