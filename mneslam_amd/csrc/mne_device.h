@@ -394,6 +394,32 @@ __device__ __forceinline__ void store_rows(const float* rows, float* tape_rows0,
     }
 }
 
+// load_rows in two halves, so that independent work (OneBlob: pure VALU) can run while the rows are in flight:
+// rows_fetch issues the coalesced loads into registers (eight float4 per lane for 64 columns), rows_commit writes them to
+// the LDS rows.  (Plain reference-to-array parameters: a wrapper struct ended up in scratch.)
+template <int NCOL>
+__device__ __forceinline__ void rows_fetch(float4 (&v)[4][NCOL / 32], const float* tape_rows0, int row_stride, int tcol, unsigned live, int lane) {
+    const int cg = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int slot = it * 8 + (lane >> 3);
+        const int src = ((live >> slot) & 1u) ? slot : 0;              // rows beyond the ray's last sample: any valid row
+#pragma unroll
+        for (int hfc = 0; hfc < NCOL / 32; ++hfc)
+            v[it][hfc] = *(const float4*)(tape_rows0 + (size_t)src * row_stride + tcol + hfc * 32 + cg * 4);
+    }
+}
+template <int NCOL>
+__device__ __forceinline__ void rows_commit(const float4 (&v)[4][NCOL / 32], float* rows, int lane) {
+    const int cg = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int slot = it * 8 + (lane >> 3);
+#pragma unroll
+        for (int hfc = 0; hfc < NCOL / 32; ++hfc) *(float4*)(rows + slot * MNE_FS + hfc * 32 + cg * 4) = v[it][hfc];
+    }
+}
+
 // the reverse of store_rows: tape columns [tcol, tcol + NCOL) of the tile's rows -> LDS rows, one batch of coalesced loads
 template <int NCOL>
 __device__ __forceinline__ void load_rows(float* rows, const float* tape_rows0, int row_stride, int tcol,

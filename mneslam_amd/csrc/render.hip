@@ -268,7 +268,25 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     tape0 = nullptr;
 #endif
     MNE_WAVE_SYNC();                                       // earlier LDS reads of this wave are done
-    if (PRE) {
+    // Pre-gathered rows, 2x32 decoders (registers to spare): the row loads are issued here and land in LDS only after the
+    // OneBlob below (3 us of VALU work that does not depend on them) -- 2 us of load latency per tile off the chain.
+#ifndef MNE_DECODE_OVERLAP
+#define MNE_DECODE_OVERLAP 1
+#endif
+    constexpr bool OVERLAP = MNE_DECODE_OVERLAP && HID == 32 && HIDC == 32;
+    float4 q0[4][MNE_FEAT / 32], q1[4][MNE_FEAT / 32];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int k = 0; k < MNE_FEAT / 32; ++k) q0[it][k] = q1[it][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool late_rows = OVERLAP && PRE;
+    if (late_rows) {
+        DEC_STAMP(1);
+        if (!CP && a.ext_rows) rows_fetch<MNE_FEAT>(q0, a.ext_rows + ((size_t)r * S + (size_t)c * TILE) * a.ext_stride, a.ext_stride, 0, live, lane);
+        else rows_fetch<MNE_FEAT>(q0, tape0, D::ROW, D::T_X, live, lane);
+        if (CP) rows_fetch<MNE_FEAT>(q1, tape0, D::ROW, D::T_CF, live, lane);
+        DEC_STAMP(2);
+    } else if (PRE) {
         DEC_STAMP(1);
         if (!CP && a.ext_rows) load_rows<MNE_FEAT>(feat, a.ext_rows + ((size_t)r * S + (size_t)c * TILE) * a.ext_stride, a.ext_stride, 0, live, lane);
         else load_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
@@ -292,6 +310,11 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     DEC_STAMP(3);
     float pos[24];
     oneblob_half<!(HID == 64 && CP)>(u, hf, pos);
+    if (late_rows) {
+        rows_commit<MNE_FEAT>(q0, feat, lane);
+        if (CP) rows_commit<MNE_FEAT>(q1, feat + TILE * MNE_FS, lane);
+        MNE_WAVE_SYNC();
+    }
     DEC_STAMP(4);
     MlpState<HID, HIDC> st;
     mlp_forward_mfma<HID, HIDC, CP, GTAB>(frow, cfrow, pos, atab, lane, st);
