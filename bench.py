@@ -54,7 +54,9 @@ def parse_args():
     ap.add_argument("--scatter", default="binned", choices=["binned", "atomics"],
                     help="fused path: tile-binned LDS scatter fused with Adam (default) or global atomics + streaming Adam")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane update and the decoder chain on ONE stream (ablation)")
-    ap.add_argument("--event-every", type=int, default=10, help="bracket the dominant launches with HIP events on every N-th timed step")
+    ap.add_argument("--event-every", type=int, default=None,
+                    help="bracket the launches with HIP events on every N-th timed step (default: 25, or one step in the "
+                         "middle of a run shorter than 50 steps): a step with its 12 event records is ~60 us longer")
     ap.add_argument("--share-decoder", action="store_true",
                     help="EXTENSION: all-reduce (mean) the decoder gradient over agents each iteration (RCCL)")
     ap.add_argument("--no-variants", dest="variants", action="store_false",
@@ -401,12 +403,13 @@ def main():
     for _ in range(args.warmup):
         agent.step()
     timers = {}
+    every = args.event_every or (25 if args.steps >= 50 else max(args.steps, 1))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):        # every timed iteration draws its own batch inside the timed region:
         # step i+1's batch is drawn while step i's planes update.  HIP events bracket the two dominant launches on
-        # every `event_every`-th step only: each record is a barrier packet on the stream (~6 us of idle time).
-        agent.step(timers if i % args.event_every == 0 else None, prefetch=i + 1 < args.steps)
+        # every `every`-th step only: each record is a barrier packet on the stream (~6 us of idle time).
+        agent.step(timers if i % every == every // 2 else None, prefetch=i + 1 < args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = mdist.max_over_ranks(elapsed, device)
