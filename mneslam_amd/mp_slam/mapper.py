@@ -192,6 +192,8 @@ class FusedMappingMixin:
         from .. import hip_path
         if not isinstance(pose_opt, torch.optim.Adam) or len(pose_opt.param_groups) != 2:
             return None
+        if not getattr(model, "all_planes", None):           # ray gradients need the plane encoding (HashJointEncoding has none)
+            return None
         g_rot, g_trans = pose_opt.param_groups
         same = all(g_rot[k] == g_trans[k] for k in ("betas", "eps")) and not any(
             g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") for g in (g_rot, g_trans))
