@@ -240,18 +240,22 @@ __global__ __launch_bounds__(256, CP ? 3 : 4) void wgrad_fused_kernel(WgradArgs 
 // too many for one wave, so a pair of waves shares a ray range -- wave parity hh takes hidden rows [32 hh, 32 hh + 32) of
 // dW1 and dV1; the even wave also accumulates dW2 (16 x 64), the odd one dV2 (3 x 64).  Waves 2,3 of the workgroup
 // work on a second range and are summed into waves 0,1 through LDS; one partial per workgroup.
-template <bool CP>
-__global__ __launch_bounds__(256) void wgrad_fused64_kernel(WgradArgs a) {
+// Round 3: like the 2x32 kernel it comes in two register-light PARTS selected by workgroup parity (it held 256 VGPRs +
+// 144-240 AGPRs at one wave per SIMD, which kept the concurrent plane update down to one workgroup on its CUs:
+// tile_adam_kernel 330 us beside it against 229 us beside the 2x32 kernel).  PART 0 = dW1 (4 tiles), PART 1 = dV1 (TNC
+// tiles) + dW2 / dV2 (2 tiles); the two parts read disjoint tape columns, so the rows are still read once.
+template <bool CP, int PART>
+__device__ __forceinline__ void wgrad_fused64_part(const WgradArgs& a, float (*red)[64 * 16]) {
     typedef DecDims<64, 64, CP> D;
     constexpr int TNC = D::CINP / 32;
     constexpr int KS = 2;
-    constexpr int NTILE = 4 + TNC + 2;
-    __shared__ float red[2][64 * 16];                            // one 32x32 tile of waves 2 and 3
+    constexpr int NTILE = PART == 0 ? 4 : TNC + 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hh = wv & 1;                                       // hidden-row half of this wave
+    const int slot = blockIdx.x >> 1, n_slots = gridDim.x >> 1;
     int r0, r1;
-    ray_range(a.R, blockIdx.x * 2 + (wv >> 1), gridDim.x * 2, r0, r1);
-    f32x16 acc[NTILE];                                           // w1[0..3] | v1[0..TNC) | (w2 or v2)[0..1]
+    ray_range(a.R, slot * 2 + (wv >> 1), n_slots * 2, r0, r1);
+    f32x16 acc[NTILE];                                           // PART 0: w1[0..3]   PART 1: v1[0..TNC) | (w2 or v2)[0..1]
 #pragma unroll
     for (int q = 0; q < NTILE; ++q)
 #pragma unroll
@@ -266,30 +270,42 @@ __global__ __launch_bounds__(256) void wgrad_fused64_kernel(WgradArgs a) {
         const int n = ray_rows(a, r);
         const float* base = a.tape + (size_t)r * a.S * D::ROW;
         for (int t = 0; t < n; t += 2 * KS) {
-            float adh[KS], adc[KS], a2[KS], bx[KS][4], bc[KS][TNC], b2[KS][2];
+            if constexpr (PART == 0) {
+                float adh[KS], bx[KS][4];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int tt = t + 2 * ks + kk;
-                const bool ok = tt < n;
-                const float* row = base + (size_t)(ok ? tt : 0) * D::ROW;
-                adh[ks] = ok ? row[D::T_DH + 32 * hh + col] : 0.f;
-                adc[ks] = ok ? row[D::T_DHC + 32 * hh + col] : 0.f;
-                a2[ks] = (ok && col < rowsA2) ? row[offA2 + col] : 0.f;
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int tt = t + 2 * ks + kk;
+                    const bool ok = tt < n;
+                    const float* row = base + (size_t)(ok ? tt : 0) * D::ROW;
+                    adh[ks] = ok ? row[D::T_DH + 32 * hh + col] : 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bx[ks][q] = (ok && 32 * q + col < MNE_IN1) ? row[D::T_X + 32 * q + col] : 0.f;
+                    for (int q = 0; q < 4; ++q) bx[ks][q] = (ok && 32 * q + col < MNE_IN1) ? row[D::T_X + 32 * q + col] : 0.f;
+                }
 #pragma unroll
-                for (int q = 0; q < TNC; ++q) bc[ks][q] = ok ? row[ccol[q]] : 0.f;
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) b2[ks][q] = ok ? row[offB2 + 32 * q + col] : 0.f;
-            }
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adh[ks], bx[ks][q], acc[q], 0, 0, 0);
+            } else {
+                float adc[KS], a2[KS], bc[KS][TNC], b2[KS][2];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int tt = t + 2 * ks + kk;
+                    const bool ok = tt < n;
+                    const float* row = base + (size_t)(ok ? tt : 0) * D::ROW;
+                    adc[ks] = ok ? row[D::T_DHC + 32 * hh + col] : 0.f;
+                    a2[ks] = (ok && col < rowsA2) ? row[offA2 + col] : 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adh[ks], bx[ks][q], acc[q], 0, 0, 0);
+                    for (int q = 0; q < TNC; ++q) bc[ks][q] = ok ? row[ccol[q]] : 0.f;
 #pragma unroll
-                for (int q = 0; q < TNC; ++q) acc[4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adc[ks], bc[ks][q], acc[4 + q], 0, 0, 0);
+                    for (int q = 0; q < 2; ++q) b2[ks][q] = ok ? row[offB2 + 32 * q + col] : 0.f;
+                }
 #pragma unroll
-                for (int q = 0; q < 2; ++q) acc[4 + TNC + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ks], b2[ks][q], acc[4 + TNC + q], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                    for (int q = 0; q < TNC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(adc[ks], bc[ks][q], acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[TNC + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ks], b2[ks][q], acc[TNC + q], 0, 0, 0);
+                }
             }
         }
     }
@@ -308,25 +324,35 @@ __global__ __launch_bounds__(256) void wgrad_fused64_kernel(WgradArgs a) {
         __syncthreads();
     }
     if (wv >= 2) return;
-    float* out = a.partials + (size_t)blockIdx.x * D::NPARAM;
+    float* out = a.partials + (size_t)slot * D::NPARAM;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int lo = (e & 3) + 8 * (e >> 2) + 4 * kk;          // row inside the 32-row tile
         const int o = 32 * hh + lo;                              // hidden unit
+        if constexpr (PART == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (32 * q + col < MNE_IN1) out[D::P_SDF0 + o * MNE_IN1 + 32 * q + col] = acc[q][e];
+            for (int q = 0; q < 4; ++q)
+                if (32 * q + col < MNE_IN1) out[D::P_SDF0 + o * MNE_IN1 + 32 * q + col] = acc[q][e];
+        } else {
 #pragma unroll
-        for (int q = 0; q < TNC; ++q) {
-            const int i = 32 * q + col;                          // element of the colour-net input
-            if (i != D::CINB) out[D::P_COL0 + o * D::CIN + (i > D::CINB ? i - 1 : i)] = acc[4 + q][e];
-        }
+            for (int q = 0; q < TNC; ++q) {
+                const int i = 32 * q + col;                      // element of the colour-net input
+                if (i != D::CINB) out[D::P_COL0 + o * D::CIN + (i > D::CINB ? i - 1 : i)] = acc[q][e];
+            }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (hh == 0) { if (lo < MNE_OUT1) out[D::P_SDF1 + lo * 64 + 32 * q + col] = acc[4 + TNC + q][e]; }
-            else if (lo < 3) out[D::P_COL1 + lo * 64 + 32 * q + col] = acc[4 + TNC + q][e];
+            for (int q = 0; q < 2; ++q) {
+                if (hh == 0) { if (lo < MNE_OUT1) out[D::P_SDF1 + lo * 64 + 32 * q + col] = acc[TNC + q][e]; }
+                else if (lo < 3) out[D::P_COL1 + lo * 64 + 32 * q + col] = acc[TNC + q][e];
+            }
         }
     }
+}
+
+template <bool CP>
+__global__ __launch_bounds__(256, 2) void wgrad_fused64_kernel(WgradArgs a) {
+    __shared__ float red[2][64 * 16];                            // one 32x32 tile of waves 2 and 3
+    if (blockIdx.x & 1) wgrad_fused64_part<CP, 1>(a, red);
+    else wgrad_fused64_part<CP, 0>(a, red);
 }
 
 // 32 parameters per block, 8 groups of partials per parameter, fixed summation order.
@@ -395,7 +421,7 @@ static int launch_wgrad(WgradArgs a, int impl, hipStream_t st) {
         const int blocks = fused_partials(HID, a.R);
         a.n_waves = blocks;
         if constexpr (HID == 32 && HIDC == 32) MNE_LAUNCH((wgrad_fused_kernel<HID, HIDC, CP>), 2 * blocks, 256, 0, st, a);   // two parts per slot
-        else MNE_LAUNCH((wgrad_fused64_kernel<CP>), blocks, 256, 0, st, a);
+        else MNE_LAUNCH((wgrad_fused64_kernel<CP>), 2 * blocks, 256, 0, st, a);                                             // likewise
         if (impl == 0) MNE_LAUNCH(wgrad_reduce_kernel, (D::NPARAM + 31) / 32, 256, 0, st, a, D::NPARAM);
         return 0;
     }
