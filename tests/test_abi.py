@@ -67,6 +67,29 @@ def test_argument_validation_without_gpu(lib_path):
     assert lib.mne_sample_z(ctypes.byref(rc), 8, None, None, None, 0, 0, None, None, None, None) < 0
     assert lib.mne_decoder_wgrad(ctypes.byref(sc), None, None, 8, 43, None, None, 0, None) < 0
     assert lib.mne_tile_count(None) == 0 and lib.mne_tape_row_floats(None) == 0
+    # round-3 entry points: list sizing with per-plane capacities, overlap rectangles, pose loop, batch / decoder update
+    sc.plane[0][0][0].h, sc.plane[0][0][0].w = 40, 33                    # 3 x 3 tiles; the other planes are empty
+    bins = _lib.TileBins()
+    bins.cap = 100
+    assert lib.mne_tile_list_entries(ctypes.byref(sc), ctypes.byref(bins)) == 9 * 100
+    bins.plane_cap[0] = 7
+    assert lib.mne_tile_list_entries(ctypes.byref(sc), ctypes.byref(bins)) == 9 * 7
+    bins.plane_cap[0] = -1
+    assert lib.mne_tile_list_entries(ctypes.byref(sc), ctypes.byref(bins)) == 0
+    ov = _lib.TileOverlap()
+    ov.n_peers = 1
+    ov.rect[0][0].x0, ov.rect[0][0].x1, ov.rect[0][0].y0, ov.rect[0][0].y1 = 2, 10, 5, 9
+    assert lib.mne_tile_overlap_floats(ctypes.byref(sc), ctypes.byref(ov), 0) == 8 * 4 * 32
+    assert lib.mne_tile_overlap_floats(ctypes.byref(sc), ctypes.byref(ov), 1) == 0
+    assert lib.mne_tile_grad_export(ctypes.byref(sc), None, None, ctypes.byref(ov), None) < 0
+    assert lib.mne_tile_adam_shared(ctypes.byref(sc), None, None, None, ctypes.byref(ov), None) < 0
+    ps = _lib.PoseState()
+    assert lib.mne_pose_rays(ctypes.byref(ps), 8, None, None, None, None) < 0 and b"NULL" in lib.mne_last_error()
+    assert lib.mne_pose_loss(8, *([None] * 4), 1.0, 1.0, None, None, None, None) < 0
+    assert lib.mne_pose_update(ctypes.byref(ps), 8, None, None, None, None, None) < 0
+    assert lib.mne_sample_batch(*([None] * 1), 0, 1, None, None, 0, None, 0, 0, 0, None, None, 0, 0, *([None] * 5),
+                                ctypes.byref(rc), *([None] * 2), 0, *([None] * 5), None) < 0
+    assert lib.mne_decoder_update(ctypes.byref(sc), None, 8, None, None, 43, None, None, None, None) < 0
     _lib.unload()
 
 
