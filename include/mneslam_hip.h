@@ -366,27 +366,28 @@ int mne_tile_adam_shared(const mne_scene_t* scene, const mne_plane_opt_t* opt, c
                          const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, void* stream);
 
 /* N2, pose alignment of loop closure (mp_slam/mapper.py:362-412) without an autograd graph or a torch.optim step:
- *   mne_pose_rays    rot / trans -> c2w, rays_o / rays_d   (SLAM.matrix_from_tensor for rot_rep 'axis_angle',
- *                    optimization/utils.py:161-197, + the ray rotation of mp_slam/mapper.py:388-392)
+ *   mne_pose_rays    rot / trans -> c2w, rays_o / rays_d   (SLAM.matrix_from_tensor for rot_rep 'axis_angle' or 'quat',
+ *                    optimization/utils.py:161-210, + the ray rotation of mp_slam/mapper.py:388-392)
  *   mne_sample_z, mne_render_forward(target_d = NULL), then
  *   mne_pose_loss    w_rgb * mse(rgb, want_rgb) + w_depth * mse(depth, want_depth) (mapper.py:394-396): gradients of the
  *                    maps for mne_render_backward(g_rgb, g_depth, d_rays_o, d_rays_d) + loss partial sums
  *   mne_pose_update  ray gradients -> d/d(rot, trans) (analytic Jacobian of the axis-angle map), best pose so far
  *                    (mapper.py:399-403), one torch.optim.Adam step on the six parameters (groups lr_rot / lr_trans,
  *                    mneslam_mp.py:577-584); the step count lives in device memory.
- * R = Rodrigues(rot) * r_base: r_base = identity is the reference's parameterisation. */
+ * R = Rot(rot) * r_base: r_base = identity is the reference's parameterisation. */
 typedef struct mne_pose_state {
-    float* rot;            /* [3] axis-angle */
+    float* rot;            /* [n_rot]: axis-angle, or quaternion (real part first) */
     float* trans;          /* [3] */
-    float* m;              /* [6] exp_avg (rot, trans), zero-initialised by the caller */
-    float* v;              /* [6] exp_avg_sq */
+    float* m;              /* [n_rot + 3] exp_avg (rot, trans), zero-initialised by the caller */
+    float* v;              /* [n_rot + 3] exp_avg_sq */
     int32_t* step;         /* [1] Adam steps taken so far */
     float* c2w;            /* [12] row-major 3x4 of the current parameters (written by mne_pose_rays) */
     float* best_loss;      /* [1] initialise to +inf */
     float* best_c2w;       /* [12] pose at which best_loss was seen */
     float* last_loss;      /* [1] */
     float r_base[9];       /* row-major */
-    float reserved;
+    int32_t n_rot;         /* 3: axis-angle (rot_rep 'axis_angle'), 4: quaternion (rot_rep 'quat',
+                            * pytorch3d.transforms.quaternion_to_matrix: normalising, real part first) */
     double lr_rot, lr_trans, beta1, beta2, eps;
 } mne_pose_state_t;
 size_t mne_sizeof_pose_state(void);

@@ -63,7 +63,7 @@ class OverlapRect(C.Structure):
 class PoseState(C.Structure):
     _fields_ = [("rot", C.c_void_p), ("trans", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p),
                 ("c2w", C.c_void_p), ("best_loss", C.c_void_p), ("best_c2w", C.c_void_p), ("last_loss", C.c_void_p),
-                ("r_base", C.c_float * 9), ("reserved", C.c_float),
+                ("r_base", C.c_float * 9), ("n_rot", C.c_int32),
                 ("lr_rot", C.c_double), ("lr_trans", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
 
 

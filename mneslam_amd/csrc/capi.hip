@@ -597,6 +597,8 @@ size_t mne_sizeof_pose_state(void) { return sizeof(mne_pose_state_t); }
 static int fill_pose(const mne_pose_state_t* ps, PoseArgs& a) {
     if (!ps || !ps->rot || !ps->trans || !ps->m || !ps->v || !ps->step || !ps->c2w || !ps->best_loss || !ps->best_c2w || !ps->last_loss)
         return fail(-1, "mne_pose_state: NULL field");
+    if (ps->n_rot != 3 && ps->n_rot != 4) return fail(-1, "mne_pose_state: n_rot must be 3 (axis-angle) or 4 (quaternion)");
+    a.n_rot = ps->n_rot;
     a.rot = ps->rot; a.trans = ps->trans; a.m = ps->m; a.v = ps->v; a.step = ps->step; a.c2w = ps->c2w;
     a.best_loss = ps->best_loss; a.best_c2w = ps->best_c2w; a.last_loss = ps->last_loss;
     for (int k = 0; k < 9; ++k) a.r_base[k] = ps->r_base[k];

@@ -223,7 +223,8 @@ struct TileOverlap {
 struct PoseArgs {
     int n;
     const float* dirs;          // [n][3] camera-frame directions
-    float* rot;                 // [3] axis-angle
+    int n_rot;                  // 3: axis-angle, 4: quaternion (w, x, y, z)
+    float* rot;                 // [n_rot]
     float* trans;               // [3]
     float r_base[9];            // row-major
     float* c2w;                 // [12] row-major 3x4 of the CURRENT parameters
@@ -238,8 +239,8 @@ struct PoseArgs {
     int n_partials;
     // update
     const float *d_rays_o, *d_rays_d;
-    float* m;                   // [6] exp_avg      (rot 0..2, trans 3..5)
-    float* v;                   // [6] exp_avg_sq
+    float* m;                   // [n_rot + 3] exp_avg      (rot, then trans)
+    float* v;                   // [n_rot + 3] exp_avg_sq
     int* step;                  // [1] steps taken so far
     float* best_loss;           // [1]
     float* best_c2w;            // [12]

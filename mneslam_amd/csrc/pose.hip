@@ -13,8 +13,10 @@
 //                       best-pose tracking, Adam on the six parameters with the step count in device memory
 // so that an iteration is six launches with no autograd graph, no torch.optim step and no host synchronisation.
 //
-// Parameterisation: R = Rodrigues(rot) * R_base with a constant R_base (identity for the reference's absolute
-// axis-angle; a host that optimises a rotation relative to the initial pose passes that pose's rotation).
+// Parameterisation: R = Rot(rot) * R_base with a constant R_base (identity for the reference; a host that optimises a
+// rotation relative to the initial pose passes that pose's rotation).  Rot = Rodrigues' formula for the reference's
+// rot_rep 'axis_angle' (optimization/utils.py:161-177) or the normalising quaternion map of rot_rep 'quat'
+// (pytorch3d.transforms.quaternion_to_matrix behind optimization/utils.py:199-210; real part first).
 #include "mne_device.h"
 #include "mne_launch.h"
 
@@ -34,9 +36,25 @@ __device__ __forceinline__ void rodrigues(const float w[3], float R[9], float K[
         }
 }
 
+// R = I + s A(q), s = 2 / (q . q)   (pytorch3d quaternion_to_matrix; q = (r, i, j, k))
+__device__ __forceinline__ void quat_matrix(const float q[4], float R[9], float A[9], float& s) {
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    s = 2.0f / (r * r + i * i + j * j + k * k);
+    A[0] = -(j * j + k * k); A[1] = i * j - k * r;    A[2] = i * k + j * r;
+    A[3] = i * j + k * r;    A[4] = -(i * i + k * k); A[5] = j * k - i * r;
+    A[6] = i * k - j * r;    A[7] = j * k + i * r;    A[8] = -(i * i + j * j);
+    for (int e = 0; e < 9; ++e) R[e] = ((e % 4 == 0) ? 1.0f : 0.0f) + s * A[e];
+}
+
 __device__ __forceinline__ void pose_matrix(const PoseArgs& a, float M[9]) {
-    float w[3] = {a.rot[0], a.rot[1], a.rot[2]}, R[9], K[9], th;
-    rodrigues(w, R, K, th);
+    float R[9], K[9], th;
+    if (a.n_rot == 4) {
+        const float q[4] = {a.rot[0], a.rot[1], a.rot[2], a.rot[3]};
+        quat_matrix(q, R, K, th);
+    } else {
+        const float w[3] = {a.rot[0], a.rot[1], a.rot[2]};
+        rodrigues(w, R, K, th);
+    }
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
             float s = 0.f;
@@ -130,43 +148,57 @@ __global__ __launch_bounds__(256) void pose_update_kernel(PoseArgs a) {
             for (int k = 0; k < 3; ++k) s += GM[i * 3 + k] * a.r_base[j * 3 + k];
             G[i * 3 + j] = s;
         }
-    float w[3] = {a.rot[0], a.rot[1], a.rot[2]}, R[9], K[9], th;
-    rodrigues(w, R, K, th);
-    const float s = sinf(th), c = cosf(th);
-    float KK[9], gk = 0.f, gkk = 0.f;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            float kk = 0.f;
-            for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
-            KK[i * 3 + j] = kk;
-            gk += G[i * 3 + j] * K[i * 3 + j];
-            gkk += G[i * 3 + j] * kk;
-        }
-    const float g_th = c * gk + s * gkk;                         // through sin / (1 - cos)
-    float dK[9];                                                 // dL/dK = s G + (1 - c)(G K^T + K^T G)
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            float t1 = 0.f, t2 = 0.f;
-            for (int k = 0; k < 3; ++k) { t1 += G[i * 3 + k] * K[j * 3 + k]; t2 += K[k * 3 + i] * G[k * 3 + j]; }
-            dK[i * 3 + j] = s * G[i * 3 + j] + (1.0f - c) * (t1 + t2);
-        }
-    const float go[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};       // d/d(omega hat)
-    const float o[3] = {w[0] / th, w[1] / th, w[2] / th};
-    const float og = o[0] * go[0] + o[1] * go[1] + o[2] * go[2];
-    float grad[6];
-    for (int j = 0; j < 3; ++j) {
-        grad[j] = (go[j] - o[j] * og) / th + g_th * o[j];
-        grad[3 + j] = red[9 + j][0];
+    float grad[7];
+    const int nr = a.n_rot;
+    if (nr == 4) {
+        // d/dq of R = I + s A(q):  s <G, dA/dq_m> - s^2 q_m <G, A>
+        const float q[4] = {a.rot[0], a.rot[1], a.rot[2], a.rot[3]};
+        float R[9], A[9], sc;
+        quat_matrix(q, R, A, sc);
+        const float r = q[0], i = q[1], j = q[2], k = q[3];
+        float ga = 0.f;
+        for (int e = 0; e < 9; ++e) ga += G[e] * A[e];
+        const float d[4] = {
+            -k * G[1] + j * G[2] + k * G[3] - i * G[5] - j * G[6] + i * G[7],
+            j * G[1] + k * G[2] + j * G[3] - 2.0f * i * G[4] - r * G[5] + k * G[6] + r * G[7] - 2.0f * i * G[8],
+            -2.0f * j * G[0] + i * G[1] + r * G[2] + i * G[3] + k * G[5] - r * G[6] + k * G[7] - 2.0f * j * G[8],
+            -2.0f * k * G[0] - r * G[1] + i * G[2] + r * G[3] - 2.0f * k * G[4] + j * G[5] + i * G[6] + j * G[7]};
+        for (int m = 0; m < 4; ++m) grad[m] = sc * d[m] - sc * sc * q[m] * ga;
+    } else {
+        float w[3] = {a.rot[0], a.rot[1], a.rot[2]}, R[9], K[9], th;
+        rodrigues(w, R, K, th);
+        const float s = sinf(th), c = cosf(th);
+        float gk = 0.f, gkk = 0.f;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                float kk = 0.f;
+                for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
+                gk += G[i * 3 + j] * K[i * 3 + j];
+                gkk += G[i * 3 + j] * kk;
+            }
+        const float g_th = c * gk + s * gkk;                         // through sin / (1 - cos)
+        float dK[9];                                                 // dL/dK = s G + (1 - c)(G K^T + K^T G)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                float t1 = 0.f, t2 = 0.f;
+                for (int k = 0; k < 3; ++k) { t1 += G[i * 3 + k] * K[j * 3 + k]; t2 += K[k * 3 + i] * G[k * 3 + j]; }
+                dK[i * 3 + j] = s * G[i * 3 + j] + (1.0f - c) * (t1 + t2);
+            }
+        const float go[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};       // d/d(omega hat)
+        const float o[3] = {w[0] / th, w[1] / th, w[2] / th};
+        const float og = o[0] * go[0] + o[1] * go[1] + o[2] * go[2];
+        for (int j = 0; j < 3; ++j) grad[j] = (go[j] - o[j] * og) / th + g_th * o[j];
     }
+    for (int j = 0; j < 3; ++j) grad[nr + j] = red[9 + j][0];
     // ---- torch.optim.Adam (amsgrad off, no weight decay), two groups
     const int t = *a.step + 1;
     *a.step = t;
     const double bc1 = 1.0 - pow(a.beta1, (double)t), bc2 = 1.0 - pow(a.beta2, (double)t);
     const float bc2_sqrt = (float)sqrt(bc2);
     const float omb1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, omb2 = (float)(1.0 - a.beta2), eps = (float)a.eps;
-    for (int k = 0; k < 6; ++k) {
-        const float step_size = (float)((k < 3 ? a.lr_rot : a.lr_trans) / bc1);
-        float* p = k < 3 ? a.rot + k : a.trans + (k - 3);
+    for (int k = 0; k < nr + 3; ++k) {
+        const float step_size = (float)((k < nr ? a.lr_rot : a.lr_trans) / bc1);
+        float* p = k < nr ? a.rot + k : a.trans + (k - nr);
         const float g = grad[k];
         float m = a.m[k], v = a.v[k];
         m = m + (g - m) * omb1;

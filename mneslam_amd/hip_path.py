@@ -427,21 +427,35 @@ def _rodrigues_host(rot):
     return torch.eye(3, dtype=rot.dtype) + torch.sin(th) * K + (1.0 - torch.cos(th)) * (K @ K)
 
 
+def _quaternion_host(q):
+    """quaternion (real part first) [4] -> 3x3, pytorch3d.transforms.quaternion_to_matrix (host-side probe only)."""
+    r, i, j, k = q
+    s = 2.0 / (q * q).sum()
+    return torch.stack([1 - s * (j * j + k * k), s * (i * j - k * r), s * (i * k + j * r),
+                        s * (i * j + k * r), 1 - s * (i * i + k * k), s * (j * k - i * r),
+                        s * (i * k - j * r), s * (j * k + i * r), 1 - s * (i * i + j * j)]).reshape(3, 3)
+
+
 def probe_axis_angle(matrix_from_tensor, rot0, trans0):
-    """Does the host's ``matrix_from_tensor(rot, trans)`` have the form  R = Rodrigues(rot) @ R_base,  t = trans ?
-    Returns R_base (3x3 float32 on the CPU; identity for the reference's ``rot_rep: 'axis_angle'``) or None (quaternions,
-    anything else): the caller then keeps the host's own autograd loop.  Two evaluations of the host function, once per
-    alignment (not per iteration)."""
-    if rot0.shape[-1] != 3 or trans0.shape[-1] != 3:
+    """Does the host's ``matrix_from_tensor(rot, trans)`` have the form  R = Rot(rot) @ R_base,  t = trans  with Rot =
+    Rodrigues' formula (3 parameters: the reference's ``rot_rep: 'axis_angle'``) or the normalising quaternion map (4
+    parameters, real part first: ``rot_rep: 'quat'``)?  Returns R_base (3x3 float32 on the CPU; identity for the
+    reference) or None (anything else): the caller then keeps the host's own autograd loop.  Two evaluations of the host
+    function, once per alignment (not per iteration)."""
+    n = rot0.shape[-1]
+    if n not in (3, 4) or trans0.shape[-1] != 3:
         return None
+    rot_of = _rodrigues_host if n == 3 else _quaternion_host
     with torch.no_grad():
-        r0, t0 = rot0.detach().reshape(1, 3).float().cpu(), trans0.detach().reshape(1, 3).float().cpu()
+        r0, t0 = rot0.detach().reshape(1, n).float().cpu(), trans0.detach().reshape(1, 3).float().cpu()
+        if n == 4 and float((r0 * r0).sum()) < 1e-12:
+            return None
         M0 = matrix_from_tensor(r0.to(rot0.device), t0.to(rot0.device)).detach().float().cpu().reshape(4, 4)
-        base = _rodrigues_host(r0[0]).T @ M0[:3, :3]
-        r1 = r0 + torch.tensor([[0.011, -0.017, 0.013]])
+        base = rot_of(r0[0]).T @ M0[:3, :3]
+        r1 = r0 + torch.tensor([[0.011, -0.017, 0.013, 0.007][:n]])
         t1 = t0 + torch.tensor([[0.02, -0.01, 0.03]])
         M1 = matrix_from_tensor(r1.to(rot0.device), t1.to(rot0.device)).detach().float().cpu().reshape(4, 4)
-        ok = (torch.allclose(_rodrigues_host(r1[0]) @ base, M1[:3, :3], atol=2e-6) and torch.allclose(M1[:3, 3], t1[0], atol=1e-7)
+        ok = (torch.allclose(rot_of(r1[0]) @ base, M1[:3, :3], atol=2e-6) and torch.allclose(M1[:3, 3], t1[0], atol=1e-7)
               and torch.allclose(base @ base.T, torch.eye(3), atol=1e-5))
     return base.contiguous() if ok else None
 
@@ -470,8 +484,9 @@ class PoseAlignment:
         self.dec_w = [w.detach() for w in model.decoder.hip_weights()]
         self.scene = scene_struct(self.info, self.planes, self.dec_w)
         self.packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(self.scene)), **f)
-        self.rot, self.trans = rot0.detach().reshape(3).to(**f).clone(), trans0.detach().reshape(3).to(**f).clone()
-        self.m, self.v = torch.zeros(6, **f), torch.zeros(6, **f)
+        n_rot = rot0.shape[-1]
+        self.rot, self.trans = rot0.detach().reshape(n_rot).to(**f).clone(), trans0.detach().reshape(3).to(**f).clone()
+        self.m, self.v = torch.zeros(n_rot + 3, **f), torch.zeros(n_rot + 3, **f)
         self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
         self.c2w, self.best_c2w = torch.zeros(12, **f), torch.zeros(12, **f)
         self.best_loss, self.last_loss = torch.full((1,), float("inf"), **f), torch.zeros(1, **f)
@@ -491,6 +506,7 @@ class PoseAlignment:
         ps = self.ps = _lib.PoseState()
         ps.rot, ps.trans, ps.m, ps.v, ps.step = (t.data_ptr() for t in (self.rot, self.trans, self.m, self.v, self.step_count))
         ps.c2w, ps.best_loss, ps.best_c2w, ps.last_loss = (t.data_ptr() for t in (self.c2w, self.best_loss, self.best_c2w, self.last_loss))
+        ps.n_rot = n_rot
         for k, val in enumerate(r_base.reshape(-1).tolist()):
             ps.r_base[k] = val
         ps.lr_rot, ps.lr_trans, (ps.beta1, ps.beta2), ps.eps = float(lr_rot), float(lr_trans), map(float, betas), float(eps)

@@ -530,6 +530,31 @@ class _PoseSLAMAbsolute(_PoseSLAM):
         return T
 
 
+class _PoseSLAMQuat(_PoseSLAM):
+    """rot_rep 'quat' (mneslam_mp.py:203-206): the pose's quaternion (real part first), c2w = [R(q) | trans] with
+    pytorch3d's normalising quaternion_to_matrix (optimization/utils.py:199-210)."""
+
+    def get_pose_param_optim(self, poses, mapping=True):
+        R = poses[0, :3, :3].detach().double()
+        w = torch.sqrt(torch.clamp(1.0 + torch.trace(R), min=1e-12)) / 2.0          # (small rotations: the trace branch)
+        q = torch.stack([w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)])
+        cur_rot = torch.nn.Parameter(q.to(poses.dtype)[None].clone())
+        cur_trans = torch.nn.Parameter(poses[:, :3, 3].detach().clone())
+        opt = torch.optim.Adam([{"params": cur_rot, "lr": self.lr_rot}, {"params": cur_trans, "lr": self.lr_trans}])
+        return cur_rot, cur_trans, opt
+
+    def matrix_from_tensor(self, rot, trans):
+        r, i, j, k = torch.unbind(rot, -1)
+        s = 2.0 / (rot * rot).sum(-1)
+        R = torch.stack([1 - s * (j * j + k * k), s * (i * j - k * r), s * (i * k + j * r),
+                         s * (i * j + k * r), 1 - s * (i * i + k * k), s * (j * k - i * r),
+                         s * (i * k - j * r), s * (j * k + i * r), 1 - s * (i * i + j * j)], -1).reshape(-1, 3, 3)
+        T = torch.eye(4, dtype=rot.dtype, device=rot.device)[None].repeat(rot.shape[0], 1, 1)
+        T[:, :3, :3] = R
+        T[:, :3, 3] = trans
+        return T
+
+
 def _alignment_setup(g, device):
     rays_o, rays_d, *_ = fixture_inputs(g)
     cam_dirs = rays_d[:48].clone()                                   # any fixed bundle of camera-frame directions
@@ -558,7 +583,7 @@ def check_pose_alignment(device, compute="autograd", absolute=False):
             model, dev = _OracleModel(oracle_scene_from_golden(g, cfg)), "cpu"
         slam = types.SimpleNamespace(model=model, model_shared=model, map_optimizer=None, device=torch.device(dev),
                                      dataset=None, video=None, get_pose_param_optim=None, matrix_from_tensor=None)
-        pose = _PoseSLAMAbsolute() if absolute else _PoseSLAM()
+        pose = _PoseSLAMQuat() if absolute == "quat" else _PoseSLAMAbsolute() if absolute else _PoseSLAM()
         slam.get_pose_param_optim, slam.matrix_from_tensor = pose.get_pose_param_optim, pose.matrix_from_tensor
         mp = Mapper(cfg, slam, compute=compute if kind == "hip" else "autograd")
         torch.manual_seed(11)

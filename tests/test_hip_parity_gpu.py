@@ -125,17 +125,19 @@ def test_fused_step_matches_autograd_path(hidden, one_grid, co):
     pc.check_fused_vs_autograd(DEV, hidden=hidden, one_grid=one_grid, co=co)
 
 
-@pytest.mark.parametrize("compute,absolute", [("autograd", False), ("fused", False), ("fused", True)])
+@pytest.mark.parametrize("compute,absolute", [("autograd", False), ("fused", False), ("fused", True), ("fused", "quat")])
 def test_loop_closure_pose_alignment(compute, absolute):
     pc.check_pose_alignment(DEV, compute, absolute)
 
 
 def test_pose_alignment_falls_back_for_other_parameterisations():
-    """A host whose matrix_from_tensor is not an axis-angle map (e.g. the reference's rot_rep 'quat') keeps its own loop."""
+    """A host whose matrix_from_tensor is neither the axis-angle nor the quaternion map keeps its own loop."""
     from mneslam_amd import hip_path
-    quat = lambda rot, trans: torch.eye(4)[None].repeat(rot.shape[0], 1, 1)
-    assert hip_path.probe_axis_angle(quat, torch.zeros(1, 4), torch.zeros(1, 3)) is None
-    assert hip_path.probe_axis_angle(quat, torch.tensor([[0.1, 0.2, 0.3]]), torch.zeros(1, 3)) is None
+    other = lambda rot, trans: torch.eye(4)[None].repeat(rot.shape[0], 1, 1)
+    assert hip_path.probe_axis_angle(other, torch.zeros(1, 4), torch.zeros(1, 3)) is None
+    assert hip_path.probe_axis_angle(other, torch.tensor([[0.9, 0.1, 0.2, 0.3]]), torch.zeros(1, 3)) is None
+    assert hip_path.probe_axis_angle(other, torch.tensor([[0.1, 0.2, 0.3]]), torch.zeros(1, 3)) is None
+    assert hip_path.probe_axis_angle(other, torch.zeros(1, 6), torch.zeros(1, 3)) is None          # e.g. a 6-D rotation
 
 
 def test_checkpoint_handoff_between_device_models(tmp_path):
