@@ -62,6 +62,11 @@ def test_shipped_build_is_clean(variant):
     assert len(hot) >= 15
     for k in hot:
         assert k["scratch"] == 0 and k.get("vgpr_spill", 0) == 0, f"{k['kernel']} uses {k['scratch']} B of scratch per lane"
+    # the weight-gradient kernels share CUs with the plane update (tile_adam_kernel: 2 workgroups of 8 waves per CU): at
+    # most 168 registers per lane and no AGPRs, or they push one of its workgroups out (330 vs 265 us)
+    for n, k in names.items():
+        if "wgrad_fused" in n:
+            assert k.get("vgpr", 0) <= 168 and k.get("agpr", 0) == 0, f"{n}: {k.get('vgpr')} VGPRs + {k.get('agpr')} AGPRs"
     # everything else: the autograd-path backward and the ray-gradient kernels of the 2x64 decoders
     for k in rep["kernels"]:
         assert k["scratch"] <= 256, f"{k['kernel']}: {k['scratch']} B of scratch per lane"
