@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- mapping iterations / second of the MNE-SLAM mapping hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: spawns its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one mapping iteration (R1-R12): sample 2048 global keyframe rays
@@ -34,7 +34,7 @@ from mneslam_amd.fused import FusedStep, HashFusedStep  # noqa: E402
 from mneslam_amd.model.scene_rep import JointEncoding  # noqa: E402
 from mneslam_amd.model.scene_rep_hash import HashJointEncoding  # noqa: E402
 
-PMC_JSON = "r03_pmc_traffic.json"      # committed counter passes of this round's kernels (profiles/r03_pmc.sh)
+PMC_JSON = "r04_pmc_traffic.json"      # committed counter passes of this round's kernels (profiles/r04_pmc.sh)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -50,7 +50,11 @@ def parse_args():
     ap.add_argument("--hidden", type=int, default=None, choices=[32, 64], help="decoder width (default: the workload's own)")
     ap.add_argument("--path", default="fused", choices=["fused", "autograd"],
                     help="fused = FusedStep + device sampler (default); autograd = the reference's call sequence")
-    ap.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=10,
+                    help="timed oracle iterations for cpu_baseline (0 = skip); the median is reported, the loop stops after ~40 s")
+    ap.add_argument("--graph", default=None, choices=["two_stream", "one_stream"],
+                    help="EXTENSION (BASELINE configs[4]): replay the steady-state iteration as ONE captured HIP graph "
+                         "(two_stream = the eager schedule's two queues captured, one_stream = one queue); default: eager launches")
     ap.add_argument("--scatter", default="binned", choices=["binned", "atomics"],
                     help="fused path: tile-binned LDS scatter fused with Adam (default) or global atomics + streaming Adam")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane update and the decoder chain on ONE stream (ablation)")
@@ -73,7 +77,7 @@ class Agent:
     """One mapping agent: scene model + optimizer + device-resident keyframe rays."""
 
     def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused", scatter="binned", share_decoder=False,
-                 overlap=True):
+                 overlap=True, graph=None):
         self.cfg, self.device, self.path = cfg, device, path
         cam = synthetic.camera_from_config(cfg)          # office0: 680x1200, fx=fy=600, cx=599, cy=339
         if small:
@@ -113,7 +117,7 @@ class Agent:
             self.fused.seed = seed
         elif path == "fused":
             self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device,
-                                   scatter=scatter, shared_decoder=share_decoder,
+                                   scatter=scatter, shared_decoder=share_decoder, use_graph=graph,
                                    overlap=overlap and os.environ.get("MNE_NO_OVERLAP", "0") != "1")
             self.fused.seed = seed
 
@@ -170,7 +174,12 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0, batch=None):
     on the very batch the device drew in its last timed iteration."""
     from oracle import mapping as omap
     from oracle.scene_rep import OracleScene
-    cores = min(os.cpu_count() or 1, 32)      # more threads only add contention on the scatter-heavy backward
+    host_cores = os.cpu_count() or 1
+    try:
+        host_cores_usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        host_cores_usable = host_cores
+    cores = min(host_cores_usable, 32)        # more threads only add contention on the scatter-heavy backward
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(seed)
     bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
@@ -203,7 +212,7 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0, batch=None):
     times = []
     t_start = time.perf_counter()
     for it in range(iters + 1):
-        if it >= 2 and time.perf_counter() - t_start > 25.0:     # keep the default run bounded
+        if it >= 4 and time.perf_counter() - t_start > 40.0:     # keep the default run bounded (>= 3 timed iterations)
             break
         t0 = time.perf_counter()
         opt.zero_grad()
@@ -212,9 +221,12 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0, batch=None):
         omap.loss_from_ret(cfg, ret, is_co_sdf=cfg["is_co_sdf"]).backward()
         opt.step()
         times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / max(len(times) - 1, 1)
+    timed = sorted(times[1:])
+    t = timed[len(timed) // 2] if len(timed) % 2 else 0.5 * (timed[len(timed) // 2 - 1] + timed[len(timed) // 2])     # median
     return {"value": 1.0 / t, "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times) - 1} mapping iterations (1 warm-up) "
+            "host_cores": host_cores, "host_cores_usable": host_cores_usable,
+            "s_per_iter_min_median_max": [timed[0], t, timed[-1]],
+            "sample": f"median of {len(timed)} mapping iterations (1 warm-up) "
                       + ("on the batch the device drew in its last timed iteration " if batch is not None else "of the same workload ")
                       + f"({n} rays x "
                       f"{cfg['training']['n_range_d'] + cfg['training']['n_samples_d']} samples, "
@@ -283,7 +295,9 @@ def account(cfg, agent, avg_ms):
     #   decode_kernel, ray_kernel : the MLP forward / composite+backward; no algorithmic HBM bytes (latency-bound)
     #   atomics variant  : adam_kernel = the sweep; the render call gathers and scatters (atomics)
     G = 3072.0 * (1 if cfg["grid"]["oneGrid"] else 2)
-    G_gather = G
+    half = cfg["grid"].get("plane_dtype", "fp32") == "fp16"
+    G_gather = G / 2 if half else G           # fp16 plane storage: 64-byte corner rows
+    sweep = 28.0 if half else 32.0            # ... and 2 bytes less for the parameter's read and for its write (8d: 16 + 12 + 4)
     binned = agent.fused is not None and agent.fused.bins is not None
     p_contrib = float(agent.fused.tape_rows.item()) if agent.fused is not None else float(R * S)
     decoded = float((agent.fused.ray_tiles[:R].long() * 32).clamp(max=S).sum().item()) if agent.fused is not None else float(R * S)
@@ -305,7 +319,7 @@ def account(cfg, agent, avg_ms):
                 "render": "whole mne_render_fused_features call (decode + ray kernels; MFMA / latency, no algorithmic HBM bytes)"}
         alg["iteration"] = alg["hash_gather"] + alg["hash_scatter"] + alg["adam"]
     elif binned:
-        alg = {"adam": p_contrib * G + 32.0 * n_par,
+        alg = {"adam": p_contrib * G + sweep * agent.n_plane_params + 32.0 * agent.n_dec_params,
                "gather_kernel": decoded * G_gather, "render": decoded * G_gather}
         kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)", "gather_kernel": "gather_kernel",
                 "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
@@ -326,25 +340,28 @@ def account(cfg, agent, avg_ms):
             "decoded": decoded, "R": R, "S": S}
 
 
-VARIANTS = (("office0_2x64", "office0", 64), ("office0_hash", "office0_hash", None), ("scannet", "scannet", None),
-            ("indoor", "indoor", None))
+# (name, workload, hidden, graph).  indoor_fp16 / indoor_fp16_graph = BASELINE configs[4] as worded (one of its agents): fp16
+# feature storage + fp32 accumulate, eager and as a hipGraph-captured iteration
+VARIANTS = (("office0_2x64", "office0", 64, None), ("office0_hash", "office0_hash", None, None), ("scannet", "scannet", None, None),
+            ("indoor", "indoor", None, None), ("indoor_fp16", "indoor_fp16", None, None),
+            ("indoor_fp16_graph", "indoor_fp16", None, "one_stream"), ("office0_fp16", "office0_fp16", None, None))
 
 
-def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, block=50):
+def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, block=50, graph=None):
     """A short (<= ~2 s of device time) run of another workload of SURVEY.md section 8d through the same step: the other
     decoder width, the hash-grid headline encoding, the ScanNet / indoor-scale plane sets.  Reported beside the metric,
     never as it."""
     make_cfg, workload = configs.WORKLOADS[config]
     cfg = make_cfg(hidden) if hidden else make_cfg()
-    agent = Agent(cfg, device, seed=0, n_keyframes=keyframes)
+    agent = Agent(cfg, device, seed=0, n_keyframes=keyframes, graph=graph)
     for _ in range(warmup):
-        agent.step()
+        agent.step(prefetch=graph is not None)
     timers, steps = {}, 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     while True:
         for i in range(block):
-            agent.step(timers if i % 10 == 0 else None, prefetch=True)
+            agent.step(timers if (i % 10 == 0 and graph is None) else None, prefetch=True)
         steps += block
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -352,18 +369,43 @@ def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, bloc
             break
     avg_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timers.items()}
     acc = account(cfg, agent, avg_ms)
+    if graph is not None:          # a replayed graph has no per-kernel events: time the iteration, name the plane update
+        avg_ms = {}
     out = {"workload": workload, "mlp_hidden": cfg["decoder"]["hidden_dim"], "value": steps / elapsed, "unit": "it/s",
+           "plane_dtype": cfg["grid"].get("plane_dtype", "fp32"), "launch": ("hipGraph replay (" + graph + ")") if graph else "eager",
            "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
            "plane_params": agent.n_plane_params, "rays_per_iter": acc["R"], "samples_per_ray": acc["S"],
            "dominant_kernel": acc["kern"][acc["dom"]], "avg_launch_ms": acc["dom_ms"],
            "achieved_GBs": acc["achieved"], "frac": acc["achieved"] / HBM_PEAK_GBS}
+    it_bytes = acc["alg"].get("iteration", acc["alg"].get("adam", 0.0) + acc["alg"].get("render", 0.0))
+    out["iteration_algorithmic_bytes"] = it_bytes
+    out["iteration_hbm_frac"] = it_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS
     del agent
     torch.cuda.empty_cache()
     return out
 
 
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves -- one process per GPU, as the reference
+    starts one process per agent (multi_agents.py:43-52) -- by re-running this command line under torch.distributed.run
+    (rendezvous on 127.0.0.1, a free port).  The ranks print the ONE JSON line (rank 0); its ``n_gpus`` and
+    ``config.ranks_seen`` are what the process group reported."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     # Launcher dry run (tests/test_dist_gloo.py): with MNE_EMULATED_LIBRARY = a host-emulator build of the kernels (test
     # infrastructure, tests/hostemu) and no GPU, the same code path runs over gloo so that the multi-process logic has been
     # executed before an 8-GPU node sees it.  Its line is marked as such and is not a measurement.
@@ -377,6 +419,9 @@ def main():
     from mneslam_amd import dist as mdist
     rank, world, device = mdist.init_agents()          # one process per GPU; RCCL when WORLD_SIZE > 1
     import torch.distributed as dist
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): one rank per GPU")
+    ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
     make_cfg, workload = configs.WORKLOADS[args.config]
     cfg = make_cfg(args.hidden) if args.hidden else make_cfg()
     args.hidden = cfg["decoder"]["hidden_dim"]
@@ -389,7 +434,7 @@ def main():
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
     agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter,
-                  share_decoder=args.share_decoder, overlap=not args.no_overlap)
+                  share_decoder=args.share_decoder, overlap=not args.no_overlap, graph=args.graph)
 
     def barrier():
         if world > 1:
@@ -444,6 +489,8 @@ def main():
                        "rays_per_iter": R, "samples_per_ray": S, "plane_params": agent.n_plane_params,
                        "decoder_params": agent.n_dec_params, "mlp_hidden": args.hidden, "keyframes": args.keyframes,
                        "frame": f"{agent.W}x{agent.H}", "path": args.path, "scatter": ("hash-" + agent.fused.table_update) if agent.hash else args.scatter if args.path == "fused" else "atomics", "agents": world,
+                       "ranks_seen": ranks_seen, "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "plane_dtype": cfg["grid"].get("plane_dtype", "fp32"), "launch": ("hipGraph replay (" + args.graph + ")") if args.graph else "eager",
                        "encoding": "hash grid (parity unpinned: tinycudann is not in the reference tree)" if agent.hash else "tri-planes (as wired)",
                        "parallelism": f"agent-per-gpu x{world}, " + ("decoder-gradient all-reduce (extension)" if args.share_decoder
                                                                      else "no data-path collective")},
@@ -470,11 +517,11 @@ def main():
             del agent
             torch.cuda.empty_cache()
             out["variants"] = {}
-            for name, c, h in VARIANTS:
-                if c == args.config and (h or args.hidden) == args.hidden:
+            for name, c, h, gr in VARIANTS:
+                if c == args.config and (h or args.hidden) == args.hidden and gr == args.graph:
                     continue
                 try:                      # a side record must never cost the metric's line
-                    out["variants"][name] = run_variant(c, h, device, args.keyframes)
+                    out["variants"][name] = run_variant(c, h, device, args.keyframes, graph=gr)
                 except Exception as e:    # noqa: BLE001
                     out["variants"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MNE_ABI_VERSION 5
+#define MNE_ABI_VERSION 6
 
 /* orientation index of a plane triple, as in JointEncoding.all_planes (scene_rep.py:117) */
 enum { MNE_XY = 0, MNE_XZ = 1, MNE_YZ = 2 };
@@ -42,12 +42,10 @@ enum { MNE_C_VALID = 0, MNE_C_E_FRONT = 1, MNE_C_E_CENTER = 2, MNE_C_E_TAIL = 3,
        MNE_N_COUNT = 8 };
 
 typedef struct mne_plane {
-    const float* data;   /* [h][w][c_dim] fp32: the parameter (what Adam updates, what the reference's tensor holds) */
-    float* grad;         /* same layout; accumulated into (atomics); NULL when not needed */
+    const void* data;    /* [h][w][c_dim]: the parameter (what Adam updates, what the reference's tensor holds); fp32, or IEEE
+                          * half precision when mne_scene_t.plane_f16 is set */
+    float* grad;         /* [h][w][c_dim] fp32; accumulated into (atomics); NULL when not needed */
     int32_t h, w;
-    /* (ABI v3-v4 carried an optional half-precision copy of `data` for the lookups -- BASELINE configs[4]'s "fp16
-     * features + fp32 accumulate".  Measured slower than fp32 on every workload in two rounds (the plane update writes
-     * 2 more bytes per parameter, the gather is latency- not byte-bound: profiles/r03_nsb_graph_fp16.txt) and removed.) */
 } mne_plane_t;
 
 /* One JointEncoding's tensors (model/scene_rep.py:15-26, :85-181). */
@@ -59,7 +57,12 @@ typedef struct mne_scene {
     int32_t geo_feat_dim;  /* decoder.geo_feat_dim; this build supports 15 */
     int32_t n_bins;        /* pos.n_bins; this build supports 16 */
     int32_t bb_is_f64;     /* OneBlob input normalised in fp64 (bounding_box is float64, A4) */
-    int32_t reserved;
+    /* EXTENSION (BASELINE configs[4], "fp16 features + fp32 accumulate"; not reference behaviour): != 0 = every plane is
+     * STORED in IEEE half precision ([h][w][c_dim] halves: 64-byte corner rows) -- there is no fp32 copy anywhere.  Lookups
+     * convert to fp32 on load; interpolation, decoder, compositing, losses, gradients and their accumulation stay fp32;
+     * the plane update (mne_tile_adam, mne_adam_step with p_f16) computes p32 = float(p16), applies Adam with fp32
+     * moments and an fp32 gradient sum, and stores round-to-nearest-even(p32). */
+    int32_t plane_f16;
     mne_plane_t plane[2][3][2];          /* [set][xy,xz,yz][coarse,fine] */
     float bound_lo[3], bound_hi[3];      /* EXTENDED bound (scene_rep.py:80-83), planes lookup */
     double bb_lo[3], bb_hi[3];           /* RAW bounding_box (scene_rep.py:292), OneBlob input */
@@ -116,6 +119,9 @@ typedef struct mne_tile_bins {
     int32_t plane_cap[12];
 } mne_tile_bins_t;
 #define MNE_TILE_SPLIT_PARTS 2048
+/* mne_tile_order snapshots the list lengths of up to this many tiles (it may then run while appends are still being added on
+ * another stream); with more tiles call it after the last append. */
+#define MNE_TILE_ORDER_SNAPSHOT 20480
 
 /* Adam state and hyper-parameters of one plane, in JointEncoding.all_planes order
  * ([set][xy,xz,yz][coarse,fine]) for mne_tile_adam. */
@@ -128,12 +134,31 @@ typedef struct mne_plane_opt {
 
 /* Per-tensor view for the fused Adam step. */
 typedef struct mne_adam_seg {
-    float* p; float* g; float* m; float* v;
+    void* p;               /* fp32, or half precision with p_f16 */
+    float* g; float* m; float* v;
     int64_t n;
     double lr, beta1, beta2, eps, weight_decay;   /* python floats of the param group */
     int32_t step;          /* 1-based step number of this tensor's group */
-    int32_t reserved;
+    int32_t p_f16;         /* != 0: p is stored in IEEE half precision (g, m, v stay fp32); see mne_scene_t.plane_f16 */
 } mne_adam_seg_t;
+
+/* Device-resident iteration state, for callers that record one mapping iteration into a HIP graph and replay it:
+ * the values that change from one iteration to the next are then read from device memory instead of kernel
+ * arguments.  Entry points that take a `const mne_clock_t* clock` behave as before when it is NULL; otherwise
+ *   iteration used = `iteration` argument + *clock->iteration     (ray sampling keys, jitter counter offset)
+ *   Adam step used = `step` field        + *clock->step_offset    (bias corrections looked up in bias_table)
+ * bias_table[t-1] = (1 - beta1^t, 1 - beta2^t) as doubles, computed by the caller for t = 1..n_table with the betas
+ * of its param groups (all groups must share them); mne_clock_advance adds 1 to both counters (one tiny kernel, the
+ * last node of a recorded iteration). */
+typedef struct mne_clock {
+    const uint64_t* iteration;     /* [1] device */
+    const int32_t* step_offset;    /* [1] device */
+    const double* bias_table;      /* [n_table][2] device */
+    int32_t n_table;
+    int32_t reserved;
+    double beta1, beta2;           /* what bias_table was computed for (checked against the optimizer's) */
+    uint64_t z_offset_stride;      /* mne_sample_z: counter offset used = offset + iteration used * z_offset_stride */
+} mne_clock_t;
 
 /* ---- library ------------------------------------------------------------------------- */
 int mne_abi_version(void);
@@ -143,7 +168,9 @@ size_t mne_sizeof_render_cfg(void);
 size_t mne_sizeof_adam_seg(void);
 size_t mne_sizeof_tile_bins(void);
 size_t mne_sizeof_plane_opt(void);
+size_t mne_sizeof_clock(void);
 size_t mne_sizeof_fused_opts(void);
+int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream);
 
 /* Number of samples per ray: n_range_d + n_samples_d with depth guidance, n_samples without
  * (model/scene_rep.py:362-374). */
@@ -163,7 +190,7 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
                     const float* cur_rays, int64_t n_cur_rays, const float* poses, int n_poses,
                     int n_global, int n_cur, const int64_t* idx_global, const int64_t* idx_cur,
                     uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
-                    float* target_d, int64_t* out_idx, void* stream);
+                    float* target_d, int64_t* out_idx, const mne_clock_t* clock, void* stream);
 
 /* mne_sample_rays + mne_sample_z + mne_loss_coef for one training batch as ONE call of two launches (the per-iteration
  * batch preparation of the fused mapping step; separately they are four): same arguments and results as the three
@@ -175,7 +202,7 @@ int mne_sample_batch(const float* kf_rays, int64_t n_kf_rays, int n_save, const 
                      uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
                      float* target_d, int64_t* out_idx, const struct mne_render_cfg* cfg, const float* u,
                      const float* lin_tables, uint64_t z_offset, float* z_vals, int32_t* counts, int32_t* ray_counts,
-                     const float* grad_losses, float* coef, void* stream);
+                     const float* grad_losses, float* coef, const mne_clock_t* clock, void* stream);
 
 /* ---- R3: z sampling -------------------------------------------------------------------- */
 /* Replaces render_rays' sampling block, model/scene_rep.py:362-381: near-surface linspace around
@@ -191,7 +218,7 @@ int mne_sample_batch(const float* kf_rays, int64_t n_kf_rays, int n_save, const 
  * summed in a fixed order; both may be NULL when target_d is NULL).  `target_d` is [R]. */
 int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d, const float* u,
                  const float* lin_tables, uint64_t seed, uint64_t offset, float* z_vals,
-                 int32_t* counts, int32_t* ray_counts, void* stream);
+                 int32_t* counts, int32_t* ray_counts, const mne_clock_t* clock, void* stream);
 
 /* ---- R8 helper: decoder weights in the kernels' packed form ------------------------------ */
 size_t mne_packed_decoder_floats(const mne_scene_t* scene);
@@ -340,7 +367,7 @@ size_t mne_tile_list_entries(const mne_scene_t* scene, const mne_tile_bins_t* bi
  * few very long lists do not form the tail of the launch.  Call after mne_render_fused, before mne_tile_adam. */
 int mne_tile_order(const mne_scene_t* scene, const mne_tile_bins_t* bins, void* stream);
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
-                  const mne_tile_bins_t* bins, void* stream);
+                  const mne_tile_bins_t* bins, const mne_clock_t* clock, void* stream);
 
 /* EXTENSION (multi-agent; the reference's agents exchange maps through files only, mp_slam/mapper.py:491-509 just tests
  * which overlap box a point is in): plane gradients of the cells two agents both map, on the binned path -- no dense
@@ -363,7 +390,7 @@ size_t mne_tile_overlap_floats(const mne_scene_t* scene, const mne_tile_overlap_
 int mne_tile_grad_export(const mne_scene_t* scene, const float* tape, const mne_tile_bins_t* bins,
                          const mne_tile_overlap_t* overlap, void* stream);
 int mne_tile_adam_shared(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
-                         const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, void* stream);
+                         const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, const mne_clock_t* clock, void* stream);
 
 /* N2, pose alignment of loop closure (mp_slam/mapper.py:362-412) without an autograd graph or a torch.optim step:
  *   mne_pose_rays    rot / trans -> c2w, rays_o / rays_d   (SLAM.matrix_from_tensor for rot_rep 'axis_angle' or 'quat',
@@ -423,14 +450,14 @@ typedef struct mne_decoder_opt {
 size_t mne_sizeof_decoder_opt(void);
 int mne_decoder_update(const mne_scene_t* scene, const float* partials, int n_rays, float* grad_out,
                        const mne_decoder_opt_t* opt, int n_samples, const float* ray_sums,
-                       const int32_t* counts, float* losses, void* stream);
+                       const int32_t* counts, float* losses, const mne_clock_t* clock, void* stream);
 
 /* ---- R12: fused dense Adam --------------------------------------------------------------- */
 /* Replaces torch.optim.Adam.step() + zero_grad() over the groups of MNESLAM.create_optimizer
  * (mneslam_mp.py:459-469): one pass, m = lerp(m,g,1-b1); v = b2 v + (1-b2) g^2;
  * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); weight_decay is L2 into g; g is zeroed
  * when zero_grad != 0.  segs is a HOST array of n_seg (<= 32) entries. */
-int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* stream);
+int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, const mne_clock_t* clock, void* stream);
 
 /* ---- point queries (forward only) -------------------------------------------------------- */
 /* Replaces JointEncoding.query_color_sdf / query_sdf / run_network_flat (scene_rep.py:232-331):

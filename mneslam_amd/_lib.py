@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmneslam_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 N_LOSS = 8
 N_COUNT = 8
 C_NEED = 6
@@ -26,7 +26,7 @@ class Plane(C.Structure):
 
 class Scene(C.Structure):
     _fields_ = [("n_sets", C.c_int32), ("c_dim", C.c_int32), ("hidden", C.c_int32), ("hidden_color", C.c_int32),
-                ("geo_feat_dim", C.c_int32), ("n_bins", C.c_int32), ("bb_is_f64", C.c_int32), ("reserved", C.c_int32),
+                ("geo_feat_dim", C.c_int32), ("n_bins", C.c_int32), ("bb_is_f64", C.c_int32), ("plane_f16", C.c_int32),
                 ("plane", Plane * 2 * 3 * 2),          # [set][orient][level]
                 ("bound_lo", C.c_float * 3), ("bound_hi", C.c_float * 3),
                 ("bb_lo", C.c_double * 3), ("bb_hi", C.c_double * 3),
@@ -43,7 +43,7 @@ class RenderCfg(C.Structure):
 class AdamSeg(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("weight_decay", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
+                ("weight_decay", C.c_double), ("step", C.c_int32), ("p_f16", C.c_int32)]
 
 
 class TileBins(C.Structure):
@@ -53,6 +53,7 @@ class TileBins(C.Structure):
 
 
 TILE_SPLIT_PARTS = 2048
+TILE_ORDER_SNAPSHOT = 20480
 MAX_OVERLAP_PEERS = 2
 
 
@@ -75,6 +76,11 @@ class TileOverlap(C.Structure):
 class PlaneOpt(C.Structure):
     _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
                 ("eps", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Clock(C.Structure):
+    _fields_ = [("iteration", C.c_void_p), ("step_offset", C.c_void_p), ("bias_table", C.c_void_p), ("n_table", C.c_int32),
+                ("reserved", C.c_int32), ("beta1", C.c_double), ("beta2", C.c_double), ("z_offset_stride", C.c_uint64)]
 
 
 class FusedOpts(C.Structure):
@@ -105,16 +111,18 @@ _PROTOS = {
     "mne_sizeof_adam_seg": (C.c_size_t, []),
     "mne_sizeof_tile_bins": (C.c_size_t, []),
     "mne_sizeof_plane_opt": (C.c_size_t, []),
+    "mne_sizeof_clock": (C.c_size_t, []),
     "mne_sizeof_fused_opts": (C.c_size_t, []),
     "mne_sizeof_decoder_opt": (C.c_size_t, []),
     "mne_sample_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5
-                         + [C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 5 + [C.c_void_p]),
+                         + [C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 5 + [C.POINTER(Clock), C.c_void_p]),
     "mne_decoder_update": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(DecoderOpt), C.c_int,
-                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Clock), C.c_void_p]),
+    "mne_clock_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_num_samples": (C.c_int, [C.POINTER(RenderCfg), C.c_int]),
     "mne_sample_z": (C.c_int, [C.POINTER(RenderCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
-                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Clock), C.c_void_p]),
     "mne_packed_decoder_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_pack_decoder": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p]),
     "mne_render_forward": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 14
@@ -150,17 +158,18 @@ _PROTOS = {
     "mne_tile_overlap_floats": (C.c_size_t, [C.POINTER(Scene), C.POINTER(TileOverlap), C.c_int]),
     "mne_tile_grad_export": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.POINTER(TileBins), C.POINTER(TileOverlap), C.c_void_p]),
     "mne_tile_adam_shared": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins),
-                                       C.POINTER(TileOverlap), C.c_void_p]),
+                                       C.POINTER(TileOverlap), C.POINTER(Clock), C.c_void_p]),
     "mne_tile_order": (C.c_int, [C.POINTER(Scene), C.POINTER(TileBins), C.c_void_p]),
-    "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.c_void_p]),
+    "mne_tile_adam": (C.c_int, [C.POINTER(Scene), C.POINTER(PlaneOpt), C.c_void_p, C.POINTER(TileBins), C.POINTER(Clock),
+                                C.c_void_p]),
     "mne_sample_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5
-                        + [C.c_void_p]),
+                        + [C.POINTER(Clock), C.c_void_p]),
     "mne_decoder_param_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_wgrad_partial_floats": (C.c_size_t, [C.POINTER(Scene)]),
     "mne_decoder_wgrad": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p]),
-    "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.c_void_p]),
+    "mne_adam_step": (C.c_int, [C.POINTER(AdamSeg), C.c_int, C.c_int, C.POINTER(Clock), C.c_void_p]),
     "mne_query_points": (C.c_int, [C.POINTER(Scene), C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "mne_grid_level_table": (C.c_int, [C.POINTER(GridCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_grid_param_count": (C.c_size_t, [C.POINTER(GridCfg)]),
@@ -204,7 +213,7 @@ def load(path=None):
             raise RuntimeError("libmneslam_hip ABI version mismatch")
         for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
                        (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),
-                       (lib.mne_sizeof_plane_opt, PlaneOpt),
+                       (lib.mne_sizeof_plane_opt, PlaneOpt), (lib.mne_sizeof_clock, Clock),
                        (lib.mne_sizeof_fused_opts, FusedOpts), (lib.mne_sizeof_decoder_opt, DecoderOpt),
                        (lib.mne_sizeof_tile_overlap, TileOverlap), (lib.mne_sizeof_pose_state, PoseState)):
             if fn() != C.sizeof(st):

@@ -154,6 +154,13 @@ WORKLOADS = {
     "office0_hash": (lambda hidden=64: bench_office0_hash(hidden=hidden), "replica_office0_hashT19_2x64_2048x128"),
     "indoor": (lambda hidden=32: _overlay(indoor_agent(0), {"decoder": {"hidden_dim": hidden, "hidden_dim_color": hidden}}),
                "ins_indoor_agent0_triplane_2048x1045"),
+    # BASELINE configs[4] as worded (one of its agents): fp16 feature storage + fp32 accumulate (EXTENSION: grid.plane_dtype);
+    # bench.py --graph adds the hipGraph-captured iteration
+    "indoor_fp16": (lambda hidden=32: _overlay(indoor_agent(0), {"decoder": {"hidden_dim": hidden, "hidden_dim_color": hidden},
+                                                                 "grid": {"plane_dtype": "fp16"}}),
+                    "ins_indoor_agent0_triplane_fp16planes_2048x1045"),
+    "office0_fp16": (lambda hidden=32: _overlay(bench_office0(hidden=hidden), {"grid": {"plane_dtype": "fp16"}}),
+                     "replica_office0_triplane_fp16planes_2048x128"),
 }
 
 

@@ -9,6 +9,22 @@
 #include "mne_launch.h"
 
 long long mne_adam_blocks_for(long long n);
+int mne_launch_clock_advance(unsigned long long* iteration, int* step_offset, hipStream_t st);
+
+static int fill_clock(const mne_clock_t* c, Clock& out, double beta1, double beta2, bool need_table) {
+    out = Clock{};
+    if (!c) return 0;
+    if (need_table) {
+        if (!c->step_offset || !c->bias_table || c->n_table < 1) return -1;
+        if (c->beta1 != beta1 || c->beta2 != beta2) return -2;
+        out.step_offset = c->step_offset; out.bias_table = c->bias_table; out.n_table = c->n_table;
+    } else {
+        if (!c->iteration) return -1;
+        out.iteration = (const unsigned long long*)c->iteration;
+        out.z_offset_stride = c->z_offset_stride;
+    }
+    return 0;
+}
 
 static thread_local std::string g_err;
 
@@ -61,8 +77,15 @@ size_t mne_sizeof_render_cfg(void) { return sizeof(mne_render_cfg_t); }
 size_t mne_sizeof_adam_seg(void) { return sizeof(mne_adam_seg_t); }
 size_t mne_sizeof_tile_bins(void) { return sizeof(mne_tile_bins_t); }
 size_t mne_sizeof_plane_opt(void) { return sizeof(mne_plane_opt_t); }
+size_t mne_sizeof_clock(void) { return sizeof(mne_clock_t); }
 size_t mne_sizeof_fused_opts(void) { return sizeof(mne_fused_opts_t); }
 size_t mne_sizeof_decoder_opt(void) { return sizeof(mne_decoder_opt_t); }
+
+int mne_clock_advance(uint64_t* iteration, int32_t* step_offset, void* stream) {
+    if (!iteration && !step_offset) return fail(-1, "mne_clock_advance: NULL argument");
+    mne_launch_clock_advance((unsigned long long*)iteration, step_offset, (hipStream_t)stream);
+    return check_launch("clock_advance");
+}
 
 int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d) {
     if (!cfg) return fail(-1, "cfg is NULL");
@@ -71,7 +94,7 @@ int mne_num_samples(const mne_render_cfg_t* cfg, int has_target_d) {
 
 int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d, const float* u,
                  const float* lin_tables, uint64_t seed, uint64_t offset, float* z_vals, int32_t* counts,
-                 int32_t* ray_counts, void* stream) {
+                 int32_t* ray_counts, const mne_clock_t* clock, void* stream) {
     if (!cfg || !z_vals || !lin_tables) return fail(-1, "mne_sample_z: NULL argument");
     if (n_rays <= 0) return 0;
     ZArgs a;
@@ -94,6 +117,7 @@ int mne_sample_z(const mne_render_cfg_t* cfg, int n_rays, const float* target_d,
     a.z_vals = z_vals;
     a.counts = counts;
     a.ray_counts = ray_counts;
+    if (fill_clock(clock, a.clk, 0, 0, false)) return fail(-1, "mne_sample_z: incomplete clock");
     hipStream_t st = (hipStream_t)stream;
     if (a.has_d && (!counts || !ray_counts)) return fail(-1, "mne_sample_z: counts and ray_counts buffers required when target_d is given");
     mne_launch_sample_z(a, st);
@@ -442,7 +466,7 @@ size_t mne_tile_overlap_floats(const mne_scene_t* scene, const mne_tile_overlap_
 }
 
 static int tile_adam_impl(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
-                          const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, int form, void* stream) {
+                          const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, int form, const mne_clock_t* clock, void* stream) {
     if (int rc = check_scene(scene, false)) return rc;
     if ((!opt && form != 1) || !tape || !bins) return fail(-1, "mne_tile_adam: NULL argument");
     TileAdamArgs a = {};
@@ -463,6 +487,8 @@ static int tile_adam_impl(const mne_scene_t* scene, const mne_plane_opt_t* opt, 
         o.step_size = (float)(g.lr / (1.0 - std::pow(g.beta1, (double)g.step)));
         o.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(g.beta2, (double)g.step));
         o.lr = g.lr; o.step = g.step;
+        if (clock && fill_clock(clock, a.clk, g.beta1, g.beta2, true))
+            return fail(-1, "mne_tile_adam: clock incomplete or made for other betas");
     }
     a.tape = tape;
     a.n_tiles = a.bins.tile_base[a.n_planes];
@@ -474,25 +500,25 @@ static int tile_adam_impl(const mne_scene_t* scene, const mne_plane_opt_t* opt, 
 }
 
 int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
-                  const mne_tile_bins_t* bins, void* stream) {
-    return tile_adam_impl(scene, opt, tape, bins, nullptr, 0, stream);
+                  const mne_tile_bins_t* bins, const mne_clock_t* clock, void* stream) {
+    return tile_adam_impl(scene, opt, tape, bins, nullptr, 0, clock, stream);
 }
 
 int mne_tile_grad_export(const mne_scene_t* scene, const float* tape, const mne_tile_bins_t* bins,
                          const mne_tile_overlap_t* overlap, void* stream) {
-    return tile_adam_impl(scene, nullptr, tape, bins, overlap, 1, stream);
+    return tile_adam_impl(scene, nullptr, tape, bins, overlap, 1, nullptr, stream);
 }
 
 int mne_tile_adam_shared(const mne_scene_t* scene, const mne_plane_opt_t* opt, const float* tape,
-                         const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, void* stream) {
-    return tile_adam_impl(scene, opt, tape, bins, overlap, 2, stream);
+                         const mne_tile_bins_t* bins, const mne_tile_overlap_t* overlap, const mne_clock_t* clock, void* stream) {
+    return tile_adam_impl(scene, opt, tape, bins, overlap, 2, clock, stream);
 }
 
 int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const int32_t* kf_pose_ids,
                     const float* cur_rays, int64_t n_cur_rays, const float* poses, int n_poses,
                     int n_global, int n_cur, const int64_t* idx_global, const int64_t* idx_cur,
                     uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
-                    float* target_d, int64_t* out_idx, void* stream) {
+                    float* target_d, int64_t* out_idx, const mne_clock_t* clock, void* stream) {
     if (!poses || !rays_o || !rays_d || !target_rgb || !target_d || n_poses < 1) return fail(-1, "mne_sample_rays: NULL argument");
     if (n_global < 0 || n_cur < 0) return fail(-1, "mne_sample_rays: negative count");
     if (n_global > 0 && (!kf_rays || n_save < 1 || n_kf_rays < n_global)) return fail(-1, "mne_sample_rays: cannot draw n_global distinct keyframe rays");
@@ -504,6 +530,7 @@ int mne_sample_rays(const float* kf_rays, int64_t n_kf_rays, int n_save, const i
     a.n_global = n_global; a.n_cur = n_cur;
     a.idx_global = (const long long*)idx_global; a.idx_cur = (const long long*)idx_cur; a.out_idx = (long long*)out_idx;
     a.rays_o = rays_o; a.rays_d = rays_d; a.target_rgb = target_rgb; a.target_d = target_d;
+    if (fill_clock(clock, a.clk, 0, 0, false)) return fail(-1, "mne_sample_rays: incomplete clock");
     mne_launch_sample_rays(a, seed, iteration, (hipStream_t)stream);
     return check_launch("sample_rays");
 }
@@ -527,7 +554,7 @@ int mne_sample_batch(const float* kf_rays, int64_t n_kf_rays, int n_save, const 
                      uint64_t seed, uint64_t iteration, float* rays_o, float* rays_d, float* target_rgb,
                      float* target_d, int64_t* out_idx, const mne_render_cfg_t* cfg, const float* u,
                      const float* lin_tables, uint64_t z_offset, float* z_vals, int32_t* counts, int32_t* ray_counts,
-                     const float* grad_losses, float* coef, void* stream) {
+                     const float* grad_losses, float* coef, const mne_clock_t* clock, void* stream) {
     if (!poses || !rays_o || !rays_d || !target_rgb || !target_d || n_poses < 1 || !cfg || !lin_tables || !z_vals || !counts ||
         !ray_counts)
         return fail(-1, "mne_sample_batch: NULL argument");
@@ -543,11 +570,13 @@ int mne_sample_batch(const float* kf_rays, int64_t n_kf_rays, int n_save, const 
     sr.n_global = n_global; sr.n_cur = n_cur;
     sr.idx_global = (const long long*)idx_global; sr.idx_cur = (const long long*)idx_cur; sr.out_idx = (long long*)out_idx;
     sr.rays_o = rays_o; sr.rays_d = rays_d; sr.target_rgb = target_rgb; sr.target_d = target_d;
+    if (fill_clock(clock, sr.clk, 0, 0, false)) return fail(-1, "mne_sample_batch: incomplete clock");
     ZArgs a = {};
     fill_zargs(a, cfg, R, true);
     if (a.S < 1 || a.S > 16384) return fail(-1, "mne_sample_batch: samples per ray out of range [1,16384]");
     a.target_d = target_d; a.u = u; a.tables = lin_tables; a.seed = seed; a.offset = z_offset;
     a.z_vals = z_vals; a.counts = counts; a.ray_counts = ray_counts;
+    a.clk = sr.clk;
     LossArgs lc = {};
     lc.R = R; lc.S = a.S; lc.counts = counts; lc.grad_losses = grad_losses; lc.coef = coef;
     lc.e_T = (float)cfg->truncation;
@@ -558,7 +587,7 @@ int mne_sample_batch(const float* kf_rays, int64_t n_kf_rays, int n_save, const 
 
 int mne_decoder_update(const mne_scene_t* scene, const float* partials, int n_rays, float* grad_out,
                        const mne_decoder_opt_t* opt, int n_samples, const float* ray_sums,
-                       const int32_t* counts, float* losses, void* stream) {
+                       const int32_t* counts, float* losses, const mne_clock_t* clock, void* stream) {
     if (int rc = check_scene(scene, false, false)) return rc;
     if (!partials || !grad_out || !opt || n_rays < 1) return fail(-1, "mne_decoder_update: NULL argument");
     if (losses && (!ray_sums || !counts || n_samples < 1)) return fail(-1, "mne_decoder_update: the loss scalars need ray_sums and counts");
@@ -576,6 +605,8 @@ int mne_decoder_update(const mne_scene_t* scene, const float* partials, int n_ra
     o.step_size = (float)(opt->lr / (1.0 - std::pow(opt->beta1, (double)opt->step)));
     o.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(opt->beta2, (double)opt->step));
     o.lr = opt->lr; o.step = opt->step;
+    if (clock && fill_clock(clock, a.clk, opt->beta1, opt->beta2, true))
+        return fail(-1, "mne_decoder_update: clock incomplete or made for other betas");
     a.fin.R = n_rays; a.fin.S = n_samples; a.fin.ray_sums = ray_sums; a.fin.counts = counts; a.fin.losses = losses;
     if (int rc = mne_launch_decoder_update(a, (hipStream_t)stream)) return fail(rc, "unsupported decoder shape");
     return check_launch("decoder_update");
@@ -638,7 +669,7 @@ int mne_pose_update(const mne_pose_state_t* pose, int n_rays, const float* dirs_
     return check_launch("pose_update");
 }
 
-int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* stream) {
+int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, const mne_clock_t* clock, void* stream) {
     if (n_seg < 0 || n_seg > 32) return fail(-1, "mne_adam_step: n_seg must be in [0,32]");
     if (n_seg == 0) return 0;
     if (!segs) return fail(-1, "mne_adam_step: segs is NULL");
@@ -655,6 +686,8 @@ int mne_adam_step(const mne_adam_seg_t* segs, int n_seg, int zero_grad, void* st
         a.step_size[s] = (float)(g.lr / bc1);
         a.bc2_sqrt[s] = (float)std::sqrt(bc2);
         a.blk_start[s + 1] = a.blk_start[s] + mne_adam_blocks_for(g.n);
+        if (clock && fill_clock(clock, a.clk, g.beta1, g.beta2, true))
+            return fail(-1, "mne_adam_step: clock incomplete or made for other betas");
     }
     mne_launch_adam(a, (hipStream_t)stream);
     return check_launch("adam_step");

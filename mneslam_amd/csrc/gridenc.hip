@@ -247,11 +247,7 @@ __global__ __launch_bounds__(256) void hash_scatter_runs_kernel(GridArgs a) {
 #ifndef HASH_LEVEL_WGS
 #define HASH_LEVEL_WGS 64
 #endif
-#ifdef HASH_ABL_NO_LDS_ADD          // timing experiment: the walk without the LDS atomics (plain racing stores)
-#define HASH_LDS_ADD(p, v) (*(p) = (v))
-#else
 #define HASH_LDS_ADD(p, v) atomicAdd((p), (v))
-#endif
 __host__ __device__ __forceinline__ int hash_slices_of(const GridArgs& a, int level) { return (int)((a.size[level] + HASH_SLICE - 1) / HASH_SLICE); }
 __host__ __device__ __forceinline__ bool hash_level_dense(const GridArgs& a, int level) {
     return (unsigned long long)a.res[level] * a.res[level] * a.res[level] <= a.size[level];

@@ -44,6 +44,13 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, 
     return (float)(w >> 8) * (1.0f / 16777216.0f);      // [0,1), 24 bits like torch.rand
 }
 
+// ---- Adam bias corrections from the device clock (graph replay): same double arithmetic as the host path --------
+__device__ __forceinline__ void clock_bias(const Clock& clk, double lr, int step, float& step_size, float& bc2_sqrt) {
+    int t = step + *clk.step_offset;
+    t = t < 1 ? 1 : (t > clk.n_table ? clk.n_table : t);
+    step_size = (float)(lr / clk.bias_table[2 * (t - 1)]);
+    bc2_sqrt = (float)sqrt(clk.bias_table[2 * (t - 1) + 1]);
+}
 
 // ---- one Adam element (torch.optim.Adam single-tensor arithmetic; constants prepared on the host in double) ------
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const PlaneOpt& o) {
@@ -161,13 +168,26 @@ __device__ __forceinline__ void oneblob8(float x, int base, float* out /*8*/, bo
 #endif
 // Tri-plane features of ONE point for the 8 lanes that share it (cg = lane & 7: float4 chunk of the 128-B rows); the
 // blended rows go to out + set * set_stride + level * 32 + cg * 4 (LDS row or tape row).
-// Four channels of one corner row
+// Four channels of one corner row at element offset e: planes are stored in fp32, or -- mne_scene_t.plane_f16, uniform over
+// the launch -- in IEEE half precision (a corner row is then 64 bytes: 8 lanes x 8 B); arithmetic is fp32 either way.
+__device__ __forceinline__ float4 half4_to_float4(uint2 u) {
+    union { uint2 u; _Float16 h[4]; } r;
+    r.u = u;
+    return make_float4((float)r.h[0], (float)r.h[1], (float)r.h[2], (float)r.h[3]);
+}
+__device__ __forceinline__ uint2 float4_to_half4(float4 v) {                  // round to nearest even
+    union { uint2 u; _Float16 h[4]; } r;
+    r.h[0] = (_Float16)v.x; r.h[1] = (_Float16)v.y; r.h[2] = (_Float16)v.z; r.h[3] = (_Float16)v.w;
+    return r.u;
+}
+template <bool F16>
 __device__ __forceinline__ float4 plane_row4(const mne_plane_t& pl, int e) {
-    return *(const float4*)(pl.data + e);
+    if (F16) return half4_to_float4(*(const uint2*)((const _Float16*)pl.data + e));
+    return *(const float4*)((const float*)pl.data + e);
 }
 
-template <int NSETS>
-__device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
+template <int NSETS, bool F16>
+__device__ __forceinline__ void gather_slot_t(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
     const int kmine = cg < 6 ? cg : cg - 6;                        // this lane's plane: k = lvl * 3 + ori
     const int lvl_m = kmine >= 3 ? 1 : 0, ori_m = kmine - 3 * lvl_m;
     constexpr int NLV = MNE_GATHER_INFLIGHT / 12;                   // levels loaded together
@@ -202,7 +222,7 @@ __device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, flo
                 const int k = l0 * 3 + j;
                 const mne_plane_t& pl = sc.plane[set][k % 3][k / 3];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[j][q] = plane_row4(pl, cg * 4 + off[j][q]);
+                for (int q = 0; q < 4; ++q) v[j][q] = plane_row4<F16>(pl, cg * 4 + off[j][q]);
             }
             MNE_SCHED_BARRIER();
 #pragma unroll
@@ -224,6 +244,12 @@ __device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, flo
             }
         }
     }
+}
+
+template <int NSETS>
+__device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
+    if (sc.plane_f16) gather_slot_t<NSETS, true>(sc, px, py, pz, cg, out, set_stride);       // (uniform over the launch)
+    else gather_slot_t<NSETS, false>(sc, px, py, pz, cg, out, set_stride);
 }
 
 template <int NSETS, int NPTS>
@@ -264,8 +290,14 @@ __device__ __forceinline__ void gather_coord_grad(const mne_scene_t& sc, const f
                     const float ux = ((gx + 1.0f) / 2.0f) * (float)(pl.w - 1), uy = ((gy + 1.0f) / 2.0f) * (float)(pl.h - 1);
                     const float fx = fminf((float)(pl.w - 1), fmaxf(ux, 0.0f)), fy = fminf((float)(pl.h - 1), fmaxf(uy, 0.0f));
                     const float x0 = floorf(fx), y0 = floorf(fy);
-                    const float4 v00 = plane_row4(pl, cg * 4 + b.o00), v01 = plane_row4(pl, cg * 4 + b.o01);
-                    const float4 v10 = plane_row4(pl, cg * 4 + b.o10), v11 = plane_row4(pl, cg * 4 + b.o11);
+                    float4 v00, v01, v10, v11;
+                    if (sc.plane_f16) {
+                        v00 = plane_row4<true>(pl, cg * 4 + b.o00); v01 = plane_row4<true>(pl, cg * 4 + b.o01);
+                        v10 = plane_row4<true>(pl, cg * 4 + b.o10); v11 = plane_row4<true>(pl, cg * 4 + b.o11);
+                    } else {
+                        v00 = plane_row4<false>(pl, cg * 4 + b.o00); v01 = plane_row4<false>(pl, cg * 4 + b.o01);
+                        v10 = plane_row4<false>(pl, cg * 4 + b.o10); v11 = plane_row4<false>(pl, cg * 4 + b.o11);
+                    }
                     const bool xin = b.ix0 + 1 < pl.w, yin = b.iy0 + 1 < pl.h;
                     // dot(dfeat, corner) over this lane's 4 channels; absent corners count as zero
                     const float d00 = df.x * v00.x + df.y * v00.y + df.z * v00.z + df.w * v00.w;

@@ -4,6 +4,15 @@
 #include "mne_platform.h"
 #include "mneslam_hip.h"
 
+// device-side view of mne_clock_t (all NULL / 0 = values come from the kernel arguments)
+struct Clock {
+    const unsigned long long* iteration;
+    const int* step_offset;
+    const double* bias_table;
+    int n_table;
+    unsigned long long z_offset_stride;
+};
+
 struct ZArgs {
     int R, S, n_a, n_b, has_d;
     float perturb;
@@ -15,6 +24,7 @@ struct ZArgs {
     float* z_vals;
     int* counts;
     int* ray_counts;     // [R][MNE_N_COUNT] scratch
+    Clock clk;
 };
 
 #define MNE_TILE 16            // plane tile edge (cells) of the binned scatter
@@ -133,7 +143,8 @@ struct SampleRaysArgs {
     long long* out_idx;          // optional [R]: the indices used
     float *rays_o, *rays_d, *target_rgb, *target_d;
     int half_bits_kf, half_bits_cur;
-    unsigned long long seed, iteration;      // keys are derived from (seed, iteration) inside the kernel
+    unsigned long long seed, iteration;      // keys are derived from (seed, iteration [+ clock]) inside the kernel
+    Clock clk;
 };
 
 struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, bc2_sqrt; double lr; int step; };
@@ -197,6 +208,7 @@ struct DecUpdateArgs {
     float* m[4]; float* v[4];    // Adam moments in decoder.parameters() order: col0, col1, sdf0, sdf1
     PlaneOpt opt;
     LossArgs fin;                // loss scalars of the iteration (fin.losses NULL: not wanted)
+    Clock clk;
 };
 
 struct TileAdamArgs {
@@ -206,6 +218,7 @@ struct TileAdamArgs {
     const float* tape;
     int row_stride, t_dfeat, t_pn;
     int n_planes, n_tiles;
+    Clock clk;
     int* prev_counts;         // [n_tiles] final list lengths of the previous tile_adam launch (NULL: none) -- balance hint of tile_order
 };
 
@@ -256,6 +269,7 @@ struct AdamArgs {
     long long blk_start[33];  // prefix sum of blocks per segment
     int n_seg;
     int zero_grad;
+    Clock clk;
 };
 
 int mne_launch_sample_z(const ZArgs& a, hipStream_t st);

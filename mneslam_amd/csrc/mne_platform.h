@@ -2,13 +2,6 @@
 // hipcc --offload-arch=gfx950) and the test-only host emulator (tests/hostemu/hip_emu.h, used by
 // the CPU test-suite to run these same kernel sources without a GPU).
 #pragma once
-// Timing-ablation switches exist only in -DMNE_ABLATION builds (profiles/ablate_*.sh); in the shipped library the
-// tests below are the constant false and the compiler removes the branches.
-#ifdef MNE_ABLATION
-#define MNE_ABL(flags, bit) (((flags) & (bit)) != 0)
-#else
-#define MNE_ABL(flags, bit) (false)
-#endif
 #ifdef MNE_HOST_EMU
 #include "hip_emu.h"
 #else

@@ -45,7 +45,7 @@ __host__ __device__ inline void ray_keys(unsigned long long seed, unsigned long 
 // Returns the target depth.
 __device__ __forceinline__ float sample_ray(const SampleRaysArgs& a, int t, bool write) {
     unsigned long long key_kf, key_cur;
-    ray_keys(a.seed, a.iteration, key_kf, key_cur);
+    ray_keys(a.seed, a.iteration + (a.clk.iteration ? *a.clk.iteration : 0ull), key_kf, key_cur);
     const float* src;
     int pose_id;
     long long idx;

@@ -34,7 +34,7 @@
 // the staged linspace tables, `vals` = S floats of this wave's LDS
 __device__ __forceinline__ void sample_z_ray(const ZArgs& a, int r, float d, int lane, const float* tab, float* vals) {
     const int S = a.S;
-    const uint64_t z_offset = a.offset;
+    const uint64_t z_offset = a.offset + (a.clk.iteration ? *a.clk.iteration * a.clk.z_offset_stride : 0ull);
     if (a.has_d) {
         const float* uni = tab;
         const float* surf = tab + a.n_a;
@@ -189,18 +189,6 @@ __global__ __launch_bounds__(256) void pack_decoder_kernel(mne_scene_t sc, float
 // -----------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x16 f32x16_zero() { f32x16 v; for (int q = 0; q < 16; ++q) v[q] = 0.0f; return v; }
 
-// -DRENDER_PROFILE (experiments only, profiles/render_phase_times.py): lane 0 stamps the constant 100 MHz clock at phase
-// boundaries into the unused tail of the spill area (decode: first task of every wave; ray: every ray).
-#ifdef RENDER_PROFILE
-#define DEC_STAMP(k) do { if (prof_slot >= 0 && (lane) == 0) \
-    ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 65536) * MNE_SPILL_WORDS))[(size_t)prof_slot * 16 + (k)] = wall_clock64(); } while (0)
-#define RAY_STAMP(k) do { if (a.bins.spill && lane == 0 && (k) < 32) \
-    ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 32768) * MNE_SPILL_WORDS))[(size_t)r * 32 + (k)] = wall_clock64(); } while (0)
-#else
-#define DEC_STAMP(k) do { } while (0)
-#define RAY_STAMP(k) do { } while (0)
-#endif
-
 struct SampleMasks { bool e_front, e_center, e_tail, co_fs, co_sdf; };
 
 __device__ __forceinline__ SampleMasks sample_masks(float z, float d, bool has_t, const RenderArgs& a) {
@@ -247,15 +235,13 @@ __device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntil
 // rows with one batch of coalesced loads instead of being gathered here (8 dependent rounds of corner-row loads).
 template <int HID, int HIDC, bool CP, bool GTAB = false>
 __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c, int lane, float* pn, float* feat,
-                                              const float* atab, float (&pnv)[3], float (&u)[3], uint2& relu, int prof_slot = -1,
-                                              bool PRE = false) {
+                                              const float* atab, float (&pnv)[3], float (&u)[3], uint2& relu, bool PRE = false) {
     typedef DecDims<HID, HIDC, CP> D;
     constexpr int NSETS = CP ? 2 : 1;
     constexpr int NT = HID / 32, NTC = HIDC / 32;
     const int S = a.S, pt = lane & 31, hf = lane >> 5;
     const int i = c * TILE + pt;
     const bool valid = i < S;
-    DEC_STAMP(0);
     const float z = a.z_vals[(size_t)r * S + (valid ? i : S - 1)];
     float p[3];
 #pragma unroll
@@ -264,16 +250,10 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     const int n_here = S - c * TILE;
     const unsigned live = n_here >= TILE ? 0xffffffffu : ((1u << n_here) - 1u);
     float* tape0 = a.tape ? a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW : nullptr;
-#ifdef ABL_NO_FWD_TAPE
-    tape0 = nullptr;
-#endif
     MNE_WAVE_SYNC();                                       // earlier LDS reads of this wave are done
     // Pre-gathered rows, 2x32 decoders (registers to spare): the row loads are issued here and land in LDS only after the
     // OneBlob below (3 us of VALU work that does not depend on them) -- 2 us of load latency per tile off the chain.
-#ifndef MNE_DECODE_OVERLAP
-#define MNE_DECODE_OVERLAP 1
-#endif
-    constexpr bool OVERLAP = MNE_DECODE_OVERLAP && HID == 32 && HIDC == 32;
+    constexpr bool OVERLAP = HID == 32 && HIDC == 32;
     float4 q0[4][MNE_FEAT / 32], q1[4][MNE_FEAT / 32];
 #pragma unroll
     for (int it = 0; it < 4; ++it)
@@ -281,25 +261,19 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
         for (int k = 0; k < MNE_FEAT / 32; ++k) q0[it][k] = q1[it][k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool late_rows = OVERLAP && PRE;
     if (late_rows) {
-        DEC_STAMP(1);
         if (!CP && a.ext_rows) rows_fetch<MNE_FEAT>(q0, a.ext_rows + ((size_t)r * S + (size_t)c * TILE) * a.ext_stride, a.ext_stride, 0, live, lane);
         else rows_fetch<MNE_FEAT>(q0, tape0, D::ROW, D::T_X, live, lane);
         if (CP) rows_fetch<MNE_FEAT>(q1, tape0, D::ROW, D::T_CF, live, lane);
-        DEC_STAMP(2);
     } else if (PRE) {
-        DEC_STAMP(1);
         if (!CP && a.ext_rows) load_rows<MNE_FEAT>(feat, a.ext_rows + ((size_t)r * S + (size_t)c * TILE) * a.ext_stride, a.ext_stride, 0, live, lane);
         else load_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
         if (CP) load_rows<MNE_FEAT>(feat + TILE * MNE_FS, tape0, D::ROW, D::T_CF, live, lane);
         MNE_WAVE_SYNC();
-        DEC_STAMP(2);
     } else {
         if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
         MNE_WAVE_SYNC();
-        DEC_STAMP(1);
         gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
         MNE_WAVE_SYNC();
-        DEC_STAMP(2);
         if (tape0) {                                       // plane features: straight from the gathered rows
             store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
             if (CP) store_rows<MNE_FEAT>(feat + TILE * MNE_FS, tape0, D::ROW, D::T_CF, live, lane);
@@ -307,7 +281,6 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     }
     float* frow = feat + pt * MNE_FS;
     const float* cfrow = feat + TILE * MNE_FS + pt * MNE_FS;
-    DEC_STAMP(3);
     float pos[24];
     oneblob_half<!(HID == 64 && CP)>(u, hf, pos);
     if (late_rows) {
@@ -315,11 +288,9 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
         if (CP) rows_commit<MNE_FEAT>(q1, feat + TILE * MNE_FS, lane);
         MNE_WAVE_SYNC();
     }
-    DEC_STAMP(4);
     MlpState<HID, HIDC> st;
     mlp_forward_mfma<HID, HIDC, CP, GTAB>(frow, cfrow, pos, atab, lane, st);
     const float4 rw = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);      // rows 0..3 live in the lower half
-    DEC_STAMP(5);
     relu = make_uint2(0u, 0u);
     if (a.relu_mask) relu_masks<HID, HIDC>(st, relu.x, relu.y);
     if (valid) {
@@ -354,7 +325,6 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
             store_rows<HIDC>(feat, tape0, D::ROW, D::T_HC, live, lane);
         }
     }
-    DEC_STAMP(6);
     return rw;
 }
 
@@ -370,7 +340,7 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
 // needs.  Here it runs by itself: one wave = 8 consecutive samples of a ray, 8 lanes per sample, no LDS, few registers,
 // 32 waves per CU -- the whole batch is in flight at once.  decode_kernel<PRE> then starts from the rows.
 // -----------------------------------------------------------------------------------------------
-template <bool CP>
+template <bool CP, bool F16>
 __global__ __launch_bounds__(256) void gather_kernel(RenderArgs a, int chunks_per_ray) {
     typedef DecDims<32, 32, CP> D0;                        // only the hidden-size independent columns are used (T_X = 0)
     constexpr int NSETS = CP ? 2 : 1;
@@ -392,7 +362,7 @@ __global__ __launch_bounds__(256) void gather_kernel(RenderArgs a, int chunks_pe
     }
     float* row = a.tape + ((size_t)r * S + ii) * a.tape_row + a.tape_tx;
     // rows of samples beyond S (last chunk of a ray) are computed on the clamped sample and written twice: harmless
-    gather_slot<NSETS>(a.sc, pnv[0], pnv[1], pnv[2], lane & 7, row, a.tape_tcf - a.tape_tx);
+    gather_slot_t<NSETS, F16>(a.sc, pnv[0], pnv[1], pnv[2], lane & 7, row, a.tape_tcf - a.tape_tx);
 }
 
 // WPB: waves per workgroup the kernel is compiled for (12 for the fused gather+MLP form: latency hiding matters most;
@@ -428,7 +398,6 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
     // persistent waves over the (tile, ray) tasks, TILE-major: the a-priori tiles of all rays come first, so the
     // skipped tasks (tiles beyond a ray's prefix) cluster at the end and the real ones spread evenly over the waves.
     // List mode (second pass): the REMAINING tiles of the rays the training kernel deferred.
-    int n_done = 0;
     const int n_rays = a.ray_list ? *a.ray_list_count : a.R;
     const long long ntask_l = (long long)n_rays * ntile;
     for (long long task = (long long)blockIdx.x * wpb + wv; task < ntask_l; task += (long long)gridDim.x * wpb) {
@@ -447,16 +416,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
         float z_lim = 0.0f, s_carry = 0.0f;
         const float* zr = a.z_vals + (size_t)r * a.S;
         while (true) {
-#ifdef RENDER_PROFILE
-            const int prof_slot = (a.bins.spill && n_done < 2 && cc == c) ? (int)(blockIdx.x * wpb + wv) * 2 + n_done : -1;
-#else
-            const int prof_slot = -1;
-#endif
-            const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, cc, lane, pn, feat, atab, pnv, u, relu, prof_slot, pre_now);
-#ifdef RENDER_PROFILE
-            if (prof_slot >= 0 && lane == 0)
-                ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 65536) * MNE_SPILL_WORDS))[(size_t)prof_slot * 16 + 7] = (unsigned long long)(c + 1);
-#endif
+            const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, cc, lane, pn, feat, atab, pnv, u, relu, pre_now);
             if (!resolver) break;
             const int i0 = cc * TILE, n_in = a.S - i0 < TILE ? a.S - i0 : TILE;
             const float s_me = rw.w;                                   // valid on lanes < 32 (rows 0..3 of the result)
@@ -476,7 +436,6 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
             pre_now = a.ext_feat != 0;                                 // tiles beyond the prefix were not pre-gathered
         }
         if (resolver && lane == 0) a.dec_tiles[r] = cc + 1;
-        ++n_done;
     }
 }
 
@@ -720,7 +679,6 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
     const int n_items = a.ray_list ? *a.ray_list_count : a.R;
     for (int item = blockIdx.x * wpb + wv; item < n_items; item += gridDim.x * wpb) {
         const int r = a.ray_list ? a.ray_list[item] : item;
-        RAY_STAMP(0);
         const float td = has_t ? a.target_d[r] : 0.0f;
         float ro[3], rd[3];
 #pragma unroll
@@ -744,7 +702,6 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             }
         }
         MNE_WAVE_SYNC();
-        RAY_STAMP(1);
         // ---- resolve: first sign change + every sample inside the render window must be known
         int first = -1, from = 0;
         bool deferred = false;
@@ -756,7 +713,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
                 // decode the next tile on demand (Dn is a multiple of TILE here)
                 float pnv[3], u[3];
                 uint2 relu;
-                const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu, -1, a.ext_feat != 0);
+                const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu, a.ext_feat != 0);
                 const int i = t_dec * TILE + pt;
                 if (i < S && hf == 0) *(float4*)(raws + 4 * i) = rw;
                 MNE_WAVE_SYNC();
@@ -777,10 +734,8 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             const bool resolved = D_ap >= S || (first >= 0 && first + 1 < D_ap && !(zr[D_ap] < zr[first] + a.win_f));
             if (!resolved && lane == 0) atomicAdd(a.adapt + 1, 1);
         }
-        RAY_STAMP(2);
         RayGrad G;
         composite_ray<BWD>(a, r, lane, raws, zr, Dn, first < 0 ? 0 : first, G);
-        RAY_STAMP(3);
         if (!BWD) continue;
         // ---- samples that can receive gradient: render window or an active loss mask (exact)
         int last = -1, n_contrib = 0;
@@ -801,9 +756,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             if (a.tape_rows && n_contrib) atomicAdd(a.tape_rows, n_contrib);
         }
         float ray_do[3] = {0.f, 0.f, 0.f}, ray_dd[3] = {0.f, 0.f, 0.f};
-        RAY_STAMP(4);
         for (int c = 0; c < nb; ++c) {
-            RAY_STAMP(5 + 6 * c);
             const int i = c * TILE + pt;
             const bool valid = i < Dn;
             const int ii = valid ? i : Dn - 1;
@@ -812,7 +765,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             const size_t e = (size_t)r * S + ii;
             uint2 mk2;
             if (LATE_DECODE && c >= t_dec) {                      // tape rows of this tile are missing: decode it now
-                decode_tile<HID, HIDC, CP, !ALDS>(a, r, c, lane, pn, feat, atab, pnv, u, mk2, -1, a.ext_feat != 0);
+                decode_tile<HID, HIDC, CP, !ALDS>(a, r, c, lane, pn, feat, atab, pnv, u, mk2, a.ext_feat != 0);
                 t_dec = c + 1;
             } else {
 #pragma unroll
@@ -847,25 +800,15 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
                 contrib = sample_contrib(z, G.z_lim, mk, use_e, use_co);
             }
             MNE_WAVE_SYNC();                                      // feat rows are about to be overwritten
-            RAY_STAMP(6 + 6 * c);
             // ---- MFMA backward chain from the saved ReLU masks; d(feature) rows land in this point's LDS rows.
             // A sample without gradient has ds = dc = 0 and therefore an all-zero backward row.
             float* frow = feat + pt * MNE_FS;
             float* cfrow = SEQ ? frow : feat + TILE * MNE_FS + pt * MNE_FS;
             f32x16 dh[NT], dout, dhc[NTC];
-#ifdef ABL_NO_APPEND
-            const bool live = false;
-#else
             const bool live = valid && contrib;
-#endif
             const unsigned live_rows = (unsigned)__ballot(live && hf == 0), valid_rows = (unsigned)__ballot(valid && hf == 0);
             float* tape0 = a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW;
             if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
-#ifdef ABL_NO_BWD_MFMA
-            dout = f32x16_zero(); dout[0] = ds + dc[0];
-            for (int t = 0; t < NT; ++t) dh[t] = f32x16_zero();
-            for (int t = 0; t < NTC; ++t) dhc[t] = f32x16_zero();
-#else
             if (SEQ || EARLY_DHC) {
                 // colour net first; what it produces leaves for the tape before the sdf net's chain starts, so that
                 // its registers (and, with colour planes, its LDS rows) are free again
@@ -887,8 +830,6 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             } else {
                 mlp_backward_mfma<HID, HIDC, CP, BIAS, !ALDS>(mk2.x, mk2.y, ds, dc, atab, lane, dh, dout, dhc, frow, cfrow);
             }
-#endif
-            RAY_STAMP(7 + 6 * c);
             if (RAYGRAD) {
                 // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates; every
                 // point of the tile belongs to this ray: summed over the wave, stored once at the end
@@ -912,11 +853,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
                 }
             }
             MNE_WAVE_SYNC();
-#ifdef ABL_NO_BWD_TAPE
-            const unsigned tape_rows_mask = 0u;
-#else
             const unsigned tape_rows_mask = valid_rows;
-#endif
             // ---- backward half of the tape rows, staged through the LDS rows (full-line stores, see store_rows)
             if (a.ext_feat) {                                     // caller-owned encoding: d(feature) rows of every valid sample
 #pragma unroll                                                    // (all-zero rows for samples without gradient)
@@ -957,14 +894,8 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             }
             MNE_WAVE_SYNC();
             store_rows<32>(feat, tape0, D::ROW, D::T_DOUT, tape_rows_mask, lane);
-            RAY_STAMP(8 + 6 * c);
             // (the list appends of the binned plane update are bin_kernel's: it reads pn and the `live` flag written above)
-            RAY_STAMP(10 + 6 * c);
         }
-#ifdef RENDER_PROFILE
-        if (a.bins.spill && lane == 0)
-            ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 32768) * MNE_SPILL_WORDS))[(size_t)r * 32 + 31] = (unsigned long long)nb;
-#endif
         if (RAYGRAD) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) { ray_do[q] = wave_sum(ray_do[q]); ray_dd[q] = wave_sum(ray_dd[q]); }
@@ -1249,6 +1180,7 @@ __global__ __launch_bounds__(256) void decoder_update_kernel(DecUpdateArgs a) {
         const int off = e - (t == 0 ? D::P_COL0 : t == 1 ? D::P_COL1 : t == 2 ? D::P_SDF0 : D::P_SDF1);
         float* P = (float*)(t == 0 ? a.sc.w_col0 : t == 1 ? a.sc.w_col1 : t == 2 ? a.sc.w_sdf0 : a.sc.w_sdf1);
         PlaneOpt o = a.opt;
+        if (a.clk.bias_table) clock_bias(a.clk, o.lr, o.step, o.step_size, o.bc2_sqrt);
         float p = P[off], m = a.m[t][off], v = a.v[t][off];
         adam_elem(p, g, m, v, o);
         P[off] = p; a.m[t][off] = m; a.v[t][off] = v;
@@ -1469,7 +1401,8 @@ static int launch_decode(RenderArgs d, hipStream_t st, const RenderHost& host, b
         const int chunks = (d.S + 7) / 8;
         const long long waves = (long long)d.R * chunks;
         mark(host, 0, st);
-        MNE_LAUNCH((gather_kernel<CP>), (unsigned)((waves + 3) / 4), 256, 0, st, d, chunks);
+        if (d.sc.plane_f16) MNE_LAUNCH((gather_kernel<CP, true>), (unsigned)((waves + 3) / 4), 256, 0, st, d, chunks);
+        else MNE_LAUNCH((gather_kernel<CP, false>), (unsigned)((waves + 3) / 4), 256, 0, st, d, chunks);
         mark(host, 1, st);
     }
     const size_t tab = table_bytes<HID, HIDC, CP>(0);
@@ -1598,9 +1531,6 @@ static int launch_query(const QueryArgs& a, hipStream_t st) {
     return 0;
 }
 
-#ifdef MNE_ONLY_SHAPE      // development builds (profiles/resource_usage.py --shape): ONE decoder shape = 2 * hidden + colour planes
-#define MNE_DISPATCH(sc, CALL, BAD) do { CALL((MNE_ONLY_SHAPE / 2), (MNE_ONLY_SHAPE / 2), ((MNE_ONLY_SHAPE & 1) != 0)); } while (0)
-#else
 #define MNE_DISPATCH(sc, CALL, BAD)                                                           \
     do {                                                                                   \
         const bool cp_ = (sc).n_sets == 2;                                                 \
@@ -1608,7 +1538,6 @@ static int launch_query(const QueryArgs& a, hipStream_t st) {
         else if ((sc).hidden == 64 && (sc).hidden_color == 64) { if (cp_) { CALL(64, 64, true); } else { CALL(64, 64, false); } } \
         else return BAD;                                                                   \
     } while (0)
-#endif
 
 int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st) {
 #define CALL(H, HC, CPV) return launch_pack<H, HC, CPV>(sc, pk, st)

@@ -45,19 +45,8 @@
 #ifndef PASS_ENTRIES
 #define PASS_ENTRIES 256
 #endif
-// -DTILE_PROFILE (experiments only, profiles/tile_phase_times.py): thread 0 of the first 4096 workgroups
-// stamps the constant 100 MHz clock at the phase boundaries into the unused tail of the spill area.
-#ifdef TILE_PROFILE
-#define TILE_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096) \
-    ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 8192) * MNE_SPILL_WORDS))[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-#else
-#define TILE_STAMP(k) do { } while (0)
-#endif
 #ifndef DB
 #define DB 8
-#endif
-#ifndef TILE_PREFETCH
-#define TILE_PREFETCH 0
 #endif
 #ifndef TILE_MIN_WAVES
 #define TILE_MIN_WAVES 4        // waves per SIMD the register allocation must allow: 2 workgroups of 8 waves per CU (LDS-limited)
@@ -88,30 +77,42 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
     if (tid < 32) hist[tid] = 0;
     if (tid == 0) { total = 0; n_split = 0; }
     __syncthreads();
-    // counts are read ONCE (this kernel is a latency chain on the critical path): up to ORDER_REGS tiles per thread stay
-    // in registers for all three passes, the rest (more than 8192 tiles) is re-read
-    constexpr int ORDER_REGS = 8;
+    // Every list length is read from memory exactly ONCE: the kernel may run while the deferred rays' appends are still
+    // being added on another stream (bins.counts grows under it), and a tile whose length changed between the classify and
+    // the place pass would be counted in one bucket and placed in another.  The first ORDER_REGS * 1024 tiles
+    // stay in registers for all three passes, the next ORDER_LDS in LDS; a scene with more tiles than that
+    // (MNE_TILE_ORDER_SNAPSHOT) re-reads the rest, and the caller must then order AFTER the last append (FusedStep does).
+    constexpr int ORDER_REGS = 8, ORDER_LDS = MNE_TILE_ORDER_SNAPSHOT - ORDER_REGS * 1024;
+    __shared__ int lcache[ORDER_LDS];
     // With prev_counts a list counts as max(length now, final length of the previous launch): the kernel may run while the
     // deferred rays' appends are still to come (scenes with many deferred rays would otherwise get yesterday's heavy lists
     // unsplit: ScanNet 1.16 ms instead of 0.44 ms).
     // (Lengths are NOT clamped to the plane's list capacity: an overflowing list -- rare, a capacity is 4x the mean -- is
     // then cut into a few more parts than its in-list entries need, which is harmless; finding the plane of every tile
     // here cost 8 us of this latency-critical kernel.)
-    auto length = [&](int t) {
+    auto length0 = [&](int t) {
         const int c = a.bins.counts[t];
         if (!a.prev_counts) return c;
         const int p = a.prev_counts[t];
         return c > p ? c : p;
+    };
+    auto length = [&](int t) {                       // tiles beyond the registers: first pass fills the LDS snapshot
+        const int k = t - ORDER_REGS * 1024;
+        return k < ORDER_LDS ? lcache[k] : length0(t);
     };
     int cnt[ORDER_REGS];
     int mine = 0;
 #pragma unroll
     for (int q = 0; q < ORDER_REGS; ++q) {
         const int t = tid + q * 1024;
-        cnt[q] = t < n_tiles ? length(t) : 0;
+        cnt[q] = t < n_tiles ? length0(t) : 0;
         mine += cnt[q];
     }
-    for (int t = tid + ORDER_REGS * 1024; t < n_tiles; t += 1024) mine += length(t);
+    for (int t = tid + ORDER_REGS * 1024; t < n_tiles; t += 1024) {      // (a thread reads back only what it wrote itself)
+        const int c = length0(t), k = t - ORDER_REGS * 1024;
+        if (k < ORDER_LDS) lcache[k] = c;
+        mine += c;
+    }
     for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
     if ((tid & 63) == 0 && mine) atomicAdd(&total, mine);
     __syncthreads();
@@ -179,7 +180,6 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     __shared__ int hist[TILE_CELLS];                              // per-cell counts, then start offsets
     __shared__ int n_contrib;
     const int tid = threadIdx.x;
-    TILE_STAMP(0);
     if (a.bins.split_state && (int)blockIdx.x >= a.bins.split_state[a.n_tiles]) return;       // the grid covers the item CAPACITY
     const unsigned item = (unsigned)a.bins.order[blockIdx.x];
     const int tile = (int)(item & 0xfffffu), part = (int)((item >> 20) & 63u), n_parts = (item >> 26) ? (int)(item >> 26) : 1;
@@ -210,42 +210,11 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         n_spill = ns < a.bins.spill_cap ? ns : a.bins.spill_cap;
     }
     const unsigned* lst = a.bins.lists + (size_t)(a.bins.list_off[pidx] + (long long)tile * cap) * MNE_ENTRY_WORDS;
-    // Adam operands of this thread's elements, requested BEFORE the list passes so that the HBM stream of the
-    // sweep (24 B/param) overlaps the LDS accumulation instead of following it (TILE_PREFETCH: 0 none, 1 p+m, 2 p+m+v)
     constexpr int NIT = (TILE_CELLS * MNE_C / 4) / TILE_THREADS;
     PlaneOpt o = a.opt[pidx];
-    float* P = (float*)pl.data;
-    float4 pre_p[NIT], pre_m[NIT], pre_v[NIT];
-#if TILE_PREFETCH == 3
-    // mode 3: the sweep's operands are requested BEHIND the first pass's entry and tape-row loads (vmcnt retires in
-    // order: waiting for those then leaves these in flight), so they land while steps B..D of that pass run
-    auto fetch_operands = [&]() {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i4 = it * TILE_THREADS + tid;
-            const int y = i4 / (MNE_TILE * MNE_C / 4), x4 = i4 % (MNE_TILE * MNE_C / 4);
-            const int gy = ty0 * MNE_TILE + y, gx = tx0 * MNE_TILE + x4 / (MNE_C / 4);
-            if (gy < pl.h && gx < pl.w) {
-                const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + (x4 % (MNE_C / 4)) * 4;
-                pre_p[it] = *(const float4*)(P + off); pre_m[it] = *(const float4*)(o.m + off); pre_v[it] = *(const float4*)(o.v + off);
-            }
-        }
-    };
-#elif TILE_PREFETCH
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i4 = it * TILE_THREADS + tid;
-        const int y = i4 / (MNE_TILE * MNE_C / 4), x4 = i4 % (MNE_TILE * MNE_C / 4);
-        const int gy = ty0 * MNE_TILE + y, gx = tx0 * MNE_TILE + x4 / (MNE_C / 4);
-        if (gy < pl.h && gx < pl.w) {
-            const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + (x4 % (MNE_C / 4)) * 4;
-            pre_p[it] = *(const float4*)(P + off); pre_m[it] = *(const float4*)(o.m + off);
-#if TILE_PREFETCH >= 2
-            pre_v[it] = *(const float4*)(o.v + off);
-#endif
-        }
-    }
-#endif
+    if (a.clk.bias_table) clock_bias(a.clk, o.lr, o.step, o.step_size, o.bc2_sqrt);       // graph replay: step from device memory
+    // (requesting the sweep's operands before / behind the first list pass was measured at three depths: no gain,
+    // profiles/r03_prefetch_and_decode12_negative.txt)
     // lane layout of the row work: 8 lanes x float4 = the 32 channels of one gradient row
     const int sub = tid & 7, grp = tid >> 3;
     const float* dfeat = a.tape + a.t_dfeat + set * MNE_FEAT + lvl * MNE_C + sub * 4;
@@ -257,11 +226,9 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     const int chunk = (n_list + n_parts - 1) / n_parts;
     const int e_lo = part * chunk < n_list ? part * chunk : n_list;
     const int e_hi = part == n_parts - 1 ? n_total : ((part + 1) * chunk < n_list ? (part + 1) * chunk : n_list);
-    TILE_STAMP(1);
     for (int p0 = e_lo; p0 < e_hi; p0 += PASS_ENTRIES) {
         for (int i = tid; i < TILE_CELLS; i += TILE_THREADS) hist[i] = 0;
         __syncthreads();
-        if (p0 == e_lo) TILE_STAMP(2);
         // ---- A: this thread's entry (kept in registers), its contributions ranked per cell
         int cellk[4] = {-1, -1, -1, -1}, rank[4] = {0, 0, 0, 0};
         float wq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -291,7 +258,6 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             erow[tid] = row;
         }
         __syncthreads();
-        if (p0 == e_lo) TILE_STAMP(3);
         // ---- every entry's gradient row (this plane level: 32 floats) is fetched ONCE per pass, by the
         // 8-lane groups round-robin, all loads in flight together; its (up to four) corner contributions
         // then read it from LDS.  The loads overlap steps B and C.
@@ -301,9 +267,6 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             const unsigned row = erow[j * TILE_GROUPS + grp];
             grow[j] = row != 0xffffffffu ? *(const float4*)(dfeat + (size_t)row * a.row_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-#if TILE_PREFETCH == 3
-        if (p0 == e_lo) { MNE_SCHED_BARRIER(); fetch_operands(); MNE_SCHED_BARRIER(); }
-#endif
         // ---- B: counts -> exclusive start offsets (one wave, 4 cells per lane)
         if (tid < MNE_WAVE) {
             const int v0 = hist[4 * tid], v1 = hist[4 * tid + 1], v2 = hist[4 * tid + 2], v3 = hist[4 * tid + 3];
@@ -330,7 +293,6 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
 #pragma unroll
         for (int j = 0; j < PASS_ENTRIES / TILE_GROUPS; ++j) *(float4*)(stage + (j * TILE_GROUPS + grp) * MNE_C + sub * 4) = grow[j];
         __syncthreads();
-        if (p0 == e_lo) TILE_STAMP(4);
         // ---- D: equal ranges of the sorted contributions, one per 8-lane group; a run of equal cells is
         // summed by the group in whose range it STARTS (that group reads on past its range end, the next
         // one skips to the end of the run using the start offsets), so the LDS tile is only ever
@@ -388,9 +350,6 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         __syncthreads();
     }
     if (!empty) __syncthreads();
-#if TILE_PREFETCH == 3
-    if (e_hi <= e_lo) fetch_operands();
-#endif
     if (n_parts > 1) {
         // ---- partial tile -> split scratch; the part that arrives last sums all of them and goes on to Adam.
         // Hand-off between workgroups on possibly different XCDs (L2s not coherent): plain stores, every wave drains
@@ -422,7 +381,6 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         __syncthreads();
         if (tid == 0) a.bins.split_state[tile] = 0;                                  // arrival counter ready for the next call
     }
-    TILE_STAMP(5);
     if constexpr (OV == 1) {                                   // ---- export the shared cells' gradient, nothing else
         for (int it = 0; it < NIT; ++it) {
             const int i4 = it * TILE_THREADS + tid;
@@ -438,6 +396,7 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         return;
     }
     // ---- Adam on the tile: 16 rows x (16 cells x 32 ch) = 2048 float4
+    const bool f16 = a.sc.plane_f16 != 0;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i4 = it * TILE_THREADS + tid;
@@ -447,13 +406,9 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         if (gy < pl.h && gx < pl.w) {
             const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + ch4 * 4;
             const size_t offmv = off;    // (moments stored tile-major were measured: no DRAM-locality effect, profiles/r02_tile_adam_variants.txt)
-#if TILE_PREFETCH >= 2
-            float4 p = pre_p[it], m = pre_m[it], v = pre_v[it];
-#elif TILE_PREFETCH == 1
-            float4 p = pre_p[it], m = pre_m[it], v = *(float4*)(o.v + off);
-#else
-            float4 p = *(float4*)(P + off), m = *(float4*)(o.m + offmv), v = *(float4*)(o.v + offmv);
-#endif
+            // parameters: fp32, or half precision (mne_scene_t.plane_f16: p32 = float(p16) -> Adam in fp32 -> round to nearest)
+            float4 p = f16 ? half4_to_float4(*(const uint2*)((const _Float16*)pl.data + off)) : *(const float4*)((const float*)pl.data + off);
+            float4 m = *(float4*)(o.m + offmv), v = *(float4*)(o.v + offmv);
             float4 gg = empty ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)g)[i4];
             if constexpr (OV == 2) {
                 if (shared_tile) {
@@ -474,14 +429,11 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             }
             adam_elem(p.x, gg.x, m.x, v.x, o); adam_elem(p.y, gg.y, m.y, v.y, o);
             adam_elem(p.z, gg.z, m.z, v.z, o); adam_elem(p.w, gg.w, m.w, v.w, o);
-            *(float4*)(P + off) = p; *(float4*)(o.m + offmv) = m; *(float4*)(o.v + offmv) = v;
+            if (f16) *(uint2*)((_Float16*)pl.data + off) = float4_to_half4(p);
+            else *(float4*)((float*)pl.data + off) = p;
+            *(float4*)(o.m + offmv) = m; *(float4*)(o.v + offmv) = v;
         }
     }
-    TILE_STAMP(6);
-#ifdef TILE_PROFILE
-    if (tid == 0 && blockIdx.x < 4096)
-        ((unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 8192) * MNE_SPILL_WORDS))[blockIdx.x * 8 + 7] = (unsigned long long)cnt;
-#endif
     if (tid == 0) {
         if (a.prev_counts) a.prev_counts[tile] = cnt;
         a.bins.counts[tile] = 0;                                               // ready for the next iteration

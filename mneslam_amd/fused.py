@@ -31,10 +31,13 @@ class FusedStep:
 
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
                  tile_capacity=None, spill_capacity=None, shared_decoder=False, overlap=True, overlap_peers=None,
-                 ):
+                 use_graph=None):
         """scatter="binned": plane gradients are accumulated per 16x16-cell tile in LDS and Adam is applied
         in the same kernel (csrc/tile_adam.hip; no gradient buffers).  scatter="atomics": global
-        atomic adds into persistent gradient buffers + the streaming Adam kernel."""
+        atomic adds into persistent gradient buffers + the streaming Adam kernel.
+        use_graph (EXTENSION, BASELINE configs[4] "hipGraph-captured mapping iteration"; default off / env MNE_GRAPH):
+        steady-state iterations are recorded once into a HIP graph and replayed -- "two_stream" captures the two-stream
+        schedule of ``step``, "one_stream" the same launches on one stream (see ``_record``)."""
         if scatter not in ("binned", "atomics"):
             raise ValueError("scatter must be binned|atomics")
         self.scatter = scatter
@@ -79,8 +82,9 @@ class FusedStep:
             for p in self.planes:
                 st = optimizer._state(p)
                 if "grad_buffer" not in st:
-                    st["grad_buffer"] = torch.zeros_like(p.data)
+                    st["grad_buffer"] = torch.zeros_like(p.data, dtype=torch.float32)
                 self.grads.append(st["grad_buffer"])
+        self._graph_mode = use_graph
         self.scene = hip_path.scene_struct(self.info, [p.data for p in self.planes], [w.data for w in self.dec_w], self.grads)
         self._alloc_buffers(config, is_co_sdf)
         self.bins = None
@@ -131,6 +135,7 @@ class FusedStep:
                 self.split_scratch = torch.empty(_lib.TILE_SPLIT_PARTS, 16 * 16 * 32, device=dev)
                 self.split_state = torch.zeros(n_tiles + 1, device=dev, dtype=torch.int32)
                 b.split_scratch, b.split_state = self.split_scratch.data_ptr(), self.split_state.data_ptr()
+            self._order_early = n_tiles <= _lib.TILE_ORDER_SNAPSHOT
             self.prev_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
             b.prev_counts = self.prev_counts.data_ptr()
             b.cap, b.spill_cap = tile_capacity, spill_capacity
@@ -195,9 +200,17 @@ class FusedStep:
     def _finish_init(self, overlap):
         # exact early ray termination (decode only the samples a ray needs; csrc/render.hip); False = decode everything
         self.early_termination = os.environ.get("MNE_NO_EARLY_TERMINATION", "0") != "1"
-        # (Recording the steady-state iteration into a HIP graph was measured twice -- 0.570 vs 0.533 ms in round 2, 0.669 vs
-        # 0.488 ms on the round-3 pipeline, profiles/r03_nsb_graph_fp16.txt: the runtime serialises the two captured streams
-        # -- and was removed together with the device clock that fed it.)
+        # Steady-state iterations can be recorded into a HIP graph and replayed (device sampler, prefetching steps): one
+        # hipGraphLaunch per iteration; what changes between iterations (sampling keys, jitter counter, Adam step) is read
+        # from a device clock (mne_clock_t).  OFF by default: the iteration is GPU-bound and its launches are enqueued far
+        # ahead anyway -- replay measured 0.570 vs 0.533 ms (round 2) and 0.669 vs 0.488 ms (round 3, two captured streams:
+        # the runtime serialises them; profiles/r03_nsb_graph_fp16.txt).  use_graph / MNE_GRAPH = two_stream | one_stream.
+        mode = getattr(self, "_graph_mode", None) or os.environ.get("MNE_GRAPH", "")
+        mode = {"": None, "0": None, "1": "two_stream", "2": "one_stream"}.get(mode, mode)
+        if mode not in (None, "two_stream", "one_stream"):
+            raise ValueError("use_graph must be None | 'two_stream' | 'one_stream'")
+        self.use_graph = mode if (self.device.type == "cuda" and self.bins is not None) else None
+        self._graphs = {}
         self.events = None          # set to {} to record HIP events around the dominant launches
         self.overlap = overlap
         self._side, self._ev, self._prefetched, self._planes_pending = None, None, None, False
@@ -244,19 +257,22 @@ class FusedStep:
         return (None if kf_rays is None else kf_rays.data_ptr(), int(n_kf_rays), int(n_save), cur_rays.data_ptr(),
                 poses.data_ptr(), poses.shape[0], int(n_global), int(n_cur), self.iteration)
 
-    def _sample_batch(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st):
-        """R1-R3 for iteration `self.iteration`: ray batch, z samples (+ mask counts), loss coefficients."""
+    def _sample_batch(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st,
+                      clock=None):
+        """R1-R3 for iteration `self.iteration` (or, with ``clock``, for the iteration the device clock holds): ray
+        batch, z samples (+ mask counts), loss coefficients."""
         lib, P, R, S = self.lib, _lib.ptr, int(n_global + n_cur), self.S
-        it = self.iteration
+        it = self.iteration if clock is None else 0
+        ck = C.byref(clock) if clock is not None else None
         # one launch: ray draw + z samples + mask counts + loss coefficients (csrc/render.hip, batch_kernel)
         _lib.check(lib.mne_sample_batch(P(kf_rays), int(n_kf_rays), int(n_save), None, P(cur_rays), cur_rays.shape[0],
                                         P(poses), poses.shape[0], n_global, n_cur, P(idx_global), P(idx_cur),
                                         self.seed, it, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb), P(self.tgt_d),
                                         P(self.idx), C.byref(self.rc), P(u), P(self.tables), it * ((R * S + 3) // 4),
                                         P(self.z_vals), P(self.counts), P(self.ray_counts), P(self.loss_w), P(self.coef),
-                                        st), "mne_sample_batch")
+                                        ck, st), "mne_sample_batch")
 
-    def _decoder_chain(self, R, S, st):
+    def _decoder_chain(self, R, S, st, clock=None):
         """wgrad -> (all-reduce) -> decoder Adam -> loss scalars -> decoder tables of the NEXT render.  Two launches
         (weight-gradient pass; decoder_update_kernel) unless the decoder gradient is shared between agents or a
         cross-check implementation of the weight gradients is selected."""
@@ -268,7 +284,7 @@ class FusedStep:
             if self.shared_decoder:
                 from . import dist as mdist
                 mdist.allreduce_mean_(self.dec_grad)
-            self.opt.step(zero_grad=False, grad_buffers=self.dec_grad_views)      # decoder tensors
+            self.opt.step(zero_grad=False, grad_buffers=self.dec_grad_views, clock=clock)      # decoder tensors
             _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
             self._packed_key = None
             return
@@ -278,17 +294,18 @@ class FusedStep:
         steps = set()
         for k, w in enumerate((w_col0, w_col1, w_sdf0, w_sdf1)):       # decoder.parameters() order
             stt = self.opt._state(w)
-            stt["step"] += 1
+            if clock is None:
+                stt["step"] += 1
             steps.add(stt["step"])
             o.m[k], o.v[k] = stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr()
         if len(steps) != 1:
             raise RuntimeError("the decoder tensors must share one Adam step count")
         o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
         o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
-        o.step = steps.pop()
+        o.step = steps.pop() + (1 if clock is not None else 0)
         _lib.check(lib.mne_decoder_update(C.byref(self.scene), P(self.partials), R, P(self.dec_grad), C.byref(o),
                                           S, P(self.ray_sums), P(self.counts), P(self.losses),
-                                          st), "mne_decoder_update")
+                                          C.byref(clock) if clock is not None else None, st), "mne_decoder_update")
         # the NEXT render's decoder tables, here in the decoder chain (beside the plane update), not in front of that render
         _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
         self._packed_key = self._decoder_key()              # self.packed now holds the tables of these weights
@@ -321,6 +338,8 @@ class FusedStep:
                     p = self.planes[n]
                     if not (p.is_contiguous(memory_format=torch.channels_last) and p.stride(1) == 1):
                         raise ValueError("fused step needs channels_last planes (a plane was re-bound with another layout)")
+                    if (p.dtype == torch.float16) != bool(self.scene.plane_f16):
+                        raise ValueError("a plane was re-bound with another dtype than the step was built for")
                     pl = self.scene.plane[s][o][l]
                     pl.data = p.data_ptr()
                     if self.grads is not None:
@@ -332,6 +351,114 @@ class FusedStep:
         w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
         self.scene.w_sdf0, self.scene.w_sdf1 = w_sdf0.data_ptr(), w_sdf1.data_ptr()
         self.scene.w_col0, self.scene.w_col1 = w_col0.data_ptr(), w_col1.data_ptr()
+
+    # ---------------------------------------------------------------- recorded iteration (HIP graph)
+    def _graph_key(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur):
+        ptrs = tuple(p.data_ptr() for p in self.planes) + tuple(w.data_ptr() for w in self.dec_w)
+        ptrs += tuple(self.opt._state(p)[k].data_ptr() for p in list(self.planes) + list(self.dec_w)
+                      for k in ("exp_avg", "exp_avg_sq"))
+        return (None if kf_rays is None else kf_rays.data_ptr(), int(n_kf_rays), int(n_save), cur_rays.data_ptr(),
+                cur_rays.shape[0], poses.data_ptr(), poses.shape[0], int(n_global), int(n_cur), ptrs)
+
+    def _make_clock(self, R, n_table=8192):
+        groups = self.opt.param_groups
+        b1, b2 = groups[0]["betas"]
+        if any(tuple(g["betas"]) != (b1, b2) for g in groups):
+            return None                                   # the bias table holds one pair of betas
+        dev = self.device
+        self.clk_iter = torch.zeros(1, device=dev, dtype=torch.int64)
+        self.clk_step = torch.zeros(1, device=dev, dtype=torch.int32)
+        t = [(1.0 - float(b1) ** k, 1.0 - float(b2) ** k) for k in range(1, n_table + 1)]     # C pow(), as the host path
+        self.clk_table = torch.tensor(t, dtype=torch.float64, device=dev)
+        ck = _lib.Clock()
+        ck.iteration, ck.step_offset, ck.bias_table = self.clk_iter.data_ptr(), self.clk_step.data_ptr(), self.clk_table.data_ptr()
+        ck.n_table, ck.beta1, ck.beta2 = n_table, float(b1), float(b2)
+        ck.z_offset_stride = (R * self.S + 3) // 4
+        return ck
+
+    def _record(self, args):
+        """Record one steady-state iteration -- render of the batch that is already in the buffers, plane update, decoder
+        chain, then the NEXT batch -- into a HIP graph.  Everything that changes between iterations (ray-sampling keys,
+        jitter counter, Adam step) is read from the device clock.  'two_stream': the schedule of ``step`` (list appends and
+        plane update on the side stream, joined by captured events); 'one_stream': the same launches in one queue (the
+        render call does its own appends), i.e. no concurrency between the plane update and the decoder chain."""
+        kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur = args
+        lib, P = self.lib, _lib.ptr
+        R, S = int(n_global + n_cur), self.S
+        clock = self._make_clock(R)
+        if clock is None:
+            return None
+        steps = {self.opt._state(p)["step"] for p in list(self.planes) + list(self.dec_w)}
+        if len(steps) != 1:
+            return None                                   # one step offset serves every tensor
+        t0 = steps.pop()
+        two = self.use_graph == "two_stream"
+        if self._side is None:
+            self._streams()
+        side = self._side
+        cap = torch.cuda.Stream(self.device)
+        cap.wait_stream(torch.cuda.current_stream(self.device))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            st = C.c_void_p(cap.cuda_stream)
+            st2 = C.c_void_p(side.cuda_stream) if two else st
+            opts = self._render_opts(None)[0]
+            if not two:
+                opts.external_bin, opts.event_after_decode = 0, None
+            self.n_active = R
+            _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),
+                                            P(self.tgt_rgb), P(self.tgt_d), P(self.z_vals),
+                                            P(self.ray_counts) if self.early_termination else None, P(self.packed),
+                                            P(self.coef), P(self.rgb), P(self.depth), P(self.raw), P(self.ray_sums),
+                                            P(self.tape), R * S, P(self.tape_rows), P(self.ray_tiles), C.byref(self.bins),
+                                            P(self.ws), self.ws_bytes, C.byref(opts), st), "mne_render_fused")
+            early = two and self._ev_decode is not None
+            if early:
+                side.wait_event(self._ev_decode)
+                self._tile_bin(0, opts, st2)
+                if self._order_early:
+                    _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
+                self._ev[2].record(side)
+            if two:
+                side.wait_stream(cap)
+            if not (early and self._order_early):
+                _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
+            for k in range(len(self.planes)):
+                self.plane_opt[k].step = t0 + 1
+            _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins),
+                                         C.byref(clock), st2), "mne_tile_adam")
+            self._decoder_chain(R, S, st, clock=clock)      # leaves the NEXT iteration's decoder tables in self.packed
+            _lib.check(lib.mne_clock_advance(P(self.clk_iter), None, st), "mne_clock_advance")
+            if early:
+                cap.wait_event(self._ev[2])               # the appends have read this batch: its buffers may be overwritten
+            self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st, clock=clock)
+            if two:
+                cap.wait_stream(side)
+            _lib.check(lib.mne_clock_advance(None, P(self.clk_step), st), "mne_clock_advance")
+        return {"graph": g, "clock": clock, "t0": t0, "iter_dev": None, "step_dev": None, "packed_for": None,
+                "keep": (self.clk_iter, self.clk_step, self.clk_table)}
+
+    def _replay(self, rec):
+        """Launch the recorded iteration; the device clock is first brought in line with the host's counters when
+        eager steps ran in between."""
+        if self._planes_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._ev[1])
+            self._planes_pending = False
+        step_now = self.opt._state(self.planes[0])["step"]
+        clk_iter, clk_step, _ = rec["keep"]
+        if rec["iter_dev"] != self.iteration:
+            clk_iter.fill_(self.iteration)
+        if rec["step_dev"] != step_now - rec["t0"]:
+            clk_step.fill_(step_now - rec["t0"])
+        if rec["packed_for"] != self.iteration:           # after eager steps: the decoder tables are one Adam step old
+            _lib.check(self.lib.mne_pack_decoder(C.byref(self.scene), _lib.ptr(self.packed), _lib.stream_for(self.rays_o)),
+                       "mne_pack_decoder")
+        rec["graph"].replay()
+        self.iteration += 1
+        for p in list(self.planes) + list(self.dec_w):
+            self.opt._state(p)["step"] += 1
+        rec["iter_dev"], rec["step_dev"], rec["packed_for"] = self.iteration, step_now + 1 - rec["t0"], self.iteration
+        self._packed_key = self._decoder_key()
 
     def step(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global=None, idx_cur=None, u=None,
              prefetch=False):
@@ -352,6 +479,20 @@ class FusedStep:
         ev = self._ev if side is not None else [None] * 4
         host_batch = idx_global is not None or idx_cur is not None or u is not None
         key = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
+        # ---- steady state (batch already drawn, next call promised alike): one hipGraphLaunch instead of ~14 launches
+        if (self.use_graph and prefetch and not host_batch and side is not None and self._prefetched == key
+                and self.events is None and not self.shared_decoder and self.tile_overlap is None):
+            gkey = self._graph_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
+            rec = self._graphs.get(gkey)
+            if rec is None:
+                if len(self._graphs) >= 4:
+                    self._graphs.clear()
+                self.synchronize()
+                rec = self._graphs[gkey] = self._record((kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)) or False
+            if rec:
+                self._replay(rec)
+                self._prefetched = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
+                return
         # Stream roles.  The caller's stream carries the whole dependency chain of the decoder:
         #   [batch] -> pack -> render (decode .. backward) -> wgrad -> decoder Adam -> loss scalars -> [next batch]
         # and the plane update (tile_order + tile_adam, HBM-bound, the longest kernel) runs on the side stream
@@ -393,11 +534,14 @@ class FusedStep:
                 # processing order of the tiles from the list lengths as they are now -- the deferred rays' appends (a
                 # handful in steady state) come later and do not change which lists are the heavy ones; tile_adam_kernel
                 # reads the final lengths itself.  Keeps tile_order_kernel (12 us + a launch gap) off the critical path.
-                _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
+                # (Only while the kernel can snapshot every list length, MNE_TILE_ORDER_SNAPSHOT: beyond that it would re-read
+                # lengths that the deferred rays' appends are changing under it)
+                if self._order_early:
+                    _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
                 ev[2].record(side)                      # "appends done": the batch buffers (rays, z, targets, coefficients)
                 self._bin_pending = True                # may be overwritten by the next batch only after this
             self._after(side, ev[0], main)              # the deferred rays' appends are part of the render call (caller's stream)
-            if self._ev_decode is None or side is None:
+            if self._ev_decode is None or side is None or not self._order_early:
                 _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
             for k, p in enumerate(self.planes):
                 stt = self.opt._state(p)
@@ -413,9 +557,9 @@ class FusedStep:
                 with torch.cuda.stream(side) if side is not None else _null_ctx():
                     mdist.exchange_buffers([peer for peer, _ in self.overlap_peers], self.ov_send, self.ov_recv)
                 _lib.check(lib.mne_tile_adam_shared(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins),
-                                                    C.byref(self.tile_overlap), st2), "mne_tile_adam_shared")
+                                                    C.byref(self.tile_overlap), None, st2), "mne_tile_adam_shared")
             else:
-                _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), st2),
+                _lib.check(lib.mne_tile_adam(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins), None, st2),
                            "mne_tile_adam")
             self._mark("adam", e0, stream=side)
             if side is not None:

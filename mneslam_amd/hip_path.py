@@ -37,8 +37,8 @@ def as_channels_last(plane):
     plane in another layout, e.g. a peer's NCHW checkpoint; the copy stays in the autograd graph)."""
     if plane.dim() != 4 or plane.shape[0] != 1:
         raise ValueError(f"plane must be [1,C,H,W], got {tuple(plane.shape)}")
-    if plane.dtype != torch.float32:
-        raise TypeError("planes must be float32")
+    if plane.dtype not in (torch.float32, torch.float16):
+        raise TypeError("planes must be float32 (or float16: the half-precision plane storage extension)")
     if plane.is_contiguous(memory_format=torch.channels_last) and plane.stride(1) == 1:
         return plane
     return plane.contiguous(memory_format=torch.channels_last)
@@ -46,7 +46,8 @@ def as_channels_last(plane):
 
 def scene_struct(model_info, planes_cl, dec_w, grads=None):
     """Fill mne_scene_t.  ``planes_cl``: flat list in all_planes order
-    (xy[coarse,fine], xz[...], yz[...], then the colour planes); ``grads``: same order or None."""
+    (xy[coarse,fine], xz[...], yz[...], then the colour planes); ``grads``: same order or None.  Planes are fp32, or ALL
+    float16 (EXTENSION, BASELINE configs[4]: half-precision plane storage, mne_scene_t.plane_f16)."""
     sc = _lib.Scene()
     n_sets = len(planes_cl) // 6
     sc.n_sets = n_sets
@@ -54,6 +55,10 @@ def scene_struct(model_info, planes_cl, dec_w, grads=None):
     sc.hidden, sc.hidden_color = model_info["hidden"], model_info["hidden_color"]
     sc.geo_feat_dim, sc.n_bins = model_info["geo_feat_dim"], model_info["n_bins"]
     sc.bb_is_f64 = 1 if model_info["bb_is_f64"] else 0
+    dtypes = {p.dtype for p in planes_cl}
+    if len(dtypes) > 1 or not dtypes <= {torch.float32, torch.float16}:
+        raise TypeError(f"planes must all be float32 or all float16, got {sorted(map(str, dtypes))}")
+    sc.plane_f16 = 1 if dtypes == {torch.float16} else 0
     for s in range(n_sets):
         for o in range(3):
             for l in range(2):
@@ -125,7 +130,7 @@ class RenderFunction(torch.autograd.Function):
         ray_counts = torch.empty(R, _lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
         seed, offset = seed_offset
         _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u_c), _lib.ptr(tables), seed, offset,
-                                    _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), st), "mne_sample_z")
+                                    _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), None, st), "mne_sample_z")
         sc = scene_struct(info, [p.detach() for p in planes], [w.detach() for w in dec_w])
         packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
         _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
@@ -166,7 +171,8 @@ class RenderFunction(torch.autograd.Function):
         # no zero-fill of 150-300 MB, no scatter)
         first_plane = 8
         want_planes = any(ctx.needs_input_grad[first_plane:first_plane + n_planes])
-        grads = [torch.zeros_like(p) for p in planes] if want_planes else None     # channels_last preserved
+        # (fp32 accumulators also for half-precision planes; autograd gets them in the planes' dtype below)
+        grads = [torch.zeros_like(p, dtype=torch.float32) for p in planes] if want_planes else None     # channels_last preserved
         sc = scene_struct(info, list(planes), list(dec_w), grads)
         coef = None
         if ctx.want_losses and g_losses is not None:
@@ -199,7 +205,8 @@ class RenderFunction(torch.autograd.Function):
         g_sdf0 = dgrad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0)
         g_sdf1 = dgrad[n0 + n1 + n2:].view_as(w_sdf1)
         return (None, None, d_o if ctx.needs_input_grad[2] else None, d_d if ctx.needs_input_grad[3] else None,
-                None, None, None, None, *(grads if grads is not None else [None] * n_planes),
+                None, None, None, None,
+                *([g if g.dtype == p.dtype else g.to(p.dtype) for g, p in zip(grads, planes)] if grads is not None else [None] * n_planes),
                 g_sdf0, g_sdf1, g_col0, g_col1)
 
 
@@ -224,7 +231,7 @@ def render_maps(info, tables, rays_o, rays_d, target_d, u, seed_offset, planes, 
     ray_counts = torch.empty(R, _lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
     seed, offset = seed_offset
     _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u_c), _lib.ptr(tables), seed, offset,
-                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), st), "mne_sample_z")
+                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), None, st), "mne_sample_z")
     sc = scene_struct(info, [as_channels_last(p.detach()) for p in planes], [w.detach() for w in dec_w])
     packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
     _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
@@ -287,7 +294,7 @@ def _hash_forward(lib, info, grid_cfg, tables, rays_o, rays_d, tgt_rgb, tgt_d, u
     ray_counts = torch.empty(R, _lib.N_COUNT, device=dev, dtype=torch.int32) if has_d else None
     seed, offset = seed_offset
     _lib.check(lib.mne_sample_z(C.byref(rc), R, _lib.ptr(tgt_d), _lib.ptr(u), _lib.ptr(tables), seed, offset,
-                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), st), "mne_sample_z")
+                                _lib.ptr(z_vals), _lib.ptr(counts), _lib.ptr(ray_counts), None, st), "mne_sample_z")
     sc = _hash_scene(info, dec_w)
     packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(sc)), **opts)
     _lib.check(lib.mne_pack_decoder(C.byref(sc), _lib.ptr(packed), st), "mne_pack_decoder")
@@ -512,6 +519,11 @@ class PoseAlignment:
         ps.lr_rot, ps.lr_trans, (ps.beta1, ps.beta2), ps.eps = float(lr_rot), float(lr_trans), map(float, betas), float(eps)
         st = _lib.stream_for(self.dirs)
         _lib.check(lib.mne_pack_decoder(C.byref(self.scene), _lib.ptr(self.packed), st), "mne_pack_decoder")   # weights are fixed here
+        # The best pose starts as the START pose (mp_slam/mapper.py:386: best_target_c2w_est = target_c2w_initial.clone()):
+        # with zero iterations, or when every loss is NaN, best() then returns a proper transform, never a singular matrix.
+        _lib.check(lib.mne_pose_rays(C.byref(self.ps), n, _lib.ptr(self.dirs), _lib.ptr(self.rays_o), _lib.ptr(self.rays_d), st),
+                   "mne_pose_rays")
+        self.best_c2w.copy_(self.c2w)
 
     def step(self, u=None, seed_offset=(0, 0)):
         """One iteration: rays from the current parameters, render, loss, ray gradients, Adam.  ``u`` [n, S] = the host's
@@ -522,7 +534,7 @@ class PoseAlignment:
         _lib.check(lib.mne_pose_rays(C.byref(self.ps), n, P(self.dirs), P(self.rays_o), P(self.rays_d), st), "mne_pose_rays")
         u_c = _f32c(u, "u") if u is not None else None
         _lib.check(lib.mne_sample_z(rc, n, None, P(u_c), P(self.tables), seed_offset[0], seed_offset[1], P(self.z), P(self.counts),
-                                    None, st), "mne_sample_z")
+                                    None, None, st), "mne_sample_z")
         _lib.check(lib.mne_render_forward(sc, rc, n, S, P(self.rays_o), P(self.rays_d), None, None, P(self.z), P(self.packed),
                                           P(self.rgb), P(self.depth), P(self.aux[0]), P(self.aux[1]), P(self.aux[2]), P(self.raw),
                                           None, None, 0, st), "mne_render_forward")

@@ -60,9 +60,14 @@ class JointEncoding(nn.Module):
             planes_xy.append(torch.empty([1, c_dim, *gs[1:]]).normal_(mean=0, std=0.01))
             planes_xz.append(torch.empty([1, c_dim, gs[0], gs[2]]).normal_(mean=0, std=0.01))
             planes_yz.append(torch.empty([1, c_dim, *gs[:2]]).normal_(mean=0, std=0.01))
+        # EXTENSION (BASELINE configs[4], "fp16 features + fp32 accumulate"): grid.plane_dtype 'fp16' STORES the planes in half
+        # precision -- the fp32 draws above rounded to nearest; no fp32 copy exists.  Lookups convert on load, everything
+        # after them (interpolation, decoder, gradients, their sums, Adam's moments) stays fp32; include/mneslam_hip.h,
+        # mne_scene_t.plane_f16.  Absent / 'fp32' = the reference's storage.
+        dtype = {"fp32": torch.float32, "fp16": torch.float16}[self.config["grid"].get("plane_dtype", "fp32")]
         for planes in (planes_xy, planes_xz, planes_yz):
             for i, p in enumerate(planes):
-                p = p.to(self.device).contiguous(memory_format=torch.channels_last)
+                p = p.to(self.device, dtype).contiguous(memory_format=torch.channels_last)
                 if p.device.type == "cpu":
                     p.share_memory_()
                 planes[i] = p

@@ -188,15 +188,19 @@ class FusedMappingMixin:
         on the device): no autograd graph, no torch.optim step, no host synchronisation inside the loop.  Used when the
         host's ``matrix_from_tensor`` IS an axis-angle map (probed: the reference's ``rot_rep: 'axis_angle'``,
         optimization/utils.py:161-197, or one relative to a constant rotation) and its optimizer is plain Adam over
-        (rot, trans); returns None otherwise and the caller runs the host's own loop."""
+        (rot, trans); returns None otherwise and the caller runs the host's own loop.  ``pose_opt`` itself is NOT stepped:
+        its state (step counts, moments) stays as it was; the reference builds a fresh optimizer per alignment
+        (mneslam_mp.py:577-584) and drops it afterwards."""
         from .. import hip_path
-        if not isinstance(pose_opt, torch.optim.Adam) or len(pose_opt.param_groups) != 2:
+        if steps < 1 or not isinstance(pose_opt, torch.optim.Adam) or len(pose_opt.param_groups) != 2:
             return None
         if not getattr(model, "all_planes", None):           # ray gradients need the plane encoding (HashJointEncoding has none)
             return None
         g_rot, g_trans = pose_opt.param_groups
         same = all(g_rot[k] == g_trans[k] for k in ("betas", "eps")) and not any(
-            g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") for g in (g_rot, g_trans))
+            g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or g.get("capturable")
+            or not isinstance(g["lr"], (int, float))                # tensor learning rates: the host's own loop handles them
+            for g in (g_rot, g_trans))
         if not same or g_rot["params"][0] is not rot or g_trans["params"][0] is not trans:
             return None
         r_base = hip_path.probe_axis_angle(self.slam.matrix_from_tensor, rot, trans)

@@ -15,10 +15,10 @@ from . import _lib
 
 
 def _dense_like(p, t):
-    """``t`` laid out exactly like ``p`` (same strides), copying only if needed."""
-    if t.stride() == p.stride() and t.dtype == p.dtype:
+    """``t`` as an fp32 tensor laid out exactly like ``p`` (same strides), copying only if needed."""
+    if t.stride() == p.stride() and t.dtype == torch.float32:
         return t
-    out = torch.empty_like(p)            # preserve_format
+    out = torch.empty_like(p, dtype=torch.float32)            # preserve_format
     out.copy_(t)
     return out
 
@@ -32,13 +32,14 @@ class FusedAdam(torch.optim.Optimizer):
         st = self.state[p]
         if len(st) == 0:
             st["step"] = 0
-            st["exp_avg"] = torch.zeros_like(p)          # preserve_format: same physical layout as p
-            st["exp_avg_sq"] = torch.zeros_like(p)
+            # preserve_format: same physical layout as p; the moments are fp32 also for half-precision planes
+            st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
+            st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
         return st
 
     def segments(self, zero_grad_buffers=None, advance=True):
-        """ctypes segment array for every parameter that has a gradient (advances the step counts unless ``advance`` is
-        False)."""
+        """ctypes segment array for every parameter that has a gradient (advances the step counts unless
+        ``advance`` is False: a recorded iteration reads its step from the device clock, ``step`` is then the base)."""
         segs = []
         keep = []
         for group in self.param_groups:
@@ -47,8 +48,8 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad if zero_grad_buffers is None else zero_grad_buffers.get(p)   # explicit map: only those params
                 if g is None:
                     continue
-                if p.dtype != torch.float32:
-                    raise TypeError("FusedAdam supports float32 parameters")
+                if p.dtype not in (torch.float32, torch.float16):
+                    raise TypeError("FusedAdam supports float32 parameters (and float16 planes: fp32 gradient and moments)")
                 if not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)):
                     raise ValueError("FusedAdam needs dense parameters")
                 st = self._state(p)
@@ -63,21 +64,26 @@ class FusedAdam(torch.optim.Optimizer):
                 s.lr, s.beta1, s.beta2 = float(group["lr"]), float(b1), float(b2)
                 s.eps, s.weight_decay = float(group["eps"]), float(group["weight_decay"])
                 s.step = st["step"] if advance else st["step"] + 1
+                s.p_f16 = 1 if p.dtype == torch.float16 else 0
                 segs.append((s, p))
         return segs, keep
 
     @torch.no_grad()
-    def step(self, closure=None, zero_grad=False, grad_buffers=None):
+    def step(self, closure=None, zero_grad=False, grad_buffers=None, clock=None):
+        """``clock`` (mneslam_amd._lib.Clock, graph recording only): the kernel adds the device step offset to the
+        parameters' CURRENT step + 1 and the python step counts are left alone (the caller advances them per replay)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        segs, keep = self.segments(grad_buffers)
+        segs, keep = self.segments(grad_buffers, advance=clock is None)
         if not segs:
             return loss
         lib = _lib.load()
         for i in range(0, len(segs), 32):
             chunk = segs[i:i + 32]
             arr = (_lib.AdamSeg * len(chunk))(*[s for s, _ in chunk])
-            _lib.check(lib.mne_adam_step(arr, len(chunk), 1 if zero_grad else 0, _lib.stream_for(chunk[0][1])), "mne_adam_step")
+            _lib.check(lib.mne_adam_step(arr, len(chunk), 1 if zero_grad else 0,
+                                         C.byref(clock) if clock is not None else None, _lib.stream_for(chunk[0][1])),
+                       "mne_adam_step")
         return loss

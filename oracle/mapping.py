@@ -183,3 +183,84 @@ def first_frame_mapping(scene: OracleScene, opt: OracleAdam, cfg, batch, H, W, n
         opt.step()
         if log is not None:
             log.append({k: float(v) for k, v in ret.items() if v.numel() == 1} | {"loss": float(loss)})
+
+
+# --------------------------------------------------------------------------------------
+# one iteration's forward + backward in ray chunks (checker convenience for batches whose autograd graph does not fit
+# in host memory: INS Indoor, 2048 rays x 1045 samples)
+# --------------------------------------------------------------------------------------
+def forward_backward_chunked(scene: OracleScene, cfg, rays_o, rays_d, target_rgb, target_d, z_vals, is_co_sdf=None,
+                             impl="grid_sample", chunk=256):
+    """``scene.forward`` + ``loss_from_ret(...).backward()`` (model/scene_rep.py:549-611, mneslam_mp.py:350-372) evaluated
+    chunk by chunk over the rays.  Every loss of the reference is a sum of per-ray / per-sample terms divided by a count
+    that depends on z and the target depth alone (mask sizes, model/scene_rep.py:489-499, model/utils.py:131-145), so the
+    counts of the WHOLE batch are taken first (no network), each chunk then contributes  weight_k * (its sum) / count_k
+    to the total and its ``backward()`` accumulates into the same ``.grad`` tensors: identical to the unchunked call up to
+    fp32 summation order (checked in tests/test_oracle_golden.py).  Returns the detached loss dict (+ 'loss')."""
+    pc = scene.pc
+    co = cfg["is_co_sdf"] if is_co_sdf is None else is_co_sdf
+    tr, mp = cfg["training"], cfg["mapping"]
+    R, S = z_vals.shape
+    td = target_d.reshape(-1)
+    z = z_vals
+    with torch.no_grad():
+        valid = (td > 0.0) & (td < pc.depth_trunc)
+        has_d = td > 0
+        g = td[:, None]
+        t = pc.truncation
+        front = (z < (g - t)) & has_d[:, None]
+        back = (z > (g + t)) & has_d[:, None]
+        center = (z > (g - 0.4 * t)) & (z < (g + 0.4 * t)) & has_d[:, None]
+        tail = (~front) & (~back) & (~center) & has_d[:, None]
+        n_front, n_center, n_tail = int(front.sum()), int(center.sum()), int(tail.sum())
+        tc = pc.trunc * pc.sc_factor
+        cf = z < (g - tc)
+        cs = (~cf) & (~(z > (g + tc))) & (g > 0.0)
+        n_fs, n_sdf = int(cf.sum()), int(cs.sum())
+        tot = n_fs + n_sdf
+        fs_w = torch.tensor(1.0) - torch.tensor(float(n_fs)) / torch.tensor(float(tot))     # fp32, as the reference's tensor ops
+        sdf_w = torch.tensor(1.0) - torch.tensor(float(n_sdf)) / torch.tensor(float(tot))
+        n_valid = int(valid.sum())
+    nan = float("nan")
+    sums = dict(rgb=0.0, depth=0.0, co_fs=0.0, co_sdf=0.0, e_fs=0.0, e_center=0.0, e_tail=0.0)
+    rgb_out, depth_out, raw_out = [], [], []
+    for lo in range(0, R, chunk):
+        sl = slice(lo, min(lo + chunk, R))
+        rd = scene.render_rays(rays_o[sl], rays_d[sl], target_d[sl], None, impl, z_vals=z[sl])
+        sdf, zc, gc = rd["raw"][..., -1], z[sl], g[sl]
+        pred_e, pred_c = zc + sdf * t, zc + sdf * tc
+        part = dict(
+            rgb=((rd["rgb"] - target_rgb[sl]) ** 2).sum(),
+            depth=((rd["depth"] - td[sl]) ** 2)[valid[sl]].sum(),
+            co_fs=((sdf - 1.0) ** 2)[cf[sl]].sum(),
+            co_sdf=((pred_c - gc) ** 2)[cs[sl]].sum(),
+            e_fs=((sdf - 1.0) ** 2)[front[sl]].sum(),
+            e_center=((pred_e - gc) ** 2)[center[sl]].sum(),
+            e_tail=((pred_e - gc) ** 2)[tail[sl]].sum())
+        loss = tr["rgb_weight"] * part["rgb"] / (3.0 * R)
+        if n_valid:
+            loss = loss + tr["depth_weight"] * part["depth"] / n_valid
+        if co:
+            if tot:
+                loss = loss + tr["sdf_weight"] * part["co_sdf"] / (R * S) * sdf_w + tr["fs_weight"] * part["co_fs"] / (R * S) * fs_w
+        else:
+            if n_front:
+                loss = loss + mp["w_sdf_fs"] * part["e_fs"] / n_front
+            if n_center:
+                loss = loss + mp["w_sdf_center"] * part["e_center"] / n_center
+            if n_tail:
+                loss = loss + mp["w_sdf_tail"] * part["e_tail"] / n_tail
+        loss.backward()
+        for k in sums:
+            sums[k] += float(part[k].detach())
+        rgb_out.append(rd["rgb"].detach()); depth_out.append(rd["depth"].detach()); raw_out.append(rd["raw"].detach())
+    T = torch.tensor
+    rgb_loss = T(sums["rgb"] / (3.0 * R))
+    ret = dict(rgb=torch.cat(rgb_out), depth=torch.cat(depth_out), raw=torch.cat(raw_out), z_vals=z,
+               rgb_loss=rgb_loss, depth_loss=T(sums["depth"] / n_valid if n_valid else nan),
+               co_sdf_loss=T(sums["co_sdf"] / (R * S)) * sdf_w, co_fs_loss=T(sums["co_fs"] / (R * S)) * fs_w,
+               e_fs_loss=T(sums["e_fs"] / n_front if n_front else nan),
+               e_center_loss=T(sums["e_center"] / n_center if n_center else nan),
+               e_tail_loss=T(sums["e_tail"] / n_tail if n_tail else nan),
+               psnr=-10.0 * torch.log(rgb_loss.reshape(1)) / torch.log(T([10.0])))
+    return ret

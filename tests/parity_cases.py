@@ -224,7 +224,7 @@ def check_device_sampler(device):
     P = _lib.ptr
     _lib.check(lib.mne_sample_rays(P(a[0]), n_kf * n_save, n_save, None, P(a[1]), HW, P(a[2]), n_kf + 1, n_g, n_c,
                                    P(a[3]), P(a[4]), 0, 0, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(oidx),
-                                   _lib.stream_for(out[0])))
+                                   None, _lib.stream_for(out[0])))
     assert_close(out[0].cpu(), ref_o, rtol=0, atol=0, what="rays_o (bit-exact)")
     assert_close(out[1].cpu(), ref_d, rtol=0, atol=0, what="rays_d (bit-exact)")
     assert_close(out[2].cpu(), ref_rgb, rtol=0, atol=0, what="target rgb")
@@ -233,7 +233,7 @@ def check_device_sampler(device):
     for it in range(3):
         _lib.check(lib.mne_sample_rays(P(a[0]), n_kf * n_save, n_save, None, P(a[1]), HW, P(a[2]), n_kf + 1, n_g, n_c,
                                        None, None, 1234, it, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(oidx),
-                                       _lib.stream_for(out[0])))
+                                       None, _lib.stream_for(out[0])))
         ii = oidx.cpu()
         g, c = ii[:n_g], ii[n_g:]
         assert g.unique().numel() == n_g and int(g.min()) >= 0 and int(g.max()) < n_kf * n_save
@@ -243,7 +243,7 @@ def check_device_sampler(device):
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
     _lib.check(lib.mne_sample_rays(P(a[0]), n_kf * n_save, n_save, None, P(a[1]), HW, P(a[2]), n_kf + 1, n_g, n_c,
                                    None, None, 1234, 0, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(oidx),
-                                   _lib.stream_for(out[0])))
+                                   None, _lib.stream_for(out[0])))
     assert torch.equal(oidx.cpu(), seen[0]), "same (seed, iteration) must give the same batch"
     # spread: owners of the global rows cover every keyframe roughly evenly
     own = torch.bincount(torch.div(torch.cat(seen)[: 3 * n_g].reshape(3, -1)[:, :n_g].reshape(-1), n_save, rounding_mode="trunc"),
@@ -704,8 +704,24 @@ def out_contrib(fs):
     return int(fs.tape_rows.item())
 
 
+# Post-Adam agreement bars.  eps = 1e-15 makes the plane groups' Adam scale-free: where a cell's gradient is fp32 summation
+# noise the step is +-lr whatever its size, so a few cells differ by O(lr) between two summation orders; all others agree to
+# rounding.  The bars are the LARGEST values observed over every case of the GPU suite on MI355X times two
+# (profiles/r04_adam_parity_stats.txt; MNE_PARITY_STATS=<file> appends each case's measured numbers).
+PLANE_ADAM_MEAN, PLANE_ADAM_OUTLIERS = 2e-3, 2e-3
+DEC_ADAM_MEAN, DEC_ADAM_OUTLIERS = 2e-3, 5e-3
+
+
+def _record_stats(what, d):
+    path = os.environ.get("MNE_PARITY_STATS")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(d, case=what, test=os.environ.get("PYTEST_CURRENT_TEST", ""))) + "\n")
+
+
 def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0, small=False, impl="grid_sample",
-                               scatter="binned", poison_tape=True):
+                               scatter="binned", poison_tape=True, oracle_chunk=None):
     """The BENCH path -- bench.Agent: device Feistel ray sampler, Philox jitter, FusedStep on two streams --
     against ONE oracle iteration on the SAME device-drawn batch: the batch (ray indices, rays, targets, z samples)
     is copied back from the device, the oracle (CPU autograd) evaluates forward, the seven losses, backward and
@@ -721,13 +737,17 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     dev = torch.device(device)
     ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, small=small, path="fused", scatter=scatter)
     fs, m = ag.fused, ag.model
+    # EXTENSION (BASELINE configs[4]): grid.plane_dtype 'fp16' -- the planes are STORED in half precision; the oracle holds the
+    # same values in fp32 tensors, computes everything in fp32 and rounds the parameters to fp16 after its Adam step
+    half = cfg["grid"].get("plane_dtype", "fp32") == "fp16"
+    assert all((p.dtype == torch.float16) == half for lst in m.all_planes for p in lst)
     for _ in range(warm_steps):
         ag.step()
     fs.synchronize()
     if dev.type == "cuda":
         torch.cuda.synchronize()
     cpu = lambda t: t.detach().to("cpu", copy=True)
-    planes0 = [[cpu(p).contiguous() for p in lst] for lst in m.all_planes]
+    planes0 = [[cpu(p).float().contiguous() for p in lst] for lst in m.all_planes]
     dec0 = {k: cpu(v) for k, v in m.decoder.state_dict().items()}
     opt_state0 = [{k: (cpu(v).contiguous() if torch.is_tensor(v) else v) for k, v in ag.opt._state(p).items()}
                   for lst in m.all_planes for p in lst]
@@ -776,9 +796,12 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
             g_.t = int(states[0]["step"])
             g_.m = [st["exp_avg"].clone() for st in states]
             g_.v = [st["exp_avg_sq"].clone() for st in states]
-    ret = sc.forward(rays_o, rays_d, tgt_rgb, tgt_d[:, None], impl=impl, z_vals=z)
-    loss = omap.loss_from_ret(cfg, ret, is_co_sdf=cfg["is_co_sdf"])
-    loss.backward()
+    if oracle_chunk:         # batches whose autograd graph does not fit in host memory (INS Indoor: 2048 x 1045): chunks of rays
+        ret = omap.forward_backward_chunked(sc, cfg, rays_o, rays_d, tgt_rgb, tgt_d[:, None], z, impl=impl, chunk=oracle_chunk)
+    else:
+        ret = sc.forward(rays_o, rays_d, tgt_rgb, tgt_d[:, None], impl=impl, z_vals=z)
+        loss = omap.loss_from_ret(cfg, ret, is_co_sdf=cfg["is_co_sdf"])
+        loss.backward()
     # ---- forward
     rgb, depth = cpu(fs.rgb), cpu(fs.depth)
     assert float((rgb - ret["rgb"].detach()).abs().mean()) < 1e-4 and float((depth - ret["depth"].detach()).abs().mean()) < 1e-4
@@ -798,7 +821,8 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     got = [dg[:n0], dg[n0:n0 + n1], dg[n0 + n1:n0 + n1 + n2], dg[n0 + n1 + n2:]]
     for gk, w, nm in zip(got, sc.decoder_list(), DEC_KEYS):
         ref = w.grad
-        assert_close(gk.reshape(ref.shape), ref, rtol=2e-3, atol=2e-5 * max(1.0, float(ref.abs().max())), what=f"decoder grad {nm}")
+        if scatter != "atomics":               # (that schedule's one Adam launch zeroes every gradient buffer it consumed)
+            assert_close(gk.reshape(ref.shape), ref, rtol=2e-3, atol=2e-5 * max(1.0, float(ref.abs().max())), what=f"decoder grad {nm}")
     flat_planes = [p for lst in m.all_planes for p in lst]
     first_step = not (opt_state0[0].get("step", 0))
     if first_step:
@@ -809,20 +833,31 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
             assert_close(g_hip, ref, rtol=2e-3, atol=2e-5 * max(1e-6, float(ref.abs().max())), what=f"plane grad {k}")
     # ---- Adam
     opt.step()
+    if half:                                   # p16' = round_to_nearest_even(Adam(float(p16), g, m, v)): no fp32 master anywhere
+        with torch.no_grad():
+            for ref_p in sc.plane_list():
+                ref_p.copy_(ref_p.half().float())
+    stats = {"plane_mean_over_lr": 0.0, "plane_outliers": 0.0, "dec_mean_over_lr": 0.0, "dec_outliers": 0.0}
     for k, (p, ref_p, g_m) in enumerate(zip(flat_planes, sc.plane_list(), opt.groups[1].m + (opt.groups[2].m if len(opt.groups) > 2 else []))):
         st = ag.opt._state(p)
         assert_close(cpu(st["exp_avg"]), g_m, rtol=2e-3, atol=2e-6 * max(1e-6, float(g_m.abs().max())), what=f"exp_avg {k}")
-        d = (cpu(p) - ref_p.detach()).abs()
+        d = (cpu(p).float() - ref_p.detach()).abs()
         # eps = 1e-15 makes Adam scale-free: where the gradient is fp32 noise the step is +-lr whatever its size,
         # so a few cells may differ by O(lr); all others agree to rounding
         lr = ag.opt.param_groups[1]["lr"]
-        assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 2e-3, \
+        stats["plane_mean_over_lr"] = max(stats["plane_mean_over_lr"], float(d.mean()) / lr)
+        stats["plane_outliers"] = max(stats["plane_outliers"], float((d > 0.05 * lr).float().mean()))
+        assert float(d.mean()) < PLANE_ADAM_MEAN * lr and float((d > 0.05 * lr).float().mean()) < PLANE_ADAM_OUTLIERS, \
             f"plane {k} after Adam: mean {float(d.mean()):.3e}, outliers {float((d > 0.05 * lr).float().mean()):.3e}"
     for w_hip, w_ref, nm in zip(dec_params, sc.decoder_list(), DEC_KEYS):
         d = (cpu(w_hip) - w_ref.detach()).abs()
         lr = ag.opt.param_groups[0]["lr"]
-        assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 5e-3, f"decoder {nm} after Adam"
-    return {"R": R, "S": S, "contributing": int(fs.tape_rows.item()),
+        stats["dec_mean_over_lr"] = max(stats["dec_mean_over_lr"], float(d.mean()) / lr)
+        stats["dec_outliers"] = max(stats["dec_outliers"], float((d > 0.05 * lr).float().mean()))
+        assert float(d.mean()) < DEC_ADAM_MEAN * lr and float((d > 0.05 * lr).float().mean()) < DEC_ADAM_OUTLIERS, f"decoder {nm} after Adam"
+    _record_stats("fused_step_vs_oracle", dict(stats, R=R, S=S, half=half, scatter=scatter, warm=warm_steps,
+                                               planes=sum(p.numel() for p in flat_planes)))
+    return {"R": R, "S": S, "contributing": int(fs.tape_rows.item()), "adam_stats": stats,
             "rgb_l1": float((rgb - ret["rgb"].detach()).abs().mean()), "depth_l1": float((depth - ret["depth"].detach()).abs().mean())}
 
 
@@ -926,6 +961,76 @@ def check_hash_fused_step_vs_oracle(device, cfg, n_keyframes=3, seed=5, warm_ste
         lr = ag.opt.param_groups[0]["lr"]
         assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 5e-3, f"decoder {nm} after Adam"
     return {"R": R, "S": S, "touched_entries": int(touched.sum()), "rgb_l1": float((rgb - ret["rgb"].detach()).abs().mean())}
+
+
+def check_device_clock(device):
+    """mne_clock_t: iteration / Adam step read from device memory (graph replay) give bit-identical results to the same
+    values passed as arguments -- ray sampling keys, the jitter counter offset, the bias corrections of both Adam kernels."""
+    import ctypes as C
+    from mneslam_amd import _lib
+    lib, P = _lib.load(), _lib.ptr
+    dev = torch.device(device)
+    gen = torch.Generator().manual_seed(8)
+    n_kf, n_save, HW, n_g, n_c = 4, 200, 500, 128, 32
+    kf = torch.randn(n_kf * n_save, 7, generator=gen).to(dev)
+    cur = torch.randn(HW, 7, generator=gen).to(dev)
+    poses = torch.randn(n_kf + 1, 4, 4, generator=gen).to(dev)
+    R = n_g + n_c
+    b1, b2, n_table = 0.9, 0.99, 64
+    table = torch.tensor([(1.0 - b1 ** k, 1.0 - b2 ** k) for k in range(1, n_table + 1)], dtype=torch.float64, device=dev)
+    clk_iter = torch.zeros(1, dtype=torch.int64, device=dev)
+    clk_step = torch.zeros(1, dtype=torch.int32, device=dev)
+    ck = _lib.Clock()
+    ck.iteration, ck.step_offset, ck.bias_table = clk_iter.data_ptr(), clk_step.data_ptr(), table.data_ptr()
+    ck.n_table, ck.beta1, ck.beta2 = n_table, b1, b2
+    cfg = configs.small_test_config()
+    from mneslam_amd import hip_path
+    rc = hip_path.render_cfg_struct(cfg)
+    S = lib.mne_num_samples(C.byref(rc), 1)
+    ck.z_offset_stride = (R * S + 3) // 4
+    tables = hip_path.linspace_tables(cfg, True, dev)
+    st = _lib.stream_for(kf)
+
+    def batch(iteration, clock):
+        o = [torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev), torch.empty(R, device=dev)]
+        idx = torch.empty(R, dtype=torch.int64, device=dev)
+        z = torch.empty(R, S, device=dev)
+        cnt, rcnt = torch.empty(8, dtype=torch.int32, device=dev), torch.empty(R, 8, dtype=torch.int32, device=dev)
+        _lib.check(lib.mne_sample_rays(P(kf), n_kf * n_save, n_save, None, P(cur), HW, P(poses), n_kf + 1, n_g, n_c, None, None,
+                                       77, iteration, P(o[0]), P(o[1]), P(o[2]), P(o[3]), P(idx),
+                                       C.byref(clock) if clock else None, st))
+        d = o[3].abs() + 0.5
+        _lib.check(lib.mne_sample_z(C.byref(rc), R, P(d), None, P(tables), 77, iteration * ck.z_offset_stride if not clock else 0,
+                                    P(z), P(cnt), P(rcnt), C.byref(clock) if clock else None, st))
+        return idx.cpu(), z.cpu()
+
+    for it in (0, 3, 11):
+        ref = batch(it, None)
+        clk_iter.fill_(it)
+        got = batch(0, ck)
+        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), f"iteration {it}: clock and argument disagree"
+    assert lib.mne_clock_advance(P(clk_iter), P(clk_step), st) == 0
+    assert int(clk_iter.item()) == 12 and int(clk_step.item()) == 1
+    # Adam: step t as argument vs step 1 + device offset t - 1
+    for t in (1, 2, 17):
+        res = []
+        for use_clock in (False, True):
+            g0 = torch.Generator().manual_seed(t)
+            p = torch.randn(1000, generator=g0).to(dev); g = torch.randn(1000, generator=g0).to(dev)
+            m = (0.1 * torch.randn(1000, generator=g0)).to(dev); v = (0.01 * torch.rand(1000, generator=g0)).to(dev)
+            seg = _lib.AdamSeg()
+            seg.p, seg.g, seg.m, seg.v, seg.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1000
+            seg.lr, seg.beta1, seg.beta2, seg.eps, seg.weight_decay = 0.005, b1, b2, 1e-15, 1e-6
+            seg.step = 1 if use_clock else t
+            clk_step.fill_(t - 1)
+            arr = (_lib.AdamSeg * 1)(seg)
+            _lib.check(lib.mne_adam_step(arr, 1, 0, C.byref(ck) if use_clock else None, st))
+            res.append((p.cpu(), m.cpu(), v.cpu()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b), f"Adam step {t}: clock and argument disagree"
+    bad = _lib.Clock(); bad.iteration = clk_iter.data_ptr(); bad.step_offset = clk_step.data_ptr(); bad.bias_table = table.data_ptr()
+    bad.n_table, bad.beta1, bad.beta2 = n_table, 0.8, b2
+    assert lib.mne_adam_step(arr, 1, 0, C.byref(bad), st) < 0 and b"betas" in lib.mne_last_error()
 
 
 def check_render_maps_fast_path(device):

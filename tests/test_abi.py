@@ -42,7 +42,7 @@ def test_struct_layouts_and_version(lib_path):
 def test_argument_validation_without_gpu(lib_path):
     _lib.unload()
     lib = _lib.load(lib_path)
-    assert lib.mne_adam_step(None, 33, 0, None) < 0
+    assert lib.mne_adam_step(None, 33, 0, None, None) < 0
     assert b"n_seg" in lib.mne_last_error()
     rc = _lib.RenderCfg()
     rc.n_samples_d, rc.n_range_d, rc.n_samples = 32, 11, 256
@@ -62,9 +62,9 @@ def test_argument_validation_without_gpu(lib_path):
     assert lib.mne_render_forward(ctypes.byref(sc), ctypes.byref(rc), 8, 43, *([None] * 14), 0, None) < 0
     assert b"plane" in lib.mne_last_error()
     assert lib.mne_tile_order(ctypes.byref(sc), None, None) < 0
-    assert lib.mne_tile_adam(ctypes.byref(sc), None, None, None, None) < 0
+    assert lib.mne_tile_adam(ctypes.byref(sc), None, None, None, None, None) < 0
     assert lib.mne_loss_finalize(8, 43, None, None, None, None) < 0 and b"NULL" in lib.mne_last_error()
-    assert lib.mne_sample_z(ctypes.byref(rc), 8, None, None, None, 0, 0, None, None, None, None) < 0
+    assert lib.mne_sample_z(ctypes.byref(rc), 8, None, None, None, 0, 0, None, None, None, None, None) < 0
     assert lib.mne_decoder_wgrad(ctypes.byref(sc), None, None, 8, 43, None, None, 0, None) < 0
     assert lib.mne_tile_count(None) == 0 and lib.mne_tape_row_floats(None) == 0
     # round-3 entry points: list sizing with per-plane capacities, overlap rectangles, pose loop, batch / decoder update
@@ -82,14 +82,14 @@ def test_argument_validation_without_gpu(lib_path):
     assert lib.mne_tile_overlap_floats(ctypes.byref(sc), ctypes.byref(ov), 0) == 8 * 4 * 32
     assert lib.mne_tile_overlap_floats(ctypes.byref(sc), ctypes.byref(ov), 1) == 0
     assert lib.mne_tile_grad_export(ctypes.byref(sc), None, None, ctypes.byref(ov), None) < 0
-    assert lib.mne_tile_adam_shared(ctypes.byref(sc), None, None, None, ctypes.byref(ov), None) < 0
+    assert lib.mne_tile_adam_shared(ctypes.byref(sc), None, None, None, ctypes.byref(ov), None, None) < 0
     ps = _lib.PoseState()
     assert lib.mne_pose_rays(ctypes.byref(ps), 8, None, None, None, None) < 0 and b"NULL" in lib.mne_last_error()
     assert lib.mne_pose_loss(8, *([None] * 4), 1.0, 1.0, None, None, None, None) < 0
     assert lib.mne_pose_update(ctypes.byref(ps), 8, None, None, None, None, None) < 0
     assert lib.mne_sample_batch(*([None] * 1), 0, 1, None, None, 0, None, 0, 0, 0, None, None, 0, 0, *([None] * 5),
-                                ctypes.byref(rc), *([None] * 2), 0, *([None] * 5), None) < 0
-    assert lib.mne_decoder_update(ctypes.byref(sc), None, 8, None, None, 43, None, None, None, None) < 0
+                                ctypes.byref(rc), *([None] * 2), 0, *([None] * 5), None, None) < 0
+    assert lib.mne_decoder_update(ctypes.byref(sc), None, 8, None, None, 43, None, None, None, None, None) < 0
     _lib.unload()
 
 

@@ -190,10 +190,13 @@ def test_two_agents_binned_overlap_shared_decoder(tmp_path):
     assert os.path.exists(ret + ".ok0") and os.path.exists(ret + ".ok1")
 
 
-def test_bench_launcher_dry_run_two_ranks(tmp_path):
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_launcher_dry_run_two_ranks(tmp_path, launcher):
     """The driver's multi-GPU command line, as written in the task contract, on two ranks over gloo with the kernels in the
     host emulator: rendezvous, one agent per rank, warm-up, barrier-bracketed timed steps, max over ranks, decoder-gradient
-    all-reduce, ONE JSON line from rank 0.  (Functional only: 16 + 4 rays on a tiny scene.)"""
+    all-reduce, ONE JSON line from rank 0.  (Functional only: 16 + 4 rays on a tiny scene.)  launcher = "self": plain
+    ``python bench.py --gpus 2`` -- bench.py starts its two ranks itself, as the reference's launcher starts its agents
+    (multi_agents.py:43-52)."""
     import json
     import subprocess
     sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
@@ -201,9 +204,11 @@ def test_bench_launcher_dry_run_two_ranks(tmp_path):
     env = dict(os.environ, MNE_EMULATED_LIBRARY=build_emu.build(), PYTHONPATH=REPO,
                MNE_NO_TILE_SPLIT="1")          # (the emulator pays one OS thread per work-item: no 2048 spare split items)
     port = 29800 + (os.getpid() % 90)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--share-decoder", "--small", "--rays", "16", "--keyframes", "2"]
+    pre = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port)] if launcher == "torchrun" else [sys.executable])
+    cmd = pre + [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                 "--share-decoder", "--small", "--rays", "16", "--keyframes", "2"]
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -211,4 +216,5 @@ def test_bench_launcher_dry_run_two_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["agents"] == 2 and "all-reduce" in d["config"]["parallelism"] and "DRY RUN" in d["data"]
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["collective_backend"] == "gloo"
     assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # whole-job rate = all agents' steps / time

@@ -73,6 +73,10 @@ def test_queries():
     pc.check_queries(DEV)
 
 
+def test_device_clock():
+    pc.check_device_clock(DEV)
+
+
 def test_render_maps_fast_path_and_render_img():
     pc.check_render_maps_fast_path(DEV)
 
@@ -208,6 +212,26 @@ def test_dense_grid_fused_step_vs_oracle():
     cfg["cam"]["far"] = 4.0
     out = pc.check_hash_fused_step_vs_oracle(DEV, cfg, n_keyframes=3, seed=2, small=True)
     assert out["touched_entries"] > 0
+
+
+@pytest.mark.parametrize("one_grid,warm", [(True, 0), (False, 2)])
+def test_bench_path_step_fp16_plane_storage_vs_oracle(one_grid, warm):
+    """BASELINE configs[4] "fp16 features + fp32 accumulate" (EXTENSION): grid.plane_dtype 'fp16' stores the planes ONLY in
+    half precision; gather / inline gather convert on load, the plane update computes Adam on float(p16) with fp32 moments
+    and an fp32 gradient sum and stores the rounded result.  Oracle: the same values in fp32 tensors, parameters rounded to
+    fp16 after its Adam step."""
+    cfg = _tiny_bench_cfg(one_grid=one_grid)
+    cfg["grid"]["plane_dtype"] = "fp16"
+    out = pc.check_fused_step_vs_oracle(DEV, cfg, n_keyframes=3, seed=2, small=True, impl="explicit", warm_steps=warm)
+    assert out["contributing"] > 0
+
+
+def test_bench_path_step_fp16_planes_atomics_scatter_vs_oracle():
+    """The same storage on the atomics schedule: fp32 gradient buffers, mne_adam_step with p_f16 segments."""
+    cfg = _tiny_bench_cfg()
+    cfg["grid"]["plane_dtype"] = "fp16"
+    out = pc.check_fused_step_vs_oracle(DEV, cfg, n_keyframes=3, seed=2, small=True, impl="explicit", scatter="atomics")
+    assert out["contributing"] > 0
 
 
 def test_bench_path_step_with_split_tile_lists(monkeypatch):

@@ -91,6 +91,32 @@ def test_gradients_match_reference(name, kw, co):
         assert_close(t.grad, ref, rtol=5e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), what=f"grad {k}")
 
 
+@pytest.mark.parametrize("name,kw", FWD_CASES)
+@pytest.mark.parametrize("co", [False, True])
+def test_chunked_forward_backward_matches_reference(name, kw, co):
+    """oracle.mapping.forward_backward_chunked (the checker's way to evaluate batches whose autograd graph does not fit in
+    host memory, INS Indoor 2048 x 1045) against the REFERENCE's losses and gradients of the golden fixtures, in chunks that
+    do not divide the batch."""
+    g = load_golden(name)
+    cfg = configs.small_test_config(**kw)
+    sc = oracle_scene_from_golden(g, cfg).requires_grad_(True)
+    rays_o, rays_d, rgb, d, U = fixture_inputs(g)
+    z = sc.sample_z(rays_o.shape[0], d, U)
+    ret = omap.forward_backward_chunked(sc, cfg, rays_o, rays_d, rgb, d, z, is_co_sdf=co, impl="explicit", chunk=23)
+    for k in ("rgb_loss", "depth_loss", "co_sdf_loss", "co_fs_loss", "e_fs_loss", "e_center_loss", "e_tail_loss", "psnr"):
+        assert_close(ret[k].reshape(-1), np.asarray(g[f"ret.{k}"]).reshape(-1), rtol=2e-5, atol=1e-7, what=k)
+    assert_close(ret["rgb"], g["ret.rgb"], rtol=2e-5, atol=2e-6, what="rgb")
+    tag = f"grad.co{int(co)}."
+    for s_ in range(n_plane_sets(g)):
+        for l in range(2):
+            ref = g[f"{tag}plane_{s_}_{l}"]
+            assert_close(sc.all_planes[s_][l].grad, ref, rtol=2e-4, atol=1e-6 * max(1.0, np.abs(ref).max()), what=f"plane grad {s_},{l}")
+    got = dict(zip(DEC_KEYS, sc.col_w + sc.sdf_w))
+    for k in DEC_KEYS:
+        ref = g[f"{tag}dec.{k}"]
+        assert_close(got[k].grad, ref, rtol=2e-4, atol=2e-6 * max(1.0, np.abs(ref).max()), what=f"decoder grad {k}")
+
+
 def test_all_invalid_depth_gives_nan_losses():
     g = load_golden("fwd_all_invalid")
     cfg = configs.small_test_config()
