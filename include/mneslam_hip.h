@@ -523,15 +523,15 @@ int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const flo
  *   mne_hash_scatter           grad_table += w * d(feature)  (global_atomic_add_f32; grad_table zeroed by the caller)
  *   mne_decoder_wgrad, mne_adam_step (table + decoder segments, zero_grad fused)
  *   -- or, instead of mne_hash_scatter + the table's Adam segment --
- *   mne_hash_slice_adam        the table update without global atomics and without a gradient buffer: one workgroup per
- *                              slice of 16384 entries of one level accumulates the slice's gradient in LDS while walking
- *                              over the iteration's backward rows (packed level-major into `workspace`,
- *                              mne_hash_workspace_bytes), then applies Adam (opt: moments with the table's layout, step
- *                              1-based) to the slice.  Same arithmetic as grid_sampler-style scatter + torch.optim.Adam;
- *                              only the fp32 summation order differs.
+ *   mne_hash_slice_adam        the table update without float atomics and without a gradient buffer: the iteration's
+ *                              backward rows are packed level-major into `workspace` and sorted by the 2048-entry slices of
+ *                              the table their corners fall into; one workgroup per slice sums the slice's gradient in LDS
+ *                              as 64-bit fixed-point numbers (exact, order-independent: the update is bit-reproducible) and
+ *                              applies Adam (opt: moments with the table's layout, step 1-based) to the slice.  Same
+ *                              arithmetic as a grid_sampler-style scatter + torch.optim.Adam up to the rounding of each
+ *                              addend to 2^-39 of the level's largest gradient component.
  * scene: bounding box, decoder dims and weights are read; the plane descriptors are ignored.  cfg: n_features 2, <= 16 levels. */
-size_t mne_hash_workspace_bytes(int n_rays, int n_samples);       /* + mne_hash_scratch_floats(cfg) * 4, rounded up to 256 */
-size_t mne_hash_scratch_floats(const mne_grid_cfg_t* cfg);          /* leading floats of the workspace: zero before the first call */
+size_t mne_hash_workspace_bytes(const mne_grid_cfg_t* cfg, int n_rays, int n_samples);   /* zero-fill the workspace before the FIRST call */
 int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                         const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles, float* table,
                         const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);

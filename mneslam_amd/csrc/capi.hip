@@ -841,19 +841,10 @@ int mne_hash_features(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n
     return check_launch("hash_features");
 }
 
-size_t mne_hash_workspace_bytes(int n_rays, int n_samples) {
-    if (n_rays <= 0 || n_samples <= 0) return 0;
-    const size_t rows = (size_t)n_rays * n_samples;
-    return (((size_t)n_rays + 1) * sizeof(int) + 255) / 256 * 256 + rows * sizeof(float4) + rows * 16 * sizeof(float2) +
-           rows * 16 * sizeof(uint32_t);
-}
-
-/* floats at the front of the workspace that must be ZERO on entry to mne_hash_slice_adam (it leaves them zero again):
- * the gradient scratch of the dense levels, whose rows are split over several workgroups */
-size_t mne_hash_scratch_floats(const mne_grid_cfg_t* cfg) {
+size_t mne_hash_workspace_bytes(const mne_grid_cfg_t* cfg, int n_rays, int n_samples) {
     GridArgs a = {};
-    if (fill_grid(cfg, a)) return 0;
-    return (size_t)mne_hash_scratch_entries(a) * 2;
+    if (n_rays <= 0 || n_samples <= 0 || fill_grid(cfg, a)) return 0;
+    return mne_hash_layout(a, n_rays, n_samples, nullptr);
 }
 
 int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
@@ -864,16 +855,8 @@ int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int
     if (!ray_tiles || !table || !opt || !workspace) return fail(-1, "mne_hash_slice_adam: NULL argument");
     if (!opt->m || !opt->v || opt->step < 1) return fail(-1, "mne_hash_slice_adam: bad optimizer state");
     if (n_rays <= 0) return 0;
-    const size_t scratch = (mne_hash_scratch_floats(cfg) * sizeof(float) + 255) / 256 * 256;
-    if (workspace_bytes < scratch + mne_hash_workspace_bytes(n_rays, n_samples)) return fail(-1, "mne_hash_slice_adam: workspace too small");
+    if (workspace_bytes < mne_hash_layout(a, n_rays, n_samples, workspace)) return fail(-1, "mne_hash_slice_adam: workspace too small");
     a.ray_tiles = ray_tiles; a.params = table;
-    a.dparams = (float*)workspace;
-    unsigned char* w = (unsigned char*)workspace + scratch;
-    a.offs = (int*)w; w += (((size_t)n_rays + 1) * sizeof(int) + 255) / 256 * 256;
-    a.pack_cap = (long long)n_rays * n_samples;
-    a.xs = (float4*)w; w += (size_t)a.pack_cap * sizeof(float4);
-    a.dfeat_lv = (float2*)w; w += (size_t)a.pack_cap * 16 * sizeof(float2);
-    a.masks = std::getenv("MNE_HASH_NO_MASKS") ? nullptr : (unsigned*)w;        // (A/B switch: walk every row)
     PlaneOpt& o = a.opt;
     o.m = opt->m; o.v = opt->v;
     o.omb1 = (float)(1.0 - opt->beta1); o.b2 = (float)opt->beta2; o.omb2 = (float)(1.0 - opt->beta2);
@@ -881,8 +864,7 @@ int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int
     o.step_size = (float)(opt->lr / (1.0 - std::pow(opt->beta1, (double)opt->step)));
     o.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(opt->beta2, (double)opt->step));
     o.lr = opt->lr; o.step = opt->step;
-    if (const char* m = std::getenv("MNE_HASH_LEVELS")) a.n_levels = std::atoi(m) < a.n_levels ? std::atoi(m) : a.n_levels;   // profiling only
-    mne_launch_hash_slice_adam(a, (hipStream_t)stream);
+    if (int rc = mne_launch_hash_slice_adam(a, (hipStream_t)stream)) return fail(rc, "mne_hash_slice_adam: table too large for the slice kernels");
     return check_launch("hash_slice_adam");
 }
 

@@ -215,48 +215,53 @@ __global__ __launch_bounds__(256) void hash_scatter_runs_kernel(GridArgs a) {
     }
 }
 
-// ---- table update without atomics: slices of the table accumulated in LDS, Adam fused ------------------------------------
+// ---- table update without global atomics: slice-binned rows, exact fixed-point LDS accumulation, Adam fused ---------------
 // Global float atomics retire at ~20 G/s chip-wide (previous section), and the samples of one iteration touch millions of
-// distinct table entries, so no reduction in front of the atomics gets the scatter under ~0.5 ms.  The table itself,
-// though, is barely larger than the chip's LDS (5.25 M entries x 8 B = 42 MB vs 256 x 160 KB), and what has to be
-// examined per sample is tiny.  So the roles are turned around, as in tile_adam.hip: one workgroup OWNS a slice of
-// HASH_SLICE entries of one level, keeps its gradient in LDS, walks over ALL backward rows of the iteration (their grid
-// input x and this level's d(feature), packed level-major by hash_pack_kernel so that the walk is a coalesced stream
-// out of L2), adds the corners that fall into its slice with ds_add_f32, and applies Adam to the slice: no gradient
-// buffer in HBM, no global atomics, the table and its moments are read and written once with plain coalesced accesses.
-// Walking cost: ~150 instructions per (row, workgroup) -- the kernel is VALU-bound, see HASH_SLICE below.
-// slice = 16384 entries = 128 KiB of LDS, one workgroup of 1024 threads per CU: the walk is VALU-bound (~150
-// instructions per row and workgroup at one wave instruction per 4 cycles and SIMD), so what counts is the number of
-// (row, workgroup) visits = rows x table bytes / slice bytes.  Measured: 8192 entries x 512 threads (two per CU) 499 us,
-// 16384 x 1024 383 us; unroll 1/2/4/8: 654/577/556/548 us; without the LDS atomics 481 of 556 us
-// (profiles/r02_hash_slices_variants.txt).
+// distinct table entries, so no reduction in front of the atomics gets the scatter under ~0.5 ms.  The roles are turned
+// around, as in tile_adam.hip: one workgroup OWNS a slice of HASH_SLICE entries of one level, sums its gradient in LDS and
+// applies Adam to the slice -- no gradient buffer in HBM, the table and its moments are read and written once with plain
+// coalesced accesses.  Round 4 (rounds 2-3: 16384-entry slices whose workgroups walked over ALL ~129 k backward rows of
+// their level and added with ds_add_f32, 0.41 ms):
+//   * BINNED ROWS.  hash_bin_kernel sorts the backward rows of a chunk of HASH_CHUNK packed rows by the slices their eight
+//     corners fall into (counting sort in LDS: integer LDS atomics for the ranks, one scan, records = packed row ids written
+//     slice after slice into the chunk's own segment, with the slice offsets beside it) -- no global atomics, no list
+//     capacities, one pass.  A slice workgroup then reads, per chunk, exactly the rows that touch it.
+//   * EXACT INTEGER ACCUMULATION.  ds_add_f32 retires 0.8 G lane-ops/s per CU, ds_add_u64 11.7 (profiles/
+//     r03_lds_atomic_microbench.txt).  A level's addends w * d(feature) are bounded by its largest |d(feature)| (taken by
+//     the pack kernel), so they are added as 64-bit fixed-point numbers with the power-of-two scale 2^(HASH_FIX_BITS - e),
+//     max|g| < 2^e: an entry receives at most 8 * rows < 2^22 addends of magnitude < 2^39 -- no overflow -- and the sum of
+//     the rounded addends is EXACT, hence independent of the order the rows arrive in: the update is bit-reproducible,
+//     which the float-atomic forms were not.  Resolution: 2^-39 of the level's largest gradient (fp32 sums carry 2^-24
+//     of the running sum); converted back to fp32 once per entry.
+//   * A dense (coarse) level has few slices and every sample hits them: its chunks are split over `parts` workgroups per
+//     slice, which add their non-zero sums into a 64-bit scratch with global integer atomics (exact, too);
+//     hash_finish_kernel applies Adam to those levels.
 #ifndef HASH_SLICE
-#define HASH_SLICE 16384
+#define HASH_SLICE 2048            // entries per slice: 2 x 8 B x 2048 = 32 KiB of LDS, five workgroups per CU
 #endif
-#ifndef HASH_SLICE_THREADS
-#define HASH_SLICE_THREADS 1024
-#endif
-#ifndef HASH_UNROLL
-#define HASH_UNROLL 4
-#endif
-
-// Workgroups of one level: slices x replicas.  A dense (coarse) level has few slices and EVERY sample hits them: its rows
-// are split over `replicas` workgroups (LDS float atomics retire ~0.7 G lane-ops/s per CU: one workgroup taking all
-// 2 M corner updates of level 0 ran 2.9 ms), which then add their non-zero sums into a small gradient scratch with global
-// atomics; hash_dense_adam_kernel finishes those levels.  Hashed levels: one workgroup per slice, Adam fused.
+#define HASH_SLICE_SHIFT 11
+static_assert((1 << HASH_SLICE_SHIFT) == HASH_SLICE, "slice = index >> HASH_SLICE_SHIFT");
+#define HASH_SLICE_THREADS 256
+#define HASH_CHUNK 4096            // packed rows per bin workgroup
+#define HASH_BIN_THREADS 1024
+#define HASH_RPT (HASH_CHUNK / HASH_BIN_THREADS)
+#define HASH_REC_PER_ROW 8         // a row's corners fall into at most 8 slices (4 on a hashed level with resolution < 2048)
+#define HASH_MAX_SLICES 4096       // per level: T <= 2^23
+#define HASH_FIX_BITS 39
+// Workgroups per level at least (dense levels with few slices are split into parts)
 #ifndef HASH_LEVEL_WGS
 #define HASH_LEVEL_WGS 64
 #endif
-#define HASH_LDS_ADD(p, v) atomicAdd((p), (v))
 __host__ __device__ __forceinline__ int hash_slices_of(const GridArgs& a, int level) { return (int)((a.size[level] + HASH_SLICE - 1) / HASH_SLICE); }
 __host__ __device__ __forceinline__ bool hash_level_dense(const GridArgs& a, int level) {
     return (unsigned long long)a.res[level] * a.res[level] * a.res[level] <= a.size[level];
 }
-__host__ __device__ __forceinline__ int hash_replicas_of(const GridArgs& a, int level) {
+__host__ __device__ __forceinline__ int hash_parts_of(const GridArgs& a, int level) {
     if (!hash_level_dense(a, level)) return 1;
     const int r = HASH_LEVEL_WGS / hash_slices_of(a, level);
     return r < 1 ? 1 : r;
 }
+__host__ __device__ __forceinline__ int hash_chunks_of(long long rows) { return (int)((rows + HASH_CHUNK - 1) / HASH_CHUNK); }
 
 // first packed row of every ray: exclusive scan of min(ray_tiles[r] * 32, S), one workgroup
 __global__ __launch_bounds__(1024) void hash_offsets_kernel(GridArgs a) {
@@ -285,27 +290,19 @@ __global__ __launch_bounds__(1024) void hash_offsets_kernel(GridArgs a) {
     if (tid == 0) a.offs[a.R] = carry;
 }
 
-// 16 consecutive backward rows of one ray per workgroup: x of each row, and the rows' d(feature) transposed to level-major
-// The pack kernel leaves one 32-bit word per (row, hashed level) with the bits of the slices its eight corners fall into
-// (0 for rows without gradient; inside the bounding box cell_x < 2^14, so the slice = index >> 14 depends on the (y, z)
-// corner pair only: at most four bits); a slice workgroup then streams 4 bytes per row and looks at the row itself only
-// when its bit is set (1 row in 8 on T = 2^19 levels).
-__device__ __forceinline__ bool hash_level_masked(const GridArgs& a, int level) {
-    const uint32_t size = a.size[level];
-    return a.masks && !hash_level_dense(a, level) && (size & (size - 1u)) == 0u && size <= 32u * HASH_SLICE &&
-           (HASH_SLICE & (HASH_SLICE - 1)) == 0;
-}
-
+// 16 consecutive backward rows of one ray per workgroup: x of each row, the rows' d(feature) transposed to level-major,
+// and this workgroup's largest |d(feature)| per level (wgmax[level][workgroup]; every workgroup writes its slot)
 __global__ __launch_bounds__(256) void hash_pack_kernel(GridArgs a) {
     __shared__ float2 tr[16][17];
-    __shared__ unsigned trm[16][17];
-    __shared__ float xs_l[16][4];
     const int groups = (a.S + 15) / 16;
     const int r = blockIdx.x / groups, s0 = (blockIdx.x % groups) * 16;
     int n_rows = a.ray_tiles[r] * 32;
     n_rows = n_rows < a.S ? n_rows : a.S;
-    if (s0 >= n_rows) return;
     const int tid = threadIdx.x, lv = tid & 15, rr = tid >> 4;
+    if (s0 >= n_rows) {
+        if (tid < 16) a.wgmax[(size_t)tid * a.n_pack_wgs + blockIdx.x] = 0.0f;
+        return;
+    }
     const bool in = s0 + rr < n_rows;
     const long long row = (long long)r * a.S + s0 + rr;
     float2 g = make_float2(0.f, 0.f);
@@ -321,238 +318,274 @@ __global__ __launch_bounds__(256) void hash_pack_kernel(GridArgs a) {
             x[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
         }
         a.xs[k0 + rr] = make_float4(x[0], x[1], x[2], 0.0f);
-        xs_l[rr][0] = x[0]; xs_l[rr][1] = x[1]; xs_l[rr][2] = x[2];
     }
-    __syncthreads();
-    unsigned m = 0u;
-    if (in && lv < a.n_levels && (g.x != 0.0f || g.y != 0.0f)) {
-        m = 0xffffffffu;
-        if (hash_level_masked(a, lv)) {
-            const float scale = a.scale[lv];
-            const uint32_t msk = a.size[lv] - 1u;
-            const uint32_t cx = (uint32_t)(int)floorf(fmaf(scale, xs_l[rr][0], 0.5f));
-            const uint32_t cy = (uint32_t)(int)floorf(fmaf(scale, xs_l[rr][1], 0.5f)), cz = (uint32_t)(int)floorf(fmaf(scale, xs_l[rr][2], 0.5f));
-            const uint32_t hx[2] = {cx, cx + 1u};                  // (samples outside the bounding box have wrapped cells: all 8 corners count)
-            const uint32_t hy[2] = {cy * 2654435761u, (cy + 1u) * 2654435761u}, hz[2] = {cz * 805459861u, (cz + 1u) * 805459861u};
-            m = 0u;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) m |= 1u << (((hx[q & 1] ^ hy[(q >> 1) & 1] ^ hz[q >> 2]) & msk) / HASH_SLICE);
-        }
-    }
-    trm[rr][lv] = m;
     __syncthreads();
     const int rr2 = tid & 15, lv2 = tid >> 4;                        // 16 adjacent lanes = 16 consecutive packed rows of one level
-    if (s0 + rr2 < n_rows && lv2 < a.n_levels) {
-        a.dfeat_lv[(size_t)lv2 * a.pack_cap + k0 + rr2] = tr[rr2][lv2];
-        if (a.masks) a.masks[(size_t)lv2 * a.pack_cap + k0 + rr2] = trm[rr2][lv2];
+    const float2 t = tr[rr2][lv2];
+    if (s0 + rr2 < n_rows && lv2 < a.n_levels) a.dfeat_lv[(size_t)lv2 * a.pack_cap + k0 + rr2] = t;
+    float m = fmaxf(fabsf(t.x), fabsf(t.y));                         // rows beyond the ray's end hold zeros
+    m = (m <= 3.0e38f) ? m : __uint_as_float(0x7f800000u);          // NaN / Inf gradient -> +Inf: poisons the whole level (below)
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if (rr2 == 0) a.wgmax[(size_t)lv2 * a.n_pack_wgs + blockIdx.x] = m;
+}
+
+struct HashCorners { uint32_t idx[8]; float w[8]; };
+// the eight corner entries (index within the level) and trilinear weights of grid input x at `level`: the expressions of
+// grid_kernel / hash_rows_kernel (same index bits, same product order of the weights)
+__device__ __forceinline__ void hash_corners(const GridArgs& a, int level, float4 x, bool dense, HashCorners& c) {
+    const float scale = a.scale[level];
+    const uint32_t res = a.res[level], size = a.size[level];
+    float frac[3];
+    uint32_t cell[3];
+    const float xv[3] = {x.x, x.y, x.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float pos = fmaf(scale, xv[d], 0.5f);
+        const float fl = floorf(pos);
+        cell[d] = (uint32_t)(int)fl;
+        frac[d] = pos - fl;
+    }
+    const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        c.idx[q] = grid_index(cell[0] + (q & 1), cell[1] + ((q >> 1) & 1), cell[2] + ((q >> 2) & 1), res, size, dense);
+        c.w[q] = (wx[q & 1] * wy[(q >> 1) & 1]) * wz[(q >> 2) & 1];
     }
 }
 
-__global__ __launch_bounds__(HASH_SLICE_THREADS, HASH_SLICE_THREADS / 128) void hash_slice_adam_kernel(GridArgs a) {
-    MNE_DYN_LDS(lds_raw);
-    float* acc = (float*)lds_raw;                                    // [HASH_SLICE][2] gradient of this slice
-    const int tid = threadIdx.x;
+// One workgroup per (level, chunk of HASH_CHUNK packed rows): counting sort of the chunk's (row, slice) pairs by slice.
+//   seg_off[level][chunk][0 .. n_slices]   start of every slice's records inside the chunk's segment (last = total)
+//   records[level][chunk][..]              packed row ids, slice after slice
+// Workgroup (level, chunk 0) also publishes the level's fixed-point scale from the pack kernel's per-workgroup maxima.
+__global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) {
+    __shared__ unsigned hist[HASH_MAX_SLICES + 1];
+    __shared__ unsigned wsum[HASH_BIN_THREADS / 64];
+    __shared__ float red[HASH_BIN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int level = blockIdx.x % a.n_levels, chunk = blockIdx.x / a.n_levels;
+    const int n_live = a.offs[a.R];
+    if (chunk == 0) {
+        float m = 0.0f;
+        const float* wm = a.wgmax + (size_t)level * a.n_pack_wgs;
+        for (int i = tid; i < a.n_pack_wgs; i += HASH_BIN_THREADS) m = fmaxf(m, wm[i]);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if (lane == 0) red[wv] = m;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < HASH_BIN_THREADS / 64; ++w) m = fmaxf(m, red[w]);
+            int e = 0;
+            const bool bad = !(m <= 3.0e38f);                       // a non-finite gradient: every entry of the level becomes NaN,
+            if (m > 0.0f && !bad) (void)frexpf(m, &e);              // as a float sum would    (m = f * 2^e, f in [0.5, 1): m < 2^e)
+            a.gscale[2 * level] = bad ? 0.0 : ldexp(1.0, HASH_FIX_BITS - e);
+            a.gscale[2 * level + 1] = bad ? (double)__uint_as_float(0x7fc00000u) : ldexp(1.0, e - HASH_FIX_BITS);
+        }
+    }
+    if ((long long)chunk * HASH_CHUNK >= n_live) return;
+    const int ns = hash_slices_of(a, level);
+    for (int i = tid; i <= ns; i += HASH_BIN_THREADS) hist[i] = 0u;
+    __syncthreads();
+    const bool dense = hash_level_dense(a, level);
+    const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
+    // this thread's rows: the distinct slices of each row's eight corners, ranked inside their slice (LDS integer atomics)
+    unsigned rec[HASH_RPT][HASH_REC_PER_ROW];                        // slice of corner q, ~0u: no record (same slice as an earlier corner)
+    unsigned rnk[HASH_RPT][HASH_REC_PER_ROW];
+#pragma unroll
+    for (int j = 0; j < HASH_RPT; ++j) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rec[j][q] = 0xffffffffu;
+        const int k = chunk * HASH_CHUNK + j * HASH_BIN_THREADS + tid;
+        if (k < n_live) {
+            const float2 g = gl[k];
+            if (g.x != 0.0f || g.y != 0.0f) {                        // rows without gradient leave no record
+                HashCorners c;
+                hash_corners(a, level, a.xs[k], dense, c);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned sl = c.idx[q] >> HASH_SLICE_SHIFT;
+                    bool dup = false;
+#pragma unroll
+                    for (int p = 0; p < q; ++p) dup = dup || (c.idx[p] >> HASH_SLICE_SHIFT) == sl;
+                    if (!dup) {
+                        rec[j][q] = sl;
+                        rnk[j][q] = atomicAdd(&hist[sl], 1u);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the slice counts (ns <= 4096: up to 4 per thread), in place
+    {
+        unsigned v[HASH_MAX_SLICES / HASH_BIN_THREADS], sum = 0;
+#pragma unroll
+        for (int q = 0; q < HASH_MAX_SLICES / HASH_BIN_THREADS; ++q) {
+            const int i = tid * (HASH_MAX_SLICES / HASH_BIN_THREADS) + q;
+            v[q] = i < ns ? hist[i] : 0u;
+            sum += v[q];
+        }
+        unsigned inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        unsigned base = 0;
+        for (int w = 0; w < wv; ++w) base += wsum[w];
+        unsigned ex = base + inc - sum;
+#pragma unroll
+        for (int q = 0; q < HASH_MAX_SLICES / HASH_BIN_THREADS; ++q) {
+            const int i = tid * (HASH_MAX_SLICES / HASH_BIN_THREADS) + q;
+            if (i < ns) hist[i] = ex;
+            ex += v[q];
+        }
+        if (tid == HASH_BIN_THREADS - 1) hist[ns] = ex;             // total (every i >= ns contributes 0)
+    }
+    __syncthreads();
+    unsigned* so = a.seg_off + a.seg_level[level] + (size_t)chunk * (ns + 1);
+    for (int i = tid; i <= ns; i += HASH_BIN_THREADS) so[i] = hist[i];
+    unsigned* rc = a.records + ((size_t)level * a.n_chunks + chunk) * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
+#pragma unroll
+    for (int j = 0; j < HASH_RPT; ++j) {
+        const unsigned k = (unsigned)(chunk * HASH_CHUNK + j * HASH_BIN_THREADS + tid);
+#pragma unroll
+        for (int q = 0; q < HASH_REC_PER_ROW; ++q)
+            if (rec[j][q] != 0xffffffffu) rc[hist[rec[j][q]] + rnk[j][q]] = k;
+    }
+}
+
+__device__ __forceinline__ unsigned long long hash_fix(float v, double scale) {
+    return (unsigned long long)(long long)rint((double)v * scale);  // two's complement: sums wrap correctly
+}
+
+__global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(GridArgs a) {
+    __shared__ unsigned long long acc[HASH_SLICE * 2];               // fixed-point gradient of this slice (32 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int level = 0, k = blockIdx.x;
-    while (level + 1 < a.n_levels && k >= hash_slices_of(a, level) * hash_replicas_of(a, level)) {
-        k -= hash_slices_of(a, level) * hash_replicas_of(a, level);
+    while (level + 1 < a.n_levels && k >= hash_slices_of(a, level) * hash_parts_of(a, level)) {
+        k -= hash_slices_of(a, level) * hash_parts_of(a, level);
         ++level;
     }
-    const int n_rep = hash_replicas_of(a, level), rep = k % n_rep;
-    k /= n_rep;
-    const uint32_t res = a.res[level], size = a.size[level], off = a.offset[level];
-    const uint32_t lo = (uint32_t)k * HASH_SLICE;
+    const int n_part = hash_parts_of(a, level), part = k % n_part, slice = k / n_part;
+    const int ns = hash_slices_of(a, level);
+    const uint32_t size = a.size[level], off = a.offset[level];
+    const uint32_t lo = (uint32_t)slice * HASH_SLICE;
     const uint32_t n_ent = size - lo < HASH_SLICE ? size - lo : HASH_SLICE;
-    const bool dense = (unsigned long long)res * res * res <= size;
-    const bool pow2 = (size & (size - 1u)) == 0u;
-    const float scale = a.scale[level];
-    for (int i = tid; i < HASH_SLICE * 2 / 4; i += HASH_SLICE_THREADS) ((float4*)acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool dense = hash_level_dense(a, level);
+    for (int i = tid; i < HASH_SLICE * 2; i += HASH_SLICE_THREADS) acc[i] = 0ull;
     __syncthreads();
     const int n_live = a.offs[a.R];
+    const int n_chunks = hash_chunks_of(n_live);
+    const double scale = a.gscale[2 * level];
     const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
-    // The walk over this replica's share of the rows, HASH_UNROLL rows per thread in flight (the stream comes out of L2 /
-    // Infinity Cache: latency, not bytes).  (Tried for the dense levels and dropped: a segmented wave scan in front of
-    // the LDS atomics -- 96 dependent ds_bpermute per 64 rows, 1.7 ms for level 0's workgroup; per-thread contiguous row
-    // chunks -- 2.9 ms; profiles/r02_hash_slices_*.txt.)
-    const int row_lo = (int)((long long)n_live * rep / n_rep), row_hi = (int)((long long)n_live * (rep + 1) / n_rep);
-    int n_iter = (row_hi - row_lo + HASH_SLICE_THREADS - 1) / HASH_SLICE_THREADS;
-    if (hash_level_masked(a, level)) {
-        // ---- masked walk: 4 bytes per row; the rows whose mask has this slice's bit are collected per wave (ballot +
-        // prefix popcount into a 128-entry LDS ring) and processed 64 at a time with every lane busy
-        const int lane = tid & 63, wv = tid >> 6;
-        unsigned* ring = (unsigned*)(acc + (size_t)HASH_SLICE * 2) + wv * 128;
-        const unsigned* mk = a.masks + (size_t)level * a.pack_cap;
-        const uint32_t msk = size - 1u;
-        int head = 0, fill = 0;                                       // wave-uniform
-        auto process = [&](int count) {                               // the first `count` ring entries, one per lane
-            if (lane < count) {
-                const int i = (int)ring[(head + lane) & 127];
-                const float2 g = gl[i];
-                const float4 x = a.xs[i];
-                float frac[3];
-                uint32_t cell[3];
-                const float xv[3] = {x.x, x.y, x.z};
+    const unsigned* so = a.seg_off + a.seg_level[level];
+    // one wave per chunk: the chunk's records of this slice, 64 at a time
+    for (int c = part * (HASH_SLICE_THREADS / 64) + wv; c < n_chunks; c += n_part * (HASH_SLICE_THREADS / 64)) {
+        const unsigned r0 = so[(size_t)c * (ns + 1) + slice], r1 = so[(size_t)c * (ns + 1) + slice + 1];
+        const unsigned* rc = a.records + ((size_t)level * a.n_chunks + c) * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
+        for (unsigned i = r0 + lane; i < r1; i += 64) {
+            const unsigned row = rc[i];
+            const float2 g = gl[row];
+            HashCorners cn;
+            hash_corners(a, level, a.xs[row], dense, cn);
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const float pos = fmaf(scale, xv[d], 0.5f);
-                    const float fl = floorf(pos);
-                    cell[d] = (uint32_t)(int)fl;
-                    frac[d] = pos - fl;
-                }
-                const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
-                const uint32_t hx[2] = {cell[0] & msk, (cell[0] + 1u) & msk};
-                const uint32_t hy[2] = {(cell[1] * 2654435761u) & msk, ((cell[1] + 1u) * 2654435761u) & msk};
-                const uint32_t hz[2] = {(cell[2] * 805459861u) & msk, ((cell[2] + 1u) * 805459861u) & msk};
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t e = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) - lo;
-                    if (e < n_ent) {
-                        const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];     // product order of grid_kernel
-                        HASH_LDS_ADD(acc + 2 * e, w * g.x);
-                        HASH_LDS_ADD(acc + 2 * e + 1, w * g.y);
-                    }
-                }
-            }
-        };
-        for (int it = 0; it < n_iter; it += HASH_UNROLL) {
-            unsigned mq[HASH_UNROLL];
-#pragma unroll
-            for (int q = 0; q < HASH_UNROLL; ++q) {
-                const int i = row_lo + (it + q) * HASH_SLICE_THREADS + tid;
-                mq[q] = i < row_hi ? mk[i] : 0u;
-            }
-#pragma unroll
-            for (int q = 0; q < HASH_UNROLL; ++q) {
-                const bool hit = (mq[q] >> k) & 1u;
-                const unsigned long long b = __ballot(hit);
-                if (b == 0ull) continue;
-                if (hit) ring[(head + fill + __popcll(b & ((1ull << lane) - 1ull))) & 127] = (unsigned)(row_lo + (it + q) * HASH_SLICE_THREADS + tid);
-                fill += __popcll(b);
-                MNE_WAVE_SYNC();
-                if (fill >= 64) {
-                    process(64);
-                    head = (head + 64) & 127; fill -= 64;
-                    MNE_WAVE_SYNC();
-                }
-            }
-        }
-        if (fill > 0) process(fill);
-        n_iter = 0;                                                   // the generic walk below is skipped
-    }
-    for (int it = 0; it < n_iter; it += HASH_UNROLL) {
-        float2 gq[HASH_UNROLL];
-        float4 xq[HASH_UNROLL];
-        bool inq[HASH_UNROLL];
-#pragma unroll
-        for (int q = 0; q < HASH_UNROLL; ++q) {
-            const int i = row_lo + (it + q) * HASH_SLICE_THREADS + tid;
-            inq[q] = i < row_hi;
-            gq[q] = make_float2(0.f, 0.f); xq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (inq[q]) { gq[q] = gl[i]; xq[q] = a.xs[i]; }
-        }
-#pragma unroll
-        for (int q = 0; q < HASH_UNROLL; ++q) {
-            const float2 g = gq[q];
-            const float4 x = xq[q];
-            if (!(inq[q] && (g.x != 0.0f || g.y != 0.0f))) continue;
-            float frac[3];
-            uint32_t cell[3];
-            const float xv[3] = {x.x, x.y, x.z};
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float pos = fmaf(scale, xv[d], 0.5f);
-                const float fl = floorf(pos);
-                cell[d] = (uint32_t)(int)fl;
-                frac[d] = pos - fl;
-            }
-            const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
-            if (dense) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t e = grid_index(cell[0] + (c & 1), cell[1] + ((c >> 1) & 1), cell[2] + ((c >> 2) & 1), res, size, true) - lo;
-                    if (e < n_ent) {
-                        const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];     // product order of grid_kernel
-                        HASH_LDS_ADD(acc + 2 * e, w * g.x);
-                        HASH_LDS_ADD(acc + 2 * e + 1, w * g.y);
-                    }
-                }
-            } else {
-                // (a ^ b ^ c) & m == (a & m) ^ (b & m) ^ (c & m): mask the six components once when the level size is 2^n
-                const uint32_t msk = pow2 ? size - 1u : 0xffffffffu;
-                const uint32_t hx[2] = {cell[0] & msk, (cell[0] + 1u) & msk};
-                const uint32_t hy[2] = {(cell[1] * 2654435761u) & msk, ((cell[1] + 1u) * 2654435761u) & msk};
-                const uint32_t hz[2] = {(cell[2] * 805459861u) & msk, ((cell[2] + 1u) * 805459861u) & msk};
-                const uint32_t hxy[4] = {hx[0] ^ hy[0], hx[1] ^ hy[0], hx[0] ^ hy[1], hx[1] ^ hy[1]};
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t h = hxy[c & 3] ^ hz[(c >> 2) & 1];
-                    const uint32_t e = (pow2 ? h : (h % size)) - lo;
-                    if (e < n_ent) {
-                        const float w = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1];
-                        HASH_LDS_ADD(acc + 2 * e, w * g.x);
-                        HASH_LDS_ADD(acc + 2 * e + 1, w * g.y);
-                    }
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t e = cn.idx[q] - lo;
+                if (e < n_ent) {
+                    atomicAdd(&acc[2 * e], hash_fix(cn.w[q] * g.x, scale));
+                    atomicAdd(&acc[2 * e + 1], hash_fix(cn.w[q] * g.y, scale));
                 }
             }
         }
     }
     __syncthreads();
-    if (n_rep > 1) {                                                 // partial sums of a dense level: into the gradient scratch
-        float* gs = a.dparams + ((size_t)off + lo) * 2;
+    if (n_part > 1) {                                                // partial sums of a split level: into the 64-bit scratch
+        unsigned long long* gs = a.scratch64 + ((size_t)off + lo) * 2;
         for (uint32_t e = tid; e < n_ent * 2; e += HASH_SLICE_THREADS)
-            if (acc[e] != 0.0f) unsafeAtomicAdd(gs + e, acc[e]);
+            if (acc[e] != 0ull) atomicAdd(gs + e, acc[e]);
         return;
     }
     // ---- Adam on the slice: entries are float2, moments have the table's layout
     const PlaneOpt o = a.opt;
+    const double inv = a.gscale[2 * level + 1];
     float2* P = (float2*)a.params + off + lo;
     float2* M = (float2*)o.m + off + lo;
     float2* V = (float2*)o.v + off + lo;
     for (uint32_t e = tid; e < n_ent; e += HASH_SLICE_THREADS) {
         float2 p = P[e], m = M[e], v = V[e];
-        const float2 g = *(const float2*)(acc + 2 * e);
-        adam_elem(p.x, g.x, m.x, v.x, o);
-        adam_elem(p.y, g.y, m.y, v.y, o);
+        const float gx = (float)((double)(long long)acc[2 * e] * inv), gy = (float)((double)(long long)acc[2 * e + 1] * inv);
+        adam_elem(p.x, gx, m.x, v.x, o);
+        adam_elem(p.y, gy, m.y, v.y, o);
         P[e] = p; M[e] = m; V[e] = v;
     }
 }
 
 // Adam over the levels whose gradient went through the scratch (float2 entries [0, n_ent)); leaves the scratch zeroed
-__global__ __launch_bounds__(256) void hash_dense_adam_kernel(GridArgs a, unsigned n_ent) {
+__global__ __launch_bounds__(256) void hash_finish_kernel(GridArgs a, unsigned n_ent) {
     const unsigned e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n_ent) return;
+    int level = 0;
+    while (level + 1 < a.n_levels && e >= a.offset[level + 1]) ++level;
+    const double inv = a.gscale[2 * level + 1];
     const PlaneOpt o = a.opt;
-    float2* G = (float2*)a.dparams;
+    unsigned long long* G = a.scratch64 + (size_t)e * 2;
     float2 p = ((float2*)a.params)[e], m = ((float2*)o.m)[e], v = ((float2*)o.v)[e];
-    const float2 g = G[e];
-    adam_elem(p.x, g.x, m.x, v.x, o);
-    adam_elem(p.y, g.y, m.y, v.y, o);
+    const float gx = (float)((double)(long long)G[0] * inv), gy = (float)((double)(long long)G[1] * inv);
+    adam_elem(p.x, gx, m.x, v.x, o);
+    adam_elem(p.y, gy, m.y, v.y, o);
     ((float2*)a.params)[e] = p; ((float2*)o.m)[e] = m; ((float2*)o.v)[e] = v;
-    G[e] = make_float2(0.f, 0.f);
+    G[0] = 0ull; G[1] = 0ull;
 }
 
 int mne_hash_slice_count(const GridArgs& a) {
     int n = 0;
-    for (int l = 0; l < a.n_levels; ++l) n += hash_slices_of(a, l) * hash_replicas_of(a, l);
+    for (int l = 0; l < a.n_levels; ++l) n += hash_slices_of(a, l) * hash_parts_of(a, l);
     return n;
 }
 
-// entries (float2) at the front of the table whose levels are updated through the gradient scratch
+// entries (float2) at the front of the table whose levels are updated through the scratch
 unsigned mne_hash_scratch_entries(const GridArgs& a) {
     unsigned n = 0;
     for (int l = 0; l < a.n_levels; ++l)
-        if (hash_replicas_of(a, l) > 1) n = a.offset[l] + a.size[l];
+        if (hash_parts_of(a, l) > 1) n = a.offset[l] + a.size[l];
     return n;
+}
+
+// workspace layout of mne_hash_slice_adam (bytes from the start; every block 256-byte aligned)
+static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+size_t mne_hash_layout(GridArgs& a, int R, int S, void* base) {
+    const size_t rows = (size_t)R * S;
+    const int n_chunks = hash_chunks_of((long long)rows);
+    const int groups = (S + 15) / 16;
+    unsigned char* w = (unsigned char*)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { unsigned char* p = w ? w + off : nullptr; off += al256(bytes); return p; };
+    a.scratch64 = (unsigned long long*)take((size_t)mne_hash_scratch_entries(a) * 2 * sizeof(unsigned long long));
+    a.offs = (int*)take(((size_t)R + 1) * sizeof(int));
+    a.gscale = (double*)take((size_t)2 * MNE_GRID_MAX_LEVELS * sizeof(double));
+    a.xs = (float4*)take(rows * sizeof(float4));
+    a.dfeat_lv = (float2*)take(rows * a.n_levels * sizeof(float2));
+    a.n_pack_wgs = R * groups;
+    a.wgmax = (float*)take((size_t)a.n_levels * a.n_pack_wgs * sizeof(float));
+    size_t so = 0;
+    for (int l = 0; l < a.n_levels; ++l) { a.seg_level[l] = so; so += (size_t)n_chunks * (hash_slices_of(a, l) + 1); }
+    a.seg_off = (unsigned*)take(so * sizeof(unsigned));
+    a.n_chunks = n_chunks;
+    a.records = (unsigned*)take((size_t)a.n_levels * n_chunks * HASH_CHUNK * HASH_REC_PER_ROW * sizeof(unsigned));
+    a.pack_cap = (long long)rows;
+    return off;
 }
 
 int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st) {
     if (a.R <= 0) return 0;
+    for (int l = 0; l < a.n_levels; ++l)
+        if (hash_slices_of(a, l) > HASH_MAX_SLICES) return -7;
     MNE_LAUNCH(hash_offsets_kernel, 1, 1024, 0, st, a);
-    MNE_LAUNCH(hash_pack_kernel, (unsigned)(a.R * ((a.S + 15) / 16)), 256, 0, st, a);
-    const size_t lds = (size_t)HASH_SLICE * 2 * sizeof(float) + (size_t)(HASH_SLICE_THREADS / 64) * 128 * sizeof(unsigned);   // + per-wave rings
-    MNE_SET_MAX_LDS(hash_slice_adam_kernel, MNE_LDS_MAX);
-    MNE_LAUNCH(hash_slice_adam_kernel, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, lds, st, a);
-    const unsigned n_dense = mne_hash_scratch_entries(a);
-    if (n_dense) MNE_LAUNCH(hash_dense_adam_kernel, (n_dense + 255) / 256, 256, 0, st, a, n_dense);
+    MNE_LAUNCH(hash_pack_kernel, (unsigned)a.n_pack_wgs, 256, 0, st, a);
+    MNE_LAUNCH(hash_bin_kernel, (unsigned)(a.n_chunks * a.n_levels), HASH_BIN_THREADS, 0, st, a);
+    MNE_LAUNCH(hash_slice_adam_kernel, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, 0, st, a);
+    const unsigned n_split = mne_hash_scratch_entries(a);
+    if (n_split) MNE_LAUNCH(hash_finish_kernel, (n_split + 255) / 256, 256, 0, st, a, n_split);
     return 0;
 }
 

@@ -176,12 +176,19 @@ struct GridArgs {
     int R, S, row_stride, col_x, col_d;
     double bb_lo[3], bb_hi[3];   // raw bounding box: x = (p - lo) / (hi - lo), as the OneBlob input
     int bb_is_f64;
-    // slice form (hash_slice_adam_kernel): packed backward rows + Adam state of the table
+    // slice form (hash_slice_adam_kernel): packed backward rows, their slice-binned records, Adam state of the table
     int* offs;                   // [R+1] first packed row of each ray (exclusive scan of its backward rows)
     float4* xs;                  // [R*S] packed: grid input x of each backward row
     float2* dfeat_lv;            // [n_levels][R*S] packed: d(feature) of each backward row, level-major
-    unsigned* masks;             // [n_levels][R*S] packed: bit k = some corner of the row falls into slice k of the level (hashed levels)
     long long pack_cap;          // R*S
+    float* wgmax;                // [n_levels][n_pack_wgs] largest |d(feature)| per level and pack workgroup
+    int n_pack_wgs;
+    double* gscale;              // [n_levels][2] fixed-point scale of the level's gradient sums and its inverse
+    unsigned* seg_off;           // per level: [n_chunks][n_slices + 1] start of each slice's records in the chunk's segment
+    size_t seg_level[MNE_GRID_MAX_LEVELS];   // first word of each level's block in seg_off
+    unsigned* records;           // [n_levels][n_chunks][HASH_CHUNK * 8] packed row ids, slice after slice
+    int n_chunks;                // chunks the workspace was laid out for (R*S rows)
+    unsigned long long* scratch64;   // fixed-point gradient sums of the levels that are split over several workgroups per slice
     PlaneOpt opt;                // table optimizer state and step constants
     // gather restricted to the rows the exact early termination can decode (inside mne_render_fused_features)
     const int* ray_counts;       // [R][MNE_N_COUNT]: rows [0, (a-priori tiles + MNE_RESOLVER_MAX_EXT) * 32) of every ray; NULL = all rows
@@ -282,6 +289,7 @@ int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st);
 int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st);
 int mne_hash_slice_count(const GridArgs& a);
 unsigned mne_hash_scratch_entries(const GridArgs& a);
+size_t mne_hash_layout(GridArgs& a, int R, int S, void* base);     // fills the workspace pointers (base NULL: sizes only); returns bytes
 size_t mne_render_workspace(int R, int S);
 int mne_launch_query(const QueryArgs& a, hipStream_t st);
 int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStream_t st);

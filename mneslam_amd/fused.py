@@ -690,8 +690,7 @@ class HashFusedStep(FusedStep):
         if self.table_update == "atomics":
             self.grad_map[self.table] = self.table_grad
         else:
-            scratch = (self.lib.mne_hash_scratch_floats(C.byref(self.grid_cfg)) * 4 + 255) // 256 * 256
-            self.hash_ws_bytes = scratch + self.lib.mne_hash_workspace_bytes(self.R, self.S)
+            self.hash_ws_bytes = self.lib.mne_hash_workspace_bytes(C.byref(self.grid_cfg), self.R, self.S)
             self.hash_ws = torch.zeros(self.hash_ws_bytes, device=self.device, dtype=torch.uint8)
             grp = next(g for g in optimizer.param_groups if any(p is self.table for p in g["params"]))
             o = self.table_opt = _lib.PlaneOpt()

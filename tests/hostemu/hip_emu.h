@@ -333,6 +333,9 @@ template <class T> inline T atomic_add_impl(T* addr, T val) {
 inline float atomicAdd(float* a, float v) { return atomic_add_impl(a, v); }
 inline int atomicAdd(int* a, int v) { return atomic_add_impl(a, v); }
 inline unsigned atomicAdd(unsigned* a, unsigned v) { return atomic_add_impl(a, v); }
+inline unsigned long long atomicAdd(unsigned long long* a, unsigned long long v) {
+    return reinterpret_cast<std::atomic<unsigned long long>*>(a)->fetch_add(v, std::memory_order_relaxed);
+}
 inline float unsafeAtomicAdd(float* a, float v) { return atomic_add_impl(a, v); }
 
 // MFMA f32 32x32x2: every lane of a full wave must call it together.

@@ -704,12 +704,25 @@ def out_contrib(fs):
     return int(fs.tape_rows.item())
 
 
-# Post-Adam agreement bars.  eps = 1e-15 makes the plane groups' Adam scale-free: where a cell's gradient is fp32 summation
-# noise the step is +-lr whatever its size, so a few cells differ by O(lr) between two summation orders; all others agree to
-# rounding.  The bars are the LARGEST values observed over every case of the GPU suite on MI355X times two
-# (profiles/r04_adam_parity_stats.txt; MNE_PARITY_STATS=<file> appends each case's measured numbers).
-PLANE_ADAM_MEAN, PLANE_ADAM_OUTLIERS = 2e-3, 2e-3
-DEC_ADAM_MEAN, DEC_ADAM_OUTLIERS = 2e-3, 5e-3
+# Post-Adam agreement bars.  eps = 1e-15 makes the plane / table groups' Adam scale-free: where a cell's gradient is fp32
+# summation noise the step is +-lr whatever its size, so a few cells differ by O(lr) between two summation orders; all others
+# agree to rounding.  MEASURED on MI355X over every fused-step case of the GPU suite and on the emulator cases
+# (profiles/r04_adam_parity_stats.txt; MNE_PARITY_STATS=<file> appends each case's numbers): planes  mean |d| / lr <= 8.4e-7,
+# cells off by more than 0.05 lr <= 4.2e-7 of a plane;  decoder  mean |d| / lr <= 3.8e-7, no weight off by more than 0.05 lr;
+# hash table  see ADAM_BARS["table"].  The bars are those maxima times ~2.4, with an absolute floor of two cells for small tensors.
+ADAM_BARS = {"plane": (2e-6, 1e-6, 2), "decoder": (1e-6, 0.0, 1), "table": (2e-6, 1e-6, 2)}
+
+
+def adam_agreement(p_hip, p_ref, lr, kind, what):
+    """(mean |d| / lr, fraction of elements off by more than 0.05 lr) of two post-Adam tensors, asserted against ADAM_BARS."""
+    d = (p_hip.float() - p_ref).abs()
+    mean_bar, frac_bar, floor = ADAM_BARS[kind]
+    n_out = int((d > 0.05 * lr).sum())
+    mean, allowed = float(d.mean()) / lr, max(floor, int(frac_bar * d.numel()))
+    # an outlier is off by up to ~2 lr: the mean bar applies to the rest
+    assert mean <= mean_bar + 2.0 * n_out / d.numel() and n_out <= allowed, \
+        f"{what} after Adam: mean |d| / lr {mean:.3e} (bar {mean_bar:.1e}), {n_out} elements off by > 0.05 lr (allowed {allowed})"
+    return mean, n_out / d.numel()
 
 
 def _record_stats(what, d):
@@ -841,20 +854,11 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     for k, (p, ref_p, g_m) in enumerate(zip(flat_planes, sc.plane_list(), opt.groups[1].m + (opt.groups[2].m if len(opt.groups) > 2 else []))):
         st = ag.opt._state(p)
         assert_close(cpu(st["exp_avg"]), g_m, rtol=2e-3, atol=2e-6 * max(1e-6, float(g_m.abs().max())), what=f"exp_avg {k}")
-        d = (cpu(p).float() - ref_p.detach()).abs()
-        # eps = 1e-15 makes Adam scale-free: where the gradient is fp32 noise the step is +-lr whatever its size,
-        # so a few cells may differ by O(lr); all others agree to rounding
-        lr = ag.opt.param_groups[1]["lr"]
-        stats["plane_mean_over_lr"] = max(stats["plane_mean_over_lr"], float(d.mean()) / lr)
-        stats["plane_outliers"] = max(stats["plane_outliers"], float((d > 0.05 * lr).float().mean()))
-        assert float(d.mean()) < PLANE_ADAM_MEAN * lr and float((d > 0.05 * lr).float().mean()) < PLANE_ADAM_OUTLIERS, \
-            f"plane {k} after Adam: mean {float(d.mean()):.3e}, outliers {float((d > 0.05 * lr).float().mean()):.3e}"
+        mean, frac = adam_agreement(cpu(p), ref_p.detach(), ag.opt.param_groups[1]["lr"], "plane", f"plane {k}")
+        stats["plane_mean_over_lr"], stats["plane_outliers"] = max(stats["plane_mean_over_lr"], mean), max(stats["plane_outliers"], frac)
     for w_hip, w_ref, nm in zip(dec_params, sc.decoder_list(), DEC_KEYS):
-        d = (cpu(w_hip) - w_ref.detach()).abs()
-        lr = ag.opt.param_groups[0]["lr"]
-        stats["dec_mean_over_lr"] = max(stats["dec_mean_over_lr"], float(d.mean()) / lr)
-        stats["dec_outliers"] = max(stats["dec_outliers"], float((d > 0.05 * lr).float().mean()))
-        assert float(d.mean()) < DEC_ADAM_MEAN * lr and float((d > 0.05 * lr).float().mean()) < DEC_ADAM_OUTLIERS, f"decoder {nm} after Adam"
+        mean, frac = adam_agreement(cpu(w_hip), w_ref.detach(), ag.opt.param_groups[0]["lr"], "decoder", f"decoder {nm}")
+        stats["dec_mean_over_lr"], stats["dec_outliers"] = max(stats["dec_mean_over_lr"], mean), max(stats["dec_outliers"], frac)
     _record_stats("fused_step_vs_oracle", dict(stats, R=R, S=S, half=half, scatter=scatter, warm=warm_steps,
                                                planes=sum(p.numel() for p in flat_planes)))
     return {"R": R, "S": S, "contributing": int(fs.tape_rows.item()), "adam_stats": stats,
@@ -950,16 +954,16 @@ def check_hash_fused_step_vs_oracle(device, cfg, n_keyframes=3, seed=5, warm_ste
     assert float(cpu(fs.table_grad).abs().max()) == 0.0, "the Adam kernel leaves the gradient accumulator zeroed"
     opt.step()
     assert_close(cpu(st_t["exp_avg"]), opt.groups[1].m[0], rtol=2e-3, atol=2e-6 * float(opt.groups[1].m[0].abs().max()), what="table exp_avg")
-    lr = ag.opt.param_groups[1]["lr"]
-    d = (cpu(m.embed_fn.params) - sc.table.detach()).abs()
-    assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 2e-3, \
-        f"table after Adam: mean {float(d.mean()):.3e}, outliers {float((d > 0.05 * lr).float().mean()):.3e}"
+    stats = {}
+    stats["table_mean_over_lr"], stats["table_outliers"] = adam_agreement(cpu(m.embed_fn.params), sc.table.detach(),
+                                                                          ag.opt.param_groups[1]["lr"], "table", "table")
     touched = ref != 0
     assert float(touched.float().mean()) > 0.001
+    dm = do = 0.0
     for w_hip, w_ref, nm in zip(dec_params, sc.decoder_list(), DEC_KEYS):
-        d = (cpu(w_hip) - w_ref.detach()).abs()
-        lr = ag.opt.param_groups[0]["lr"]
-        assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 5e-3, f"decoder {nm} after Adam"
+        mean, frac = adam_agreement(cpu(w_hip), w_ref.detach(), ag.opt.param_groups[0]["lr"], "decoder", f"decoder {nm}")
+        dm, do = max(dm, mean), max(do, frac)
+    _record_stats("hash_fused_step_vs_oracle", dict(stats, dec_mean_over_lr=dm, dec_outliers=do, R=R, S=S, table=int(ref.numel())))
     return {"R": R, "S": S, "touched_entries": int(touched.sum()), "rgb_l1": float((rgb - ret["rgb"].detach()).abs().mean())}
 
 
@@ -1392,14 +1396,10 @@ def run_overlap_agent(rank, device, comm):
                 gs = comm.all_gather(w.grad.clone())
                 w.grad.copy_((gs[0] + gs[1]) / 2)
         oopt.step()
-        lr = opt.param_groups[1]["lr"]
         for k, (p, ref) in enumerate(zip(flat, sc.plane_list())):
-            d = (cpu(p) - ref.detach()).abs()
-            assert float(d.mean()) < 2e-3 * lr and float((d > 0.05 * lr).float().mean()) < 2e-3, \
-                f"iteration {it} plane {k}: mean {float(d.mean()):.3e}, outliers {float((d > 0.05 * lr).float().mean()):.3e}"
+            adam_agreement(cpu(p), ref.detach(), opt.param_groups[1]["lr"], "plane", f"iteration {it} plane {k}")
         for w_hip, w_ref in zip(model.decoder.parameters(), sc.decoder_list()):
-            d = (cpu(w_hip) - w_ref.detach()).abs()
-            assert float(d.mean()) < 2e-3 * opt.param_groups[0]["lr"], f"iteration {it}: decoder after Adam"
+            adam_agreement(cpu(w_hip), w_ref.detach(), opt.param_groups[0]["lr"], "decoder", f"iteration {it}: decoder")
     # the exchange carried something: the shared cells' first moments hold the peer's share too
     ex = fs.ov_recv[0]
     assert float(ex.abs().max()) > 0
