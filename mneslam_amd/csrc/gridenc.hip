@@ -15,6 +15,19 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t cx, uint32_t cy, uint32_
     return idx % size;
 }
 
+// grid_index without the integer division: a hashed level's size is the power of two T; a dense index of a point inside the
+// bounding box is below 2 * size (cell + 1 <= res: res * (1 + res + res^2) < 2 res^3); anything else (points outside the box:
+// wrapped cells) takes the division.  Same value as grid_index for every input.
+__device__ __forceinline__ uint32_t grid_index_fast(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res, uint32_t size, bool dense) {
+    uint32_t idx;
+    if (dense) idx = cx + cy * res + cz * res * res;
+    else idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
+    if ((size & (size - 1u)) == 0u) return idx & (size - 1u);
+    if (idx < size) return idx;
+    if (idx - size < size) return idx - size;
+    return idx % size;
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void grid_kernel(GridArgs a) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(GridArgs a) {
             if ((c >> d) & 1) { cc[d] = cell[d] + 1u; w[c] *= frac[d]; }
             else { cc[d] = cell[d]; w[c] *= 1.0f - frac[d]; }
         }
-        idx[c] = grid_index(cc[0], cc[1], cc[2], res, size, dense);
+        idx[c] = grid_index_fast(cc[0], cc[1], cc[2], res, size, dense);
         if (!BWD) v[c] = table[idx[c]];                                            // 8 independent 8-byte reads in flight
     }
     if (BWD) {
@@ -349,15 +362,18 @@ __device__ __forceinline__ void hash_corners(const GridArgs& a, int level, float
     const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        c.idx[q] = grid_index(cell[0] + (q & 1), cell[1] + ((q >> 1) & 1), cell[2] + ((q >> 2) & 1), res, size, dense);
+        c.idx[q] = grid_index_fast(cell[0] + (q & 1), cell[1] + ((q >> 1) & 1), cell[2] + ((q >> 2) & 1), res, size, dense);
         c.w[q] = (wx[q & 1] * wy[(q >> 1) & 1]) * wz[(q >> 2) & 1];
     }
 }
 
-// One workgroup per (level, chunk of HASH_CHUNK packed rows): counting sort of the chunk's (row, slice) pairs by slice.
+// One workgroup per (BINNED level, chunk of HASH_CHUNK packed rows): counting sort of the chunk's (row, slice) pairs by
+// slice.  (Levels that are split into parts -- few slices, every row hits them -- are not binned: their workgroups walk row
+// ranges directly.)
 //   seg_off[level][chunk][0 .. n_slices]   start of every slice's records inside the chunk's segment (last = total)
 //   records[level][chunk][..]              packed row ids, slice after slice
-// Workgroup (level, chunk 0) also publishes the level's fixed-point scale from the pack kernel's per-workgroup maxima.
+// Workgroup (level, chunk 0) of EVERY level also publishes the level's fixed-point scale from the pack kernel's
+// per-workgroup maxima.
 __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) {
     __shared__ unsigned hist[HASH_MAX_SLICES + 1];
     __shared__ unsigned wsum[HASH_BIN_THREADS / 64];
@@ -382,35 +398,40 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
             a.gscale[2 * level + 1] = bad ? (double)__uint_as_float(0x7fc00000u) : ldexp(1.0, e - HASH_FIX_BITS);
         }
     }
-    if ((long long)chunk * HASH_CHUNK >= n_live) return;
+    if ((long long)chunk * HASH_CHUNK >= n_live || hash_parts_of(a, level) > 1) return;
     const int ns = hash_slices_of(a, level);
     for (int i = tid; i <= ns; i += HASH_BIN_THREADS) hist[i] = 0u;
-    __syncthreads();
     const bool dense = hash_level_dense(a, level);
     const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
-    // this thread's rows: the distinct slices of each row's eight corners, ranked inside their slice (LDS integer atomics)
+    // this thread's rows, all loads first (one round trip)
+    float2 g[HASH_RPT];
+    float4 x[HASH_RPT];
+#pragma unroll
+    for (int j = 0; j < HASH_RPT; ++j) {
+        const int k = chunk * HASH_CHUNK + j * HASH_BIN_THREADS + tid;
+        g[j] = make_float2(0.f, 0.f); x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < n_live) { g[j] = gl[k]; x[j] = a.xs[k]; }
+    }
+    __syncthreads();
+    // the distinct slices of each row's eight corners, ranked inside their slice (LDS integer atomics)
     unsigned rec[HASH_RPT][HASH_REC_PER_ROW];                        // slice of corner q, ~0u: no record (same slice as an earlier corner)
     unsigned rnk[HASH_RPT][HASH_REC_PER_ROW];
 #pragma unroll
     for (int j = 0; j < HASH_RPT; ++j) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) rec[j][q] = 0xffffffffu;
-        const int k = chunk * HASH_CHUNK + j * HASH_BIN_THREADS + tid;
-        if (k < n_live) {
-            const float2 g = gl[k];
-            if (g.x != 0.0f || g.y != 0.0f) {                        // rows without gradient leave no record
-                HashCorners c;
-                hash_corners(a, level, a.xs[k], dense, c);
+        if (g[j].x != 0.0f || g[j].y != 0.0f) {                      // rows without gradient leave no record
+            HashCorners c;
+            hash_corners(a, level, x[j], dense, c);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const unsigned sl = c.idx[q] >> HASH_SLICE_SHIFT;
-                    bool dup = false;
+            for (int q = 0; q < 8; ++q) {
+                const unsigned sl = c.idx[q] >> HASH_SLICE_SHIFT;
+                bool dup = false;
 #pragma unroll
-                    for (int p = 0; p < q; ++p) dup = dup || (c.idx[p] >> HASH_SLICE_SHIFT) == sl;
-                    if (!dup) {
-                        rec[j][q] = sl;
-                        rnk[j][q] = atomicAdd(&hist[sl], 1u);
-                    }
+                for (int p = 0; p < q; ++p) dup = dup || (c.idx[p] >> HASH_SLICE_SHIFT) == sl;
+                if (!dup) {
+                    rec[j][q] = sl;
+                    rnk[j][q] = atomicAdd(&hist[sl], 1u);
                 }
             }
         }
@@ -458,9 +479,27 @@ __device__ __forceinline__ unsigned long long hash_fix(float v, double scale) {
     return (unsigned long long)(long long)rint((double)v * scale);  // two's complement: sums wrap correctly
 }
 
+// the corners of one backward row that fall into [lo, lo + n_ent) -> the slice's fixed-point sums
+__device__ __forceinline__ void hash_accumulate(const GridArgs& a, int level, bool dense, float4 x, float2 g, uint32_t lo, uint32_t n_ent,
+                                                double scale, unsigned long long* acc) {
+    HashCorners cn;
+    hash_corners(a, level, x, dense, cn);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t e = cn.idx[q] - lo;
+        if (e < n_ent) {
+            atomicAdd(&acc[2 * e], hash_fix(cn.w[q] * g.x, scale));
+            atomicAdd(&acc[2 * e + 1], hash_fix(cn.w[q] * g.y, scale));
+        }
+    }
+}
+
+#define HASH_SLICE_UNROLL 4
 __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(GridArgs a) {
     __shared__ unsigned long long acc[HASH_SLICE * 2];               // fixed-point gradient of this slice (32 KiB)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ unsigned cstart[HASH_SLICE_THREADS + 1];              // binned levels: prefix of the chunks' record counts
+    __shared__ unsigned cbase[HASH_SLICE_THREADS];                   //   ... and where each chunk's records of this slice begin
+    const int tid = threadIdx.x;
     int level = 0, k = blockIdx.x;
     while (level + 1 < a.n_levels && k >= hash_slices_of(a, level) * hash_parts_of(a, level)) {
         k -= hash_slices_of(a, level) * hash_parts_of(a, level);
@@ -472,39 +511,88 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     const uint32_t lo = (uint32_t)slice * HASH_SLICE;
     const uint32_t n_ent = size - lo < HASH_SLICE ? size - lo : HASH_SLICE;
     const bool dense = hash_level_dense(a, level);
-    for (int i = tid; i < HASH_SLICE * 2; i += HASH_SLICE_THREADS) acc[i] = 0ull;
-    __syncthreads();
     const int n_live = a.offs[a.R];
     const int n_chunks = hash_chunks_of(n_live);
+    // binned levels: the offsets of this slice's records in every chunk, requested before anything else (one round trip)
+    unsigned r0 = 0, r1 = 0;
+    if (n_part == 1) {
+        const unsigned* so = a.seg_off + a.seg_level[level];
+        if (tid < n_chunks) { r0 = so[(size_t)tid * (ns + 1) + slice]; r1 = so[(size_t)tid * (ns + 1) + slice + 1]; }
+    }
+    for (int i = tid; i < HASH_SLICE * 2; i += HASH_SLICE_THREADS) acc[i] = 0ull;
     const double scale = a.gscale[2 * level];
     const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
-    const unsigned* so = a.seg_off + a.seg_level[level];
-    // one wave per chunk: the chunk's records of this slice, 64 at a time
-    for (int c = part * (HASH_SLICE_THREADS / 64) + wv; c < n_chunks; c += n_part * (HASH_SLICE_THREADS / 64)) {
-        const unsigned r0 = so[(size_t)c * (ns + 1) + slice], r1 = so[(size_t)c * (ns + 1) + slice + 1];
-        const unsigned* rc = a.records + ((size_t)level * a.n_chunks + c) * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
-        for (unsigned i = r0 + lane; i < r1; i += 64) {
-            const unsigned row = rc[i];
-            const float2 g = gl[row];
-            HashCorners cn;
-            hash_corners(a, level, a.xs[row], dense, cn);
+    if (n_part > 1) {
+        // ---- split level: this part's share of ALL rows, straight from the packed arrays (coalesced), a few rows in flight
+        __syncthreads();
+        const int row_lo = (int)((long long)n_live * part / n_part), row_hi = (int)((long long)n_live * (part + 1) / n_part);
+        for (int i0 = row_lo; i0 < row_hi; i0 += HASH_SLICE_THREADS * HASH_SLICE_UNROLL) {
+            float2 g[HASH_SLICE_UNROLL];
+            float4 x[HASH_SLICE_UNROLL];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint32_t e = cn.idx[q] - lo;
-                if (e < n_ent) {
-                    atomicAdd(&acc[2 * e], hash_fix(cn.w[q] * g.x, scale));
-                    atomicAdd(&acc[2 * e + 1], hash_fix(cn.w[q] * g.y, scale));
-                }
+            for (int q = 0; q < HASH_SLICE_UNROLL; ++q) {
+                const int i = i0 + q * HASH_SLICE_THREADS + tid;
+                g[q] = make_float2(0.f, 0.f); x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < row_hi) { g[q] = gl[i]; x[q] = a.xs[i]; }
             }
+#pragma unroll
+            for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
+                if (g[q].x != 0.0f || g[q].y != 0.0f) hash_accumulate(a, level, dense, x[q], g[q], lo, n_ent, scale, acc);
         }
-    }
-    __syncthreads();
-    if (n_part > 1) {                                                // partial sums of a split level: into the 64-bit scratch
-        unsigned long long* gs = a.scratch64 + ((size_t)off + lo) * 2;
+        __syncthreads();
+        unsigned long long* gs = a.scratch64 + ((size_t)off + lo) * 2;       // partial sums -> the 64-bit scratch (exact)
         for (uint32_t e = tid; e < n_ent * 2; e += HASH_SLICE_THREADS)
             if (acc[e] != 0ull) atomicAdd(gs + e, acc[e]);
         return;
     }
+    // ---- binned level: exclusive scan of the chunks' record counts (n_chunks <= HASH_SLICE_THREADS), then a flat walk over
+    // this slice's records of ALL chunks: record ids first, then their rows -- two more round trips whatever the count
+    cbase[tid] = r0;
+    cstart[tid] = r1 - r0;
+    __syncthreads();
+    if (tid < 64) {                                                  // 256 counts, 4 per lane of one wave
+        unsigned v[HASH_SLICE_THREADS / 64], sum = 0;
+#pragma unroll
+        for (int q = 0; q < HASH_SLICE_THREADS / 64; ++q) { v[q] = cstart[tid * (HASH_SLICE_THREADS / 64) + q]; sum += v[q]; }
+        unsigned inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned u = __shfl_up(inc, d); if (tid >= d) inc += u; }
+        unsigned ex = inc - sum;
+#pragma unroll
+        for (int q = 0; q < HASH_SLICE_THREADS / 64; ++q) { cstart[tid * (HASH_SLICE_THREADS / 64) + q] = ex; ex += v[q]; }
+        if (tid == 63) cstart[HASH_SLICE_THREADS] = ex;
+    }
+    __syncthreads();
+    const unsigned total = cstart[HASH_SLICE_THREADS];
+    const unsigned* rec0 = a.records + (size_t)level * a.n_chunks * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
+    for (unsigned i0 = 0; i0 < total; i0 += HASH_SLICE_THREADS * HASH_SLICE_UNROLL) {
+        unsigned row[HASH_SLICE_UNROLL];
+        bool in[HASH_SLICE_UNROLL];
+#pragma unroll
+        for (int q = 0; q < HASH_SLICE_UNROLL; ++q) {
+            const unsigned i = i0 + q * HASH_SLICE_THREADS + tid;
+            in[q] = i < total;
+            row[q] = 0u;
+            if (in[q]) {
+                int c = 0;                                           // chunk of flat record i: last c with cstart[c] <= i
+#pragma unroll
+                for (int st = HASH_SLICE_THREADS / 2; st >= 1; st >>= 1)
+                    if (c + st < n_chunks && cstart[c + st] <= i) c += st;
+                row[q] = rec0[(size_t)c * (HASH_CHUNK * HASH_REC_PER_ROW) + cbase[c] + (i - cstart[c])];
+            }
+        }
+        float2 g[HASH_SLICE_UNROLL];
+        float4 x[HASH_SLICE_UNROLL];
+#pragma unroll
+        for (int q = 0; q < HASH_SLICE_UNROLL; ++q) {
+            g[q] = make_float2(0.f, 0.f); x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in[q]) { g[q] = gl[row[q]]; x[q] = a.xs[row[q]]; }
+        }
+#pragma unroll
+        for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
+            if (in[q]) hash_accumulate(a, level, dense, x[q], g[q], lo, n_ent, scale, acc);
+    }
+    __syncthreads();
     // ---- Adam on the slice: entries are float2, moments have the table's layout
     const PlaneOpt o = a.opt;
     const double inv = a.gscale[2 * level + 1];
@@ -580,6 +668,7 @@ int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st) {
     if (a.R <= 0) return 0;
     for (int l = 0; l < a.n_levels; ++l)
         if (hash_slices_of(a, l) > HASH_MAX_SLICES) return -7;
+    if (a.n_chunks > HASH_SLICE_THREADS) return -7;                 // (a slice workgroup scans its chunks' counts in one pass: <= 1 M rows)
     MNE_LAUNCH(hash_offsets_kernel, 1, 1024, 0, st, a);
     MNE_LAUNCH(hash_pack_kernel, (unsigned)a.n_pack_wgs, 256, 0, st, a);
     MNE_LAUNCH(hash_bin_kernel, (unsigned)(a.n_chunks * a.n_levels), HASH_BIN_THREADS, 0, st, a);

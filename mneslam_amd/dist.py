@@ -37,7 +37,7 @@ def init_agents(backend=None):
 
 def _meta_tensor(model):
     """[n_planes, then (C,H,W) per plane, then 6 bound + 6 bounding-box values, then 1.0 if the bounding box is
-    float64 (it is in the live system, mneslam_mp.py:223) else 0.0] as float64."""
+    float64 (it is in the live system, mneslam_mp.py:223) else 0.0, then 1.0 if the planes are stored in fp16] as float64."""
     planes = [p for lst in model.all_planes for p in lst]
     vals = [float(len(planes))]
     for p in planes:
@@ -46,32 +46,33 @@ def _meta_tensor(model):
     bb = torch.as_tensor(model.bounding_box).detach().cpu()
     vals += [float(v) for v in bb.reshape(-1)]
     vals.append(1.0 if bb.dtype == torch.float64 else 0.0)
+    vals.append(1.0 if planes and planes[0].dtype == torch.float16 else 0.0)      # half-precision plane storage (extension)
     return torch.tensor(vals, dtype=torch.float64)
 
 
-def send_model(model, dst, device=None):
+def send_model(model, dst, device=None, group=None):
     """Hand this agent's map (planes, decoder, bounds) to agent ``dst`` -- what the reference does by
-    writing ``latest_checkpoint.pt`` for a peer to ``torch.load`` (mneslam_mp.py:294-315)."""
+    writing ``latest_checkpoint.pt`` for a peer to ``torch.load`` (mneslam_mp.py:294-315).  ``dst`` is a global rank."""
     planes = [p for lst in model.all_planes for p in lst]
     device = device or planes[0].device
     meta = _meta_tensor(model).to(device)
     n = torch.tensor([meta.numel()], dtype=torch.int64, device=device)
-    dist.send(n, dst)
-    dist.send(meta, dst)
+    dist.send(n, dst, group=group)
+    dist.send(meta, dst, group=group)
     for p in planes:                     # logical NCHW order on the wire, whatever the physical layout
-        dist.send(p.detach().contiguous(), dst)
+        dist.send(p.detach().contiguous(), dst, group=group)
     for w in model.decoder.parameters():
-        dist.send(w.detach().contiguous(), dst)
+        dist.send(w.detach().contiguous(), dst, group=group)
 
 
-def recv_model_into(model_shared, src, device=None):
+def recv_model_into(model_shared, src, device=None, group=None):
     """Receive a peer's map into ``model_shared`` (mp_slam/mapper.py:708-726: replaces all_planes, bound,
     bounding_box and the decoder weights wholesale; the receiving model is put in eval mode)."""
     device = device or next(model_shared.decoder.parameters()).device
     n = torch.zeros(1, dtype=torch.int64, device=device)
-    dist.recv(n, src)
+    dist.recv(n, src, group=group)
     meta = torch.zeros(int(n.item()), dtype=torch.float64, device=device)
-    dist.recv(meta, src)
+    dist.recv(meta, src, group=group)
     meta = meta.cpu()
     n_planes = int(meta[0].item())
     shapes = meta[1:1 + 3 * n_planes].reshape(n_planes, 3).to(torch.int64).tolist()
@@ -79,10 +80,11 @@ def recv_model_into(model_shared, src, device=None):
     bbox = meta[7 + 3 * n_planes:13 + 3 * n_planes].reshape(3, 2)
     if float(meta[13 + 3 * n_planes]) == 0.0:        # the sender's box was fp32: keep its dtype (torch.load would)
         bbox = bbox.float()
+    plane_dtype = torch.float16 if meta.numel() > 14 + 3 * n_planes and float(meta[14 + 3 * n_planes]) != 0.0 else torch.float32
     planes = []
     for c, h, w in shapes:
-        buf = torch.empty(1, c, h, w, device=device)
-        dist.recv(buf, src)
+        buf = torch.empty(1, c, h, w, device=device, dtype=plane_dtype)
+        dist.recv(buf, src, group=group)
         planes.append(buf.contiguous(memory_format=torch.channels_last))
     lists = [planes[i:i + 2] for i in range(0, n_planes, 2)]        # [coarse, fine] per orientation
     model_shared.all_planes = tuple(lists)
@@ -90,11 +92,79 @@ def recv_model_into(model_shared, src, device=None):
     model_shared.bounding_box = bbox.to(device)
     for w in model_shared.decoder.parameters():
         buf = torch.empty_like(w)
-        dist.recv(buf, src)
+        dist.recv(buf, src, group=group)
         with torch.no_grad():
             w.copy_(buf)
     model_shared.eval()
     return model_shared
+
+
+class ModelExchange:
+    """The reference's map hand-off at loop closure / fusion is ONE-SIDED: the agent that detects the loop reads the peer's
+    last ``latest_checkpoint.pt`` whenever it wants (mp_slam/mapper.py:708-726); the peer does not take part.  Over a
+    process group that becomes a tiny service: every agent runs ``serve()`` in a daemon thread which waits for a request
+    from ANY peer on a control group (gloo: any-source receive) and answers with ``send_model`` on the data group (RCCL
+    point-to-point over xGMI between GPUs; gloo on CPU), on its own HIP stream; ``fetch(model_shared, src)`` is what
+    ``Mapper.load_foreign_model`` calls instead of ``torch.load``.  Both groups are private to the exchange (created
+    collectively in ``__init__``), so it never interleaves with the agents' own collectives (shared-decoder all-reduce,
+    overlap rectangles).  ``lock`` is held while a map is being sent: a mapper that wants its peers to see maps only at
+    keyframe boundaries -- where the reference writes its checkpoint (mneslam_mp.py:294-315) -- holds it during an update."""
+
+    STOP, FETCH = 0, 1
+
+    def __init__(self, model, device=None):
+        import threading
+        if not dist.is_initialized():
+            raise RuntimeError("ModelExchange needs an initialised process group (dist.init_agents)")
+        self.model, self.rank, self.world = model, dist.get_rank(), dist.get_world_size()
+        self.device = torch.device(device) if device is not None else next(model.decoder.parameters()).device
+        on_gpu = self.device.type == "cuda"
+        # collective calls: every agent builds its exchange at the same point of its start-up
+        self.ctrl = dist.new_group(backend="gloo")
+        self.data = dist.new_group(backend="nccl") if on_gpu else dist.new_group(backend="gloo")
+        self.lock = threading.Lock()
+        self._thread, self.served = None, 0
+
+    def start(self):
+        import threading
+        if self._thread is None:
+            self._thread = threading.Thread(target=self.serve, name=f"mne-model-exchange-{self.rank}", daemon=True)
+            self._thread.start()
+        return self
+
+    def serve(self):
+        stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        while True:
+            req = torch.zeros(2, dtype=torch.int64)
+            src = dist.recv(req, group=self.ctrl)                  # any source
+            if int(req[0]) == self.STOP:
+                return
+            with self.lock:
+                if stream is not None:
+                    stream.wait_stream(torch.cuda.current_stream(self.device))     # the map as enqueued so far
+                    with torch.cuda.stream(stream):
+                        send_model(self.model, src, self.device, group=self.data)
+                    stream.synchronize()
+                else:
+                    send_model(self.model, src, self.device, group=self.data)
+            self.served += 1
+
+    def fetch(self, model_shared, src):
+        """The peer's CURRENT map into ``model_shared`` (planes, decoder, both boxes; eval mode): one request + the transfer."""
+        if src == self.rank:
+            raise ValueError("an agent does not fetch its own map")
+        dist.send(torch.tensor([self.FETCH, self.rank], dtype=torch.int64), src, group=self.ctrl)
+        return recv_model_into(model_shared, src, self.device, group=self.data)
+
+    def stop(self):
+        """Ends this agent's service thread (a request to itself); call on every agent before destroy_process_group."""
+        if self._thread is not None:
+            if self.world > 1:
+                # any peer may stop us; we stop ourselves through our ring neighbour's thread being symmetrical: send to self is
+                # not defined for gloo point-to-point, so the STOP goes around: rank r stops rank (r + 1) % world
+                dist.send(torch.tensor([self.STOP, self.rank], dtype=torch.int64), (self.rank + 1) % self.world, group=self.ctrl)
+            self._thread.join(timeout=30)
+            self._thread = None
 
 
 def gather_keyframe_poses(poses, timestamps):

@@ -220,6 +220,15 @@ class FusedMappingMixin:
             trans.copy_(pa.trans.reshape(trans.shape))
         return pa.best()
 
+    def load_foreign_model(self, other_rank):
+        """mp_slam/mapper.py:708-726 -- called by the host's ``handle_loop_closure`` / ``bound_based_fusion`` (:340-360,
+        :700-706).  When the SLAM object carries a running ``model_exchange`` (mneslam_amd.dist.ModelExchange: the agents are
+        ranks of one process group) the peer's map is fetched from its device memory over the group (RCCL over xGMI) into
+        ``model_shared``; otherwise the peer's ``latest_checkpoint.pt`` is read like the reference does."""
+        from .. import slam_glue
+        return slam_glue.load_foreign_model(self.model_shared, self.config, other_rank, self.device,
+                                            exchange=getattr(self.slam, "model_exchange", None))
+
     def distillation(self, other_rank, expanded_foreign_kfs_for_distill, num_expanded_kfs):
         """Distil a foreign agent's map (``model_shared`` = teacher) into ``model`` (the training loop of
         mp_slam/mapper.py:594-644): every iteration draws camera rays at each foreign keyframe pose, the teacher renders

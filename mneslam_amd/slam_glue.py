@@ -125,10 +125,18 @@ def save_latest_checkpoint(model, config, rank):
     return path
 
 
-def load_foreign_model(model_shared, config, other_rank, device):
-    """Read a peer's ``latest_checkpoint.pt`` into ``model_shared`` (decoder weights, planes, both boxes) and put it
-    in eval mode.  Planes written by a reference agent are NCHW-contiguous: they are re-laid channels_last HERE, once,
-    so that rendering never converts per call."""
+def load_foreign_model(model_shared, config, other_rank, device, exchange=None):
+    """A peer's map into ``model_shared`` (decoder weights, planes, both boxes), which is put in eval mode.
+    With ``exchange`` (mneslam_amd.dist.ModelExchange, running on both agents) the map comes straight from the peer's
+    device memory over the process group -- RCCL point-to-point over xGMI between GPUs -- and the returned dict has the
+    checkpoint's keys; otherwise (and whenever no process group is up) the peer's ``latest_checkpoint.pt`` is read, the
+    reference's own path (mp_slam/mapper.py:708-726), which stays format-compatible with a reference agent's files.
+    Planes written by a reference agent are NCHW-contiguous: they are re-laid channels_last HERE, once, so that rendering
+    never converts per call."""
+    if exchange is not None:
+        exchange.fetch(model_shared, other_rank)
+        return {"model": model_shared.state_dict(), "all_planes": model_shared.all_planes,
+                "bound": model_shared.bound, "bounding_box": model_shared.bounding_box, "source": f"exchange:{other_rank}"}
     path = os.path.join(agent_dir(config, other_rank), "latest_checkpoint.pt")
     ckpt = torch.load(path, map_location=device, weights_only=False)
     model_shared.load_state_dict(ckpt["model"])

@@ -190,6 +190,68 @@ def test_two_agents_binned_overlap_shared_decoder(tmp_path):
     assert os.path.exists(ret + ".ok0") and os.path.exists(ret + ".ok1")
 
 
+def _exchange_worker(rank, world, port, ret):
+    """Two agents as ranks of one process group, each running the map-exchange service; the mixin's loop-closure entry
+    ``Mapper.load_foreign_model`` (what the host's handle_loop_closure / bound_based_fusion call) fetches the peer's
+    CURRENT map over the group; the file path stays the fallback and gives the same map."""
+    import copy
+    import types
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mneslam_amd import configs, dist as mdist, slam_glue
+    from mneslam_amd.model.scene_rep import JointEncoding
+    from mneslam_amd.mp_slam.mapper import Mapper
+    mdist.init_agents(backend="gloo")
+    cfg = configs.small_test_config(one_grid=False)                 # one decoder architecture (load_state_dict, :716), own bounds
+    cfg["mapping"]["bound"] = [[-1.0, 1.0 + 0.4 * rank], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["data"].update(output=ret + "_out", exp_name="exchange")
+    if rank == 1:
+        cfg["grid"]["plane_dtype"] = "fp16"                        # (and in storage: the wire carries the planes as stored)
+    torch.manual_seed(100 + rank)
+    bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
+    model = JointEncoding(cfg, bb)
+    shared = JointEncoding(copy.deepcopy(cfg), bb)                  # placeholder, replaced wholesale by every load
+    slam = types.SimpleNamespace(model=model, model_shared=shared, map_optimizer=None, device=torch.device("cpu"),
+                                 dataset=None, video=None, rank=rank, world_size=world,
+                                 model_exchange=mdist.ModelExchange(model).start())
+    mapper = Mapper(cfg, slam)
+    slam_glue.save_latest_checkpoint(model, cfg, rank)               # the reference's publication (the fallback's source)
+    dist.barrier()
+    other = 1 - rank
+    ck = mapper.load_foreign_model(other)                            # both directions at once: each serves while it fetches
+    assert ck["source"] == f"exchange:{other}" and {"model", "all_planes", "bound", "bounding_box"} <= set(ck)
+    got = [p.clone() for lst in shared.all_planes for p in lst]
+    got_dec = [w.detach().clone() for w in shared.decoder.parameters()]
+    got_bound, got_bb = shared.bound.clone(), shared.bounding_box.clone()
+    assert len(got) == 12 and not shared.training
+    assert tuple(got[0].shape) != tuple(next(iter(model.all_planes[0])).shape)       # the peer's own lattice, not ours
+    assert all(p.dtype == (torch.float16 if other == 1 else torch.float32) for p in got)
+    assert slam.model_exchange.served == 0 or slam.model_exchange.served == 1
+    # the same map through the file, with the exchange switched off
+    slam.model_exchange, ex = None, slam.model_exchange
+    ck2 = mapper.load_foreign_model(other)
+    assert "source" not in ck2
+    for a, b in zip(got, [p for lst in shared.all_planes for p in lst]):
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b) and b.is_contiguous(memory_format=torch.channels_last)
+    for a, b in zip(got_dec, shared.decoder.parameters()):
+        assert torch.equal(a, b)
+    assert torch.equal(got_bound, shared.bound.cpu().float()) and torch.equal(got_bb.double(), shared.bounding_box.cpu().double())
+    # the fetched map is usable as a teacher: a no-grad render runs on it (emulated kernels)
+    dist.barrier()
+    assert ex.served == 1
+    ex.stop()
+    dist.barrier()
+    open(ret + f".ok{rank}", "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_two_agents_map_exchange_through_load_foreign_model(tmp_path):
+    port = 29650 + (os.getpid() % 80)
+    ret = str(tmp_path / "x")
+    mp.spawn(_exchange_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert os.path.exists(ret + ".ok0") and os.path.exists(ret + ".ok1")
+
+
 @pytest.mark.parametrize("launcher", ["torchrun", "self"])
 def test_bench_launcher_dry_run_two_ranks(tmp_path, launcher):
     """The driver's multi-GPU command line, as written in the task contract, on two ranks over gloo with the kernels in the
