@@ -314,7 +314,11 @@ typedef struct mne_fused_opts {
      * before mne_tile_adam.  The deferred rays' appends stay in this call (behind its deferred pass).  0 / NULL: the call
      * does all appends itself. */
     int32_t external_bin;
-    int32_t reserved;
+    /* mne_render_fused_features with grid_cfg + table: != 0 = the rows of the first pass (a-priori tiles + the resolver's
+     * extension) were already gathered by the caller -- mne_hash_gather with the same ray_counts, e.g. on the caller's stream
+     * while the decoder of the previous iteration is still being updated on another; the call then gathers only the
+     * deferred rays' remaining rows. */
+    int32_t features_pregathered;
     void* event_after_decode;
 } mne_fused_opts_t;
 
@@ -535,8 +539,10 @@ size_t mne_hash_workspace_bytes(const mne_grid_cfg_t* cfg, int n_rays, int n_sam
 int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                         const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles, float* table,
                         const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
+/* ray_counts (optional, the per-ray counts of mne_sample_z): only the rows the exact early termination can decode in its first
+ * pass -- the a-priori tiles of every ray plus the resolver's extension; NULL = every row */
 int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
-                    const float* rays_d, const float* z_vals, const float* table, float* tape, void* stream);
+                    const float* rays_d, const float* z_vals, const int32_t* ray_counts, const float* table, float* tape, void* stream);
 /* the grid features of every sample as compact rows: features [R*S][64], columns [0, n_levels*2) written, the rest
  * untouched (zero-initialise once): the input of mne_render_forward_features */
 int mne_hash_features(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,

@@ -86,7 +86,7 @@ class Clock(C.Structure):
 class FusedOpts(C.Structure):
     """mne_fused_opts_t: per-call extras of mne_render_fused / mne_render_fused_features."""
     _fields_ = [("timing_events", C.POINTER(C.c_void_p)), ("n_timing_events", C.c_int32), ("lds_samples_cap", C.c_int32),
-                ("adapt_state", C.c_void_p), ("external_bin", C.c_int32), ("reserved", C.c_int32),
+                ("adapt_state", C.c_void_p), ("external_bin", C.c_int32), ("features_pregathered", C.c_int32),
                 ("event_after_decode", C.c_void_p)]
 
 
@@ -176,7 +176,7 @@ _PROTOS = {
     "mne_grid_encode": (C.c_int, [C.POINTER(GridCfg), C.c_int64] + [C.c_void_p] * 5),
     "mne_grid_encode_backward": (C.c_int, [C.POINTER(GridCfg), C.c_int64] + [C.c_void_p] * 4),
     "mne_encode_oneblob": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mne_hash_gather": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "mne_hash_gather": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 7),
     "mne_render_fused_features": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 13
                                   + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GridCfg), C.c_void_p,
                                      C.POINTER(FusedOpts), C.c_void_p]),

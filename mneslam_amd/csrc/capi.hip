@@ -339,6 +339,7 @@ static int render_fused(bool ext_feat, const GridArgs* ext_grid, const mne_scene
         if (opts->lds_samples_cap > 0) a.lds_samples = opts->lds_samples_cap;
         a.adapt = ray_counts ? opts->adapt_state : nullptr;       // without per-ray counts everything is decoded a priori anyway
         host.external_bin = opts->external_bin; host.ev_after_decode = opts->event_after_decode;
+        host.features_pregathered = opts->features_pregathered;
     }
     if (bins)
         if (int rc = fill_bins(scene, bins, a.bins)) return rc;
@@ -819,12 +820,13 @@ static int fill_hash_rows(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, i
 extern "C" {
 
 int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
-                    const float* rays_d, const float* z_vals, const float* table, float* tape, void* stream) {
+                    const float* rays_d, const float* z_vals, const int32_t* ray_counts, const float* table, float* tape, void* stream) {
     GridArgs a = {};
     if (int rc = fill_hash_rows(cfg, scene, n_rays, n_samples, rays_o, rays_d, z_vals, tape, a)) return rc;
     if (!table) return fail(-1, "mne_hash_gather: NULL argument");
     if (n_rays <= 0) return 0;
     a.params = table;
+    a.ray_counts = ray_counts;
     mne_launch_hash_rows(a, 0, (hipStream_t)stream);
     return check_launch("hash_gather");
 }

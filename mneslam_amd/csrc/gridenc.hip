@@ -74,35 +74,18 @@ __global__ __launch_bounds__(256) void grid_kernel(GridArgs a) {
         for (int f = 0; f < F; ++f) a.out[t * ostr + level * F + f] = acc[f];
 }
 
-// ---- fused form: the encoding of a ray batch's samples, written as (read from) rows of the render tape ----------
-// One lane per (sample, level): a wave covers 4 samples x 16 levels, so the 16 levels x 2 features of a sample are one
-// 128-byte line of its tape row (full-line stores; the level-major kernel above would write 8 bytes per line).  The
-// sample position is recomputed from the ray and z exactly as decode_tile does (render.hip), x = the OneBlob input.
-// Backward: d(table) += w * d(feature) with global_atomic_add_f32; rows past a ray's last backward tile were never
-// written by ray_kernel and are skipped, all-zero rows (samples without gradient) issue no atomics.
-template <bool BWD>
-__global__ __launch_bounds__(256) void hash_rows_kernel(GridArgs a) {
+// ---- fused form: the encoding of a ray batch's samples, read from / written as rows of the render tape -------------------
+// hash_scatter_kernel (the plain atomic scatter, kept as the cross-check of mne_hash_scatter impl 1): one lane per
+// (sample, level), d(table) += w * d(feature) with global_atomic_add_f32; rows past a ray's last backward tile were never
+// written by ray_kernel and are skipped, all-zero rows (samples without gradient) issue no atomics.  The sample position
+// is recomputed from the ray and z exactly as decode_tile does (render.hip), x = the OneBlob input.
+__global__ __launch_bounds__(256) void hash_scatter_kernel(GridArgs a) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int level = (int)(gid & 15);
-    long long row = gid >> 4;
+    const long long row = gid >> 4;
     if (row >= (long long)a.R * a.S || level >= a.n_levels) return;
-    int r = (int)(row / a.S);
-    const int s = (int)(row % a.S);
-    if (BWD && a.ray_tiles && s >= a.ray_tiles[r] * 32) return;
-    if (!BWD && a.ray_counts) {
-        // forward under early termination: the first pass fills the tiles decode_kernel can reach (a-priori prefix + the
-        // resolver's extension), the list pass the rest of the rays that were deferred
-        if (a.ray_list) {
-            if (r >= *a.ray_list_count) return;
-            r = a.ray_list[r];
-            row = (long long)r * a.S + s;
-        }
-        const int ntile = (a.S + 31) / 32;
-        const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
-        int t = (need + 31) / 32;
-        t = (t < 1 ? 1 : (t > ntile ? ntile : t)) + MNE_RESOLVER_MAX_EXT;         // = prefix_tiles() of render.hip + extension
-        if (a.ray_list ? s < t * 32 : s >= t * 32) return;
-    }
+    const int r = (int)(row / a.S), s = (int)(row % a.S);
+    if (a.ray_tiles && s >= a.ray_tiles[r] * 32) return;
     const float z = a.z_vals[row];
     const float scale = a.scale[level];
     const uint32_t res = a.res[level], size = a.size[level], off = a.offset[level];
@@ -118,39 +101,112 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(GridArgs a) {
         cell[d] = (uint32_t)(int)fl;
         frac[d] = pos - fl;
     }
-    float* trow = a.tape + (size_t)row * a.row_stride;
-    float2 acc = make_float2(0.f, 0.f);
-    if (BWD) {
-        acc = *(const float2*)(trow + a.col_d + level * 2);
-        if (acc.x == 0.0f && acc.y == 0.0f) return;
-    }
-    const float2* table = (const float2*)a.params + off;
-    float2 v[8];
-    float w[8];
-    uint32_t idx[8];
+    const float2 acc = *(const float2*)(a.tape + (size_t)row * a.row_stride + a.col_d + level * 2);
+    if (acc.x == 0.0f && acc.y == 0.0f) return;
+    float* g = a.dparams + ((size_t)off) * 2;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        w[c] = 1.0f;
+        float w = 1.0f;
         uint32_t cc[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            if ((c >> d) & 1) { cc[d] = cell[d] + 1u; w[c] *= frac[d]; }
-            else { cc[d] = cell[d]; w[c] *= 1.0f - frac[d]; }
+            if ((c >> d) & 1) { cc[d] = cell[d] + 1u; w *= frac[d]; }
+            else { cc[d] = cell[d]; w *= 1.0f - frac[d]; }
         }
-        idx[c] = grid_index_fast(cc[0], cc[1], cc[2], res, size, dense);
-        if (!BWD) v[c] = table[idx[c]];                                            // 8 independent 8-byte reads in flight
+        const uint32_t idx = grid_index_fast(cc[0], cc[1], cc[2], res, size, dense);
+        unsafeAtomicAdd(g + (size_t)idx * 2, w * acc.x);
+        unsafeAtomicAdd(g + (size_t)idx * 2 + 1, w * acc.y);
     }
-    if (BWD) {
-        float* g = a.dparams + ((size_t)off) * 2;
+}
+
+// ---- gather of a ray batch, level-major waves ----------------------------------------------------------------------------
+// (Rounds 2-3 mapped a wave to 4 samples x 16 levels: every load instruction of a wave touched 64 different cache lines in
+// 16 different level tables.)  Here a workgroup takes 64 CONSECUTIVE samples of one ray and a wave = those 64
+// samples at ONE level (each thread: its sample at 4 levels, 32 independent 8-byte reads in flight): on the dense levels
+// consecutive samples sit in the same or neighbouring cells, so the 64 lanes of a load fall into a handful of lines instead
+// of 64 (the hashed levels have no locality either way).  The 16 x 2 features of a sample leave through an LDS transpose
+// as full 128-byte lines of its tape row, as before.  Same arithmetic, same bits.
+__global__ __launch_bounds__(256) void hash_gather_kernel(GridArgs a) {
+    __shared__ float2 tile[64][17];                                  // [sample][level], padded: conflict-free both ways
+    const int tid = threadIdx.x, sm = tid & 63, lq = tid >> 6;
+    const int groups = (a.S + 63) / 64;
+    int r = blockIdx.x / groups;
+    const int s0 = (blockIdx.x % groups) * 64;
+    int s_lo = 0, s_hi = a.S;                                        // rows [s_lo, s_hi) of the ray are wanted
+    if (a.ray_counts) {
+        // under early termination: the first pass fills the tiles decode_kernel can reach (a-priori prefix + the resolver's
+        // extension), the list pass the rest of the rays that were deferred
+        if (a.ray_list) {
+            if (r >= *a.ray_list_count) return;
+            r = a.ray_list[r];
+        }
+        const int ntile = (a.S + 31) / 32;
+        const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
+        int t = (need + 31) / 32;
+        t = (t < 1 ? 1 : (t > ntile ? ntile : t)) + MNE_RESOLVER_MAX_EXT;         // = prefix_tiles() of render.hip + extension
+        if (a.ray_list) s_lo = t * 32; else s_hi = t * 32 < a.S ? t * 32 : a.S;
+    }
+    if (s0 >= s_hi || s0 + 64 <= s_lo) return;                        // (whole workgroup)
+    const int s = s0 + sm;
+    const bool in = s >= s_lo && s < s_hi;
+    const long long row = (long long)r * a.S + (s < a.S ? s : a.S - 1);
+    const float z = a.z_vals[row];
+    float x[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float p = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;              // scene_rep.py:384
+        x[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
+    }
+    float2 v[4][8];
+    float w[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int level = lq + 4 * j;
+        const bool live = in && level < a.n_levels;
+        const int lv = level < a.n_levels ? level : 0;
+        const float scale = a.scale[lv];
+        const uint32_t res = a.res[lv], size = a.size[lv];
+        const bool dense = (unsigned long long)res * res * res <= size;
+        const float2* table = (const float2*)a.params + a.offset[lv];
+        float frac[3];
+        uint32_t cell[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float pos = fmaf(scale, x[d], 0.5f);
+            const float fl = floorf(pos);
+            cell[d] = (uint32_t)(int)fl;
+            frac[d] = pos - fl;
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            unsafeAtomicAdd(g + (size_t)idx[c] * 2, w[c] * acc.x);
-            unsafeAtomicAdd(g + (size_t)idx[c] * 2 + 1, w[c] * acc.y);
-        }
-    } else {
+            float wc = 1.0f;
+            uint32_t cc[3];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { acc.x = fmaf(w[c], v[c].x, acc.x); acc.y = fmaf(w[c], v[c].y, acc.y); }   // corner order of grid_kernel
-        *(float2*)(trow + a.col_x + level * 2) = acc;
+            for (int d = 0; d < 3; ++d) {
+                if ((c >> d) & 1) { cc[d] = cell[d] + 1u; wc *= frac[d]; }
+                else { cc[d] = cell[d]; wc *= 1.0f - frac[d]; }
+            }
+            w[j][c] = wc;
+            const uint32_t idx = grid_index_fast(cc[0], cc[1], cc[2], res, size, dense);
+            v[j][c] = live ? table[idx] : make_float2(0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { acc.x = fmaf(w[j][c], v[j][c].x, acc.x); acc.y = fmaf(w[j][c], v[j][c].y, acc.y); }   // corner order of grid_kernel
+        tile[sm][lq + 4 * j] = acc;
+    }
+    __syncthreads();
+    // 4 lanes x 32 B = the 128-byte feature line of one row
+    const int rs = tid >> 2, part = tid & 3;
+    const int so = s0 + rs;
+    if (so >= s_lo && so < s_hi) {
+        float* dst = a.tape + ((size_t)r * a.S + so) * a.row_stride + a.col_x + part * 8;
+        const float2 t0 = tile[rs][part * 4], t1 = tile[rs][part * 4 + 1], t2 = tile[rs][part * 4 + 2], t3 = tile[rs][part * 4 + 3];
+        *(float4*)dst = make_float4(t0.x, t0.y, t1.x, t1.y);
+        *(float4*)(dst + 4) = make_float4(t2.x, t2.y, t3.x, t3.y);
     }
 }
 
@@ -255,7 +311,7 @@ __global__ __launch_bounds__(256) void hash_scatter_runs_kernel(GridArgs a) {
 #define HASH_SLICE_SHIFT 11
 static_assert((1 << HASH_SLICE_SHIFT) == HASH_SLICE, "slice = index >> HASH_SLICE_SHIFT");
 #define HASH_SLICE_THREADS 256
-#define HASH_CHUNK 4096            // packed rows per bin workgroup
+#define HASH_CHUNK 2048            // packed rows per bin workgroup (2 per thread: the slot words of more rows spill)
 #define HASH_BIN_THREADS 1024
 #define HASH_RPT (HASH_CHUNK / HASH_BIN_THREADS)
 #define HASH_REC_PER_ROW 8         // a row's corners fall into at most 8 slices (4 on a hashed level with resolution < 2048)
@@ -345,7 +401,7 @@ __global__ __launch_bounds__(256) void hash_pack_kernel(GridArgs a) {
 
 struct HashCorners { uint32_t idx[8]; float w[8]; };
 // the eight corner entries (index within the level) and trilinear weights of grid input x at `level`: the expressions of
-// grid_kernel / hash_rows_kernel (same index bits, same product order of the weights)
+// grid_kernel / hash_gather_kernel (same index bits, same product order of the weights)
 __device__ __forceinline__ void hash_corners(const GridArgs& a, int level, float4 x, bool dense, HashCorners& c) {
     const float scale = a.scale[level];
     const uint32_t res = a.res[level], size = a.size[level];
@@ -367,11 +423,21 @@ __device__ __forceinline__ void hash_corners(const GridArgs& a, int level, float
     }
 }
 
-// One workgroup per (BINNED level, chunk of HASH_CHUNK packed rows): counting sort of the chunk's (row, slice) pairs by
+// A record of the binned table update: one backward row as seen by ONE slice of one level -- the grid input, the level's
+// d(feature) and the set of the row's eight corners that fall into the slice.  24 bytes, self-contained: the slice
+// workgroup streams its records (contiguous per chunk) and never goes back to the packed arrays (with 4-byte row ids it
+// did: ~10 M random 8 / 16-byte reads through eight L2s that cannot hold 18 MB of rows, 553 MB of fabric traffic).
+struct HashRecord { float x, y, z, gx, gy; unsigned mask; };
+static_assert(sizeof(HashRecord) == 24, "record layout");
+
+// One workgroup per (BINNED level, chunk of HASH_CHUNK packed rows): counting sort of the chunk's (row, slice) records by
 // slice.  (Levels that are split into parts -- few slices, every row hits them -- are not binned: their workgroups walk row
 // ranges directly.)
 //   seg_off[level][chunk][0 .. n_slices]   start of every slice's records inside the chunk's segment (last = total)
-//   records[level][chunk][..]              packed row ids, slice after slice
+//   records[level][chunk][..]              HashRecords, slice after slice
+// Ranks inside a slice come from LDS integer atomics, ONE per run of consecutive rows with the same slice: consecutive
+// packed rows are consecutive samples of a ray, which on a dense level stay in one cell for dozens of samples -- per-row
+// returning atomics on the same counter serialise (the appends of render.hip's bin_kernel know the problem).
 // Workgroup (level, chunk 0) of EVERY level also publishes the level's fixed-point scale from the pack kernel's
 // per-workgroup maxima.
 __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) {
@@ -403,7 +469,8 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     for (int i = tid; i <= ns; i += HASH_BIN_THREADS) hist[i] = 0u;
     const bool dense = hash_level_dense(a, level);
     const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
-    // this thread's rows, all loads first (one round trip)
+    // this thread's rows, all loads first (one round trip).  Row j of thread tid = chunk row j * 1024 + tid: the lanes of a
+    // wave hold CONSECUTIVE rows.
     float2 g[HASH_RPT];
     float4 x[HASH_RPT];
 #pragma unroll
@@ -413,27 +480,44 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
         if (k < n_live) { g[j] = gl[k]; x[j] = a.xs[k]; }
     }
     __syncthreads();
-    // the distinct slices of each row's eight corners, ranked inside their slice (LDS integer atomics)
-    unsigned rec[HASH_RPT][HASH_REC_PER_ROW];                        // slice of corner q, ~0u: no record (same slice as an earlier corner)
-    unsigned rnk[HASH_RPT][HASH_REC_PER_ROW];
+    // slot q of a row = the slice of its corner q if no earlier corner has the same slice (then it carries the mask of all
+    // corners in that slice), else empty
+    static_assert(HASH_MAX_SLICES <= 4096 && HASH_CHUNK <= 4096, "slot word: slice (12 bits) | corner mask (8) | rank in the slice (12)");
+    unsigned rec[HASH_RPT][HASH_REC_PER_ROW];                        // slice | corner mask << 12 | rank << 20   (mask 0: empty slot)
 #pragma unroll
     for (int j = 0; j < HASH_RPT; ++j) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) rec[j][q] = 0xffffffffu;
-        if (g[j].x != 0.0f || g[j].y != 0.0f) {                      // rows without gradient leave no record
+        unsigned sl[8];
+        const bool row_live = g[j].x != 0.0f || g[j].y != 0.0f;      // rows without gradient leave no record
+        {
             HashCorners c;
             hash_corners(a, level, x[j], dense, c);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const unsigned sl = c.idx[q] >> HASH_SLICE_SHIFT;
-                bool dup = false;
+            for (int q = 0; q < 8; ++q) sl[q] = c.idx[q] >> HASH_SLICE_SHIFT;
+        }
 #pragma unroll
-                for (int p = 0; p < q; ++p) dup = dup || (c.idx[p] >> HASH_SLICE_SHIFT) == sl;
-                if (!dup) {
-                    rec[j][q] = sl;
-                    rnk[j][q] = atomicAdd(&hist[sl], 1u);
-                }
+        for (int q = 0; q < 8; ++q) {
+            bool dup = false;
+            unsigned mask = 0u;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                if (p < q) dup = dup || sl[p] == sl[q];
+                mask |= (sl[p] == sl[q]) ? (1u << p) : 0u;
             }
+            const bool have = row_live && !dup;
+            const unsigned key = have ? sl[q] : 0xffffffffu;
+            rec[j][q] = have ? (sl[q] | (mask << 12)) : 0u;
+            // one returning LDS atomic per RUN of consecutive lanes with the same slice in slot q
+            const unsigned prev = __shfl_up(key, 1);
+            const bool start = lane == 0 || key != prev;
+            const unsigned long long sm = __ballot(start);
+            const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+            const int leader = 63 - __clzll(sm & upto);
+            const unsigned long long above = sm & ~upto;
+            const int next = above ? __ffsll(above) - 1 : 64;
+            unsigned base = 0u;
+            if (have && leader == lane) base = atomicAdd(&hist[sl[q]], (unsigned)(next - leader));
+            base = __shfl(base, leader);
+            rec[j][q] |= (base + (unsigned)(lane - leader)) << 20;
         }
     }
     __syncthreads();
@@ -465,13 +549,17 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     __syncthreads();
     unsigned* so = a.seg_off + a.seg_level[level] + (size_t)chunk * (ns + 1);
     for (int i = tid; i <= ns; i += HASH_BIN_THREADS) so[i] = hist[i];
-    unsigned* rc = a.records + ((size_t)level * a.n_chunks + chunk) * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
+    HashRecord* rc = (HashRecord*)a.records + ((size_t)level * a.n_chunks + chunk) * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
 #pragma unroll
     for (int j = 0; j < HASH_RPT; ++j) {
-        const unsigned k = (unsigned)(chunk * HASH_CHUNK + j * HASH_BIN_THREADS + tid);
 #pragma unroll
         for (int q = 0; q < HASH_REC_PER_ROW; ++q)
-            if (rec[j][q] != 0xffffffffu) rc[hist[rec[j][q]] + rnk[j][q]] = k;
+            if ((rec[j][q] >> 12) & 0xffu) {
+                HashRecord* d = rc + hist[rec[j][q] & 0xfffu] + (rec[j][q] >> 20);
+                *(float2*)&d->x = make_float2(x[j].x, x[j].y);
+                *(float2*)&d->z = make_float2(x[j].z, g[j].x);
+                *(float2*)&d->gy = make_float2(g[j].y, __uint_as_float((rec[j][q] >> 12) & 0xffu));
+            }
     }
 }
 
@@ -479,15 +567,16 @@ __device__ __forceinline__ unsigned long long hash_fix(float v, double scale) {
     return (unsigned long long)(long long)rint((double)v * scale);  // two's complement: sums wrap correctly
 }
 
-// the corners of one backward row that fall into [lo, lo + n_ent) -> the slice's fixed-point sums
-__device__ __forceinline__ void hash_accumulate(const GridArgs& a, int level, bool dense, float4 x, float2 g, uint32_t lo, uint32_t n_ent,
-                                                double scale, unsigned long long* acc) {
+// the corners `mask` of one backward row -> the fixed-point sums of the slice [lo, lo + n_ent) (corners of the mask that
+// fall outside it -- the unbinned walk passes all eight -- are skipped)
+__device__ __forceinline__ void hash_accumulate(const GridArgs& a, int level, bool dense, float4 x, float2 g, unsigned mask, uint32_t lo,
+                                                uint32_t n_ent, double scale, unsigned long long* acc) {
     HashCorners cn;
     hash_corners(a, level, x, dense, cn);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const uint32_t e = cn.idx[q] - lo;
-        if (e < n_ent) {
+        if (((mask >> q) & 1u) && e < n_ent) {
             atomicAdd(&acc[2 * e], hash_fix(cn.w[q] * g.x, scale));
             atomicAdd(&acc[2 * e + 1], hash_fix(cn.w[q] * g.y, scale));
         }
@@ -521,9 +610,9 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     }
     for (int i = tid; i < HASH_SLICE * 2; i += HASH_SLICE_THREADS) acc[i] = 0ull;
     const double scale = a.gscale[2 * level];
-    const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
     if (n_part > 1) {
         // ---- split level: this part's share of ALL rows, straight from the packed arrays (coalesced), a few rows in flight
+        const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
         __syncthreads();
         const int row_lo = (int)((long long)n_live * part / n_part), row_hi = (int)((long long)n_live * (part + 1) / n_part);
         for (int i0 = row_lo; i0 < row_hi; i0 += HASH_SLICE_THREADS * HASH_SLICE_UNROLL) {
@@ -537,7 +626,7 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
             }
 #pragma unroll
             for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
-                if (g[q].x != 0.0f || g[q].y != 0.0f) hash_accumulate(a, level, dense, x[q], g[q], lo, n_ent, scale, acc);
+                if (g[q].x != 0.0f || g[q].y != 0.0f) hash_accumulate(a, level, dense, x[q], g[q], 0xffu, lo, n_ent, scale, acc);
         }
         __syncthreads();
         unsigned long long* gs = a.scratch64 + ((size_t)off + lo) * 2;       // partial sums -> the 64-bit scratch (exact)
@@ -546,7 +635,7 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
         return;
     }
     // ---- binned level: exclusive scan of the chunks' record counts (n_chunks <= HASH_SLICE_THREADS), then a flat walk over
-    // this slice's records of ALL chunks: record ids first, then their rows -- two more round trips whatever the count
+    // this slice's records of ALL chunks (each chunk's are contiguous): one more round trip whatever the count
     cbase[tid] = r0;
     cstart[tid] = r1 - r0;
     __syncthreads();
@@ -564,33 +653,28 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     }
     __syncthreads();
     const unsigned total = cstart[HASH_SLICE_THREADS];
-    const unsigned* rec0 = a.records + (size_t)level * a.n_chunks * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
+    const HashRecord* rec0 = (const HashRecord*)a.records + (size_t)level * a.n_chunks * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
     for (unsigned i0 = 0; i0 < total; i0 += HASH_SLICE_THREADS * HASH_SLICE_UNROLL) {
-        unsigned row[HASH_SLICE_UNROLL];
+        float2 w0[HASH_SLICE_UNROLL], w1[HASH_SLICE_UNROLL], w2[HASH_SLICE_UNROLL];
         bool in[HASH_SLICE_UNROLL];
 #pragma unroll
         for (int q = 0; q < HASH_SLICE_UNROLL; ++q) {
             const unsigned i = i0 + q * HASH_SLICE_THREADS + tid;
             in[q] = i < total;
-            row[q] = 0u;
+            w0[q] = w1[q] = w2[q] = make_float2(0.f, 0.f);
             if (in[q]) {
                 int c = 0;                                           // chunk of flat record i: last c with cstart[c] <= i
 #pragma unroll
                 for (int st = HASH_SLICE_THREADS / 2; st >= 1; st >>= 1)
                     if (c + st < n_chunks && cstart[c + st] <= i) c += st;
-                row[q] = rec0[(size_t)c * (HASH_CHUNK * HASH_REC_PER_ROW) + cbase[c] + (i - cstart[c])];
+                const HashRecord* d = rec0 + (size_t)c * (HASH_CHUNK * HASH_REC_PER_ROW) + cbase[c] + (i - cstart[c]);
+                w0[q] = *(const float2*)&d->x; w1[q] = *(const float2*)&d->z; w2[q] = *(const float2*)&d->gy;
             }
-        }
-        float2 g[HASH_SLICE_UNROLL];
-        float4 x[HASH_SLICE_UNROLL];
-#pragma unroll
-        for (int q = 0; q < HASH_SLICE_UNROLL; ++q) {
-            g[q] = make_float2(0.f, 0.f); x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in[q]) { g[q] = gl[row[q]]; x[q] = a.xs[row[q]]; }
         }
 #pragma unroll
         for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
-            if (in[q]) hash_accumulate(a, level, dense, x[q], g[q], lo, n_ent, scale, acc);
+            if (in[q]) hash_accumulate(a, level, dense, make_float4(w0[q].x, w0[q].y, w1[q].x, 0.0f), make_float2(w1[q].y, w2[q].x),
+                                       __float_as_uint(w2[q].y), lo, n_ent, scale, acc);
     }
     __syncthreads();
     // ---- Adam on the slice: entries are float2, moments have the table's layout
@@ -659,7 +743,7 @@ size_t mne_hash_layout(GridArgs& a, int R, int S, void* base) {
     for (int l = 0; l < a.n_levels; ++l) { a.seg_level[l] = so; so += (size_t)n_chunks * (hash_slices_of(a, l) + 1); }
     a.seg_off = (unsigned*)take(so * sizeof(unsigned));
     a.n_chunks = n_chunks;
-    a.records = (unsigned*)take((size_t)a.n_levels * n_chunks * HASH_CHUNK * HASH_REC_PER_ROW * sizeof(unsigned));
+    a.records = (unsigned*)take((size_t)a.n_levels * n_chunks * HASH_CHUNK * HASH_REC_PER_ROW * sizeof(HashRecord));
     a.pack_cap = (long long)rows;
     return off;
 }
@@ -686,8 +770,8 @@ int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st) {
     }
     const long long n = (long long)a.R * a.S * 16;
     if (n <= 0) return 0;
-    if (bwd) MNE_LAUNCH(hash_rows_kernel<true>, (unsigned)((n + 255) / 256), 256, 0, st, a);
-    else MNE_LAUNCH(hash_rows_kernel<false>, (unsigned)((n + 255) / 256), 256, 0, st, a);
+    if (bwd) MNE_LAUNCH(hash_scatter_kernel, (unsigned)((n + 255) / 256), 256, 0, st, a);
+    else MNE_LAUNCH(hash_gather_kernel, (unsigned)(a.R * ((a.S + 63) / 64)), 256, 0, st, a);
     return 0;
 }
 

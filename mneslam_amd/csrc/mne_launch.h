@@ -106,6 +106,7 @@ struct RenderHost {
     int n_marks = 0;
     int external_bin = 0;                        // the caller runs the list appends itself (mne_tile_bin)
     void* ev_after_decode = nullptr;             // hipEvent_t recorded once the prefix decode is enqueued
+    int features_pregathered = 0;                // ext_grid: the caller already gathered the first pass's rows (mne_hash_gather with ray_counts)
 };
 
 struct LossArgs {
@@ -186,7 +187,7 @@ struct GridArgs {
     double* gscale;              // [n_levels][2] fixed-point scale of the level's gradient sums and its inverse
     unsigned* seg_off;           // per level: [n_chunks][n_slices + 1] start of each slice's records in the chunk's segment
     size_t seg_level[MNE_GRID_MAX_LEVELS];   // first word of each level's block in seg_off
-    unsigned* records;           // [n_levels][n_chunks][HASH_CHUNK * 8] packed row ids, slice after slice
+    unsigned* records;           // [n_levels][n_chunks][HASH_CHUNK * 8] 24-byte records (gridenc.hip: HashRecord), slice after slice
     int n_chunks;                // chunks the workspace was laid out for (R*S rows)
     unsigned long long* scratch64;   // fixed-point gradient sums of the levels that are split over several workgroups per slice
     PlaneOpt opt;                // table optimizer state and step constants

@@ -1462,7 +1462,7 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         if (!workspace) return -6;
         carve_workspace(a, workspace);
     }
-    if (mode == 2 && a.ext_feat && host.ext_grid) {       // hash-grid rows of the tiles the first pass can decode
+    if (mode == 2 && a.ext_feat && host.ext_grid && !host.features_pregathered) {       // hash-grid rows of the tiles the first pass can decode
         GridArgs g = *host.ext_grid;
         g.ray_counts = a.ray_counts; g.ray_list = nullptr; g.ray_list_count = nullptr;
         mark(host, 0, st);

@@ -650,13 +650,19 @@ class FusedStep:
 
 class HashFusedStep(FusedStep):
     """The mapping iteration of ``model.scene_rep_hash.HashJointEncoding`` (EXTENSION: the hash-grid wiring the reference
-    keeps commented out, parity unpinned).  Same batch sampler, decoder / compositing / loss kernels, weight-gradient
-    and Adam kernels as FusedStep; the plane gather and the binned plane update are replaced by
+    keeps commented out, parity unpinned).  Same batch sampler, decoder / compositing / loss kernels and weight-gradient
+    kernels as FusedStep; the plane gather and the binned plane update are replaced by the grid's (include/mneslam_hip.h,
+    section NS-a).  One iteration on two HIP streams and TWO tapes (alternating: the next gather may overwrite feature
+    columns that the weight-gradient pass of this iteration is still reading):
 
-        mne_hash_gather -> mne_render_fused_features -> mne_hash_scatter -> ... -> mne_adam_step(table + decoder)
+      caller's stream   gather(i) [rows the early termination can decode] -> wait "decoder(i-1) updated" -> decode .. backward
+                        (mne_render_fused_features) -> *event "backward done"* -> table update (mne_hash_slice_adam: binned rows,
+                        exact fixed-point LDS sums, Adam fused) -> loss scalars -> batch(i+1) -> gather(i+1) ...
+      side stream       wait "backward done" -> mne_decoder_wgrad (no reduction) -> mne_decoder_update (reduce + decoder Adam)
+                        -> decoder tables of the next render -> *event "decoder updated"*
 
-    on one stream (include/mneslam_hip.h, section NS-a).  The grid features of EVERY sample are gathered (the tiles a ray
-    needs beyond its a-priori prefix are only known while decoding); the decode itself terminates rays early, exactly."""
+    The table's critical chain is  backward -> table update -> next gather -> next decode;  the decoder's chain (~0.2 ms with
+    2x64 decoders) runs beside the table update AND the next gather."""
 
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None):
         if not isinstance(optimizer, FusedAdam):
@@ -676,16 +682,19 @@ class HashFusedStep(FusedStep):
             raise ValueError("the hash table must live on the compute device")
         self.grid_cfg = model.embed_fn.cfg
         self.dec_w = model.decoder.hip_weights()
+        self.group_of = {p: g for g in optimizer.param_groups for p in g["params"]}
+        self.group_of_dec = self.group_of[self.dec_w[0]]
         self.scene = hip_path.scene_struct(self.info, [], [w.data for w in self.dec_w], None)
         self.scene.n_sets = 1
         self._alloc_buffers(config, is_co_sdf)
         self.tape.zero_()                                  # feature columns the grid does not fill must read as zero
+        self.tapes = [self.tape, torch.zeros_like(self.tape)]
         st = optimizer._state(self.table)
         if "grad_buffer" not in st:
             st["grad_buffer"] = torch.zeros_like(self.table.data)
         self.table_grad = st["grad_buffer"]
-        # table update: "slices" = LDS-accumulated slices + fused Adam (no atomics, no gradient buffer; default);
-        # "atomics" = run-reduced global atomics into a gradient buffer + the streaming Adam kernel
+        # table update: "slices" = slice-binned rows + exact LDS sums + fused Adam (no float atomics, no gradient buffer; default);
+        # "atomics" = run-reduced global atomics into a gradient buffer + the streaming Adam kernel (cross-check)
         self.table_update = os.environ.get("MNE_HASH_UPDATE", "slices")
         if self.table_update == "atomics":
             self.grad_map[self.table] = self.table_grad
@@ -697,7 +706,9 @@ class HashFusedStep(FusedStep):
             o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
             o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
         self._finish_init(overlap=os.environ.get("MNE_NO_OVERLAP", "0") != "1")
+        self.use_graph = None
         self._decoder_pending = False
+        self._gathered = None                 # (batch key, tape index): the first-pass rows of that batch are in that tape already
 
     def _refresh_pointers(self):
         w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
@@ -712,6 +723,15 @@ class HashFusedStep(FusedStep):
     def check(self):
         self.synchronize()
 
+    def _gather(self, tape, st, e_name="hash_gather"):
+        """The grid features of the rows the first pass of the render can decode (every row without early termination)."""
+        R, S, P = self.n_active, self.S, _lib.ptr
+        e0 = self._mark(e_name)
+        _lib.check(self.lib.mne_hash_gather(C.byref(self.grid_cfg), C.byref(self.scene), R, S, P(self.rays_o), P(self.rays_d),
+                                            P(self.z_vals), P(self.ray_counts) if self.early_termination else None,
+                                            P(self.table.data), P(tape), st), "mne_hash_gather")
+        self._mark(e_name, e0)
+
     def step(self, kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global=None, idx_cur=None, u=None,
              prefetch=False):
         lib, P = self.lib, _lib.ptr
@@ -722,79 +742,114 @@ class HashFusedStep(FusedStep):
         self._refresh_pointers()
         st = _lib.stream_for(self.rays_o)
         main = side = None
-        if self.rays_o.is_cuda and self.overlap and self.table_update != "atomics":
+        slices = self.table_update != "atomics"
+        if self.rays_o.is_cuda and self.overlap and slices:
             if self._side is None:
                 self._side = torch.cuda.Stream(self.device)
                 self._ev = [torch.cuda.Event() for _ in range(2)]
             main, side = torch.cuda.current_stream(self.device), self._side
-            if self._decoder_pending:                         # previous step's decoder update (side stream)
-                main.wait_event(self._ev[1])
-                self._decoder_pending = False
         host_batch = idx_global is not None or idx_cur is not None or u is not None
         key = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
         if host_batch or self._prefetched != key:
             self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st)
         self._prefetched = None
         sc, gc = C.byref(self.scene), C.byref(self.grid_cfg)
-        _lib.check(lib.mne_pack_decoder(sc, P(self.packed), st), "mne_pack_decoder")
-        inline_gather = self.early_termination           # the render call gathers only the rows it can decode
-        if not inline_gather:
-            e0 = self._mark("hash_gather")
-            _lib.check(lib.mne_hash_gather(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.table.data),
-                                           P(self.tape), st), "mne_hash_gather")
-            self._mark("hash_gather", e0)
+        ti = self.iteration & 1
+        tape = self.tapes[ti]
+        self.tape = tape                                            # (what tests and bench read back)
+        if self._gathered != (key, ti):                             # not pre-gathered at the end of the previous step
+            self._gather(tape, st)
+        self._gathered = None
+        if self._decoder_pending:                                   # previous step's decoder update + tables (side stream)
+            main.wait_event(self._ev[1])
+            self._decoder_pending = False
+        self._pack_if_stale(st)
         e0 = self._mark("render")
         opts, marks = self._render_opts(torch.cuda.current_stream(self.device) if self.rays_o.is_cuda else None, force=True)
         opts.adapt_state = None                           # (the hash gather sizes its row set from the a-priori prefix)
+        opts.external_bin, opts.event_after_decode = 0, None
+        opts.features_pregathered = 1
         _lib.check(lib.mne_render_fused_features(sc, C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d), P(self.tgt_rgb),
                                                  P(self.tgt_d), P(self.z_vals),
                                                  P(self.ray_counts) if self.early_termination else None, P(self.packed), P(self.coef), P(self.rgb),
-                                                 P(self.depth), P(self.raw), P(self.ray_sums), P(self.tape), R * S,
+                                                 P(self.depth), P(self.raw), P(self.ray_sums), P(tape), R * S,
                                                  P(self.tape_rows), P(self.ray_tiles), P(self.ws), self.ws_bytes,
-                                                 gc if inline_gather else None, P(self.table.data) if inline_gather else None,
-                                                 C.byref(opts), st),
+                                                 gc, P(self.table.data), C.byref(opts), st),
                    "mne_render_fused_features")
         self._mark("render", e0)
         if marks:
-            for name, a, b in ((("hash_gather", 0, 1),) if inline_gather else ()) + (("decode_kernel", 1, 2), ("ray_kernel", 2, 3), ("deferred_pass", 3, 4)):
+            for name, a, b in (("decode_kernel", 1, 2), ("ray_kernel", 2, 3), ("deferred_pass", 3, 4)):
                 self.events.setdefault(name, []).append((marks[a], marks[b]))
         if side is not None:
             self._ev[0].record(main)
             side.wait_event(self._ev[0])
-            # decoder chain (weight gradients -> decoder Adam) on the side stream, concurrent with the table update
-            # (VALU-bound, one 1024-thread workgroup per CU: leaves registers and LDS for the weight-gradient blocks)
+            # decoder chain (weight gradients -> reduce + decoder Adam -> next tables) on the side stream, beside the table
+            # update and the next gather
             with torch.cuda.stream(side):
                 e0 = self._mark("wgrad", stream=side)
-                _lib.check(lib.mne_decoder_wgrad(sc, P(self.tape), P(self.ray_tiles), R, S, P(self.partials), P(self.dec_grad),
-                                                 self.model.wgrad_impl, C.c_void_p(side.cuda_stream)), "mne_decoder_wgrad")
+                self._decoder_chain_hash(R, S, tape, C.c_void_p(side.cuda_stream))
                 self._mark("wgrad", e0, stream=side)
-                self.opt.step(zero_grad=True, grad_buffers=self.grad_map)
                 self._ev[1].record(side)
             self._decoder_pending = True
         e0 = self._mark("hash_scatter")
-        if self.table_update == "atomics":
-            _lib.check(lib.mne_hash_scatter(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.tape),
+        if not slices:
+            _lib.check(lib.mne_hash_scatter(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(tape),
                                             P(self.ray_tiles), P(self.table_grad), st), "mne_hash_scatter")
         else:
             stt, o = self.opt._state(self.table), self.table_opt
             stt["step"] += 1
             o.m, o.v, o.step = stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr(), stt["step"]
-            _lib.check(lib.mne_hash_slice_adam(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(self.tape),
+            _lib.check(lib.mne_hash_slice_adam(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(tape),
                                                P(self.ray_tiles), P(self.table.data), C.byref(o), P(self.hash_ws),
                                                self.hash_ws_bytes, st), "mne_hash_slice_adam")
         self._mark("hash_scatter", e0)
         if side is None:
             e0 = self._mark("wgrad")
-            _lib.check(lib.mne_decoder_wgrad(sc, P(self.tape), P(self.ray_tiles), R, S, P(self.partials), P(self.dec_grad),
-                                             self.model.wgrad_impl, st), "mne_decoder_wgrad")
+            if slices:
+                self._decoder_chain_hash(R, S, tape, st)
+            else:
+                _lib.check(lib.mne_decoder_wgrad(sc, P(tape), P(self.ray_tiles), R, S, P(self.partials), P(self.dec_grad),
+                                                 self.model.wgrad_impl, st), "mne_decoder_wgrad")
+                self.opt.step(zero_grad=True, grad_buffers=self.grad_map)            # table + decoder tensors, one launch
+                self._packed_key = None
             self._mark("wgrad", e0)
-            e0 = self._mark("adam")
-            self.opt.step(zero_grad=True, grad_buffers=self.grad_map)            # (table +) decoder tensors, one launch
-            self._mark("adam", e0)
         _lib.check(lib.mne_loss_finalize(R, S, P(self.ray_sums), P(self.counts), P(self.losses), st), "mne_loss_finalize")
         self.iteration += 1
         if prefetch and not host_batch:
             self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, None, None, None, st)
             self._prefetched = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
+            if side is not None:        # the next batch's rows into the OTHER tape, while the decoder chain still reads this one
+                self._gather(self.tapes[self.iteration & 1], st, e_name="hash_gather")
+                self._gathered = (self._prefetched, self.iteration & 1)
         else:
             self.synchronize()                                # whatever the caller enqueues next sees the updated decoder
+
+    def _decoder_chain_hash(self, R, S, tape, st):
+        """wgrad (no reduction) -> decoder_update_kernel (fixed-order reduce + decoder Adam) -> the next render's tables: three
+        launches, as in FusedStep (the loss scalars stay on the caller's stream: they read this batch's mask counts)."""
+        lib, P = self.lib, _lib.ptr
+        fused = self.model.wgrad_impl == 0
+        _lib.check(lib.mne_decoder_wgrad(C.byref(self.scene), P(tape), P(self.ray_tiles), R, S, P(self.partials),
+                                         P(self.dec_grad), 3 if fused else self.model.wgrad_impl, st), "mne_decoder_wgrad")
+        if not fused:
+            self.opt.step(zero_grad=False, grad_buffers=self.dec_grad_views)
+            self._packed_key = None
+            return
+        w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
+        grp = self.group_of_dec
+        o = _lib.DecoderOpt()
+        steps = set()
+        for k, w in enumerate((w_col0, w_col1, w_sdf0, w_sdf1)):       # decoder.parameters() order
+            stt = self.opt._state(w)
+            stt["step"] += 1
+            steps.add(stt["step"])
+            o.m[k], o.v[k] = stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr()
+        if len(steps) != 1:
+            raise RuntimeError("the decoder tensors must share one Adam step count")
+        o.lr, (o.beta1, o.beta2) = float(grp["lr"]), map(float, grp["betas"])
+        o.eps, o.weight_decay = float(grp["eps"]), float(grp["weight_decay"])
+        o.step = steps.pop()
+        _lib.check(lib.mne_decoder_update(C.byref(self.scene), P(self.partials), R, P(self.dec_grad), C.byref(o),
+                                          S, None, None, None, None, st), "mne_decoder_update")
+        _lib.check(lib.mne_pack_decoder(C.byref(self.scene), P(self.packed), st), "mne_pack_decoder")
+        self._packed_key = self._decoder_key()

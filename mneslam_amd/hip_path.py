@@ -361,7 +361,7 @@ class HashRenderFunction(torch.autograd.Function):
         row = lib.mne_tape_row_floats(C.byref(sc))
         tape = torch.empty(R * S, row, **opts)
         tape[:, :64].zero_()                               # feature columns the grid does not fill must read as zero
-        _lib.check(lib.mne_hash_gather(C.byref(gc), C.byref(sc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals),
+        _lib.check(lib.mne_hash_gather(C.byref(gc), C.byref(sc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals), None,
                                        _lib.ptr(table.detach()), _lib.ptr(tape), st), "mne_hash_gather")
         tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
         ray_tiles = torch.empty(R, device=dev, dtype=torch.int32)

@@ -225,9 +225,11 @@ class FusedMappingMixin:
         :700-706).  When the SLAM object carries a running ``model_exchange`` (mneslam_amd.dist.ModelExchange: the agents are
         ranks of one process group) the peer's map is fetched from its device memory over the group (RCCL over xGMI) into
         ``model_shared``; otherwise the peer's ``latest_checkpoint.pt`` is read like the reference does."""
+        exchange = getattr(self.slam, "model_exchange", None)
+        if exchange is None:
+            return super().load_foreign_model(other_rank)          # the host's own method: reads the peer's file
         from .. import slam_glue
-        return slam_glue.load_foreign_model(self.model_shared, self.config, other_rank, self.device,
-                                            exchange=getattr(self.slam, "model_exchange", None))
+        return slam_glue.load_foreign_model(self.model_shared, self.config, other_rank, self.device, exchange=exchange)
 
     def distillation(self, other_rank, expanded_foreign_kfs_for_distill, num_expanded_kfs):
         """Distil a foreign agent's map (``model_shared`` = teacher) into ``model`` (the training loop of
@@ -320,6 +322,11 @@ class _PlainMapper:
         self.slam.get_loss_from_ret(ret, is_co_sdf=self.config["is_co_sdf"]).backward()
         self.map_optimizer.step()
         return ret
+
+    def load_foreign_model(self, other_rank):
+        """mp_slam/mapper.py:708-726: the peer's ``latest_checkpoint.pt`` into ``model_shared``."""
+        from .. import slam_glue
+        return slam_glue.load_foreign_model(self.model_shared, self.config, other_rank, self.device)
 
     def first_frame_mapping(self, batch, n_iters=100):
         if batch["frame_id"] != 0:

@@ -130,11 +130,23 @@ def test_bound_mapper_class_structure(ref):
     """bind(host Mapper): the mixin sits in front of the reference's class and replaces exactly the two training loops."""
     Bound = repo_mapper.bind(ref.Mapper, compute="fused", sampler="host")
     assert Bound.__mro__[1] is repo_mapper.FusedMappingMixin and Bound.__mro__[2] is ref.Mapper
-    for name in ("run", "final_run", "handle_loop_closure", "bound_based_fusion", "load_foreign_model",
+    for name in ("run", "final_run", "handle_loop_closure", "bound_based_fusion",
                  "save_keyframe_data_atomic", "__init__"):
         assert getattr(Bound, name) is getattr(ref.Mapper, name), f"{name} must stay the host's"
-    for name in ("mapping_optimize", "first_frame_mapping"):
+    for name in ("mapping_optimize", "first_frame_mapping", "load_foreign_model"):
         assert getattr(Bound, name) is getattr(repo_mapper.FusedMappingMixin, name)
+    # load_foreign_model: the host's own method unless the SLAM object carries a running map exchange (process group)
+    import types
+    calls = []
+    fake = types.SimpleNamespace(slam=types.SimpleNamespace())
+    orig = ref.Mapper.load_foreign_model
+    try:
+        ref.Mapper.load_foreign_model = lambda self, other_rank: calls.append(other_rank) or "host"
+        obj = Bound.__new__(Bound)
+        obj.slam = fake.slam
+        assert obj.load_foreign_model(3) == "host" and calls == [3]
+    finally:
+        ref.Mapper.load_foreign_model = orig
     with pytest.raises(ValueError):
         repo_mapper.bind(ref.Mapper, compute="autograd", sampler="device")
 
@@ -146,8 +158,7 @@ def test_fused_mixin_over_reference_mapper(ref, tmp_path):
     Bound = repo_mapper.bind(ref.Mapper, compute="fused", sampler="host")
     mapper = Bound(cfg, slam)
     assert Bound.__mro__[1] is repo_mapper.FusedMappingMixin and Bound.__mro__[2] is ref.Mapper
-    for name in ("run", "final_run", "handle_loop_closure", "bound_based_fusion", "load_foreign_model",
-                 "save_keyframe_data_atomic"):
+    for name in ("run", "final_run", "handle_loop_closure", "bound_based_fusion", "save_keyframe_data_atomic"):
         assert getattr(Bound, name) is getattr(ref.Mapper, name), f"{name} must stay the host's"
     poses = torch.stack([f["c2w"] for f in frames])
     random.seed(22)
