@@ -306,29 +306,47 @@ __global__ __launch_bounds__(256) void hash_scatter_runs_kernel(GridArgs a) {
 //     slice, which add their non-zero sums into a 64-bit scratch with global integer atomics (exact, too);
 //     hash_finish_kernel applies Adam to those levels.
 #ifndef HASH_SLICE
-#define HASH_SLICE 2048            // entries per slice: 2 x 8 B x 2048 = 32 KiB of LDS, five workgroups per CU
+#define HASH_SLICE 2048            // entries a slice holds at most: 2 x 8 B x 2048 = 32 KiB of LDS, four workgroups per CU
 #endif
-#define HASH_SLICE_SHIFT 11
-static_assert((1 << HASH_SLICE_SHIFT) == HASH_SLICE, "slice = index >> HASH_SLICE_SHIFT");
+#define HASH_GRAN 16               // a slice owns whole 128-byte granules of 16 entries
 #define HASH_SLICE_THREADS 256
-#define HASH_CHUNK 2048            // packed rows per bin workgroup (2 per thread: the slot words of more rows spill)
-#define HASH_BIN_THREADS 1024
+#define HASH_CHUNK 1024            // packed rows per bin workgroup (2 per thread)
+#define HASH_BIN_THREADS 512
 #define HASH_RPT (HASH_CHUNK / HASH_BIN_THREADS)
-#define HASH_REC_PER_ROW 8         // a row's corners fall into at most 8 slices (4 on a hashed level with resolution < 2048)
+#define HASH_REC_PER_ROW 8         // a row's corners fall into at most 8 slices (typically 4: the x-neighbours share a granule)
 #define HASH_MAX_SLICES 4096       // per level: T <= 2^23
+#define HASH_MAX_CHUNKS (2 * HASH_SLICE_THREADS)
 #define HASH_FIX_BITS 39
-// Workgroups per level at least (dense levels with few slices are split into parts)
+// Levels with at most this many slices are not binned: every row touches most of their slices anyway; their slices are split
+// into row-range parts instead (HASH_LEVEL_WGS workgroups per level)
+#define HASH_SPLIT_MAX_SLICES 16
 #ifndef HASH_LEVEL_WGS
 #define HASH_LEVEL_WGS 64
 #endif
-__host__ __device__ __forceinline__ int hash_slices_of(const GridArgs& a, int level) { return (int)((a.size[level] + HASH_SLICE - 1) / HASH_SLICE); }
+// Slices are INTERLEAVED: a level has ns = 2^L slices, granule g = index / 16 belongs to slice g mod ns and sits at local
+// granule g / ns -- so the entries of any compact region of a dense level (the floor: one z-layer of the lattice) are spread
+// over ALL slices of the level, as a hashed level's are by the hash.  (Contiguous slices put every sample near the floor into
+// two or three slices of each dense level: one workgroup each, the tail of the launch.)
+__host__ __device__ __forceinline__ int hash_log2_slices(const GridArgs& a, int level) {
+    const unsigned n_gran = (a.size[level] + HASH_GRAN - 1) / HASH_GRAN;
+    int L = 0;
+    while (((n_gran + (1u << L) - 1u) >> L) > HASH_SLICE / HASH_GRAN) ++L;
+    return L;
+}
+__host__ __device__ __forceinline__ int hash_slices_of(const GridArgs& a, int level) { return 1 << hash_log2_slices(a, level); }
 __host__ __device__ __forceinline__ bool hash_level_dense(const GridArgs& a, int level) {
     return (unsigned long long)a.res[level] * a.res[level] * a.res[level] <= a.size[level];
 }
 __host__ __device__ __forceinline__ int hash_parts_of(const GridArgs& a, int level) {
-    if (!hash_level_dense(a, level)) return 1;
-    const int r = HASH_LEVEL_WGS / hash_slices_of(a, level);
+    const int ns = hash_slices_of(a, level);
+    if (ns > HASH_SPLIT_MAX_SLICES) return 1;
+    const int r = HASH_LEVEL_WGS / ns;
     return r < 1 ? 1 : r;
+}
+__device__ __forceinline__ unsigned hash_slice_of(unsigned idx, int L) { return (idx / HASH_GRAN) & ((1u << L) - 1u); }
+__device__ __forceinline__ unsigned hash_local_of(unsigned idx, int L) { return ((idx / HASH_GRAN) >> L) * HASH_GRAN + (idx % HASH_GRAN); }
+__device__ __forceinline__ unsigned hash_global_of(unsigned local, unsigned slice, int L) {
+    return ((((local / HASH_GRAN) << L) | slice) * HASH_GRAN) + (local % HASH_GRAN);
 }
 __host__ __device__ __forceinline__ int hash_chunks_of(long long rows) { return (int)((rows + HASH_CHUNK - 1) / HASH_CHUNK); }
 
@@ -465,12 +483,12 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
         }
     }
     if ((long long)chunk * HASH_CHUNK >= n_live || hash_parts_of(a, level) > 1) return;
-    const int ns = hash_slices_of(a, level);
+    const int L = hash_log2_slices(a, level), ns = 1 << L;
     for (int i = tid; i <= ns; i += HASH_BIN_THREADS) hist[i] = 0u;
     const bool dense = hash_level_dense(a, level);
     const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
-    // this thread's rows, all loads first (one round trip).  Row j of thread tid = chunk row j * 1024 + tid: the lanes of a
-    // wave hold CONSECUTIVE rows.
+    // this thread's rows, all loads first (one round trip).  Row j of thread tid = chunk row j * HASH_BIN_THREADS + tid: the
+    // lanes of a wave hold CONSECUTIVE rows.
     float2 g[HASH_RPT];
     float4 x[HASH_RPT];
 #pragma unroll
@@ -492,7 +510,7 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
             HashCorners c;
             hash_corners(a, level, x[j], dense, c);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sl[q] = c.idx[q] >> HASH_SLICE_SHIFT;
+            for (int q = 0; q < 8; ++q) sl[q] = hash_slice_of(c.idx[q], L);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -563,50 +581,93 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     }
 }
 
-__device__ __forceinline__ unsigned long long hash_fix(float v, double scale) {
-    return (unsigned long long)(long long)rint((double)v * scale);  // two's complement: sums wrap correctly
+__device__ __forceinline__ long long hash_fix(float v, double scale) { return (long long)rint((double)v * scale); }
+
+__device__ __forceinline__ long long shfl_up_i64(long long v, int d) {
+    const unsigned lo = (unsigned)__shfl_up((int)(unsigned)((unsigned long long)v & 0xffffffffull), d);
+    const unsigned hi = (unsigned)__shfl_up((int)(unsigned)((unsigned long long)v >> 32), d);
+    return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
-// the corners `mask` of one backward row -> the fixed-point sums of the slice [lo, lo + n_ent) (corners of the mask that
-// fall outside it -- the unbinned walk passes all eight -- are skipped)
-__device__ __forceinline__ void hash_accumulate(const GridArgs& a, int level, bool dense, float4 x, float2 g, unsigned mask, uint32_t lo,
-                                                uint32_t n_ent, double scale, unsigned long long* acc) {
-    HashCorners cn;
-    hash_corners(a, level, x, dense, cn);
+// One backward row per lane (`live`: this lane holds one): the corners `mask` that fall into slice `slice` of the level are
+// added to the slice's fixed-point sums.  WAVE-WIDE call (every lane of the wave, live or not).  Consecutive lanes hold
+// consecutive samples of a ray: on a dense level dozens of them sit in ONE cell and would add to the same eight LDS
+// addresses in the same instruction; such runs are summed across the lanes first (segmented scan of the exact integers)
+// and only a run's last lane touches LDS.  Waves without any run of two lanes skip the scan (the hashed fine levels).
+__device__ __forceinline__ void hash_accumulate(const GridArgs& a, int level, bool dense, int L, bool live, float4 x, float2 g,
+                                                unsigned mask, unsigned slice, double scale, unsigned long long* acc, int lane) {
+    const float sc = a.scale[level];
+    const uint32_t res = a.res[level], size = a.size[level];
+    float frac[3];
+    uint32_t cell[3];
+    const float xv[3] = {x.x, x.y, x.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float pos = fmaf(sc, xv[d], 0.5f);
+        const float fl = floorf(pos);
+        cell[d] = (uint32_t)(int)fl;
+        frac[d] = pos - fl;
+    }
+    const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
+    // runs of lanes in the same cell with the same corner set
+    const unsigned p0 = __shfl_up(cell[0], 1), p1 = __shfl_up(cell[1], 1), p2 = __shfl_up(cell[2], 1);
+    const unsigned pm = __shfl_up(live ? mask : 0u, 1);
+    const bool head = lane == 0 || !live || p0 != cell[0] || p1 != cell[1] || p2 != cell[2] || pm != mask;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int start = 63 - __clzll(below);                            // first lane of my run
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    const bool scan = heads != ~0ull;                                 // wave-uniform: some run is longer than one lane
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const uint32_t e = cn.idx[q] - lo;
-        if (((mask >> q) & 1u) && e < n_ent) {
-            atomicAdd(&acc[2 * e], hash_fix(cn.w[q] * g.x, scale));
-            atomicAdd(&acc[2 * e + 1], hash_fix(cn.w[q] * g.y, scale));
+        const uint32_t idx = grid_index_fast(cell[0] + (q & 1), cell[1] + ((q >> 1) & 1), cell[2] + ((q >> 2) & 1), res, size, dense);
+        const bool mine = live && ((mask >> q) & 1u) && hash_slice_of(idx, L) == slice;
+        if (__ballot(mine) == 0ull) continue;                         // (uniform) nobody has this corner in the slice
+        const float w = (wx[q & 1] * wy[(q >> 1) & 1]) * wz[(q >> 2) & 1];     // product order of grid_kernel
+        long long vx = mine ? hash_fix(w * g.x, scale) : 0ll, vy = mine ? hash_fix(w * g.y, scale) : 0ll;
+        if (scan) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const long long ux = shfl_up_i64(vx, d), uy = shfl_up_i64(vy, d);
+                if (lane - d >= start) { vx += ux; vy += uy; }
+            }
+        }
+        if (mine && tail) {                                           // (a run shares cell and mask: `mine` is the same on all its lanes)
+            const unsigned e = hash_local_of(idx, L);
+            if (vx != 0ll) atomicAdd(&acc[2 * e], (unsigned long long)vx);
+            if (vy != 0ll) atomicAdd(&acc[2 * e + 1], (unsigned long long)vy);
         }
     }
 }
 
-#define HASH_SLICE_UNROLL 4
+#define HASH_SLICE_UNROLL 2
 __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(GridArgs a) {
     __shared__ unsigned long long acc[HASH_SLICE * 2];               // fixed-point gradient of this slice (32 KiB)
-    __shared__ unsigned cstart[HASH_SLICE_THREADS + 1];              // binned levels: prefix of the chunks' record counts
-    __shared__ unsigned cbase[HASH_SLICE_THREADS];                   //   ... and where each chunk's records of this slice begin
-    const int tid = threadIdx.x;
+    __shared__ unsigned cstart[HASH_MAX_CHUNKS + 1];                 // binned levels: prefix of the chunks' record counts
+    __shared__ unsigned cbase[HASH_MAX_CHUNKS];                      //   ... and where each chunk's records of this slice begin
+    const int tid = threadIdx.x, lane = tid & 63;
     int level = 0, k = blockIdx.x;
     while (level + 1 < a.n_levels && k >= hash_slices_of(a, level) * hash_parts_of(a, level)) {
         k -= hash_slices_of(a, level) * hash_parts_of(a, level);
         ++level;
     }
-    const int n_part = hash_parts_of(a, level), part = k % n_part, slice = k / n_part;
-    const int ns = hash_slices_of(a, level);
+    const int n_part = hash_parts_of(a, level), part = k % n_part;
+    const unsigned slice = (unsigned)(k / n_part);
+    const int L = hash_log2_slices(a, level), ns = 1 << L;
     const uint32_t size = a.size[level], off = a.offset[level];
-    const uint32_t lo = (uint32_t)slice * HASH_SLICE;
-    const uint32_t n_ent = size - lo < HASH_SLICE ? size - lo : HASH_SLICE;
     const bool dense = hash_level_dense(a, level);
     const int n_live = a.offs[a.R];
     const int n_chunks = hash_chunks_of(n_live);
     // binned levels: the offsets of this slice's records in every chunk, requested before anything else (one round trip)
-    unsigned r0 = 0, r1 = 0;
-    if (n_part == 1) {
-        const unsigned* so = a.seg_off + a.seg_level[level];
-        if (tid < n_chunks) { r0 = so[(size_t)tid * (ns + 1) + slice]; r1 = so[(size_t)tid * (ns + 1) + slice + 1]; }
+    unsigned r0[HASH_MAX_CHUNKS / HASH_SLICE_THREADS], r1[HASH_MAX_CHUNKS / HASH_SLICE_THREADS];
+#pragma unroll
+    for (int j = 0; j < HASH_MAX_CHUNKS / HASH_SLICE_THREADS; ++j) {
+        r0[j] = r1[j] = 0u;
+        const int c = tid + j * HASH_SLICE_THREADS;
+        if (n_part == 1 && c < n_chunks) {
+            const unsigned* so = a.seg_off + a.seg_level[level] + (size_t)c * (ns + 1) + slice;
+            r0[j] = so[0]; r1[j] = so[1];
+        }
     }
     for (int i = tid; i < HASH_SLICE * 2; i += HASH_SLICE_THREADS) acc[i] = 0ull;
     const double scale = a.gscale[2 * level];
@@ -626,33 +687,42 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
             }
 #pragma unroll
             for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
-                if (g[q].x != 0.0f || g[q].y != 0.0f) hash_accumulate(a, level, dense, x[q], g[q], 0xffu, lo, n_ent, scale, acc);
+                hash_accumulate(a, level, dense, L, g[q].x != 0.0f || g[q].y != 0.0f, x[q], g[q], 0xffu, slice, scale, acc, lane);
         }
         __syncthreads();
-        unsigned long long* gs = a.scratch64 + ((size_t)off + lo) * 2;       // partial sums -> the 64-bit scratch (exact)
-        for (uint32_t e = tid; e < n_ent * 2; e += HASH_SLICE_THREADS)
-            if (acc[e] != 0ull) atomicAdd(gs + e, acc[e]);
+        unsigned long long* gs = a.scratch64 + (size_t)off * 2;               // partial sums -> the 64-bit scratch (exact)
+        for (unsigned e = tid; e < HASH_SLICE; e += HASH_SLICE_THREADS) {
+            const unsigned gi = hash_global_of(e, slice, L);
+            if (gi < size) {
+                if (acc[2 * e] != 0ull) atomicAdd(gs + 2 * (size_t)gi, acc[2 * e]);
+                if (acc[2 * e + 1] != 0ull) atomicAdd(gs + 2 * (size_t)gi + 1, acc[2 * e + 1]);
+            }
+        }
         return;
     }
-    // ---- binned level: exclusive scan of the chunks' record counts (n_chunks <= HASH_SLICE_THREADS), then a flat walk over
-    // this slice's records of ALL chunks (each chunk's are contiguous): one more round trip whatever the count
-    cbase[tid] = r0;
-    cstart[tid] = r1 - r0;
-    __syncthreads();
-    if (tid < 64) {                                                  // 256 counts, 4 per lane of one wave
-        unsigned v[HASH_SLICE_THREADS / 64], sum = 0;
+    // ---- binned level: exclusive scan of the chunks' record counts, then a flat walk over this slice's records of ALL chunks
+    // (each chunk's are contiguous): one more round trip whatever the count
 #pragma unroll
-        for (int q = 0; q < HASH_SLICE_THREADS / 64; ++q) { v[q] = cstart[tid * (HASH_SLICE_THREADS / 64) + q]; sum += v[q]; }
+    for (int j = 0; j < HASH_MAX_CHUNKS / HASH_SLICE_THREADS; ++j) {
+        cbase[tid + j * HASH_SLICE_THREADS] = r0[j];
+        cstart[tid + j * HASH_SLICE_THREADS] = r1[j] - r0[j];
+    }
+    __syncthreads();
+    if (tid < 64) {                                                  // HASH_MAX_CHUNKS counts, 8 per lane of one wave
+        constexpr int PER = HASH_MAX_CHUNKS / 64;
+        unsigned v[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { v[q] = cstart[tid * PER + q]; sum += v[q]; }
         unsigned inc = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const unsigned u = __shfl_up(inc, d); if (tid >= d) inc += u; }
         unsigned ex = inc - sum;
 #pragma unroll
-        for (int q = 0; q < HASH_SLICE_THREADS / 64; ++q) { cstart[tid * (HASH_SLICE_THREADS / 64) + q] = ex; ex += v[q]; }
-        if (tid == 63) cstart[HASH_SLICE_THREADS] = ex;
+        for (int q = 0; q < PER; ++q) { cstart[tid * PER + q] = ex; ex += v[q]; }
+        if (tid == 63) cstart[HASH_MAX_CHUNKS] = ex;
     }
     __syncthreads();
-    const unsigned total = cstart[HASH_SLICE_THREADS];
+    const unsigned total = cstart[HASH_MAX_CHUNKS];
     const HashRecord* rec0 = (const HashRecord*)a.records + (size_t)level * a.n_chunks * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
     for (unsigned i0 = 0; i0 < total; i0 += HASH_SLICE_THREADS * HASH_SLICE_UNROLL) {
         float2 w0[HASH_SLICE_UNROLL], w1[HASH_SLICE_UNROLL], w2[HASH_SLICE_UNROLL];
@@ -665,7 +735,7 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
             if (in[q]) {
                 int c = 0;                                           // chunk of flat record i: last c with cstart[c] <= i
 #pragma unroll
-                for (int st = HASH_SLICE_THREADS / 2; st >= 1; st >>= 1)
+                for (int st = HASH_MAX_CHUNKS / 2; st >= 1; st >>= 1)
                     if (c + st < n_chunks && cstart[c + st] <= i) c += st;
                 const HashRecord* d = rec0 + (size_t)c * (HASH_CHUNK * HASH_REC_PER_ROW) + cbase[c] + (i - cstart[c]);
                 w0[q] = *(const float2*)&d->x; w1[q] = *(const float2*)&d->z; w2[q] = *(const float2*)&d->gy;
@@ -673,22 +743,25 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
         }
 #pragma unroll
         for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
-            if (in[q]) hash_accumulate(a, level, dense, make_float4(w0[q].x, w0[q].y, w1[q].x, 0.0f), make_float2(w1[q].y, w2[q].x),
-                                       __float_as_uint(w2[q].y), lo, n_ent, scale, acc);
+            hash_accumulate(a, level, dense, L, in[q], make_float4(w0[q].x, w0[q].y, w1[q].x, 0.0f), make_float2(w1[q].y, w2[q].x),
+                            __float_as_uint(w2[q].y), slice, scale, acc, lane);
     }
     __syncthreads();
-    // ---- Adam on the slice: entries are float2, moments have the table's layout
+    // ---- Adam on the slice: entries are float2, moments have the table's layout; a slice's entries are whole 128-byte granules
     const PlaneOpt o = a.opt;
     const double inv = a.gscale[2 * level + 1];
-    float2* P = (float2*)a.params + off + lo;
-    float2* M = (float2*)o.m + off + lo;
-    float2* V = (float2*)o.v + off + lo;
-    for (uint32_t e = tid; e < n_ent; e += HASH_SLICE_THREADS) {
-        float2 p = P[e], m = M[e], v = V[e];
-        const float gx = (float)((double)(long long)acc[2 * e] * inv), gy = (float)((double)(long long)acc[2 * e + 1] * inv);
-        adam_elem(p.x, gx, m.x, v.x, o);
-        adam_elem(p.y, gy, m.y, v.y, o);
-        P[e] = p; M[e] = m; V[e] = v;
+    float2* P = (float2*)a.params + off;
+    float2* M = (float2*)o.m + off;
+    float2* V = (float2*)o.v + off;
+    for (unsigned e = tid; e < HASH_SLICE; e += HASH_SLICE_THREADS) {
+        const unsigned gi = hash_global_of(e, slice, L);
+        if (gi < size) {
+            float2 p = P[gi], m = M[gi], v = V[gi];
+            const float gx = (float)((double)(long long)acc[2 * e] * inv), gy = (float)((double)(long long)acc[2 * e + 1] * inv);
+            adam_elem(p.x, gx, m.x, v.x, o);
+            adam_elem(p.y, gy, m.y, v.y, o);
+            P[gi] = p; M[gi] = m; V[gi] = v;
+        }
     }
 }
 
@@ -752,7 +825,7 @@ int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st) {
     if (a.R <= 0) return 0;
     for (int l = 0; l < a.n_levels; ++l)
         if (hash_slices_of(a, l) > HASH_MAX_SLICES) return -7;
-    if (a.n_chunks > HASH_SLICE_THREADS) return -7;                 // (a slice workgroup scans its chunks' counts in one pass: <= 1 M rows)
+    if (a.n_chunks > HASH_MAX_CHUNKS) return -7;                    // (a slice workgroup scans its chunks' counts in one pass: <= 512 K rows)
     MNE_LAUNCH(hash_offsets_kernel, 1, 1024, 0, st, a);
     MNE_LAUNCH(hash_pack_kernel, (unsigned)a.n_pack_wgs, 256, 0, st, a);
     MNE_LAUNCH(hash_bin_kernel, (unsigned)(a.n_chunks * a.n_levels), HASH_BIN_THREADS, 0, st, a);
