@@ -308,7 +308,6 @@ __global__ __launch_bounds__(256) void hash_scatter_runs_kernel(GridArgs a) {
 #ifndef HASH_SLICE
 #define HASH_SLICE 2048            // entries a slice holds at most: 2 x 8 B x 2048 = 32 KiB of LDS, four workgroups per CU
 #endif
-#define HASH_GRAN 16               // a slice owns whole 128-byte granules of 16 entries
 #define HASH_SLICE_THREADS 256
 #define HASH_CHUNK 1024            // packed rows per bin workgroup (2 per thread)
 #define HASH_BIN_THREADS 512
@@ -317,36 +316,24 @@ __global__ __launch_bounds__(256) void hash_scatter_runs_kernel(GridArgs a) {
 #define HASH_MAX_SLICES 4096       // per level: T <= 2^23
 #define HASH_MAX_CHUNKS (2 * HASH_SLICE_THREADS)
 #define HASH_FIX_BITS 39
-// Levels with at most this many slices are not binned: every row touches most of their slices anyway; their slices are split
-// into row-range parts instead (HASH_LEVEL_WGS workgroups per level)
-#define HASH_SPLIT_MAX_SLICES 16
 #ifndef HASH_LEVEL_WGS
-#define HASH_LEVEL_WGS 64
+#define HASH_LEVEL_WGS 256         // workgroups a dense level gets at least (slices x parts)
 #endif
-// Slices are INTERLEAVED: a level has ns = 2^L slices, granule g = index / 16 belongs to slice g mod ns and sits at local
-// granule g / ns -- so the entries of any compact region of a dense level (the floor: one z-layer of the lattice) are spread
-// over ALL slices of the level, as a hashed level's are by the hash.  (Contiguous slices put every sample near the floor into
-// two or three slices of each dense level: one workgroup each, the tail of the launch.)
-__host__ __device__ __forceinline__ int hash_log2_slices(const GridArgs& a, int level) {
-    const unsigned n_gran = (a.size[level] + HASH_GRAN - 1) / HASH_GRAN;
-    int L = 0;
-    while (((n_gran + (1u << L) - 1u) >> L) > HASH_SLICE / HASH_GRAN) ++L;
-    return L;
-}
-__host__ __device__ __forceinline__ int hash_slices_of(const GridArgs& a, int level) { return 1 << hash_log2_slices(a, level); }
+// Slice geometry: contiguous slices of HASH_SLICE entries.  A hashed level has one workgroup per slice (the hash spreads the
+// rows evenly).  A DENSE level's rows are concentrated -- every sample near the floor lands in the two or three slices that
+// hold that z-layer of the lattice, and the coarse levels have only a handful of slices altogether -- so each of its slices
+// is split into `parts` workgroups (every parts-th chunk of rows each) whose exact integer sums meet in a 64-bit scratch;
+// hash_finish_kernel applies Adam to those levels.  (Measured alternatives, profiles/r04_hash_levels.txt: unbinned row walks
+// for the coarse levels 180 us; interleaved slices + a segmented scan of same-cell lanes in front of the LDS atomics 2x slower
+// than the contended atomics themselves.)
+__host__ __device__ __forceinline__ int hash_slices_of(const GridArgs& a, int level) { return (int)((a.size[level] + HASH_SLICE - 1) / HASH_SLICE); }
 __host__ __device__ __forceinline__ bool hash_level_dense(const GridArgs& a, int level) {
     return (unsigned long long)a.res[level] * a.res[level] * a.res[level] <= a.size[level];
 }
 __host__ __device__ __forceinline__ int hash_parts_of(const GridArgs& a, int level) {
-    const int ns = hash_slices_of(a, level);
-    if (ns > HASH_SPLIT_MAX_SLICES) return 1;
-    const int r = HASH_LEVEL_WGS / ns;
+    if (!hash_level_dense(a, level)) return 1;
+    const int r = HASH_LEVEL_WGS / hash_slices_of(a, level);
     return r < 1 ? 1 : r;
-}
-__device__ __forceinline__ unsigned hash_slice_of(unsigned idx, int L) { return (idx / HASH_GRAN) & ((1u << L) - 1u); }
-__device__ __forceinline__ unsigned hash_local_of(unsigned idx, int L) { return ((idx / HASH_GRAN) >> L) * HASH_GRAN + (idx % HASH_GRAN); }
-__device__ __forceinline__ unsigned hash_global_of(unsigned local, unsigned slice, int L) {
-    return ((((local / HASH_GRAN) << L) | slice) * HASH_GRAN) + (local % HASH_GRAN);
 }
 __host__ __device__ __forceinline__ int hash_chunks_of(long long rows) { return (int)((rows + HASH_CHUNK - 1) / HASH_CHUNK); }
 
@@ -448,16 +435,13 @@ __device__ __forceinline__ void hash_corners(const GridArgs& a, int level, float
 struct HashRecord { float x, y, z, gx, gy; unsigned mask; };
 static_assert(sizeof(HashRecord) == 24, "record layout");
 
-// One workgroup per (BINNED level, chunk of HASH_CHUNK packed rows): counting sort of the chunk's (row, slice) records by
-// slice.  (Levels that are split into parts -- few slices, every row hits them -- are not binned: their workgroups walk row
-// ranges directly.)
+// One workgroup per (level, chunk of HASH_CHUNK packed rows): counting sort of the chunk's (row, slice) records by slice.
 //   seg_off[level][chunk][0 .. n_slices]   start of every slice's records inside the chunk's segment (last = total)
 //   records[level][chunk][..]              HashRecords, slice after slice
 // Ranks inside a slice come from LDS integer atomics, ONE per run of consecutive rows with the same slice: consecutive
 // packed rows are consecutive samples of a ray, which on a dense level stay in one cell for dozens of samples -- per-row
 // returning atomics on the same counter serialise (the appends of render.hip's bin_kernel know the problem).
-// Workgroup (level, chunk 0) of EVERY level also publishes the level's fixed-point scale from the pack kernel's
-// per-workgroup maxima.
+// Workgroup (level, chunk 0) also publishes the level's fixed-point scale from the pack kernel's per-workgroup maxima.
 __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) {
     __shared__ unsigned hist[HASH_MAX_SLICES + 1];
     __shared__ unsigned wsum[HASH_BIN_THREADS / 64];
@@ -482,8 +466,8 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
             a.gscale[2 * level + 1] = bad ? (double)__uint_as_float(0x7fc00000u) : ldexp(1.0, e - HASH_FIX_BITS);
         }
     }
-    if ((long long)chunk * HASH_CHUNK >= n_live || hash_parts_of(a, level) > 1) return;
-    const int L = hash_log2_slices(a, level), ns = 1 << L;
+    if ((long long)chunk * HASH_CHUNK >= n_live) return;
+    const int ns = hash_slices_of(a, level);
     for (int i = tid; i <= ns; i += HASH_BIN_THREADS) hist[i] = 0u;
     const bool dense = hash_level_dense(a, level);
     const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
@@ -510,7 +494,7 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
             HashCorners c;
             hash_corners(a, level, x[j], dense, c);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sl[q] = hash_slice_of(c.idx[q], L);
+            for (int q = 0; q < 8; ++q) sl[q] = c.idx[q] / HASH_SLICE;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -581,127 +565,45 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     }
 }
 
-__device__ __forceinline__ long long hash_fix(float v, double scale) { return (long long)rint((double)v * scale); }
-
-__device__ __forceinline__ long long shfl_up_i64(long long v, int d) {
-    const unsigned lo = (unsigned)__shfl_up((int)(unsigned)((unsigned long long)v & 0xffffffffull), d);
-    const unsigned hi = (unsigned)__shfl_up((int)(unsigned)((unsigned long long)v >> 32), d);
-    return (long long)(((unsigned long long)hi << 32) | lo);
+__device__ __forceinline__ unsigned long long hash_fix(float v, double scale) {
+    return (unsigned long long)(long long)rint((double)v * scale);  // two's complement: sums wrap correctly
 }
 
-// One backward row per lane (`live`: this lane holds one): the corners `mask` that fall into slice `slice` of the level are
-// added to the slice's fixed-point sums.  WAVE-WIDE call (every lane of the wave, live or not).  Consecutive lanes hold
-// consecutive samples of a ray: on a dense level dozens of them sit in ONE cell and would add to the same eight LDS
-// addresses in the same instruction; such runs are summed across the lanes first (segmented scan of the exact integers)
-// and only a run's last lane touches LDS.  Waves without any run of two lanes skip the scan (the hashed fine levels).
-__device__ __forceinline__ void hash_accumulate(const GridArgs& a, int level, bool dense, int L, bool live, float4 x, float2 g,
-                                                unsigned mask, unsigned slice, double scale, unsigned long long* acc, int lane) {
-    const float sc = a.scale[level];
-    const uint32_t res = a.res[level], size = a.size[level];
-    float frac[3];
-    uint32_t cell[3];
-    const float xv[3] = {x.x, x.y, x.z};
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float pos = fmaf(sc, xv[d], 0.5f);
-        const float fl = floorf(pos);
-        cell[d] = (uint32_t)(int)fl;
-        frac[d] = pos - fl;
-    }
-    const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
-    // runs of lanes in the same cell with the same corner set
-    const unsigned p0 = __shfl_up(cell[0], 1), p1 = __shfl_up(cell[1], 1), p2 = __shfl_up(cell[2], 1);
-    const unsigned pm = __shfl_up(live ? mask : 0u, 1);
-    const bool head = lane == 0 || !live || p0 != cell[0] || p1 != cell[1] || p2 != cell[2] || pm != mask;
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    const int start = 63 - __clzll(below);                            // first lane of my run
-    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-    const bool scan = heads != ~0ull;                                 // wave-uniform: some run is longer than one lane
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const uint32_t idx = grid_index_fast(cell[0] + (q & 1), cell[1] + ((q >> 1) & 1), cell[2] + ((q >> 2) & 1), res, size, dense);
-        const bool mine = live && ((mask >> q) & 1u) && hash_slice_of(idx, L) == slice;
-        if (__ballot(mine) == 0ull) continue;                         // (uniform) nobody has this corner in the slice
-        const float w = (wx[q & 1] * wy[(q >> 1) & 1]) * wz[(q >> 2) & 1];     // product order of grid_kernel
-        long long vx = mine ? hash_fix(w * g.x, scale) : 0ll, vy = mine ? hash_fix(w * g.y, scale) : 0ll;
-        if (scan) {
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const long long ux = shfl_up_i64(vx, d), uy = shfl_up_i64(vy, d);
-                if (lane - d >= start) { vx += ux; vy += uy; }
-            }
-        }
-        if (mine && tail) {                                           // (a run shares cell and mask: `mine` is the same on all its lanes)
-            const unsigned e = hash_local_of(idx, L);
-            if (vx != 0ll) atomicAdd(&acc[2 * e], (unsigned long long)vx);
-            if (vy != 0ll) atomicAdd(&acc[2 * e + 1], (unsigned long long)vy);
-        }
-    }
-}
-
-#define HASH_SLICE_UNROLL 2
+#define HASH_SLICE_UNROLL 4
 __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(GridArgs a) {
     __shared__ unsigned long long acc[HASH_SLICE * 2];               // fixed-point gradient of this slice (32 KiB)
-    __shared__ unsigned cstart[HASH_MAX_CHUNKS + 1];                 // binned levels: prefix of the chunks' record counts
+    __shared__ unsigned cstart[HASH_MAX_CHUNKS + 1];                 // prefix of the chunks' record counts (this slice, this part)
     __shared__ unsigned cbase[HASH_MAX_CHUNKS];                      //   ... and where each chunk's records of this slice begin
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     int level = 0, k = blockIdx.x;
     while (level + 1 < a.n_levels && k >= hash_slices_of(a, level) * hash_parts_of(a, level)) {
         k -= hash_slices_of(a, level) * hash_parts_of(a, level);
         ++level;
     }
-    const int n_part = hash_parts_of(a, level), part = k % n_part;
-    const unsigned slice = (unsigned)(k / n_part);
-    const int L = hash_log2_slices(a, level), ns = 1 << L;
+    const int n_part = hash_parts_of(a, level), part = k % n_part, slice = k / n_part;
+    const int ns = hash_slices_of(a, level);
     const uint32_t size = a.size[level], off = a.offset[level];
+    const uint32_t lo = (uint32_t)slice * HASH_SLICE;
+    const uint32_t n_ent = size - lo < HASH_SLICE ? size - lo : HASH_SLICE;
     const bool dense = hash_level_dense(a, level);
     const int n_live = a.offs[a.R];
     const int n_chunks = hash_chunks_of(n_live);
-    // binned levels: the offsets of this slice's records in every chunk, requested before anything else (one round trip)
+    // the offsets of this slice's records in every chunk of this part (a split level: every n_part-th chunk), requested
+    // before anything else (one round trip)
     unsigned r0[HASH_MAX_CHUNKS / HASH_SLICE_THREADS], r1[HASH_MAX_CHUNKS / HASH_SLICE_THREADS];
 #pragma unroll
     for (int j = 0; j < HASH_MAX_CHUNKS / HASH_SLICE_THREADS; ++j) {
         r0[j] = r1[j] = 0u;
         const int c = tid + j * HASH_SLICE_THREADS;
-        if (n_part == 1 && c < n_chunks) {
+        if (c < n_chunks && c % n_part == part) {
             const unsigned* so = a.seg_off + a.seg_level[level] + (size_t)c * (ns + 1) + slice;
             r0[j] = so[0]; r1[j] = so[1];
         }
     }
     for (int i = tid; i < HASH_SLICE * 2; i += HASH_SLICE_THREADS) acc[i] = 0ull;
     const double scale = a.gscale[2 * level];
-    if (n_part > 1) {
-        // ---- split level: this part's share of ALL rows, straight from the packed arrays (coalesced), a few rows in flight
-        const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
-        __syncthreads();
-        const int row_lo = (int)((long long)n_live * part / n_part), row_hi = (int)((long long)n_live * (part + 1) / n_part);
-        for (int i0 = row_lo; i0 < row_hi; i0 += HASH_SLICE_THREADS * HASH_SLICE_UNROLL) {
-            float2 g[HASH_SLICE_UNROLL];
-            float4 x[HASH_SLICE_UNROLL];
-#pragma unroll
-            for (int q = 0; q < HASH_SLICE_UNROLL; ++q) {
-                const int i = i0 + q * HASH_SLICE_THREADS + tid;
-                g[q] = make_float2(0.f, 0.f); x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < row_hi) { g[q] = gl[i]; x[q] = a.xs[i]; }
-            }
-#pragma unroll
-            for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
-                hash_accumulate(a, level, dense, L, g[q].x != 0.0f || g[q].y != 0.0f, x[q], g[q], 0xffu, slice, scale, acc, lane);
-        }
-        __syncthreads();
-        unsigned long long* gs = a.scratch64 + (size_t)off * 2;               // partial sums -> the 64-bit scratch (exact)
-        for (unsigned e = tid; e < HASH_SLICE; e += HASH_SLICE_THREADS) {
-            const unsigned gi = hash_global_of(e, slice, L);
-            if (gi < size) {
-                if (acc[2 * e] != 0ull) atomicAdd(gs + 2 * (size_t)gi, acc[2 * e]);
-                if (acc[2 * e + 1] != 0ull) atomicAdd(gs + 2 * (size_t)gi + 1, acc[2 * e + 1]);
-            }
-        }
-        return;
-    }
-    // ---- binned level: exclusive scan of the chunks' record counts, then a flat walk over this slice's records of ALL chunks
-    // (each chunk's are contiguous): one more round trip whatever the count
+    // exclusive scan of the chunks' record counts, then a flat walk over this slice's records of ALL its chunks (each chunk's
+    // are contiguous): one more round trip whatever the count
 #pragma unroll
     for (int j = 0; j < HASH_MAX_CHUNKS / HASH_SLICE_THREADS; ++j) {
         cbase[tid + j * HASH_SLICE_THREADS] = r0[j];
@@ -743,25 +645,39 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
         }
 #pragma unroll
         for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
-            hash_accumulate(a, level, dense, L, in[q], make_float4(w0[q].x, w0[q].y, w1[q].x, 0.0f), make_float2(w1[q].y, w2[q].x),
-                            __float_as_uint(w2[q].y), slice, scale, acc, lane);
+            if (in[q]) {
+                HashCorners cn;
+                hash_corners(a, level, make_float4(w0[q].x, w0[q].y, w1[q].x, 0.0f), dense, cn);
+                const float gx = w1[q].y, gy = w2[q].x;
+                const unsigned mask = __float_as_uint(w2[q].y);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if ((mask >> c) & 1u) {                          // the corners of this record: inside [lo, lo + n_ent) by construction
+                        const uint32_t e = cn.idx[c] - lo;
+                        atomicAdd(&acc[2 * e], hash_fix(cn.w[c] * gx, scale));
+                        atomicAdd(&acc[2 * e + 1], hash_fix(cn.w[c] * gy, scale));
+                    }
+            }
     }
     __syncthreads();
-    // ---- Adam on the slice: entries are float2, moments have the table's layout; a slice's entries are whole 128-byte granules
+    if (n_part > 1) {                                                // a split level's partial sums -> the 64-bit scratch (exact)
+        unsigned long long* gs = a.scratch64 + ((size_t)off + lo) * 2;
+        for (uint32_t e = tid; e < n_ent * 2; e += HASH_SLICE_THREADS)
+            if (acc[e] != 0ull) atomicAdd(gs + e, acc[e]);
+        return;
+    }
+    // ---- Adam on the slice: entries are float2, moments have the table's layout
     const PlaneOpt o = a.opt;
     const double inv = a.gscale[2 * level + 1];
-    float2* P = (float2*)a.params + off;
-    float2* M = (float2*)o.m + off;
-    float2* V = (float2*)o.v + off;
-    for (unsigned e = tid; e < HASH_SLICE; e += HASH_SLICE_THREADS) {
-        const unsigned gi = hash_global_of(e, slice, L);
-        if (gi < size) {
-            float2 p = P[gi], m = M[gi], v = V[gi];
-            const float gx = (float)((double)(long long)acc[2 * e] * inv), gy = (float)((double)(long long)acc[2 * e + 1] * inv);
-            adam_elem(p.x, gx, m.x, v.x, o);
-            adam_elem(p.y, gy, m.y, v.y, o);
-            P[gi] = p; M[gi] = m; V[gi] = v;
-        }
+    float2* P = (float2*)a.params + off + lo;
+    float2* M = (float2*)o.m + off + lo;
+    float2* V = (float2*)o.v + off + lo;
+    for (uint32_t e = tid; e < n_ent; e += HASH_SLICE_THREADS) {
+        float2 p = P[e], m = M[e], v = V[e];
+        const float gx = (float)((double)(long long)acc[2 * e] * inv), gy = (float)((double)(long long)acc[2 * e + 1] * inv);
+        adam_elem(p.x, gx, m.x, v.x, o);
+        adam_elem(p.y, gy, m.y, v.y, o);
+        P[e] = p; M[e] = m; V[e] = v;
     }
 }
 
