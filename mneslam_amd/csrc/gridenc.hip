@@ -337,72 +337,6 @@ __host__ __device__ __forceinline__ int hash_parts_of(const GridArgs& a, int lev
 }
 __host__ __device__ __forceinline__ int hash_chunks_of(long long rows) { return (int)((rows + HASH_CHUNK - 1) / HASH_CHUNK); }
 
-// first packed row of every ray: exclusive scan of min(ray_tiles[r] * 32, S), one workgroup
-__global__ __launch_bounds__(1024) void hash_offsets_kernel(GridArgs a) {
-    __shared__ int part[1024];
-    __shared__ int carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < a.R; base += 1024) {
-        const int r = base + tid;
-        int n = 0;
-        if (r < a.R) { n = a.ray_tiles[r] * 32; n = n < a.S ? n : a.S; }
-        part[tid] = n;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const int v = tid >= d ? part[tid - d] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        if (r < a.R) a.offs[r] = carry + part[tid] - n;
-        __syncthreads();
-        if (tid == 1023) carry += part[1023];
-        __syncthreads();
-    }
-    if (tid == 0) a.offs[a.R] = carry;
-}
-
-// 16 consecutive backward rows of one ray per workgroup: x of each row, the rows' d(feature) transposed to level-major,
-// and this workgroup's largest |d(feature)| per level (wgmax[level][workgroup]; every workgroup writes its slot)
-__global__ __launch_bounds__(256) void hash_pack_kernel(GridArgs a) {
-    __shared__ float2 tr[16][17];
-    const int groups = (a.S + 15) / 16;
-    const int r = blockIdx.x / groups, s0 = (blockIdx.x % groups) * 16;
-    int n_rows = a.ray_tiles[r] * 32;
-    n_rows = n_rows < a.S ? n_rows : a.S;
-    const int tid = threadIdx.x, lv = tid & 15, rr = tid >> 4;
-    if (s0 >= n_rows) {
-        if (tid < 16) a.wgmax[(size_t)tid * a.n_pack_wgs + blockIdx.x] = 0.0f;
-        return;
-    }
-    const bool in = s0 + rr < n_rows;
-    const long long row = (long long)r * a.S + s0 + rr;
-    float2 g = make_float2(0.f, 0.f);
-    if (in && lv < a.n_levels) g = *(const float2*)(a.tape + (size_t)row * a.row_stride + a.col_d + lv * 2);
-    tr[rr][lv] = g;
-    const long long k0 = a.offs[r] + s0;
-    if (lv == 0 && in) {
-        const float z = a.z_vals[row];
-        float x[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float p = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;              // scene_rep.py:384
-            x[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
-        }
-        a.xs[k0 + rr] = make_float4(x[0], x[1], x[2], 0.0f);
-    }
-    __syncthreads();
-    const int rr2 = tid & 15, lv2 = tid >> 4;                        // 16 adjacent lanes = 16 consecutive packed rows of one level
-    const float2 t = tr[rr2][lv2];
-    if (s0 + rr2 < n_rows && lv2 < a.n_levels) a.dfeat_lv[(size_t)lv2 * a.pack_cap + k0 + rr2] = t;
-    float m = fmaxf(fabsf(t.x), fabsf(t.y));                         // rows beyond the ray's end hold zeros
-    m = (m <= 3.0e38f) ? m : __uint_as_float(0x7f800000u);          // NaN / Inf gradient -> +Inf: poisons the whole level (below)
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if (rr2 == 0) a.wgmax[(size_t)lv2 * a.n_pack_wgs + blockIdx.x] = m;
-}
 
 struct HashCorners { uint32_t idx[8]; float w[8]; };
 // the eight corner entries (index within the level) and trilinear weights of grid input x at `level`: the expressions of
@@ -435,53 +369,62 @@ __device__ __forceinline__ void hash_corners(const GridArgs& a, int level, float
 struct HashRecord { float x, y, z, gx, gy; unsigned mask; };
 static_assert(sizeof(HashRecord) == 24, "record layout");
 
-// One workgroup per (level, chunk of HASH_CHUNK packed rows): counting sort of the chunk's (row, slice) records by slice.
+// One workgroup per (level, chunk of HASH_CHUNK consecutive tape rows): counting sort of the chunk's (row, slice) records by
+// slice.  Rows come straight from the iteration's buffers -- row = ray * S + sample; the sample's position is recomputed from
+// the ray and z exactly as decode_tile does (render.hip), x = the OneBlob input; d(feature) of this level from the row's tape
+// line; rows past a ray's last backward tile were never written by ray_kernel and are skipped, rows without gradient leave
+// no record.
 //   seg_off[level][chunk][0 .. n_slices]   start of every slice's records inside the chunk's segment (last = total)
 //   records[level][chunk][..]              HashRecords, slice after slice
-// Ranks inside a slice come from LDS integer atomics, ONE per run of consecutive rows with the same slice: consecutive
-// packed rows are consecutive samples of a ray, which on a dense level stay in one cell for dozens of samples -- per-row
-// returning atomics on the same counter serialise (the appends of render.hip's bin_kernel know the problem).
-// Workgroup (level, chunk 0) also publishes the level's fixed-point scale from the pack kernel's per-workgroup maxima.
+//   wgmax[level][chunk]                    largest |d(feature)| of the chunk: the slice workgroups derive the level's
+//                                          fixed-point scale from these
+// Ranks inside a slice come from LDS integer atomics, ONE per run of consecutive rows with the same slice: consecutive rows
+// are consecutive samples of a ray, which on a dense level stay in one cell for dozens of samples -- per-row returning
+// atomics on the same counter serialise (the appends of render.hip's bin_kernel know the problem).
 __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) {
     __shared__ unsigned hist[HASH_MAX_SLICES + 1];
     __shared__ unsigned wsum[HASH_BIN_THREADS / 64];
     __shared__ float red[HASH_BIN_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int level = blockIdx.x % a.n_levels, chunk = blockIdx.x / a.n_levels;
-    const int n_live = a.offs[a.R];
-    if (chunk == 0) {
-        float m = 0.0f;
-        const float* wm = a.wgmax + (size_t)level * a.n_pack_wgs;
-        for (int i = tid; i < a.n_pack_wgs; i += HASH_BIN_THREADS) m = fmaxf(m, wm[i]);
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
-        if (lane == 0) red[wv] = m;
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < HASH_BIN_THREADS / 64; ++w) m = fmaxf(m, red[w]);
-            int e = 0;
-            const bool bad = !(m <= 3.0e38f);                       // a non-finite gradient: every entry of the level becomes NaN,
-            if (m > 0.0f && !bad) (void)frexpf(m, &e);              // as a float sum would    (m = f * 2^e, f in [0.5, 1): m < 2^e)
-            a.gscale[2 * level] = bad ? 0.0 : ldexp(1.0, HASH_FIX_BITS - e);
-            a.gscale[2 * level + 1] = bad ? (double)__uint_as_float(0x7fc00000u) : ldexp(1.0, e - HASH_FIX_BITS);
-        }
-    }
-    if ((long long)chunk * HASH_CHUNK >= n_live) return;
+    const long long n_rows = (long long)a.R * a.S;
     const int ns = hash_slices_of(a, level);
     for (int i = tid; i <= ns; i += HASH_BIN_THREADS) hist[i] = 0u;
     const bool dense = hash_level_dense(a, level);
-    const float2* gl = a.dfeat_lv + (size_t)level * a.pack_cap;
-    // this thread's rows, all loads first (one round trip).  Row j of thread tid = chunk row j * HASH_BIN_THREADS + tid: the
-    // lanes of a wave hold CONSECUTIVE rows.
+    // this thread's rows, all loads first.  Row j of thread tid = chunk row j * HASH_BIN_THREADS + tid: the lanes of a wave
+    // hold CONSECUTIVE rows.
     float2 g[HASH_RPT];
     float4 x[HASH_RPT];
+    float m = 0.0f;
 #pragma unroll
     for (int j = 0; j < HASH_RPT; ++j) {
-        const int k = chunk * HASH_CHUNK + j * HASH_BIN_THREADS + tid;
+        const long long k = (long long)chunk * HASH_CHUNK + j * HASH_BIN_THREADS + tid;
         g[j] = make_float2(0.f, 0.f); x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < n_live) { g[j] = gl[k]; x[j] = a.xs[k]; }
+        if (k < n_rows) {
+            const int r = (int)(k / a.S), sidx = (int)(k % a.S);
+            if (sidx < a.ray_tiles[r] * 32) {
+                g[j] = *(const float2*)(a.tape + (size_t)k * a.row_stride + a.col_d + level * 2);
+                const float z = a.z_vals[k];
+                float xv[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float p = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;          // scene_rep.py:384
+                    xv[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
+                }
+                x[j] = make_float4(xv[0], xv[1], xv[2], 0.0f);
+                const float mj = fmaxf(fabsf(g[j].x), fabsf(g[j].y));
+                m = fmaxf(m, (mj <= 3.0e38f) ? mj : __uint_as_float(0x7f800000u));       // NaN / Inf gradient -> +Inf: poisons the level
+            }
+        }
     }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if (lane == 0) red[wv] = m;
     __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < HASH_BIN_THREADS / 64; ++w) m = fmaxf(m, red[w]);
+        a.wgmax[(size_t)level * a.n_chunks + chunk] = m;
+    }
     // slot q of a row = the slice of its corner q if no earlier corner has the same slice (then it carries the mask of all
     // corners in that slice), else empty
     static_assert(HASH_MAX_SLICES <= 4096 && HASH_CHUNK <= 4096, "slot word: slice (12 bits) | corner mask (8) | rank in the slice (12)");
@@ -574,6 +517,7 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     __shared__ unsigned long long acc[HASH_SLICE * 2];               // fixed-point gradient of this slice (32 KiB)
     __shared__ unsigned cstart[HASH_MAX_CHUNKS + 1];                 // prefix of the chunks' record counts (this slice, this part)
     __shared__ unsigned cbase[HASH_MAX_CHUNKS];                      //   ... and where each chunk's records of this slice begin
+    __shared__ float wmaxs[HASH_SLICE_THREADS / 64];
     const int tid = threadIdx.x;
     int level = 0, k = blockIdx.x;
     while (level + 1 < a.n_levels && k >= hash_slices_of(a, level) * hash_parts_of(a, level)) {
@@ -586,8 +530,7 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     const uint32_t lo = (uint32_t)slice * HASH_SLICE;
     const uint32_t n_ent = size - lo < HASH_SLICE ? size - lo : HASH_SLICE;
     const bool dense = hash_level_dense(a, level);
-    const int n_live = a.offs[a.R];
-    const int n_chunks = hash_chunks_of(n_live);
+    const int n_chunks = a.n_chunks;
     // the offsets of this slice's records in every chunk of this part (a split level: every n_part-th chunk), requested
     // before anything else (one round trip)
     unsigned r0[HASH_MAX_CHUNKS / HASH_SLICE_THREADS], r1[HASH_MAX_CHUNKS / HASH_SLICE_THREADS];
@@ -601,7 +544,22 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
         }
     }
     for (int i = tid; i < HASH_SLICE * 2; i += HASH_SLICE_THREADS) acc[i] = 0ull;
-    const double scale = a.gscale[2 * level];
+    // the level's fixed-point scale: max |d(feature)| over the chunks' maxima (every workgroup of the level computes the
+    // same value; (slice 0, part 0) publishes it for hash_finish_kernel)
+    float gm = 0.0f;
+    for (int c = tid; c < n_chunks; c += HASH_SLICE_THREADS) gm = fmaxf(gm, a.wgmax[(size_t)level * n_chunks + c]);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) gm = fmaxf(gm, __shfl_xor(gm, d));
+    if ((tid & 63) == 0) wmaxs[tid >> 6] = gm;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < HASH_SLICE_THREADS / 64; ++w) gm = fmaxf(gm, wmaxs[w]);
+    int ge = 0;
+    const bool bad = !(gm <= 3.0e38f);                                // a non-finite gradient: every entry of the level becomes NaN,
+    if (gm > 0.0f && !bad) (void)frexpf(gm, &ge);                    // as a float sum would    (gm = f * 2^ge, f in [0.5, 1): gm < 2^ge)
+    const double scale = bad ? 0.0 : ldexp(1.0, HASH_FIX_BITS - ge);
+    const double inv = bad ? (double)__uint_as_float(0x7fc00000u) : ldexp(1.0, ge - HASH_FIX_BITS);
+    if (blockIdx.x == 0 || (slice == 0 && part == 0)) { if (tid == 0) a.gscale[level] = inv; }
     // exclusive scan of the chunks' record counts, then a flat walk over this slice's records of ALL its chunks (each chunk's
     // are contiguous): one more round trip whatever the count
 #pragma unroll
@@ -668,7 +626,6 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     }
     // ---- Adam on the slice: entries are float2, moments have the table's layout
     const PlaneOpt o = a.opt;
-    const double inv = a.gscale[2 * level + 1];
     float2* P = (float2*)a.params + off + lo;
     float2* M = (float2*)o.m + off + lo;
     float2* V = (float2*)o.v + off + lo;
@@ -687,7 +644,7 @@ __global__ __launch_bounds__(256) void hash_finish_kernel(GridArgs a, unsigned n
     if (e >= n_ent) return;
     int level = 0;
     while (level + 1 < a.n_levels && e >= a.offset[level + 1]) ++level;
-    const double inv = a.gscale[2 * level + 1];
+    const double inv = a.gscale[level];
     const PlaneOpt o = a.opt;
     unsigned long long* G = a.scratch64 + (size_t)e * 2;
     float2 p = ((float2*)a.params)[e], m = ((float2*)o.m)[e], v = ((float2*)o.v)[e];
@@ -717,23 +674,17 @@ static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 size_t mne_hash_layout(GridArgs& a, int R, int S, void* base) {
     const size_t rows = (size_t)R * S;
     const int n_chunks = hash_chunks_of((long long)rows);
-    const int groups = (S + 15) / 16;
     unsigned char* w = (unsigned char*)base;
     size_t off = 0;
     auto take = [&](size_t bytes) { unsigned char* p = w ? w + off : nullptr; off += al256(bytes); return p; };
     a.scratch64 = (unsigned long long*)take((size_t)mne_hash_scratch_entries(a) * 2 * sizeof(unsigned long long));
-    a.offs = (int*)take(((size_t)R + 1) * sizeof(int));
-    a.gscale = (double*)take((size_t)2 * MNE_GRID_MAX_LEVELS * sizeof(double));
-    a.xs = (float4*)take(rows * sizeof(float4));
-    a.dfeat_lv = (float2*)take(rows * a.n_levels * sizeof(float2));
-    a.n_pack_wgs = R * groups;
-    a.wgmax = (float*)take((size_t)a.n_levels * a.n_pack_wgs * sizeof(float));
+    a.gscale = (double*)take((size_t)MNE_GRID_MAX_LEVELS * sizeof(double));
+    a.n_chunks = n_chunks;
+    a.wgmax = (float*)take((size_t)a.n_levels * n_chunks * sizeof(float));
     size_t so = 0;
     for (int l = 0; l < a.n_levels; ++l) { a.seg_level[l] = so; so += (size_t)n_chunks * (hash_slices_of(a, l) + 1); }
     a.seg_off = (unsigned*)take(so * sizeof(unsigned));
-    a.n_chunks = n_chunks;
     a.records = (unsigned*)take((size_t)a.n_levels * n_chunks * HASH_CHUNK * HASH_REC_PER_ROW * sizeof(HashRecord));
-    a.pack_cap = (long long)rows;
     return off;
 }
 
@@ -742,8 +693,6 @@ int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st) {
     for (int l = 0; l < a.n_levels; ++l)
         if (hash_slices_of(a, l) > HASH_MAX_SLICES) return -7;
     if (a.n_chunks > HASH_MAX_CHUNKS) return -7;                    // (a slice workgroup scans its chunks' counts in one pass: <= 512 K rows)
-    MNE_LAUNCH(hash_offsets_kernel, 1, 1024, 0, st, a);
-    MNE_LAUNCH(hash_pack_kernel, (unsigned)a.n_pack_wgs, 256, 0, st, a);
     MNE_LAUNCH(hash_bin_kernel, (unsigned)(a.n_chunks * a.n_levels), HASH_BIN_THREADS, 0, st, a);
     MNE_LAUNCH(hash_slice_adam_kernel, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, 0, st, a);
     const unsigned n_split = mne_hash_scratch_entries(a);

@@ -177,18 +177,13 @@ struct GridArgs {
     int R, S, row_stride, col_x, col_d;
     double bb_lo[3], bb_hi[3];   // raw bounding box: x = (p - lo) / (hi - lo), as the OneBlob input
     int bb_is_f64;
-    // slice form (hash_slice_adam_kernel): packed backward rows, their slice-binned records, Adam state of the table
-    int* offs;                   // [R+1] first packed row of each ray (exclusive scan of its backward rows)
-    float4* xs;                  // [R*S] packed: grid input x of each backward row
-    float2* dfeat_lv;            // [n_levels][R*S] packed: d(feature) of each backward row, level-major
-    long long pack_cap;          // R*S
-    float* wgmax;                // [n_levels][n_pack_wgs] largest |d(feature)| per level and pack workgroup
-    int n_pack_wgs;
-    double* gscale;              // [n_levels][2] fixed-point scale of the level's gradient sums and its inverse
+    // slice form (hash_bin_kernel / hash_slice_adam_kernel): the backward rows' slice-binned records, Adam state of the table
+    float* wgmax;                // [n_levels][n_chunks] largest |d(feature)| per level and chunk of rows
+    double* gscale;              // [n_levels] inverse fixed-point scale of each level's gradient sums (for hash_finish_kernel)
     unsigned* seg_off;           // per level: [n_chunks][n_slices + 1] start of each slice's records in the chunk's segment
     size_t seg_level[MNE_GRID_MAX_LEVELS];   // first word of each level's block in seg_off
     unsigned* records;           // [n_levels][n_chunks][HASH_CHUNK * 8] 24-byte records (gridenc.hip: HashRecord), slice after slice
-    int n_chunks;                // chunks the workspace was laid out for (R*S rows)
+    int n_chunks;                // chunks of HASH_CHUNK tape rows: ceil(R*S / HASH_CHUNK)
     unsigned long long* scratch64;   // fixed-point gradient sums of the levels that are split over several workgroups per slice
     PlaneOpt opt;                // table optimizer state and step constants
     // gather restricted to the rows the exact early termination can decode (inside mne_render_fused_features)
