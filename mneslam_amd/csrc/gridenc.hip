@@ -362,12 +362,13 @@ __device__ __forceinline__ void hash_corners(const GridArgs& a, int level, float
     }
 }
 
-// A record of the binned table update: one backward row as seen by ONE slice of one level -- the grid input, the level's
-// d(feature) and the set of the row's eight corners that fall into the slice.  24 bytes, self-contained: the slice
-// workgroup streams its records (contiguous per chunk) and never goes back to the packed arrays (with 4-byte row ids it
-// did: ~10 M random 8 / 16-byte reads through eight L2s that cannot hold 18 MB of rows, 553 MB of fabric traffic).
-struct HashRecord { float x, y, z, gx, gy; unsigned mask; };
-static_assert(sizeof(HashRecord) == 24, "record layout");
+// A record of the binned table update: one backward row as seen by ONE slice of one level -- its ray and z (the slice
+// workgroup recomputes the grid input from the ray: 24 bytes per ray, cached), the level's d(feature) and the set of the
+// row's eight corners that fall into the slice.  16 bytes = ONE store / load instruction per record (the bin kernel's
+// scattered record stores are its cost: 8-byte pieces of a 24-byte record took three requests each), self-contained: the
+// slice workgroup streams its records (contiguous per chunk) and never gathers from per-row arrays.
+struct HashRecord { unsigned ray_mask; float z, gx, gy; };       // ray | corner mask << 24
+static_assert(sizeof(HashRecord) == 16, "record layout");
 
 // One workgroup per (level, chunk of HASH_CHUNK consecutive tape rows): counting sort of the chunk's (row, slice) records by
 // slice.  Rows come straight from the iteration's buffers -- row = ray * S + sample; the sample's position is recomputed from
@@ -394,14 +395,16 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     // this thread's rows, all loads first.  Row j of thread tid = chunk row j * HASH_BIN_THREADS + tid: the lanes of a wave
     // hold CONSECUTIVE rows.
     float2 g[HASH_RPT];
-    float4 x[HASH_RPT];
+    float4 x[HASH_RPT];                                              // (x, y, z of the grid input, w = the sample's z along its ray)
+    int ray[HASH_RPT];
     float m = 0.0f;
 #pragma unroll
     for (int j = 0; j < HASH_RPT; ++j) {
         const long long k = (long long)chunk * HASH_CHUNK + j * HASH_BIN_THREADS + tid;
-        g[j] = make_float2(0.f, 0.f); x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g[j] = make_float2(0.f, 0.f); x[j] = make_float4(0.f, 0.f, 0.f, 0.f); ray[j] = 0;
         if (k < n_rows) {
             const int r = (int)(k / a.S), sidx = (int)(k % a.S);
+            ray[j] = r;
             if (sidx < a.ray_tiles[r] * 32) {
                 g[j] = *(const float2*)(a.tape + (size_t)k * a.row_stride + a.col_d + level * 2);
                 const float z = a.z_vals[k];
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
                     const float p = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * z;          // scene_rep.py:384
                     xv[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
                 }
-                x[j] = make_float4(xv[0], xv[1], xv[2], 0.0f);
+                x[j] = make_float4(xv[0], xv[1], xv[2], z);
                 const float mj = fmaxf(fabsf(g[j].x), fabsf(g[j].y));
                 m = fmaxf(m, (mj <= 3.0e38f) ? mj : __uint_as_float(0x7f800000u));       // NaN / Inf gradient -> +Inf: poisons the level
             }
@@ -499,12 +502,9 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     for (int j = 0; j < HASH_RPT; ++j) {
 #pragma unroll
         for (int q = 0; q < HASH_REC_PER_ROW; ++q)
-            if ((rec[j][q] >> 12) & 0xffu) {
-                HashRecord* d = rc + hist[rec[j][q] & 0xfffu] + (rec[j][q] >> 20);
-                *(float2*)&d->x = make_float2(x[j].x, x[j].y);
-                *(float2*)&d->z = make_float2(x[j].z, g[j].x);
-                *(float2*)&d->gy = make_float2(g[j].y, __uint_as_float((rec[j][q] >> 12) & 0xffu));
-            }
+            if ((rec[j][q] >> 12) & 0xffu)
+                *(float4*)(rc + hist[rec[j][q] & 0xfffu] + (rec[j][q] >> 20)) =
+                    make_float4(__uint_as_float((unsigned)ray[j] | (((rec[j][q] >> 12) & 0xffu) << 24)), x[j].w, g[j].x, g[j].y);
     }
 }
 
@@ -585,29 +585,34 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     const unsigned total = cstart[HASH_MAX_CHUNKS];
     const HashRecord* rec0 = (const HashRecord*)a.records + (size_t)level * a.n_chunks * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
     for (unsigned i0 = 0; i0 < total; i0 += HASH_SLICE_THREADS * HASH_SLICE_UNROLL) {
-        float2 w0[HASH_SLICE_UNROLL], w1[HASH_SLICE_UNROLL], w2[HASH_SLICE_UNROLL];
+        float4 rw[HASH_SLICE_UNROLL];
         bool in[HASH_SLICE_UNROLL];
 #pragma unroll
         for (int q = 0; q < HASH_SLICE_UNROLL; ++q) {
             const unsigned i = i0 + q * HASH_SLICE_THREADS + tid;
             in[q] = i < total;
-            w0[q] = w1[q] = w2[q] = make_float2(0.f, 0.f);
+            rw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (in[q]) {
                 int c = 0;                                           // chunk of flat record i: last c with cstart[c] <= i
 #pragma unroll
                 for (int st = HASH_MAX_CHUNKS / 2; st >= 1; st >>= 1)
                     if (c + st < n_chunks && cstart[c + st] <= i) c += st;
-                const HashRecord* d = rec0 + (size_t)c * (HASH_CHUNK * HASH_REC_PER_ROW) + cbase[c] + (i - cstart[c]);
-                w0[q] = *(const float2*)&d->x; w1[q] = *(const float2*)&d->z; w2[q] = *(const float2*)&d->gy;
+                rw[q] = *(const float4*)(rec0 + (size_t)c * (HASH_CHUNK * HASH_REC_PER_ROW) + cbase[c] + (i - cstart[c]));
             }
         }
 #pragma unroll
         for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
             if (in[q]) {
+                const unsigned rm = __float_as_uint(rw[q].x), r = rm & 0xffffffu, mask = rm >> 24;
+                float xv[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float p = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * rw[q].y;      // scene_rep.py:384 (as the bin kernel)
+                    xv[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
+                }
                 HashCorners cn;
-                hash_corners(a, level, make_float4(w0[q].x, w0[q].y, w1[q].x, 0.0f), dense, cn);
-                const float gx = w1[q].y, gy = w2[q].x;
-                const unsigned mask = __float_as_uint(w2[q].y);
+                hash_corners(a, level, make_float4(xv[0], xv[1], xv[2], 0.0f), dense, cn);
+                const float gx = rw[q].z, gy = rw[q].w;
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
                     if ((mask >> c) & 1u) {                          // the corners of this record: inside [lo, lo + n_ent) by construction
@@ -692,7 +697,7 @@ int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st) {
     if (a.R <= 0) return 0;
     for (int l = 0; l < a.n_levels; ++l)
         if (hash_slices_of(a, l) > HASH_MAX_SLICES) return -7;
-    if (a.n_chunks > HASH_MAX_CHUNKS) return -7;                    // (a slice workgroup scans its chunks' counts in one pass: <= 512 K rows)
+    if (a.n_chunks > HASH_MAX_CHUNKS || a.R >= (1 << 24)) return -7;                    // (a slice workgroup scans its chunks' counts in one pass: <= 512 K rows)
     MNE_LAUNCH(hash_bin_kernel, (unsigned)(a.n_chunks * a.n_levels), HASH_BIN_THREADS, 0, st, a);
     MNE_LAUNCH(hash_slice_adam_kernel, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, 0, st, a);
     const unsigned n_split = mne_hash_scratch_entries(a);
