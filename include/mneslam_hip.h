@@ -536,9 +536,12 @@ int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const flo
  *                              addend to 2^-39 of the level's largest gradient component.
  * scene: bounding box, decoder dims and weights are read; the plane descriptors are ignored.  cfg: n_features 2, <= 16 levels. */
 size_t mne_hash_workspace_bytes(const mne_grid_cfg_t* cfg, int n_rays, int n_samples);   /* zero-fill the workspace before the FIRST call */
+/* event_after_bin (optional hipEvent_t): recorded on `stream` behind the binning launch, in front of the slice launch -- a caller
+ * that runs the decoder's weight-gradient chain on another stream starts it there: beside the HBM-bound slice / Adam launch
+ * instead of beside the latency-bound binning. */
 int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                         const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles, float* table,
-                        const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
+                        const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* event_after_bin, void* stream);
 /* ray_counts (optional, the per-ray counts of mne_sample_z): only the rows the exact early termination can decode in its first
  * pass -- the a-priori tiles of every ray plus the resolver's extension; NULL = every row */
 int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,

@@ -182,7 +182,7 @@ _PROTOS = {
                                      C.POINTER(FusedOpts), C.c_void_p]),
     "mne_hash_workspace_bytes": (C.c_size_t, [C.POINTER(GridCfg), C.c_int, C.c_int]),
     "mne_hash_slice_adam": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 6
-                            + [C.POINTER(PlaneOpt), C.c_void_p, C.c_size_t, C.c_void_p]),
+                            + [C.POINTER(PlaneOpt), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "mne_hash_scatter": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 7),
 }
 

@@ -851,7 +851,7 @@ size_t mne_hash_workspace_bytes(const mne_grid_cfg_t* cfg, int n_rays, int n_sam
 
 int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                         const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles, float* table,
-                        const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream) {
+                        const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* event_after_bin, void* stream) {
     GridArgs a = {};
     if (int rc = fill_hash_rows(cfg, scene, n_rays, n_samples, rays_o, rays_d, z_vals, (float*)tape, a)) return rc;
     if (!ray_tiles || !table || !opt || !workspace) return fail(-1, "mne_hash_slice_adam: NULL argument");
@@ -866,7 +866,7 @@ int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int
     o.step_size = (float)(opt->lr / (1.0 - std::pow(opt->beta1, (double)opt->step)));
     o.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(opt->beta2, (double)opt->step));
     o.lr = opt->lr; o.step = opt->step;
-    if (int rc = mne_launch_hash_slice_adam(a, (hipStream_t)stream)) return fail(rc, "mne_hash_slice_adam: table too large for the slice kernels");
+    if (int rc = mne_launch_hash_slice_adam(a, (hipStream_t)stream, event_after_bin)) return fail(rc, "mne_hash_slice_adam: table too large for the slice kernels");
     return check_launch("hash_slice_adam");
 }
 

@@ -392,6 +392,7 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     const int ns = hash_slices_of(a, level);
     for (int i = tid; i <= ns; i += HASH_BIN_THREADS) hist[i] = 0u;
     const bool dense = hash_level_dense(a, level);
+    const bool xpair = !dense && (a.size[level] & (a.size[level] - 1u)) == 0u && a.res[level] < HASH_SLICE;
     // this thread's rows, all loads first.  Row j of thread tid = chunk row j * HASH_BIN_THREADS + tid: the lanes of a wave
     // hold CONSECUTIVE rows.
     float2 g[HASH_RPT];
@@ -444,6 +445,9 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
+            // a hashed level with resolution < HASH_SLICE: the x-neighbours (q, q ^ 1) differ in the low index bits only and
+            // share their slice -- the odd slots are always empty (uniform: nothing to rank, no collective skipped unevenly)
+            if (xpair && (q & 1)) { rec[j][q] = 0u; continue; }
             bool dup = false;
             unsigned mask = 0u;
 #pragma unroll
@@ -693,12 +697,13 @@ size_t mne_hash_layout(GridArgs& a, int R, int S, void* base) {
     return off;
 }
 
-int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st) {
+int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st, void* event_after_bin) {
     if (a.R <= 0) return 0;
     for (int l = 0; l < a.n_levels; ++l)
         if (hash_slices_of(a, l) > HASH_MAX_SLICES) return -7;
     if (a.n_chunks > HASH_MAX_CHUNKS || a.R >= (1 << 24)) return -7;                    // (a slice workgroup scans its chunks' counts in one pass: <= 512 K rows)
     MNE_LAUNCH(hash_bin_kernel, (unsigned)(a.n_chunks * a.n_levels), HASH_BIN_THREADS, 0, st, a);
+    if (event_after_bin) (void)hipEventRecord((hipEvent_t)event_after_bin, st);
     MNE_LAUNCH(hash_slice_adam_kernel, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, 0, st, a);
     const unsigned n_split = mne_hash_scratch_entries(a);
     if (n_split) MNE_LAUNCH(hash_finish_kernel, (n_split + 255) / 256, 256, 0, st, a, n_split);

@@ -282,7 +282,7 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
 int mne_launch_render(const RenderArgs& a, int mode, void* workspace, const RenderHost& host, hipStream_t st);
 int mne_launch_bin(RenderArgs a, int pass, void* workspace, hipStream_t st);
 int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st);
-int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st);
+int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st, void* event_after_bin = nullptr);
 int mne_hash_slice_count(const GridArgs& a);
 unsigned mne_hash_scratch_entries(const GridArgs& a);
 size_t mne_hash_layout(GridArgs& a, int R, int S, void* base);     // fills the workspace pointers (base NULL: sizes only); returns bytes

@@ -747,6 +747,8 @@ class HashFusedStep(FusedStep):
             if self._side is None:
                 self._side = torch.cuda.Stream(self.device)
                 self._ev = [torch.cuda.Event() for _ in range(2)]
+                for e in self._ev:
+                    e.record(torch.cuda.current_stream(self.device))        # (recorded once so that the handles exist)
             main, side = torch.cuda.current_stream(self.device), self._side
         host_batch = idx_global is not None or idx_cur is not None or u is not None
         key = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
@@ -780,17 +782,6 @@ class HashFusedStep(FusedStep):
         if marks:
             for name, a, b in (("decode_kernel", 1, 2), ("ray_kernel", 2, 3), ("deferred_pass", 3, 4)):
                 self.events.setdefault(name, []).append((marks[a], marks[b]))
-        if side is not None:
-            self._ev[0].record(main)
-            side.wait_event(self._ev[0])
-            # decoder chain (weight gradients -> reduce + decoder Adam -> next tables) on the side stream, beside the table
-            # update and the next gather
-            with torch.cuda.stream(side):
-                e0 = self._mark("wgrad", stream=side)
-                self._decoder_chain_hash(R, S, tape, C.c_void_p(side.cuda_stream))
-                self._mark("wgrad", e0, stream=side)
-                self._ev[1].record(side)
-            self._decoder_pending = True
         e0 = self._mark("hash_scatter")
         if not slices:
             _lib.check(lib.mne_hash_scatter(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(tape),
@@ -799,9 +790,21 @@ class HashFusedStep(FusedStep):
             stt, o = self.opt._state(self.table), self.table_opt
             stt["step"] += 1
             o.m, o.v, o.step = stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr(), stt["step"]
+            # "rows binned": recorded by the call between its binning and its slice launch -- the decoder chain starts there
             _lib.check(lib.mne_hash_slice_adam(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(tape),
                                                P(self.ray_tiles), P(self.table.data), C.byref(o), P(self.hash_ws),
-                                               self.hash_ws_bytes, st), "mne_hash_slice_adam")
+                                               self.hash_ws_bytes, C.c_void_p(self._ev[0].cuda_event) if side is not None else None, st),
+                       "mne_hash_slice_adam")
+        if side is not None:
+            side.wait_event(self._ev[0])
+            # decoder chain (weight gradients -> reduce + decoder Adam -> next tables) on the side stream, beside the slice /
+            # Adam launch of the table update and the next gather (not beside the latency-bound binning, which it slowed by 70 %)
+            with torch.cuda.stream(side):
+                e1 = self._mark("wgrad", stream=side)
+                self._decoder_chain_hash(R, S, tape, C.c_void_p(side.cuda_stream))
+                self._mark("wgrad", e1, stream=side)
+                self._ev[1].record(side)
+            self._decoder_pending = True
         self._mark("hash_scatter", e0)
         if side is None:
             e0 = self._mark("wgrad")

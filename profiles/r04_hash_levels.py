@@ -33,7 +33,7 @@ for k in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16):
     o.m, o.v, o.step = stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr(), max(stt["step"], 1)
     def call():
         _lib.check(lib.mne_hash_slice_adam(C.byref(gc), C.byref(fs.scene), R, S, P(fs.rays_o), P(fs.rays_d), P(fs.z_vals), P(fs.tape),
-                                           P(fs.ray_tiles), P(fs.table.data), C.byref(o), P(ws), nb, st), "slice")
+                                           P(fs.ray_tiles), P(fs.table.data), C.byref(o), P(ws), nb, None, st), "slice")
     for _ in range(3):
         call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
