@@ -382,6 +382,8 @@ static_assert(sizeof(HashRecord) == 16, "record layout");
 // Ranks inside a slice come from LDS integer atomics, ONE per run of consecutive rows with the same slice: consecutive rows
 // are consecutive samples of a ray, which on a dense level stay in one cell for dozens of samples -- per-row returning
 // atomics on the same counter serialise (the appends of render.hip's bin_kernel know the problem).
+// (Skipping the odd corners' slots on hashed levels -- x-neighbours share their slice -- is NOT valid: a sample outside the
+// bounding box has wrapped cell coordinates, its x-neighbours then differ in every index bit; caught by the GPU parity test.)
 __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) {
     __shared__ unsigned hist[HASH_MAX_SLICES + 1];
     __shared__ unsigned wsum[HASH_BIN_THREADS / 64];
@@ -392,7 +394,6 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     const int ns = hash_slices_of(a, level);
     for (int i = tid; i <= ns; i += HASH_BIN_THREADS) hist[i] = 0u;
     const bool dense = hash_level_dense(a, level);
-    const bool xpair = !dense && (a.size[level] & (a.size[level] - 1u)) == 0u && a.res[level] < HASH_SLICE;
     // this thread's rows, all loads first.  Row j of thread tid = chunk row j * HASH_BIN_THREADS + tid: the lanes of a wave
     // hold CONSECUTIVE rows.
     float2 g[HASH_RPT];
@@ -445,9 +446,6 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            // a hashed level with resolution < HASH_SLICE: the x-neighbours (q, q ^ 1) differ in the low index bits only and
-            // share their slice -- the odd slots are always empty (uniform: nothing to rank, no collective skipped unevenly)
-            if (xpair && (q & 1)) { rec[j][q] = 0u; continue; }
             bool dup = false;
             unsigned mask = 0u;
 #pragma unroll
