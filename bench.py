@@ -319,7 +319,17 @@ def account(cfg, agent, avg_ms):
                 "render": "whole mne_render_fused_features call (decode + ray kernels; MFMA / latency, no algorithmic HBM bytes)"}
         alg["iteration"] = alg["hash_gather"] + alg["hash_scatter"] + alg["adam"]
     elif binned:
-        alg = {"adam": p_contrib * G + sweep * agent.n_plane_params + 32.0 * agent.n_dec_params,
+        # parameters the plane update really sweeps: tiles that have never received a gradient keep m = v = 0, Adam leaves them
+        # bit-for-bit unchanged and the kernel skips them (tile_adam.hip) -- they carry no algorithmic bytes either
+        swept = float(agent.n_plane_params)
+        live = getattr(agent.fused, "tile_live", None)
+        if live is not None:
+            lv, off_, swept = live.cpu(), 0, 0.0
+            for p_ in agent.fused.planes:
+                t_ = ((p_.shape[2] + 15) // 16) * ((p_.shape[3] + 15) // 16)
+                swept += p_.numel() * float((lv[off_:off_ + t_] != 0).float().mean())
+                off_ += t_
+        alg = {"adam": p_contrib * G + sweep * swept + 32.0 * agent.n_dec_params, "_swept": swept,
                "gather_kernel": decoded * G_gather, "render": decoded * G_gather}
         kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)", "gather_kernel": "gather_kernel",
                 "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
@@ -337,7 +347,7 @@ def account(cfg, agent, avg_ms):
     dom_ms = avg_ms.get(dom, 0.0)
     achieved = alg.get(dom, 0.0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     return {"alg": alg, "kern": kern, "dom": dom, "dom_ms": dom_ms, "achieved": achieved, "p_contrib": p_contrib,
-            "decoded": decoded, "R": R, "S": S}
+            "decoded": decoded, "R": R, "S": S, "swept": alg.pop("_swept", None)}
 
 
 # (name, workload, hidden, graph).  indoor_fp16 / indoor_fp16_graph = BASELINE configs[4] as worded (one of its agents): fp16
@@ -500,10 +510,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg.get(dom, 0.0), "avg_launch_ms": dom_ms,
                          "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms > 0) else None,
                          "mfma_busy": mfma_busy,
+                         "plane_params_swept": acc["swept"],
                          "contributing_samples_last_iter": p_contrib, "gathered_samples_last_iter_lower_bound": decoded,
                          "nominal_samples": float(R * S),
                          "other_kernels_avg_ms": {kern[k]: v for k, v in avg_ms.items() if k != dom},
-                         "other_kernels_algorithmic_bytes": {kern[k]: alg[k] for k in alg if k != dom and k not in ("render", "iteration")},
+                         "other_kernels_algorithmic_bytes": {kern[k]: alg[k] for k in alg if k != dom and k not in ("render", "iteration") and k in kern},
                          "iteration_algorithmic_bytes": alg.get("iteration", alg["adam"] + alg["render"]),
                          "iteration_hbm_frac": alg.get("iteration", alg["adam"] + alg["render"]) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }

@@ -111,6 +111,12 @@ typedef struct mne_tile_bins {
      * and mne_tile_order balances on max(length now, length of the previous call): it may then run BEFORE the lists are
      * complete (beside the deferred rays' second pass) without mis-judging scenes where many rays are deferred. */
     int32_t* prev_counts;
+    /* Optional: [mne_tile_count()], 0 = "this tile's Adam moments are identically zero" (it has never received a gradient since
+     * the optimizer state was created), anything else = live.  mne_tile_adam sets a tile's word when it first sees a non-empty list
+     * and SKIPS tiles whose word is 0 and whose list is empty: Adam leaves them bit-for-bit unchanged (m = v = 0, no weight decay on
+     * plane groups), so they are neither read nor written.  Zero-initialise only together with fresh (all-zero) moments; fill with
+     * ones whenever the moments come from somewhere else (a loaded optimizer state).  NULL = every tile is swept. */
+    int32_t* live;
     /* Optional per-plane list capacities in JointEncoding.all_planes order ([set][xy,xz,yz][coarse,fine]); an entry of 0
      * means `cap`.  One capacity for all tiles reserves tens of GB on scenes whose coarse planes have a few dozen tiles
      * taking 10^4-10^5 entries each next to thousands of fine tiles taking a few hundred (ScanNet with colour planes, INS

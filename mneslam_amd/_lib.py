@@ -49,7 +49,8 @@ class AdamSeg(C.Structure):
 class TileBins(C.Structure):
     _fields_ = [("lists", C.c_void_p), ("counts", C.c_void_p), ("spill", C.c_void_p), ("spill_count", C.c_void_p),
                 ("order", C.c_void_p), ("cap", C.c_int32), ("spill_cap", C.c_int32), ("dropped", C.c_void_p),
-                ("split_scratch", C.c_void_p), ("split_state", C.c_void_p), ("prev_counts", C.c_void_p), ("plane_cap", C.c_int32 * 12)]
+                ("split_scratch", C.c_void_p), ("split_state", C.c_void_p), ("prev_counts", C.c_void_p), ("live", C.c_void_p),
+                ("plane_cap", C.c_int32 * 12)]
 
 
 TILE_SPLIT_PARTS = 2048

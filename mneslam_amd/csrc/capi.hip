@@ -475,6 +475,7 @@ static int tile_adam_impl(const mne_scene_t* scene, const mne_plane_opt_t* opt, 
     a.n_planes = scene->n_sets * 6;
     if (int rc = fill_bins(scene, bins, a.bins)) return rc;
     a.prev_counts = bins->prev_counts;
+    a.live = bins->live;
     TileOverlap ov = {};
     if (form != 0)
         if (int rc = fill_overlap(scene, overlap, ov, true, form == 2)) return rc;

@@ -223,6 +223,7 @@ struct TileAdamArgs {
     int n_planes, n_tiles;
     Clock clk;
     int* prev_counts;         // [n_tiles] final list lengths of the previous tile_adam launch (NULL: none) -- balance hint of tile_order
+    int* live;                // [n_tiles] 1 = the tile has received a gradient at some point (its moments may be non-zero); NULL: every tile is swept
 };
 
 // EXTENSION (multi-agent): node rectangles of this agent's planes that a peer maps as well, with the exchange buffers

@@ -200,6 +200,17 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         if (OV == 1 && !shared_tile) return;                   // export: only the shared tiles have anything to say
     }
     const bool empty = TILE_EMPTY_FAST && cnt == 0;            // no contribution: the sweep runs with g = 0, LDS untouched
+    if (a.live) {
+        // A tile that has NEVER received a gradient has m = v = 0, and Adam then leaves it exactly as it is:
+        // p - step_size * (0 / (sqrt(0) / bc2 + eps)) = p, m and v stay 0 (plane groups carry no weight decay; checked).
+        // Such tiles -- the margin of the extended bound, the part of the volume no keyframe has looked into yet: 30 % of
+        // office0's parameters in every iteration, profiles/r04_empty_tiles.txt -- are neither read nor written.
+        if (cnt == 0 && !shared_tile && a.live[tile] == 0 && a.opt[pidx].wd == 0.0f) {
+            if (tid == 0 && a.prev_counts) a.prev_counts[tile] = 0;
+            return;
+        }
+        if (cnt > 0 && tid == 0 && OV != 1) a.live[tile] = 1;
+    }
     if (!empty)
         for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int cap = a.bins.pcap[pidx];

@@ -138,6 +138,13 @@ class FusedStep:
             self._order_early = n_tiles <= _lib.TILE_ORDER_SNAPSHOT
             self.prev_counts = torch.zeros(n_tiles, device=dev, dtype=torch.int32)
             b.prev_counts = self.prev_counts.data_ptr()
+            # tiles that never received a gradient keep m = v = 0 and are skipped by the plane update (bit-identical: Adam
+            # does not move them).  Valid while the moments are the ones THIS object has seen grow from zero: an optimizer
+            # that already stepped, or moments re-bound later (load_state_dict), make every tile live (_refresh_pointers).
+            fresh = all(optimizer._state(p)["step"] == 0 for p in self.planes) and os.environ.get("MNE_SWEEP_ALL_TILES", "0") != "1"
+            self.tile_live = (torch.zeros if fresh else torch.ones)(n_tiles, device=dev, dtype=torch.int32)
+            b.live = self.tile_live.data_ptr()
+            self._moment_ptrs = None
             b.cap, b.spill_cap = tile_capacity, spill_capacity
             if self.overlap_peers:
                 from . import dist as mdist
@@ -348,6 +355,11 @@ class FusedStep:
                         st = self.opt._state(p)
                         self.plane_opt[n].m, self.plane_opt[n].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                     n += 1
+        if self.bins is not None:
+            ptrs = tuple((o.m, o.v) for o in self.plane_opt)
+            if self._moment_ptrs is not None and ptrs != self._moment_ptrs:
+                self.tile_live.fill_(1)              # moments re-bound (optimizer.load_state_dict): nothing is known to be zero
+            self._moment_ptrs = ptrs
         w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
         self.scene.w_sdf0, self.scene.w_sdf1 = w_sdf0.data_ptr(), w_sdf1.data_ptr()
         self.scene.w_col0, self.scene.w_col1 = w_col0.data_ptr(), w_col1.data_ptr()

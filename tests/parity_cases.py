@@ -859,6 +859,21 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     for w_hip, w_ref, nm in zip(dec_params, sc.decoder_list(), DEC_KEYS):
         mean, frac = adam_agreement(cpu(w_hip), w_ref.detach(), ag.opt.param_groups[0]["lr"], "decoder", f"decoder {nm}")
         stats["dec_mean_over_lr"], stats["dec_outliers"] = max(stats["dec_mean_over_lr"], mean), max(stats["dec_outliers"], frac)
+    # tiles the plane update skipped (never received a gradient: m = v = 0, Adam is the identity there): parameters bit-equal to
+    # what they were, moments still zero -- and the oracle's DENSE Adam agrees (the comparison above covered them)
+    skipped = 0
+    if getattr(fs, "tile_live", None) is not None:
+        live, off = cpu(fs.tile_live), 0
+        for p, p0 in zip(flat_planes, [q for lst in planes0 for q in lst]):
+            ty, tx = (p.shape[2] + 15) // 16, (p.shape[3] + 15) // 16
+            dead = (live[off:off + ty * tx] == 0).reshape(ty, tx).repeat_interleave(16, 0).repeat_interleave(16, 1)[:p.shape[2], :p.shape[3]]
+            off += ty * tx
+            if bool(dead.any()):
+                st = ag.opt._state(p)
+                assert torch.equal(cpu(p).float()[0][:, dead], p0[0][:, dead]), "a skipped tile's parameters changed"
+                assert float(cpu(st["exp_avg"])[0][:, dead].abs().max()) == 0.0 and float(cpu(st["exp_avg_sq"])[0][:, dead].abs().max()) == 0.0
+                skipped += int(dead.sum()) * p.shape[1]
+    stats["skipped_params"] = skipped
     _record_stats("fused_step_vs_oracle", dict(stats, R=R, S=S, half=half, scatter=scatter, warm=warm_steps,
                                                planes=sum(p.numel() for p in flat_planes)))
     return {"R": R, "S": S, "contributing": int(fs.tape_rows.item()), "adam_stats": stats,

@@ -301,6 +301,7 @@ def test_full_size_fused_step_vs_oracle(warm):
     from mneslam_amd import configs
     out = pc.check_fused_step_vs_oracle(DEV, configs.bench_office0(), n_keyframes=4, seed=3, warm_steps=warm)
     assert out["R"] == 2048 + 512 and out["S"] == 128 and out["contributing"] > 10000
+    assert out["adam_stats"]["skipped_params"] > 1_000_000      # the never-touched tiles (the bound's margin) are skipped, not swept
 
 
 @pytest.mark.parametrize("workload,hidden,rays", [("office0", 64, 2048), ("apartment", 32, 2048), ("scannet", 32, 2048),
