@@ -329,15 +329,18 @@ typedef struct mne_fused_opts {
 } mne_fused_opts_t;
 
 /* mne_render_backward for a caller-owned encoding: the feature columns of every tape row ([64] floats at column 0 of row
- * ray * n_samples + sample) are filled by the caller before the call (mne_hash_gather); no plane gradients and no ray
- * gradients -- the d(feature) rows of every sample of the first ray_tiles[r] tiles of ray r are left in the tape (column
- * mne_tape_dfeat_offset) for the caller's scatter (mne_hash_scatter); tape rows for mne_decoder_wgrad as usual. */
+ * ray * n_samples + sample) are filled by the caller before the call (mne_hash_gather); no plane gradients -- the d(feature)
+ * rows of every sample of the first ray_tiles[r] tiles of ray r are left in the tape (column mne_tape_dfeat_offset) for the
+ * caller's scatter (mne_hash_scatter); tape rows for mne_decoder_wgrad as usual.  d_rays_o / d_rays_d (optional, [R][3]):
+ * the share of the ray gradients that goes through the OneBlob input; the caller ADDS its encoding's share
+ * (mne_hash_ray_grad) -- together R13 for the hash / dense grid model. */
 int mne_render_backward_features(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_rays, int n_samples,
                                  const float* rays_o, const float* rays_d, const float* target_rgb,
                                  const float* target_d, const float* z_vals, const int32_t* ray_counts,
                                  const float* packed_decoder, const float* raw, const float* coef, const float* g_rgb,
                                  const float* g_depth, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                                 int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream);
+                                 int32_t* ray_tiles, float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 
 /* Fused training form of the two calls above (what Mapper.mapping_optimize runs per iteration), with early ray
  * termination: decodes every ray up to the last sample it needs (tile-parallel for the samples ray_counts marks,
@@ -565,6 +568,11 @@ int mne_render_fused_features(const mne_scene_t* scene, const mne_render_cfg_t* 
 int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                      const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles,
                      float* grad_table, void* stream);
+/* R13 for the grid: d(total)/d(rays_o), d(total)/d(rays_d) through the trilinear weights of every level, from the d(feature)
+ * rows mne_render_backward_features left in the tape; ADDED to d_rays_o / d_rays_d [R][3] (which hold the OneBlob share). */
+int mne_hash_ray_grad(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                      const float* rays_d, const float* z_vals, const float* table, const float* tape, const int32_t* ray_tiles,
+                      float* d_rays_o, float* d_rays_d, void* stream);
 
 #ifdef __cplusplus
 }

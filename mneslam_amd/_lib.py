@@ -131,7 +131,8 @@ _PROTOS = {
     "mne_render_forward_features": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 15
                                     + [C.c_int, C.c_void_p]),
     "mne_render_backward_features": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 12
-                                     + [C.c_int64] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]),
+                                     + [C.c_int64] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
+    "mne_hash_ray_grad": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 9),
     "mne_query_features": (C.c_int, [C.POINTER(Scene), C.c_int64] + [C.c_void_p] * 6),
     "mne_grid_encode_box": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p]),

@@ -247,7 +247,6 @@ static int render_backward(bool ext_feat, const mne_scene_t* scene, const mne_re
                         void* stream) {
     // plane gradients are optional as a whole: all plane[].grad NULL = ray / decoder gradients only
     if (int rc = check_scene(scene, !ext_feat && scene && scene->plane[0][0][0].grad != nullptr, !ext_feat)) return rc;
-    if (ext_feat && (d_rays_o || d_rays_d)) return fail(-2, "ray gradients need the plane encoding (not provided for caller-supplied features)");
     if (ext_feat && scene->n_sets != 1) return fail(-2, "caller-supplied features replace ONE plane set (no colour planes)");
     if (!cfg || !rays_o || !rays_d || !z_vals || !packed_decoder || !raw || !tape || !tape_rows || !ray_tiles || !workspace)
         return fail(-1, "mne_render_backward: NULL argument");
@@ -291,9 +290,10 @@ int mne_render_backward_features(const mne_scene_t* scene, const mne_render_cfg_
                                  const float* target_d, const float* z_vals, const int32_t* ray_counts,
                                  const float* packed_decoder, const float* raw, const float* coef, const float* g_rgb,
                                  const float* g_depth, float* tape, int64_t tape_capacity_rows, int32_t* tape_rows,
-                                 int32_t* ray_tiles, void* workspace, size_t workspace_bytes, void* stream) {
+                                 int32_t* ray_tiles, float* d_rays_o, float* d_rays_d, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
     return render_backward(true, scene, cfg, n_rays, n_samples, rays_o, rays_d, target_rgb, target_d, z_vals, ray_counts, packed_decoder,
-                           raw, coef, g_rgb, g_depth, tape, tape_capacity_rows, tape_rows, ray_tiles, nullptr, nullptr, workspace,
+                           raw, coef, g_rgb, g_depth, tape, tape_capacity_rows, tape_rows, ray_tiles, d_rays_o, d_rays_d, workspace,
                            workspace_bytes, stream);
 }
 }   // extern "C"
@@ -869,6 +869,18 @@ int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int
     o.lr = opt->lr; o.step = opt->step;
     if (int rc = mne_launch_hash_slice_adam(a, (hipStream_t)stream, event_after_bin)) return fail(rc, "mne_hash_slice_adam: table too large for the slice kernels");
     return check_launch("hash_slice_adam");
+}
+
+int mne_hash_ray_grad(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
+                      const float* rays_d, const float* z_vals, const float* table, const float* tape, const int32_t* ray_tiles,
+                      float* d_rays_o, float* d_rays_d, void* stream) {
+    GridArgs a = {};
+    if (int rc = fill_hash_rows(cfg, scene, n_rays, n_samples, rays_o, rays_d, z_vals, (float*)tape, a)) return rc;
+    if (!table || !ray_tiles || (!d_rays_o && !d_rays_d)) return fail(-1, "mne_hash_ray_grad: NULL argument");
+    if (n_rays <= 0) return 0;
+    a.params = table; a.ray_tiles = ray_tiles;
+    mne_launch_hash_raygrad(a, d_rays_o, d_rays_d, (hipStream_t)stream);
+    return check_launch("hash_ray_grad");
 }
 
 int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,

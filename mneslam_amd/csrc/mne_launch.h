@@ -283,6 +283,7 @@ int mne_launch_pack(const mne_scene_t& sc, float* pk, hipStream_t st);
 int mne_launch_render(const RenderArgs& a, int mode, void* workspace, const RenderHost& host, hipStream_t st);
 int mne_launch_bin(RenderArgs a, int pass, void* workspace, hipStream_t st);
 int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st);
+int mne_launch_hash_raygrad(const GridArgs& a, float* d_rays_o, float* d_rays_d, hipStream_t st);
 int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st, void* event_after_bin = nullptr);
 int mne_hash_slice_count(const GridArgs& a);
 unsigned mne_hash_scratch_entries(const GridArgs& a);

@@ -836,7 +836,9 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
                 float* dprow = dposL + pt * 64;
                 mlp_backward_dpos<HID, HIDC, CP, !ALDS>(dh, dhc, atab, lane, dprow);
                 MNE_WAVE_SYNC();
-                gather_coord_grad<NSETS, TILE>(a.sc, pn, feat, dpnL, lane);
+                // (a caller-owned encoding -- hash / dense grid -- differentiates its own features: mne_hash_ray_grad adds
+                // that part from the d(feature) rows this kernel leaves in the tape; here only the OneBlob input's share)
+                if (!a.ext_feat) gather_coord_grad<NSETS, TILE>(a.sc, pn, feat, dpnL, lane);
                 MNE_WAVE_SYNC();
                 float du[3];
                 oneblob_half_backward(u, hf, dprow, du);
@@ -846,8 +848,8 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
                 for (int q = 0; q < 3; ++q) {
                     const float inv_bb = a.sc.bb_is_f64 ? (float)(1.0 / (a.sc.bb_hi[q] - a.sc.bb_lo[q]))
                                                         : 1.0f / ((float)a.sc.bb_hi[q] - (float)a.sc.bb_lo[q]);
-                    const float dp = (valid && contrib && hf == 0)
-                        ? dpnL[pt * 4 + q] * (2.0f / (a.sc.bound_hi[q] - a.sc.bound_lo[q])) + du[q] * inv_bb : 0.0f;
+                    const float dplane = a.ext_feat ? 0.0f : dpnL[pt * 4 + q] * (2.0f / (a.sc.bound_hi[q] - a.sc.bound_lo[q]));
+                    const float dp = (valid && contrib && hf == 0) ? dplane + du[q] * inv_bb : 0.0f;
                     ray_do[q] += dp;
                     ray_dd[q] += z * dp;
                 }

@@ -320,7 +320,8 @@ class HashRenderFunction(torch.autograd.Function):
        (rays, targets, jitter, table, decoder weights...) -> rgb, depth, disp, acc, depth_var, z_vals, raw, losses[8].
     forward  = mne_sample_z + mne_pack_decoder + mne_hash_features + mne_render_forward_features (+ mne_loss_finalize)
     backward = mne_loss_coef + mne_hash_gather + mne_render_backward_features + mne_hash_scatter + mne_decoder_wgrad.
-    Differentiable w.r.t. the table and the decoder; ray gradients need the plane encoding and raise."""
+    backward (+ rays) adds mne_hash_ray_grad.  Differentiable w.r.t. the table, the decoder and the rays (R13: the pose
+    loops of loop closure, mp_slam/mapper.py:388-408, run on this model through the host's own autograd loop)."""
 
     @staticmethod
     def forward(ctx, info, grid_cfg, tables, rays_o, rays_d, target_rgb, target_d, u, seed_offset, table, *dec_w):
@@ -343,10 +344,9 @@ class HashRenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_disp, g_acc, g_var, g_z, g_raw, g_losses):
-        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-            raise NotImplementedError("ray gradients (pose optimisation) are provided for the tri-plane encoding only")
         lib = _lib.load()
         info, S, gc = ctx.info, ctx.S, ctx.grid_cfg
+        want_ray = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         rays_o, rays_d, tgt_rgb, tgt_d, z_vals, raw, counts, ray_counts, packed, table, *dec_w = ctx.saved_tensors
         dev, st = rays_o.device, _lib.stream_for(rays_o)
         rc = info["render_cfg"]
@@ -367,12 +367,18 @@ class HashRenderFunction(torch.autograd.Function):
         ray_tiles = torch.empty(R, device=dev, dtype=torch.int32)
         ws_bytes = lib.mne_render_workspace_bytes(R, S)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        d_o = torch.zeros(R, 3, **opts) if want_ray else None
+        d_d = torch.zeros(R, 3, **opts) if want_ray else None
         _lib.check(lib.mne_render_backward_features(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d),
                                                     _lib.ptr(tgt_rgb) if coef is not None else None, _lib.ptr(tgt_d),
                                                     _lib.ptr(z_vals), _lib.ptr(ray_counts), _lib.ptr(packed), _lib.ptr(raw),
                                                     _lib.ptr(coef), _lib.ptr(_f32c(g_rgb, "g_rgb")), _lib.ptr(_f32c(g_depth, "g_depth")),
-                                                    _lib.ptr(tape), R * S, _lib.ptr(tape_rows), _lib.ptr(ray_tiles), _lib.ptr(ws),
-                                                    ws_bytes, st), "mne_render_backward_features")
+                                                    _lib.ptr(tape), R * S, _lib.ptr(tape_rows), _lib.ptr(ray_tiles), _lib.ptr(d_o), _lib.ptr(d_d),
+                                                    _lib.ptr(ws), ws_bytes, st), "mne_render_backward_features")
+        if want_ray:                                    # + the grid's share (trilinear weights of every level)
+            _lib.check(lib.mne_hash_ray_grad(C.byref(gc), C.byref(sc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals),
+                                             _lib.ptr(table.detach()), _lib.ptr(tape), _lib.ptr(ray_tiles), _lib.ptr(d_o), _lib.ptr(d_d), st),
+                       "mne_hash_ray_grad")
         g_table = None
         if ctx.needs_input_grad[9]:
             g_table = torch.zeros_like(table)
@@ -384,7 +390,8 @@ class HashRenderFunction(torch.autograd.Function):
                                          _lib.ptr(dgrad), info.get("wgrad_impl", 0), st), "mne_decoder_wgrad")
         w_sdf0, w_sdf1, w_col0, w_col1 = dec_w
         n0, n1, n2 = w_col0.numel(), w_col1.numel(), w_sdf0.numel()
-        return (None, None, None, None, None, None, None, None, None, g_table,
+        return (None, None, None, d_o if ctx.needs_input_grad[3] else None, d_d if ctx.needs_input_grad[4] else None,
+                None, None, None, None, g_table,
                 dgrad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0), dgrad[n0 + n1 + n2:].view_as(w_sdf1),
                 dgrad[:n0].view_as(w_col0), dgrad[n0:n0 + n1].view_as(w_col1))
 

@@ -597,6 +597,39 @@ def check_pose_alignment(device, compute="autograd", absolute=False):
     assert not torch.allclose(rel_h, base @ torch.inverse(target0))     # the pose moved
 
 
+def check_pose_alignment_hash(device):
+    """The same loop on the hash-grid model (R13 through the grid: OneBlob share from the render backward + trilinear-weight
+    share from mne_hash_ray_grad): Mapper.optimize_relative_pose with the host's own autograd loop -- the device loop of
+    csrc/pose.hip belongs to the plane encoding -- against the loop driven by the oracle's autograd."""
+    cfg = hash_test_config(hash_size=12, hidden=32, desired_resolution=128)
+    cfg["mapping"]["loop_iters"] = 3
+    cfg["training"]["n_samples"] = 40
+    m, sc = _hash_model_and_oracle(device, cfg)
+    rays_o, rays_d, _, _, fr = _synthetic_rays(cfg, 40, img=(12, 20))
+    cam_dirs = fr["direction"].reshape(-1, 3)[:40].clone()
+    base = fr["c2w"].clone()
+    target0 = base.clone()
+    target0[:3, :3] = _rodrigues(torch.tensor([[0.02, -0.015, 0.01]]))[0] @ base[:3, :3]
+    target0[:3, 3] += torch.tensor([0.03, -0.02, 0.025])
+    results = []
+    for kind in ("hip", "oracle"):
+        model, dev = (m.eval(), device) if kind == "hip" else (_OracleModel(sc), "cpu")
+        slam = types.SimpleNamespace(model=model, model_shared=model, map_optimizer=None, device=torch.device(dev),
+                                     dataset=None, video=None, get_pose_param_optim=None, matrix_from_tensor=None)
+        pose = _PoseSLAM()
+        slam.get_pose_param_optim, slam.matrix_from_tensor = pose.get_pose_param_optim, pose.matrix_from_tensor
+        mp = Mapper(cfg, slam, compute="fused" if kind == "hip" else "autograd")
+        torch.manual_seed(11)
+        rel, best = mp.optimize_relative_pose(base.clone(), target0.clone(), model, model, rays_d_cam_batch=cam_dirs.clone())
+        if kind == "hip":
+            assert mp.last_pose_loop == "host"
+        results.append((rel.detach().cpu(), best))
+    (rel_h, best_h), (rel_o, best_o) = results
+    assert best_h == best_h and abs(best_h - best_o) <= 1e-3 * abs(best_o) + 1e-7, (best_h, best_o)
+    assert_close(rel_h, rel_o, rtol=1e-4, atol=5e-5, what="relative transform (hash model)")
+    assert not torch.allclose(rel_h, base @ torch.inverse(target0))     # the pose moved
+
+
 def check_distillation(device, compute="autograd"):
     """Mapper.distillation (reference loop: mp_slam/mapper.py:598-640): teacher = model_shared, student = model; three
     iterations on the HIP path vs the same loop on the CPU oracle (oracle forward/backward + OracleAdam).
@@ -1227,6 +1260,22 @@ def check_hash_scene_api(device, cfg, n_rays=48, co=False, img=(34, 60)):
     for w, w_ref, nm in zip([m.decoder.color_net.model[0].weight, m.decoder.color_net.model[2].weight,
                              m.decoder.sdf_net.model[0].weight, m.decoder.sdf_net.model[2].weight], sc.decoder_list(), DEC_KEYS):
         assert_close(w.grad.cpu(), w_ref.grad, rtol=2e-3, atol=2e-5 * max(1.0, float(w_ref.grad.abs().max())), what=f"hash decoder grad {nm}")
+    # ---- R13 on the grid model: gradients of a loss on the rendered maps w.r.t. the RAYS (what the pose loops of loop closure
+    # differentiate, mp_slam/mapper.py:388-408) -- OneBlob share + trilinear-weight share -- against autograd through the spec
+    if tr.get("n_samples"):
+        U3 = torch.rand(n_rays, tr["n_samples"], generator=torch.Generator().manual_seed(11))
+        ro_g, rd_g = ro.clone().requires_grad_(True), rd.clone().requires_grad_(True)
+        o3 = m._render(ro_g, rd_g, None, None, u=U3.to(dev))
+        wr = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(12))
+        wd_ = torch.rand(n_rays, generator=torch.Generator().manual_seed(13))
+        ((o3[0] * wr.to(dev)).sum() + 0.1 * (o3[1] * wd_.to(dev)).sum()).backward()
+        ro_r, rd_r = rays_o.clone().requires_grad_(True), rays_d.clone().requires_grad_(True)
+        ref3 = sc.render_rays(ro_r, rd_r, target_d=None, z_vals=o3[5].detach().cpu())
+        ((ref3["rgb"] * wr).sum() + 0.1 * (ref3["depth"] * wd_).sum()).backward()
+        assert float(ro_r.grad.abs().max()) > 0 and float(rd_r.grad.abs().max()) > 0
+        assert_close(ro_g.grad.cpu(), ro_r.grad, rtol=2e-3, atol=2e-4 * float(ro_r.grad.abs().max()), what="hash d/d rays_o")
+        assert_close(rd_g.grad.cpu(), rd_r.grad, rtol=2e-3, atol=2e-4 * float(rd_r.grad.abs().max()), what="hash d/d rays_d")
+        m.zero_grad(set_to_none=True)
     # ---- the public entry points with their own jitter: shapes / finiteness, eval-mode forward == render_rays dict
     d1 = m.render_rays(ro, rd, target_d=td)
     assert set(d1) == {"rgb", "depth", "disp_map", "acc_map", "depth_var", "z_vals", "raw"} and d1["raw"].shape == (n_rays, S, 4)
@@ -1277,10 +1326,11 @@ def check_hash_scene_api(device, cfg, n_rays=48, co=False, img=(34, 60)):
     feat_ref = sc.grid_features(pts.reshape(-1, 3))[:, :emb.shape[-1]].reshape(5, 37, -1)
     assert_close(emb.cpu(), feat_ref, rtol=1e-5, atol=1e-7, what="hash query_sdf(embed=True)")
     assert_close(m.run_network(pts.to(dev)).cpu(), raw_ref, rtol=1e-4, atol=2e-5, what="hash run_network")
-    with pytest.raises(NotImplementedError):
-        ro_g = ro.clone().requires_grad_(True)
-        m.train()
-        m.render_rays(ro_g, rd, target_d=td)["depth"].sum().backward()
+    # ray gradients through the public method, with depth guidance as well: finite and non-zero
+    ro_g = ro.clone().requires_grad_(True)
+    m.train()
+    m.render_rays(ro_g, rd, target_d=td)["depth"].sum().backward()
+    assert torch.isfinite(ro_g.grad).all() and float(ro_g.grad.abs().max()) > 0
     return {"S": S}
 
 

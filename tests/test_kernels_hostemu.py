@@ -129,6 +129,10 @@ def test_loop_closure_pose_alignment(compute, absolute):
     pc.check_pose_alignment(DEV, compute, absolute)
 
 
+def test_loop_closure_pose_alignment_on_the_hash_model():
+    pc.check_pose_alignment_hash(DEV)
+
+
 def test_pose_alignment_falls_back_for_other_parameterisations():
     """A host whose matrix_from_tensor is neither the axis-angle nor the quaternion map keeps its own loop."""
     from mneslam_amd import hip_path
