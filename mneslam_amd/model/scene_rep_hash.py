@@ -15,8 +15,10 @@ kernels serve both encodings.
 
 The mapping iteration is ``mneslam_amd.fused.HashFusedStep`` (bench workload ``replica_office0_hashT19_2x64_2048x128``);
 ``render_rays`` / ``forward`` / ``render_img`` / ``render_maps`` / ``query_*`` / ``run_network*`` keep JointEncoding's
-signatures and run the same kernels with the grid features as caller-supplied feature rows (``hip_path.Hash*``); ray
-gradients (pose loops) need the plane encoding and raise.  ``grid.enc: dense`` gives BASELINE configs[0]'s 16^3 grid.
+signatures and run the same kernels with the grid features as caller-supplied feature rows (``hip_path.Hash*``),
+differentiable w.r.t. the table, the decoder AND the rays (R13: OneBlob share from the render backward + the grid's
+trilinear-weight share, ``mne_hash_ray_grad``), so the pose loops of loop closure run on this model through the host's
+autograd loop.  ``grid.enc: dense`` gives BASELINE configs[0]'s 16^3 grid.
 """
 import torch
 

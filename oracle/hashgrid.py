@@ -12,6 +12,38 @@ executed by the reference (model/scene_rep.py:160 is commented out).  The arithm
               else (c.x*1) ^ (c.y*2654435761) ^ (c.z*805459861)   [uint32],   then  % size_l
     out[l*F + f] = sum over the 8 corners of  prod_d (frac_d or 1-frac_d) * table[offset_l + index][f]
 Parameters: one flat fp32 vector, level after level, F features per entry, init U(-1e-4, 1e-4).
+
+Where each line comes from in tiny-cuda-nn (NVlabs/tiny-cuda-nn; unpinned in the reference, requirements.txt:120; fallback
+commit 91ee479d275d322a65726435040fc20b56b9c991, README.md:99).  Recorded from the published source as known to the author of
+this file -- tinycudann is NOT available in the build container, so a maintainer with a checkout must confirm it; the
+helpers below sit in ``include/tiny-cuda-nn/encodings/grid.h`` in older commits and in
+``include/tiny-cuda-nn/common_device.h`` in newer ones, their NAMES are stable:
+
+    this file                            tiny-cuda-nn
+    ----------------------------------   ---------------------------------------------------------------------------
+    scale_l (level_table)                ``grid_scale(level, log2_per_level_scale, base_resolution)``:
+                                           exp2f(level * log2_per_level_scale) * base_resolution - 1.0f
+                                         (log2_per_level_scale = std::log2(per_level_scale), GridEncodingTemplated ctor)
+    res_l                                ``grid_resolution(scale)``: (uint32_t)ceilf(scale) + 1
+    size_l, offsets (level_table)        ``GridEncodingTemplated`` constructor: params_in_level = res^3 (capped against
+                                           overflow); ``next_multiple(params_in_level, 8u)``; for GridType::Hash
+                                           ``std::min(params_in_level, 1u << log2_hashmap_size)``; offsets = running sum
+    pos / cell / frac (grid_indices)     ``pos_fract(input, &pos, &pos_derivative, &pos_grid, scale, identity_fun)``:
+                                           *pos = fmaf(scale, input, 0.5f);  tmp = floorf(*pos);  *pos_grid = (uint32_t)(int)tmp;
+                                           *pos -= tmp        (InterpolationType::Linear: weights frac / 1 - frac)
+    dense index  c.x + c.y res + c.z     ``grid_index<N_POS_DIMS, HASH_TYPE>(grid_type, hashmap_size, grid_resolution, pos_grid)``:
+      res^2,  chosen when res^3 <= size    stride loop ``index += pos_grid[dim] * stride; stride *= grid_resolution`` while
+                                           ``stride <= hashmap_size``; ``if (grid_type == GridType::Hash && hashmap_size < stride)
+                                           index = grid_hash<N_POS_DIMS, HASH_TYPE>(pos_grid)``
+    hash  x*1 ^ y*2654435761 ^           ``coherent_prime_hash(pos_grid)`` (HashType::CoherentPrime, the default): primes
+      z*805459861  (uint32)                {1, 2654435761, 805459861, 3674653429, ...}, ``result ^= pos_grid[i] * primes[i]``
+    % size_l                             ``return index % hashmap_size``
+    out[l*F + f] = sum_c w_c table[..]   ``kernel_grid``: loop ``for (idx = 0; idx < (1 << N_POS_DIMS); ++idx)``, weight *= pos[dim] or
+                                           (1 - pos[dim]) by bit ``idx & (1 << dim)``, ``result[f] = fmaf(weight, val[f], result[f])``
+    d/d table (autograd here)            ``kernel_grid_backward``: atomicAdd of weight * dL_dy per corner
+    d/d x (autograd here; csrc/          ``kernel_grid`` with ``dy_dx`` / ``kernel_grid_backward_input``: d weight / d pos_d * scale
+      gridenc.hip hash_raygrad_kernel)
+    init U(-1e-4, 1e-4)                  ``GridEncodingTemplated::initialize_params``: generate_random_uniform(..., -1e-4f, 1e-4f)
 """
 import math
 

@@ -12,6 +12,31 @@ restates tinycudann's published OneBlob: per input dim x and bin b in [0, n):
 with the right boundary of the last bin taken as cdf(0/n - x) + 1 (wrap).  All
 arithmetic is fp32 in the op order written below (no FMA contraction); the
 input is cast to fp32 first, as tinycudann does.
+
+Where each line comes from in tiny-cuda-nn (NVlabs/tiny-cuda-nn; the reference pins nothing, requirements.txt:120, and
+names commit 91ee479d275d322a65726435040fc20b56b9c991 as its fallback, README.md:99).  Recorded from the published source
+as known to the author of this file -- tinycudann is NOT available in the build container (no network), so a maintainer
+with a checkout must confirm the line-for-line correspondence; file placement of the helpers moved between
+``encodings/oneblob.h`` and ``common_device.h`` across commits, the function NAMES below are stable:
+
+    this file                            tiny-cuda-nn
+    ----------------------------------   ---------------------------------------------------------------------------
+    quartic_cdf(t, inv_radius)           ``quartic_cdf(const float x, const float inv_radius)``
+                                         (include/tiny-cuda-nn/common_device.h; the kernel family ``quartic`` /
+                                         ``quartic_cdf`` / ``quartic_cdf_deriv``):  u = x * inv_radius;  u2 = u*u;  u4 = u2*u2;
+                                         fmaxf(0, fminf(1, (15/16) * u * (1 - (2/3) u2 + (1/5) u4) + 0.5))
+    oneblob(): left boundary b / n,      ``one_blob_subwarp_aligned(kernel, data_in, elem_index, encoded_index,
+    left_cdf = K(l-x) + K(l-x-1)           num_bins_log2)`` (include/tiny-cuda-nn/encodings/oneblob.h):
+               + K(l-x+1)                  left_boundary = scalbnf(bin_index, -num_bins_log2);  left_cdf = kernel(left_boundary
+                                           - x, n_bins) + kernel(left_boundary - x - 1, n_bins) + kernel(left_boundary - x + 1, n_bins)
+    right_cdf = roll(left_cdf, -1)       ``right_cdf = __shfl_sync(0xffffffff, left_cdf, bin_index + 1, n_bins)``  (the right
+                                           boundary of bin b is the left boundary of bin b + 1, taken from the neighbouring lane)
+    wrap[-1] = 1                         ``if (bin_index == n_bins - 1) right_cdf += 1``  (the wrapped CDF lost one saturated term)
+    out = right_cdf - left_cdf           ``return right_cdf - left_cdf``; kernel ``kernel_one_blob`` writes it at
+                                           [dim * n_bins + bin] of the encoded row
+    derivative 15/16 (1 - u^2)^2 n       ``quartic_cdf_deriv`` / ``kernel_one_blob_backward`` (used by csrc/render.hip's
+                                           oneblob_half_backward for the ray gradients, R13)
+    n_bins power of two                  ``OneBlobEncoding`` constructor: "Number of bins must be a power of 2"
 """
 import torch
 
