@@ -310,8 +310,8 @@ def account(cfg, agent, avg_ms):
         if slices:       # the table update = scatter + Adam sweep of the table in one call
             alg["hash_scatter"] += 32.0 * agent.n_plane_params
             alg["adam"] = 32.0 * agent.n_dec_params
-        kern = {"hash_gather": "hash_rows_kernel<false> (grid gather into the tape)",
-                "hash_scatter": ("hash_offsets + hash_pack + hash_slice_adam + hash_dense_adam kernels (LDS slices, Adam fused; one mne_hash_slice_adam call)"
+        kern = {"hash_gather": "hash_gather_kernel (grid gather into the tape; the next batch's rows are gathered behind the table update)",
+                "hash_scatter": ("hash_bin + hash_slice_adam + hash_finish kernels (slice-binned rows, exact fixed-point LDS sums, Adam fused; one mne_hash_slice_adam call)"
                                  if slices else "hash_scatter_runs_kernel (run-reduced global atomics)"),
                 "adam": "adam_kernel (decoder)" if slices else "adam_kernel (table + decoder, one launch)", "wgrad": "wgrad kernels",
                 "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
@@ -357,7 +357,20 @@ VARIANTS = (("office0_2x64", "office0", 64, None), ("office0_hash", "office0_has
             ("indoor_fp16_graph", "indoor_fp16", None, "one_stream"), ("office0_fp16", "office0_fp16", None, None))
 
 
-def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, block=50, graph=None):
+def pmc_traffic(tag, needle):
+    """HBM bytes per iteration of the kernels whose name contains ``needle``, from the committed counter passes of workload
+    ``tag`` (profiles/r04_pmc_traffic_<tag>.json, profiles/r04_pmc.sh; the hash grid: r04_hash_pmc_traffic.json, per launch)."""
+    try:
+        if tag == "office0_hash":
+            per_k = json.load(open(os.path.join(REPO, "profiles", "r04_hash_pmc_traffic.json")))["per_kernel_hbm_bytes"]
+        else:
+            per_k = json.load(open(os.path.join(REPO, "profiles", f"r04_pmc_traffic_{tag}.json")))["per_kernel_hbm_bytes_per_iteration"]
+        return sum(v for k, v in per_k.items() if needle in k) or None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, block=50, graph=None, name=None):
     """A short (<= ~2 s of device time) run of another workload of SURVEY.md section 8d through the same step: the other
     decoder width, the hash-grid headline encoding, the ScanNet / indoor-scale plane sets.  Reported beside the metric,
     never as it."""
@@ -387,6 +400,9 @@ def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, bloc
            "plane_params": agent.n_plane_params, "rays_per_iter": acc["R"], "samples_per_ray": acc["S"],
            "dominant_kernel": acc["kern"][acc["dom"]], "avg_launch_ms": acc["dom_ms"],
            "achieved_GBs": acc["achieved"], "frac": acc["achieved"] / HBM_PEAK_GBS}
+    needle = {"adam": "tile_adam_kernel", "hash_scatter": "hash_slice_adam_kernel", "hash_gather": "hash_gather_kernel"}.get(acc["dom"], acc["dom"])
+    out["traffic"] = pmc_traffic(name, needle) if (name and graph is None) else None
+    out["traffic_frac"] = (out["traffic"] / (acc["dom_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (out["traffic"] and acc["dom_ms"] > 0) else None
     it_bytes = acc["alg"].get("iteration", acc["alg"].get("adam", 0.0) + acc["alg"].get("render", 0.0))
     out["iteration_algorithmic_bytes"] = it_bytes
     out["iteration_hbm_frac"] = it_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS
@@ -532,7 +548,7 @@ def main():
                 if c == args.config and (h or args.hidden) == args.hidden and gr == args.graph:
                     continue
                 try:                      # a side record must never cost the metric's line
-                    out["variants"][name] = run_variant(c, h, device, args.keyframes, graph=gr)
+                    out["variants"][name] = run_variant(c, h, device, args.keyframes, graph=gr, name=name)
                 except Exception as e:    # noqa: BLE001
                     out["variants"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)

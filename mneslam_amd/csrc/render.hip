@@ -1006,6 +1006,15 @@ __device__ __forceinline__ int first_crossing_g(const float* raw_ray, int D, int
     return -1;
 }
 
+// INVARIANTS of pass 0 running on another stream beside the backward kernels and the deferred pass (exercised by
+// tests/test_kernels_hostemu.py::test_bench_path_step_external_bin_with_many_deferred_rays):
+//   (1) a ray's decoded-tile count dec_tiles[r] is written ONLY by the resolver wave of the first decode launch (decode_kernel:
+//       `resolver` requires !a.ray_list): the list decode of the deferred pass never touches it -- otherwise pass 0 could see a
+//       deferred ray as fully decoded and append it a second time;
+//   (2) pass 0 takes every ray's prefix from dec_tiles (or, without per-ray counts, from prefix_default), never from the
+//       adaptive-schedule word adapt[0], which the LAST ray launch of the render call rewrites for the next call while pass 0
+//       may still be running (prefix_tiles() reads it: bin_kernel therefore calls it only for list passes, where it returns
+//       ntile before looking at adapt, and without dec_tiles).
 template <bool CP>
 __global__ __launch_bounds__(256) void bin_kernel(RenderArgs a) {
     constexpr int NSETS = CP ? 2 : 1;

@@ -225,6 +225,10 @@ class FusedStep:
         self._ev_decode = None       # event "prefix decode enqueued" (two-stream runs with the binned plane update)
         self._bin_pending = False
         self.concurrent_bin = os.environ.get("MNE_SERIAL_BIN", "0") != "1"
+        # tests (one-stream runs, the host emulator): hand the resolved rays' appends to mne_tile_bin(pass 0) as the two-stream
+        # schedule does, here AFTER the render call returned -- i.e. after the deferred pass and its appends (pass 1): pass 0 must
+        # then still see exactly the rays the a-priori prefix resolved (dec_tiles untouched by the list decode), ADVICE r03
+        self.split_bin_calls = os.environ.get("MNE_FORCE_EXTERNAL_BIN", "0") == "1"
         # Adaptive a-priori prefix (mne_fused_opts_t::adapt_state): 4 device words that carry the schedule decision from
         # one iteration to the next (mode 0: prefix + deferred pass; mode 1: decode everything a priori while most rays are
         # unresolved, i.e. while the SDF is untrained).  Exact either way.  MNE_NO_ADAPT=1 pins mode 0 (A/B).
@@ -552,6 +556,8 @@ class FusedStep:
                     _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
                 ev[2].record(side)                      # "appends done": the batch buffers (rays, z, targets, coefficients)
                 self._bin_pending = True                # may be overwritten by the next batch only after this
+            if (self._ev_decode is None or side is None) and self.split_bin_calls:
+                self._tile_bin(0, opts, st2)            # (tests) pass 0 as a call of its own, behind the whole render call
             self._after(side, ev[0], main)              # the deferred rays' appends are part of the render call (caller's stream)
             if self._ev_decode is None or side is None or not self._order_early:
                 _lib.check(lib.mne_tile_order(C.byref(self.scene), C.byref(self.bins), st2), "mne_tile_order")
@@ -630,6 +636,8 @@ class FusedStep:
             o.adapt_state = self.adapt_state.data_ptr()
         if self._ev_decode is not None:                # the list appends run on the side stream beside the backward kernels
             o.external_bin, o.event_after_decode = 1, self._ev_decode.cuda_event
+        elif getattr(self, "split_bin_calls", False) and self.bins is not None:
+            o.external_bin = 1
         marks = None
         if self.events is not None and self.rays_o.is_cuda and (self.bins is not None or force):
             marks = [torch.cuda.Event(enable_timing=True) for _ in range(self.N_MARKS)]

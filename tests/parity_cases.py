@@ -909,7 +909,13 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     stats["skipped_params"] = skipped
     _record_stats("fused_step_vs_oracle", dict(stats, R=R, S=S, half=half, scatter=scatter, warm=warm_steps,
                                                planes=sum(p.numel() for p in flat_planes)))
-    return {"R": R, "S": S, "contributing": int(fs.tape_rows.item()), "adam_stats": stats,
+    n_defer = -1
+    if fs.bins is not None:                # (the deferred-list length of the call sits in the render workspace, behind the lists)
+        import struct
+        a16 = lambda x: (x + 15) & ~15
+        off_cnt = a16(R * S * 16) + 3 * a16(R * 4)
+        n_defer = struct.unpack("i", bytes(cpu(fs.ws)[off_cnt:off_cnt + 4].tolist()))[0]
+    return {"R": R, "S": S, "contributing": int(fs.tape_rows.item()), "adam_stats": stats, "deferred_rays": n_defer,
             "rgb_l1": float((rgb - ret["rgb"].detach()).abs().mean()), "depth_l1": float((depth - ret["depth"].detach()).abs().mean())}
 
 

@@ -238,6 +238,72 @@ def test_bench_path_step_fp16_planes_atomics_scatter_vs_oracle():
     assert out["contributing"] > 0
 
 
+def test_bench_path_step_external_bin_with_many_deferred_rays(monkeypatch):
+    """the resolved rays' appends as a call of their own (mne_tile_bin pass 0, mne_fused_opts_t.external_bin) on an
+    UNTRAINED map pinned to the prefix schedule (MNE_NO_ADAPT): most rays are unresolved and go through the deferred pass; pass
+    0 -- here run after the whole render call, i.e. after the deferred decode and its appends -- must append exactly the rays
+    the a-priori prefix resolved: a ray appended twice or not at all shows up in the plane gradients vs the oracle."""
+    monkeypatch.setenv("MNE_FORCE_EXTERNAL_BIN", "1")
+    monkeypatch.setenv("MNE_NO_ADAPT", "1")
+    cfg = _tiny_bench_cfg()
+    cfg["training"]["n_samples_d"] = 88            # 97 samples = 4 tiles per ray: the a-priori prefix is shorter than the ray
+    out = pc.check_fused_step_vs_oracle(DEV, cfg, n_keyframes=3, seed=2, small=True, impl="explicit")
+    assert out["contributing"] > 0 and out["deferred_rays"] > 0
+
+
+@pytest.mark.parametrize("hw", [(1500, 1600), (2300, 2400)])      # 6 planes x ~9.4 k tiles (LDS snapshot) / ~21.6 k tiles each > 20480 (re-read)
+def test_tile_order_with_more_tiles_than_registers(hw, monkeypatch):
+    """tile_order_kernel keeps the first 8192 list lengths in registers and the next 12288 in LDS (every length is
+    read from memory once); beyond MNE_TILE_ORDER_SNAPSHOT tiles it re-reads.  Synthetic lengths with split lists forced
+    (MNE_TILE_SPLIT_MIN): the order must hold every split list's parts (consecutive, first) and every other tile exactly
+    once, heaviest length bucket first."""
+    import ctypes as C
+    monkeypatch.setenv("MNE_TILE_SPLIT_MIN", "64")
+    lib = _lib.load()
+    h, w = hw
+    sc = _lib.Scene()
+    sc.n_sets, sc.c_dim, sc.hidden, sc.hidden_color, sc.geo_feat_dim, sc.n_bins = 1, 32, 32, 32, 15, 16
+    dummy = torch.zeros(16)
+    for o in range(3):
+        for l in range(2):
+            pl = sc.plane[0][o][l]
+            pl.data, pl.h, pl.w = dummy.data_ptr(), (h if l else 40), (w if l else 33)
+    sc.w_sdf0 = sc.w_sdf1 = sc.w_col0 = sc.w_col1 = dummy.data_ptr()
+    n_tiles = lib.mne_tile_count(C.byref(sc))
+    assert n_tiles > 8192
+    gen = torch.Generator().manual_seed(h)
+    counts = torch.randint(0, 40, (n_tiles,), generator=gen, dtype=torch.int32)
+    heavy = torch.randperm(n_tiles, generator=gen)[:37]
+    counts[heavy] = torch.randint(200, 3000, (37,), generator=gen, dtype=torch.int32)
+    counts[n_tiles - 1] = 2500                                   # a heavy list among the tiles beyond the registers / the snapshot
+    order = torch.full((n_tiles + _lib.TILE_SPLIT_PARTS,), -1, dtype=torch.int32)
+    split_scratch = torch.zeros(4)                               # (only its presence matters to tile_order)
+    split_state = torch.zeros(n_tiles + 1, dtype=torch.int32)
+    prev = torch.zeros(n_tiles, dtype=torch.int32)
+    b = _lib.TileBins()
+    b.counts, b.order, b.cap, b.spill_cap = counts.data_ptr(), order.data_ptr(), 4096, 0
+    b.split_scratch, b.split_state, b.prev_counts = split_scratch.data_ptr(), split_state.data_ptr(), prev.data_ptr()
+    _lib.check(lib.mne_tile_order(C.byref(sc), C.byref(b), None), "mne_tile_order")
+    n_items = int(split_state[n_tiles])
+    total = int(counts.sum())
+    split = max(64, (2 * total + _lib.TILE_SPLIT_PARTS - 1) // _lib.TILE_SPLIT_PARTS)
+    items = order[:n_items].tolist()
+    seen, k = {}, 0
+    while k < n_items and (items[k] >> 26) & 63:                 # split items first: tile | part << 20 | parts << 26
+        t, part, parts = items[k] & 0xfffff, (items[k] >> 20) & 63, (items[k] >> 26) & 63
+        assert part == 0 and int(counts[t]) > split and parts == min(63, -(-int(counts[t]) // split))
+        for q in range(parts):
+            assert items[k + q] == (t | (q << 20) | (parts << 26))
+        seen[t] = parts
+        k += parts
+    whole = items[k:]
+    assert all((x >> 20) == 0 for x in whole) and len(set(whole)) == len(whole) and not (set(whole) & set(seen))
+    assert len(whole) + len(seen) == n_tiles
+    bucket = [(int(counts[t]) + 1).bit_length() - 1 for t in whole]
+    assert bucket == sorted(bucket, reverse=True), "heaviest length bucket first"
+    assert all(int(counts[t]) <= split for t in whole) and sorted(seen) == sorted(t for t in range(n_tiles) if int(counts[t]) > split)
+
+
 def test_bench_path_step_with_split_tile_lists(monkeypatch):
     """Long tile lists are cut into parts accumulated by several workgroups and combined by the last arriver
     (tile_adam.hip); forced here on a tiny scene with MNE_TILE_SPLIT_MIN."""
