@@ -891,9 +891,7 @@ int mne_hash_scatter(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_
     if (!ray_tiles || !grad_table) return fail(-1, "mne_hash_scatter: NULL argument");
     if (n_rays <= 0) return 0;
     a.ray_tiles = ray_tiles; a.dparams = grad_table;
-    static const int impl = std::getenv("MNE_HASH_SCATTER") ? std::atoi(std::getenv("MNE_HASH_SCATTER")) : 2;   // 1: one atomic pair per (sample, corner)
-    if (const char* m = std::getenv("MNE_HASH_LEVELS")) a.n_levels = std::atoi(m) < a.n_levels ? std::atoi(m) : a.n_levels;   // profiling only
-    mne_launch_hash_rows(a, impl == 1 ? 1 : 2, (hipStream_t)stream);
+    mne_launch_hash_rows(a, 2, (hipStream_t)stream);                    // run-reduced global atomics
     return check_launch("hash_scatter");
 }
 

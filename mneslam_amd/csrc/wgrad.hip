@@ -117,6 +117,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
 #ifndef WG_KS
 #define WG_KS 4
 #endif
+#ifndef WG_KS64
+#define WG_KS64 2                    // row pairs per batch of the 2x64 kernel
+#endif
 #ifndef WG_FUSED_BLOCKS
 #define WG_FUSED_BLOCKS 256          // x 4 waves; one partial result per workgroup
 #endif
@@ -248,7 +251,7 @@ template <bool CP, int PART>
 __device__ __forceinline__ void wgrad_fused64_part(const WgradArgs& a, float (*red)[64 * 16]) {
     typedef DecDims<64, 64, CP> D;
     constexpr int TNC = D::CINP / 32;
-    constexpr int KS = 2;
+    constexpr int KS = WG_KS64;
     constexpr int NTILE = PART == 0 ? 4 : TNC + 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hh = wv & 1;                                       // hidden-row half of this wave
