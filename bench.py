@@ -441,7 +441,8 @@ def main():
     if dry:
         from mneslam_amd import _lib
         _lib.load(dry)
-        args.event_every, args.cpu_iters, args.variants = 1 << 30, 0, False
+        args.event_every, args.cpu_iters = 1 << 30, 0
+        args.variants = args.variants and int(os.environ.get("WORLD_SIZE", "1")) > 1      # (the N > 1 side record is launcher logic too)
     from mneslam_amd import dist as mdist
     rank, world, device = mdist.init_agents()          # one process per GPU; RCCL when WORLD_SIZE > 1
     import torch.distributed as dist
@@ -486,6 +487,29 @@ def main():
     elapsed = mdist.max_over_ranks(elapsed, device)
     avg_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timers.items()}
     psnr, depth_l1 = agent.quality()
+    multi = None
+    if world > 1 and args.variants and not args.share_decoder and args.mode != "render_img":
+        # N > 1: the same workload with the one data-path collective this build has -- the agents share ONE decoder and all-reduce
+        # its weight gradients every iteration (RCCL; EXTENSION, mneslam_amd/dist.py) -- as a side record of the line.  Collective:
+        # every rank runs it; a failure must not cost the metric's line, and must fail on every rank alike.
+        try:
+            shared = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter,
+                           share_decoder=True, overlap=not args.no_overlap, graph=None)
+            n_var = max(min(args.steps, 200), 1)
+            for _ in range(min(args.warmup, 10)):
+                shared.step()
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(n_var):
+                shared.step(None, prefetch=i + 1 < n_var)
+            barrier()
+            el = mdist.max_over_ranks(time.perf_counter() - t1, device)
+            multi = {"share_decoder": {"value": world * n_var / el, "unit": "it/s", "ms_per_step": 1e3 * el / n_var, "steps": n_var,
+                                       "collective": "all-reduce of the decoder's weight gradients every iteration ("
+                                                     + str(dist.get_backend()) + "), planes private to each agent"}}
+            del shared
+        except Exception as e:    # noqa: BLE001
+            multi = {"share_decoder": {"error": f"{type(e).__name__}: {e}"[:300]}}
     if rank == 0:
         acc = account(cfg, agent, avg_ms)
         alg, kern, dom, dom_ms, achieved = acc["alg"], acc["kern"], acc["dom"], acc["dom_ms"], acc["achieved"]
@@ -551,6 +575,8 @@ def main():
                     out["variants"][name] = run_variant(c, h, device, args.keyframes, graph=gr, name=name)
                 except Exception as e:    # noqa: BLE001
                     out["variants"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if multi:
+            out["variants"] = multi
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

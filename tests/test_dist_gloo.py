@@ -268,8 +268,10 @@ def test_bench_launcher_dry_run_two_ranks(tmp_path, launcher):
     port = 29800 + (os.getpid() % 90)
     pre = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
             "--master-port", str(port)] if launcher == "torchrun" else [sys.executable])
-    cmd = pre + [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                 "--share-decoder", "--small", "--rays", "16", "--keyframes", "2"]
+    # launcher "self" runs the metric's line with private decoders and lets bench.py add its N > 1 side record (the same
+    # workload with the decoder-gradient all-reduce); "torchrun" puts the all-reduce into the timed line itself
+    cmd = pre + [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"] \
+        + (["--share-decoder"] if launcher == "torchrun" else []) + ["--small", "--rays", "16", "--keyframes", "2"]
     env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -277,6 +279,12 @@ def test_bench_launcher_dry_run_two_ranks(tmp_path, launcher):
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["agents"] == 2 and "all-reduce" in d["config"]["parallelism"] and "DRY RUN" in d["data"]
+    assert d["config"]["agents"] == 2 and "DRY RUN" in d["data"]
+    if launcher == "torchrun":
+        assert "all-reduce" in d["config"]["parallelism"] and "variants" not in d
+    else:
+        assert "no data-path collective" in d["config"]["parallelism"]
+        side = d["variants"]["share_decoder"]
+        assert side.get("value", 0) > 0 and "all-reduce" in side["collective"], side
     assert d["config"]["ranks_seen"] == 2 and d["config"]["collective_backend"] == "gloo"
     assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # whole-job rate = all agents' steps / time
