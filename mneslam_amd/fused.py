@@ -811,15 +811,10 @@ class HashFusedStep(FusedStep):
             stt["step"] += 1
             o.m, o.v, o.step = stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr(), stt["step"]
             # "rows binned": recorded by the call between its binning and its slice launch -- the decoder chain starts there
-            where = os.environ.get("MNE_HASH_WGRAD_AT", "slice")       # EXPERIMENT (profiles/r04_hash_wgrad_at.sh)
-            if side is not None and where == "bin":
-                self._ev[0].record(main)
             _lib.check(lib.mne_hash_slice_adam(gc, sc, R, S, P(self.rays_o), P(self.rays_d), P(self.z_vals), P(tape),
                                                P(self.ray_tiles), P(self.table.data), C.byref(o), P(self.hash_ws),
-                                               self.hash_ws_bytes, C.c_void_p(self._ev[0].cuda_event) if (side is not None and where == "slice") else None, st),
+                                               self.hash_ws_bytes, C.c_void_p(self._ev[0].cuda_event) if side is not None else None, st),
                        "mne_hash_slice_adam")
-            if side is not None and where == "end":
-                self._ev[0].record(main)
         if side is not None:
             side.wait_event(self._ev[0])
             # decoder chain (weight gradients -> reduce + decoder Adam -> next tables) on the side stream, beside the slice /
