@@ -130,23 +130,24 @@ __global__ __launch_bounds__(256) void hash_gather_kernel(GridArgs a) {
     __shared__ float2 tile[64][17];                                  // [sample][level], padded: conflict-free both ways
     const int tid = threadIdx.x, sm = tid & 63, lq = tid >> 6;
     const int groups = (a.S + 63) / 64;
-    int r = blockIdx.x / groups;
-    const int s0 = (blockIdx.x % groups) * 64;
+    // first pass: one workgroup per (ray, group of 64 samples); list pass (the deferred rays' remaining rows): a small grid
+    // strides over (list entry, group) -- the list is empty or short in steady state
+    const long long n_items = (a.ray_counts && a.ray_list) ? (long long)*a.ray_list_count * groups : (long long)a.R * groups;
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    int r = (int)(item / groups);
+    const int s0 = (int)(item % groups) * 64;
     int s_lo = 0, s_hi = a.S;                                        // rows [s_lo, s_hi) of the ray are wanted
     if (a.ray_counts) {
         // under early termination: the first pass fills the tiles decode_kernel can reach (a-priori prefix + the resolver's
         // extension), the list pass the rest of the rays that were deferred
-        if (a.ray_list) {
-            if (r >= *a.ray_list_count) return;
-            r = a.ray_list[r];
-        }
+        if (a.ray_list) r = a.ray_list[r];
         const int ntile = (a.S + 31) / 32;
         const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
         int t = (need + 31) / 32;
         t = (t < 1 ? 1 : (t > ntile ? ntile : t)) + MNE_RESOLVER_MAX_EXT;         // = prefix_tiles() of render.hip + extension
         if (a.ray_list) s_lo = t * 32; else s_hi = t * 32 < a.S ? t * 32 : a.S;
     }
-    if (s0 >= s_hi || s0 + 64 <= s_lo) return;                        // (whole workgroup)
+    if (s0 >= s_hi || s0 + 64 <= s_lo) continue;                      // (whole workgroup)
     const int s = s0 + sm;
     const bool in = s >= s_lo && s < s_hi;
     const long long row = (long long)r * a.S + (s < a.S ? s : a.S - 1);
@@ -207,6 +208,8 @@ __global__ __launch_bounds__(256) void hash_gather_kernel(GridArgs a) {
         const float2 t0 = tile[rs][part * 4], t1 = tile[rs][part * 4 + 1], t2 = tile[rs][part * 4 + 2], t3 = tile[rs][part * 4 + 3];
         *(float4*)dst = make_float4(t0.x, t0.y, t1.x, t1.y);
         *(float4*)(dst + 4) = make_float4(t2.x, t2.y, t3.x, t3.y);
+    }
+    __syncthreads();                                                  // the tile is reused by the next item
     }
 }
 
@@ -463,8 +466,8 @@ static_assert(sizeof(HashRecord) == 16, "record layout");
 //   records[level][chunk][..]              HashRecords, slice after slice
 //   wgmax[level][chunk]                    largest |d(feature)| of the chunk: the slice workgroups derive the level's
 //                                          fixed-point scale from these
-// Ranks inside a slice come from LDS integer atomics, ONE per run of consecutive rows with the same slice: consecutive rows
-// are consecutive samples of a ray, which on a dense level stay in one cell for dozens of samples -- per-row returning
+// Ranks inside a slice come from LDS integer atomics; on a dense level ONE per run of consecutive rows with the same slice:
+// consecutive rows are consecutive samples of a ray, which stay in one cell for dozens of samples -- per-row returning
 // atomics on the same counter serialise (the appends of render.hip's bin_kernel know the problem).
 // (Skipping the odd corners' slots on hashed levels -- x-neighbours share their slice -- is NOT valid: a sample outside the
 // bounding box has wrapped cell coordinates, its x-neighbours then differ in every index bit; caught by the GPU parity test.)
@@ -478,6 +481,10 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     const int ns = hash_slices_of(a, level);
     for (int i = tid; i <= ns; i += HASH_BIN_THREADS) hist[i] = 0u;
     const bool dense = hash_level_dense(a, level);
+    const long long k_first = (long long)chunk * HASH_CHUNK;
+    const int r_first = (int)(k_first / a.S);
+    const unsigned s_first = (unsigned)(k_first - (long long)r_first * a.S);
+    const float inv_S = 1.0f / (float)a.S;
     // this thread's rows, all loads first.  Row j of thread tid = chunk row j * HASH_BIN_THREADS + tid: the lanes of a wave
     // hold CONSECUTIVE rows.
     float2 g[HASH_RPT];
@@ -489,7 +496,13 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
         const long long k = (long long)chunk * HASH_CHUNK + j * HASH_BIN_THREADS + tid;
         g[j] = make_float2(0.f, 0.f); x[j] = make_float4(0.f, 0.f, 0.f, 0.f); ray[j] = 0;
         if (k < n_rows) {
-            const int r = (int)(k / a.S), sidx = (int)(k % a.S);
+            // (ray, sample) of row k without a 64-bit division per row: the chunk's first row is divided once (uniform),
+            // the offset inside the chunk (< HASH_CHUNK + S) by a float reciprocal with one correction step each way
+            const unsigned t = s_first + (unsigned)(j * HASH_BIN_THREADS + tid);
+            unsigned dq = (unsigned)((float)t * inv_S);
+            dq -= (dq * (unsigned)a.S > t) ? 1u : 0u;
+            dq += ((dq + 1u) * (unsigned)a.S <= t) ? 1u : 0u;
+            const int r = r_first + (int)dq, sidx = (int)(t - dq * (unsigned)a.S);
             ray[j] = r;
             if (sidx < a.ray_tiles[r] * 32) {
                 g[j] = *(const float2*)(a.tape + (size_t)k * a.row_stride + a.col_d + level * 2);
@@ -540,18 +553,24 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
             const bool have = row_live && !dup;
             const unsigned key = have ? sl[q] : 0xffffffffu;
             rec[j][q] = have ? (sl[q] | (mask << 12)) : 0u;
-            // one returning LDS atomic per RUN of consecutive lanes with the same slice in slot q
-            const unsigned prev = __shfl_up(key, 1);
-            const bool start = lane == 0 || key != prev;
-            const unsigned long long sm = __ballot(start);
-            const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-            const int leader = 63 - __clzll(sm & upto);
-            const unsigned long long above = sm & ~upto;
-            const int next = above ? __ffsll(above) - 1 : 64;
-            unsigned base = 0u;
-            if (have && leader == lane) base = atomicAdd(&hist[sl[q]], (unsigned)(next - leader));
-            base = __shfl(base, leader);
-            rec[j][q] |= (base + (unsigned)(lane - leader)) << 20;
+            if (dense) {
+                // one returning LDS atomic per RUN of consecutive lanes with the same slice in slot q
+                const unsigned prev = __shfl_up(key, 1);
+                const bool start = lane == 0 || key != prev;
+                const unsigned long long sm = __ballot(start);
+                const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+                const int leader = 63 - __clzll(sm & upto);
+                const unsigned long long above = sm & ~upto;
+                const int next = above ? __ffsll(above) - 1 : 64;
+                unsigned base = 0u;
+                if (have && leader == lane) base = atomicAdd(&hist[sl[q]], (unsigned)(next - leader));
+                base = __shfl(base, leader);
+                rec[j][q] |= (base + (unsigned)(lane - leader)) << 20;
+            } else if (have) {
+                // a hashed level scatters consecutive samples over unrelated slices: no runs to find (the search for them was
+                // a third of this kernel's instructions, profiles/r04_hash_sq_counters.txt), no contention on the counters either
+                rec[j][q] |= atomicAdd(&hist[sl[q]], 1u) << 20;
+            }
         }
     }
     __syncthreads();
@@ -594,8 +613,14 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
     }
 }
 
+// rint(v * scale) as a two's-complement 64-bit integer (sums wrap correctly).  v * scale is exact in double (a float times
+// a power of two) and below 2^40 in magnitude, so adding 2^52 + 2^51 rounds it to the nearest integer, ties to even -- what
+// rint does -- and leaves that integer in the low mantissa bits: two double instructions and one 64-bit subtraction
+// instead of rint + the emulated double -> int64 conversion.
 __device__ __forceinline__ unsigned long long hash_fix(float v, double scale) {
-    return (unsigned long long)(long long)rint((double)v * scale);  // two's complement: sums wrap correctly
+    const double magic = 6755399441055744.0;                         // 2^52 + 2^51
+    const double t = fma((double)v, scale, magic);
+    return (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(magic));
 }
 
 #define HASH_SLICE_UNROLL 4
@@ -801,7 +826,11 @@ int mne_launch_hash_rows(const GridArgs& a, int bwd, hipStream_t st) {
     const long long n = (long long)a.R * a.S * 16;
     if (n <= 0) return 0;
     if (bwd) MNE_LAUNCH(hash_scatter_kernel, (unsigned)((n + 255) / 256), 256, 0, st, a);
-    else MNE_LAUNCH(hash_gather_kernel, (unsigned)(a.R * ((a.S + 63) / 64)), 256, 0, st, a);
+    else {
+        long long grid = (long long)a.R * ((a.S + 63) / 64);
+        if (a.ray_counts && a.ray_list && grid > 256) grid = 256;     // list pass: grid-stride over the deferred rays
+        MNE_LAUNCH(hash_gather_kernel, (unsigned)grid, 256, 0, st, a);
+    }
     return 0;
 }
 

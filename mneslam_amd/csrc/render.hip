@@ -1401,6 +1401,16 @@ static inline void mark(const RenderHost& h, int i, hipStream_t st) {
     if (i < h.n_marks && h.marks && h.marks[i]) (void)hipEventRecord((hipEvent_t)h.marks[i], st);
 }
 
+// The deferred pass (decode -> ray -> appends of the rays the training kernel could not resolve) sits on the critical path of
+// every iteration, and in steady state its list is EMPTY or a handful of rays (an untrained map, where it is not, switches to
+// decoding every sample a priori: adapt_state): what it costs then is dispatching three full-size grids that leave at once.
+// Its kernels loop over the list with a grid stride, so a small grid is enough: 64 workgroups decode ~500 tile tasks / hold
+// ~380 rays at a time.  (Measured: +1 % on the first iterations of a fresh map, nothing in steady state -- an empty launch
+// costs its ~5 us whatever its grid, profiles/r04_list_pass_grid.txt.)
+#ifndef MNE_LIST_PASS_BLOCKS
+#define MNE_LIST_PASS_BLOCKS 64
+#endif
+
 // pre = true: the a-priori tiles' plane features are gathered by gather_kernel first (needs the tape)
 template <int HID, int HIDC, bool CP>
 static int launch_decode(RenderArgs d, hipStream_t st, const RenderHost& host, bool pre = false) {
@@ -1423,6 +1433,7 @@ static int launch_decode(RenderArgs d, hipStream_t st, const RenderHost& host, b
     const long long ntask = (long long)d.R * ((d.S + TILE - 1) / TILE);
     long long grid = (ntask + wpb - 1) / wpb;
     if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
+    if (d.ray_list && grid > MNE_LIST_PASS_BLOCKS) grid = MNE_LIST_PASS_BLOCKS;      // deferred pass: see MNE_LIST_PASS_BLOCKS
     // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
     if (lds > 64 * 1024) MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB>), MNE_LDS_MAX);
     MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB>), (unsigned)grid, 64 * wpb, lds, st, d, pre ? 1 : 0);
@@ -1437,6 +1448,7 @@ static int launch_bin(RenderArgs b, int pass, hipStream_t st) {
     else { b.ray_list = nullptr; b.ray_list_count = nullptr; }
     long long grid = ((long long)b.R + 3) / 4;
     if (grid > MNE_NUM_CU * 8) grid = MNE_NUM_CU * 8;
+    if (pass && grid > MNE_LIST_PASS_BLOCKS) grid = MNE_LIST_PASS_BLOCKS;
     MNE_LAUNCH((bin_kernel<CP>), (unsigned)grid, 256, 0, st, b);
     return 0;
 }
@@ -1516,7 +1528,7 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         }
         launch_decode<HID, HIDC, CP>(d, st, host);         // their remaining tiles, tile-parallel
         d.adapt_update = 1;                                // the last ray launch of the call decides the next call's schedule
-        if (int rc = launch_ray<HID, HIDC, CP, 4>(d, st)) return rc;    // the same lean kernel: now every listed ray resolves
+        if (int rc = launch_ray<HID, HIDC, CP, 4>(d, st, MNE_LIST_PASS_BLOCKS / 2)) return rc;    // the same lean kernel: now every listed ray resolves
         mark(host, 4, st);
         if (a.bins.lists) {                                // list appends: the resolved rays' (pass 0) here unless the host runs
             if (!host.external_bin) launch_bin<CP>(a, 0, st);   // them beside the backward (mne_tile_bin on a second stream);
