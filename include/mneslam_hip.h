@@ -537,7 +537,7 @@ int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const flo
  *   mne_decoder_wgrad, mne_adam_step (table + decoder segments, zero_grad fused)
  *   -- or, instead of mne_hash_scatter + the table's Adam segment --
  *   mne_hash_slice_adam        the table update without float atomics and without a gradient buffer: the iteration's
- *                              backward rows are packed level-major into `workspace` and sorted by the 2048-entry slices of
+ *                              backward rows are packed level-major into `workspace` and sorted by the 1024-entry slices of
  *                              the table their corners fall into; one workgroup per slice sums the slice's gradient in LDS
  *                              as 64-bit fixed-point numbers (exact, order-independent: the update is bit-reproducible) and
  *                              applies Adam (opt: moments with the table's layout, step 1-based) to the slice.  Same

@@ -393,14 +393,16 @@ __global__ __launch_bounds__(256) void hash_scatter_runs_kernel(GridArgs a) {
 //     slice, which add their non-zero sums into a 64-bit scratch with global integer atomics (exact, too);
 //     hash_finish_kernel applies Adam to those levels.
 #ifndef HASH_SLICE
-#define HASH_SLICE 2048            // entries a slice holds at most: 2 x 8 B x 2048 = 32 KiB of LDS, four workgroups per CU
+#define HASH_SLICE 1024            // entries a slice holds at most: 2 x 8 B x 1024 = 16 KiB of LDS, eight workgroups per CU: a slice workgroup is a
+                                   // chain of dependent round trips (offsets -> records -> rays -> Adam operands), so more, smaller ones
+                                   // hide each other's latency -- 2048: 145 us stand-alone, 1024: 135, 4096: 217 (profiles/r04_hash_slice_size.txt)
 #endif
 #define HASH_SLICE_THREADS 256
 #define HASH_CHUNK 1024            // packed rows per bin workgroup (2 per thread)
 #define HASH_BIN_THREADS 512
 #define HASH_RPT (HASH_CHUNK / HASH_BIN_THREADS)
 #define HASH_REC_PER_ROW 8         // a row's corners fall into at most 8 slices (typically 4: the x-neighbours share a granule)
-#define HASH_MAX_SLICES 4096       // per level: T <= 2^23
+#define HASH_MAX_SLICES 4096       // per level: T <= 2^22
 #define HASH_MAX_CHUNKS (2 * HASH_SLICE_THREADS)
 #define HASH_FIX_BITS 39
 #ifndef HASH_LEVEL_WGS

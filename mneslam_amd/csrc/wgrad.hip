@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
 #define WG_KS 4
 #endif
 #ifndef WG_KS64
-#define WG_KS64 2                    // row pairs per batch of the 2x64 kernel
+#define WG_KS64 4                    // row pairs per batch of the 2x64 kernel (2 / 4 / 8: profiles/r04_wgrad64_ks.txt, r04_hash_slice_size.txt)
 #endif
 #ifndef WG_FUSED_BLOCKS
 #define WG_FUSED_BLOCKS 256          // x 4 waves; one partial result per workgroup
