@@ -301,6 +301,10 @@ def account(cfg, agent, avg_ms):
     binned = agent.fused is not None and agent.fused.bins is not None
     p_contrib = float(agent.fused.tape_rows.item()) if agent.fused is not None else float(R * S)
     decoded = float((agent.fused.ray_tiles[:R].long() * 32).clamp(max=S).sum().item()) if agent.fused is not None else float(R * S)
+    # decoder weight-gradient pass: the tape columns it reads of every backward row -- x 112 | out 16 | h | hc | dh | dhc | dout 16 | dc 4
+    # (+ the 64 colour-plane features); a streaming read, MFMA work hidden behind it (wgrad.hip)
+    hid = cfg["decoder"]["hidden_dim"]
+    wgrad_bytes = decoded * 4.0 * (112 + 16 + 4 * hid + 16 + 4 + (0 if cfg["grid"]["oneGrid"] else 64))
     if agent.hash:
         # hash grid: 16 levels x 8 corners x 2 features x 4 B = 1,024 B per point per gather or scatter pass
         Gh = agent.model.embed_fn.cfg.n_levels * 8 * agent.model.embed_fn.cfg.n_features * 4.0
@@ -317,6 +321,7 @@ def account(cfg, agent, avg_ms):
                 "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
                 "deferred_pass": "hash gather + decode_kernel + ray_kernel over the deferred-ray list",
                 "render": "whole mne_render_fused_features call (decode + ray kernels; MFMA / latency, no algorithmic HBM bytes)"}
+        alg["wgrad"] = wgrad_bytes
         alg["iteration"] = alg["hash_gather"] + alg["hash_scatter"] + alg["adam"]
     elif binned:
         # parameters the plane update really sweeps: tiles that have never received a gradient keep m = v = 0, Adam leaves them
@@ -330,7 +335,7 @@ def account(cfg, agent, avg_ms):
                 swept += p_.numel() * float((lv[off_:off_ + t_] != 0).float().mean())
                 off_ += t_
         alg = {"adam": p_contrib * G + sweep * swept + 32.0 * agent.n_dec_params, "_swept": swept,
-               "gather_kernel": decoded * G_gather, "render": decoded * G_gather}
+               "gather_kernel": decoded * G_gather, "render": decoded * G_gather, "wgrad": wgrad_bytes}
         kern = {"adam": "tile_adam_kernel (binned scatter + Adam, one launch)", "gather_kernel": "gather_kernel",
                 "decode_kernel": "decode_kernel", "ray_kernel": "ray_kernel (composite + loss + backward)",
                 "deferred_pass": "decode_kernel + ray_kernel over the deferred-ray list",
