@@ -8,6 +8,9 @@ timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err;
 for i in 1 2 3; do timeout 600 python bench.py --steps 20 --warmup 5 $([ $i != 1 ] && echo --no-variants --cpu-iters 0) > $OUT/bench_driver_form_$i.json 2>> $OUT/bench_driver.err; cut -c1-160 $OUT/bench_driver_form_$i.json; done
 B="python $REPO/bench.py --config office0_hash --no-variants --cpu-iters 0"
 cd /tmp
+# configs[4] as a replayed graph: the kernel table of that variant (events cannot be recorded inside a graph)
+rm -rf /tmp/ks_g; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ks_g -o k -- python $REPO/bench.py --config indoor_fp16 --graph one_stream --no-variants --cpu-iters 0 --steps 100 --warmup 20 > $OUT/ks_indoor_fp16_graph.log 2>&1
+python $REPO/profiles/summarize_rocprof_db.py $(find /tmp/ks_g -name '*.db' | head -1) > $OUT/kernel_stats_indoor_fp16_graph.txt 2>&1; head -8 $OUT/kernel_stats_indoor_fp16_graph.txt | cut -c1-150
 rm -rf /tmp/ks_h; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ks_h -o k -- $B --steps 100 --warmup 20 > $OUT/ks_hash.log 2>&1
 d=$(find /tmp/ks_h -name '*.db' | head -1)
 python $REPO/profiles/summarize_rocprof_db.py $d > $OUT/hash_kernel_stats.txt 2>&1; head -14 $OUT/hash_kernel_stats.txt | cut -c1-170

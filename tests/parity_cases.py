@@ -927,6 +927,47 @@ def hash_test_config(hash_size=12, hidden=32, desired_resolution=128):
     return cfg
 
 
+def check_hash_update_bit_reproducible(device, cfg, n_keyframes=3, seed=5, warm_steps=2, small=True, repeats=2):
+    """The hash-grid table update sums 64-bit fixed-point addends with LDS / global INTEGER atomics: whatever order the rows
+    arrive in, the sums -- and therefore the table and its moments after Adam -- are the same bits.  Checked the way the
+    domain offers it: the update of a real iteration (run inside the pipeline, beside the weight-gradient kernel) is
+    repeated stand-alone on copies of the pre-step state, each time on a fresh workspace; every result must equal the
+    pipeline's bit for bit."""
+    import ctypes as C
+    import bench
+    from mneslam_amd import _lib
+    dev = torch.device(device)
+    ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, small=small, path="fused")
+    fs, m = ag.fused, ag.model
+    for _ in range(warm_steps):
+        ag.step()
+    sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
+    sync()
+    stt = ag.opt._state(m.embed_fn.params)
+    table0, m0, v0, t0 = m.embed_fn.params.detach().clone(), stt["exp_avg"].clone(), stt["exp_avg_sq"].clone(), int(stt["step"])
+    ag.step()
+    sync()
+    assert int(stt["step"]) == t0 + 1
+    want = (m.embed_fn.params.detach().clone(), stt["exp_avg"].clone(), stt["exp_avg_sq"].clone())
+    assert not torch.equal(want[0], table0), "the step did not move the table"
+    lib, P = fs.lib, _lib.ptr
+    R, S, tape = fs.n_active, fs.S, fs.tape
+    for k in range(repeats):
+        tb, mm, vv = table0.clone(), m0.clone(), v0.clone()
+        ws = torch.zeros(fs.hash_ws_bytes, device=dev, dtype=torch.uint8)
+        o = _lib.PlaneOpt()
+        for f in ("lr", "beta1", "beta2", "eps", "weight_decay"):
+            setattr(o, f, getattr(fs.table_opt, f))
+        o.m, o.v, o.step = mm.data_ptr(), vv.data_ptr(), t0 + 1
+        _lib.check(lib.mne_hash_slice_adam(C.byref(fs.grid_cfg), C.byref(fs.scene), R, S, P(fs.rays_o), P(fs.rays_d), P(fs.z_vals),
+                                           P(tape), P(fs.ray_tiles), P(tb), C.byref(o), P(ws), fs.hash_ws_bytes, None,
+                                           _lib.stream_for(fs.rays_o)), "mne_hash_slice_adam")
+        sync()
+        for name, a, b in zip(("table", "exp_avg", "exp_avg_sq"), (tb, mm, vv), want):
+            assert torch.equal(a, b), f"repeat {k}: {name} differs from the pipeline's result in {int((a != b).sum())} entries"
+    return {"moved": int((want[0] != table0).sum()), "R": R, "S": S}
+
+
 def check_hash_fused_step_vs_oracle(device, cfg, n_keyframes=3, seed=5, warm_steps=0, small=True):
     """HashFusedStep (hash-grid wiring, EXTENSION, parity unpinned) against one iteration of the build's own CPU oracle
     (oracle.scene_rep.OracleHashScene + oracle.hashgrid) on the same device-drawn batch and parameters:

@@ -405,6 +405,15 @@ def test_hash_grid_headline_config_vs_oracle():
     assert out["R"] == 2048 + 512 and out["S"] == 128
 
 
+def test_hash_table_update_is_bit_reproducible_at_the_headline_size():
+    """BASELINE configs[1] literal (T = 2^19 x 16 levels, 2560 rays x 128 samples): the table update of a pipeline iteration --
+    run beside the weight-gradient kernel -- repeated three times stand-alone on copies of the pre-step state gives the table,
+    exp_avg and exp_avg_sq bit for bit (order-independent 64-bit fixed-point sums; a size-independent property of the path)."""
+    from mneslam_amd import configs
+    out = pc.check_hash_update_bit_reproducible(DEV, configs.bench_office0_hash(), n_keyframes=4, seed=3, warm_steps=3, small=False, repeats=3)
+    assert out["R"] == 2048 + 512 and out["moved"] > 100000
+
+
 @pytest.mark.parametrize("hidden,co", [(32, False), (64, True)])
 def test_hash_scene_api_vs_oracle(hidden, co):
     """The whole JointEncoding surface of the hash-grid model -- render_rays (with / without depth), forward + autograd

@@ -198,6 +198,17 @@ def test_hash_grid_fused_step_vs_oracle():
     assert out["touched_entries"] > 0
 
 
+def test_hash_table_update_is_bit_reproducible():
+    """NS-a: exact integer sums -> the table update gives the same bits whatever the arrival order of its rows"""
+    cfg = pc.hash_test_config(hash_size=9, hidden=32, desired_resolution=64)
+    cfg["training"]["n_range_d"], cfg["training"]["n_samples_d"] = 9, 20
+    cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+    cfg["mapping"]["sample"], cfg["mapping"]["min_pixels_cur"] = 24, 8
+    cfg["cam"]["far"] = 4.0
+    out = pc.check_hash_update_bit_reproducible(DEV, cfg, n_keyframes=3, seed=2, warm_steps=1, small=True)
+    assert out["moved"] > 0
+
+
 def test_hash_scene_api_vs_oracle():
     """NS-a: render_rays / forward + backward / render_maps / render_img / query_* of the hash-grid scene model"""
     cfg = pc.hash_test_config(hash_size=9, hidden=32, desired_resolution=64)
