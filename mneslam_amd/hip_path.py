@@ -177,8 +177,12 @@ class RenderFunction(torch.autograd.Function):
         coef = None
         if ctx.want_losses and g_losses is not None:
             coef = torch.empty(_lib.N_LOSS, **opts)
-            _lib.check(lib.mne_loss_coef(C.byref(rc), R, S, _lib.ptr(counts), _lib.ptr(_f32c(g_losses, "g")),
+            g_l = _f32c(g_losses, "g")                   # (named: a converted copy must outlive the launch that reads it)
+            _lib.check(lib.mne_loss_coef(C.byref(rc), R, S, _lib.ptr(counts), _lib.ptr(g_l),
                                          _lib.ptr(coef), st), "mne_loss_coef")
+        # incoming gradients as dense fp32: a converted / made-contiguous COPY is a temporary -- it is kept in a name until the
+        # call that enqueues its reader has returned (found by the emulator's AddressSanitizer build: use after free)
+        g_rgb_c, g_depth_c = _f32c(g_rgb, "g_rgb"), _f32c(g_depth, "g_depth")
         row = lib.mne_tape_row_floats(C.byref(sc))
         tape = torch.empty(R * S, row, **opts)
         tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -188,8 +192,8 @@ class RenderFunction(torch.autograd.Function):
         _lib.check(lib.mne_render_backward(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d),
                                            _lib.ptr(tgt_rgb) if coef is not None else None,
                                            _lib.ptr(tgt_d), _lib.ptr(z_vals), _lib.ptr(ray_counts), _lib.ptr(packed),
-                                           _lib.ptr(raw), _lib.ptr(coef), _lib.ptr(_f32c(g_rgb, "g_rgb")),
-                                           _lib.ptr(_f32c(g_depth, "g_depth")), _lib.ptr(tape), R * S,
+                                           _lib.ptr(raw), _lib.ptr(coef), _lib.ptr(g_rgb_c),
+                                           _lib.ptr(g_depth_c), _lib.ptr(tape), R * S,
                                            _lib.ptr(tape_rows), _lib.ptr(ray_tiles), _lib.ptr(d_o), _lib.ptr(d_d),
                                            _lib.ptr(ws), ws_bytes, st),
                    "mne_render_backward")
@@ -356,8 +360,10 @@ class HashRenderFunction(torch.autograd.Function):
         coef = None
         if ctx.want_losses and g_losses is not None:
             coef = torch.empty(_lib.N_LOSS, **opts)
-            _lib.check(lib.mne_loss_coef(C.byref(rc), R, S, _lib.ptr(counts), _lib.ptr(_f32c(g_losses, "g")), _lib.ptr(coef), st),
+            g_l = _f32c(g_losses, "g")                   # (named: a converted copy must outlive the launch that reads it)
+            _lib.check(lib.mne_loss_coef(C.byref(rc), R, S, _lib.ptr(counts), _lib.ptr(g_l), _lib.ptr(coef), st),
                        "mne_loss_coef")
+        g_rgb_c, g_depth_c = _f32c(g_rgb, "g_rgb"), _f32c(g_depth, "g_depth")
         row = lib.mne_tape_row_floats(C.byref(sc))
         tape = torch.empty(R * S, row, **opts)
         tape[:, :64].zero_()                               # feature columns the grid does not fill must read as zero
@@ -372,7 +378,7 @@ class HashRenderFunction(torch.autograd.Function):
         _lib.check(lib.mne_render_backward_features(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o), _lib.ptr(rays_d),
                                                     _lib.ptr(tgt_rgb) if coef is not None else None, _lib.ptr(tgt_d),
                                                     _lib.ptr(z_vals), _lib.ptr(ray_counts), _lib.ptr(packed), _lib.ptr(raw),
-                                                    _lib.ptr(coef), _lib.ptr(_f32c(g_rgb, "g_rgb")), _lib.ptr(_f32c(g_depth, "g_depth")),
+                                                    _lib.ptr(coef), _lib.ptr(g_rgb_c), _lib.ptr(g_depth_c),
                                                     _lib.ptr(tape), R * S, _lib.ptr(tape_rows), _lib.ptr(ray_tiles), _lib.ptr(d_o), _lib.ptr(d_d),
                                                     _lib.ptr(ws), ws_bytes, st), "mne_render_backward_features")
         if want_ray:                                    # + the grid's share (trilinear weights of every level)
