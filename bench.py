@@ -57,6 +57,8 @@ def parse_args():
                          "(two_stream = the eager schedule's two queues captured, one_stream = one queue); default: eager launches")
     ap.add_argument("--scatter", default="binned", choices=["binned", "atomics"],
                     help="fused path: tile-binned LDS scatter fused with Adam (default) or global atomics + streaming Adam")
+    ap.add_argument("--pretrain", type=int, default=10, help="--mode render_img: mapping iterations before the timed renders (an untrained "
+                    "SDF has no zero crossing: no ray terminates early)")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane update and the decoder chain on ONE stream (ablation)")
     ap.add_argument("--event-every", type=int, default=None,
                     help="bracket the launches with HIP events on every N-th timed step (default: 25, or one step in the "
@@ -238,8 +240,8 @@ def bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, m
     """N1: JointEncoding.render_img on whole frames -- one no-grad launch sequence per frame with exact early ray
     termination.  One step = the reference's per-keyframe pair: a depth-guided render (n_range_d + n_samples_d samples
     per ray) and a free render (training.n_samples)."""
-    for _ in range(10):
-        agent.step()                                     # a few mapping iterations so that the SDF has a surface
+    for _ in range(args.pretrain):
+        agent.step()                                     # mapping iterations in front of the renders: the SDF needs a surface
     torch.cuda.synchronize()
     m = agent.model
     m.eval()
