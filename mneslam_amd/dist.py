@@ -103,12 +103,25 @@ class ModelExchange:
     """The reference's map hand-off at loop closure / fusion is ONE-SIDED: the agent that detects the loop reads the peer's
     last ``latest_checkpoint.pt`` whenever it wants (mp_slam/mapper.py:708-726); the peer does not take part.  Over a
     process group that becomes a tiny service: every agent runs ``serve()`` in a daemon thread which waits for a request
-    from ANY peer on a control group (gloo: any-source receive) and answers with ``send_model`` on the data group (RCCL
+    from ANY peer on a control group (gloo: any-source receive) and answers with ``send_model`` on a data group (RCCL
     point-to-point over xGMI between GPUs; gloo on CPU), on its own HIP stream; ``fetch(model_shared, src)`` is what
-    ``Mapper.load_foreign_model`` calls instead of ``torch.load``.  Both groups are private to the exchange (created
+    ``Mapper.load_foreign_model`` calls instead of ``torch.load``.  All groups are private to the exchange (created
     collectively in ``__init__``), so it never interleaves with the agents' own collectives (shared-decoder all-reduce,
-    overlap rectangles).  ``lock`` is held while a map is being sent: a mapper that wants its peers to see maps only at
-    keyframe boundaries -- where the reference writes its checkpoint (mneslam_mp.py:294-315) -- holds it during an update."""
+    overlap rectangles).
+
+    * **One data group per DIRECTION** (``data_up``: the sender's rank is below the receiver's, ``data_down``: above).
+      Loop closure is symmetric, so two agents can fetch each other at the same moment: each then has a receive posted by
+      its mapping thread and a send posted by its service thread for the SAME peer.  On one RCCL communicator those two
+      point-to-point operations are executed in the order they were enqueued -- receive first on both sides, each waiting
+      for a send that sits behind the other's receive.  With a group per direction a communicator only ever
+      carries transfers from ONE side of a pair to the other, so no receive can be queued in front of a send.
+    * **A consistent map.**  ``lock`` is held while a map is being sent, and the mapper (``FusedMappingMixin``) holds it
+      while it updates the map -- ``mapping_optimize`` / ``first_frame_mapping`` / ``distillation`` -- and leaves with every
+      stream of the fused step joined (``FusedStep.check``): peers see maps at keyframe boundaries only, where the
+      reference writes its checkpoint (mneslam_mp.py:294-315), never planes and decoder of different iterations.  The
+      service additionally waits for the work enqueued so far on the stream the exchange was created on (the mapper's).
+    * ``stop()`` is collective (a barrier over the control group, then the STOP messages): no agent's service ends while a
+      peer may still fetch from it, and every service thread has left ``recv`` before ``destroy_process_group``."""
 
     STOP, FETCH = 0, 1
 
@@ -121,9 +134,14 @@ class ModelExchange:
         on_gpu = self.device.type == "cuda"
         # collective calls: every agent builds its exchange at the same point of its start-up
         self.ctrl = dist.new_group(backend="gloo")
-        self.data = dist.new_group(backend="nccl") if on_gpu else dist.new_group(backend="gloo")
-        self.lock = threading.Lock()
+        self.data_up = dist.new_group(backend="nccl" if on_gpu else "gloo")
+        self.data_down = dist.new_group(backend="nccl" if on_gpu else "gloo")
+        self.lock = threading.RLock()
+        self.producer_stream = torch.cuda.current_stream(self.device) if on_gpu else None
         self._thread, self.served = None, 0
+
+    def _data(self, sender, receiver):
+        return self.data_up if sender < receiver else self.data_down
 
     def start(self):
         import threading
@@ -139,31 +157,36 @@ class ModelExchange:
             src = dist.recv(req, group=self.ctrl)                  # any source
             if int(req[0]) == self.STOP:
                 return
-            with self.lock:
+            group = self._data(self.rank, src)
+            with self.lock:                                        # not while the mapper is inside an update
                 if stream is not None:
-                    stream.wait_stream(torch.cuda.current_stream(self.device))     # the map as enqueued so far
+                    stream.wait_stream(self.producer_stream)       # the map as enqueued so far by the mapping thread
                     with torch.cuda.stream(stream):
-                        send_model(self.model, src, self.device, group=self.data)
+                        send_model(self.model, src, self.device, group=group)
                     stream.synchronize()
                 else:
-                    send_model(self.model, src, self.device, group=self.data)
+                    send_model(self.model, src, self.device, group=group)
             self.served += 1
 
     def fetch(self, model_shared, src):
-        """The peer's CURRENT map into ``model_shared`` (planes, decoder, both boxes; eval mode): one request + the transfer."""
+        """The peer's CURRENT map into ``model_shared`` (planes, decoder, both boxes; eval mode): one request + the transfer.
+        The caller must not hold ``lock`` (two agents fetching each other would then wait for each other's service)."""
         if src == self.rank:
             raise ValueError("an agent does not fetch its own map")
         dist.send(torch.tensor([self.FETCH, self.rank], dtype=torch.int64), src, group=self.ctrl)
-        return recv_model_into(model_shared, src, self.device, group=self.data)
+        return recv_model_into(model_shared, src, self.device, group=self._data(src, self.rank))
 
     def stop(self):
-        """Ends this agent's service thread (a request to itself); call on every agent before destroy_process_group."""
+        """COLLECTIVE: every agent calls it once it will fetch no more (before destroy_process_group).  The barrier makes
+        sure nobody's service ends while a peer is still fetching; then rank r ends the service of rank r + 1 (gloo has no
+        send-to-self) and joins its own thread, which rank r - 1 is ending at the same time."""
         if self._thread is not None:
             if self.world > 1:
-                # any peer may stop us; we stop ourselves through our ring neighbour's thread being symmetrical: send to self is
-                # not defined for gloo point-to-point, so the STOP goes around: rank r stops rank (r + 1) % world
+                dist.barrier(group=self.ctrl)
                 dist.send(torch.tensor([self.STOP, self.rank], dtype=torch.int64), (self.rank + 1) % self.world, group=self.ctrl)
-            self._thread.join(timeout=30)
+            self._thread.join(timeout=60)
+            if self._thread.is_alive():
+                raise RuntimeError("ModelExchange.stop: the service thread did not end (did every agent call stop()?)")
             self._thread = None
 
 

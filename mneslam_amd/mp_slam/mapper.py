@@ -27,6 +27,14 @@ import torch
 from ..fused import FusedStep
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 def frame_ray_table(batch):
     """[H*W, 7] = dir3 | rgb3 | depth1 of one frame dict, row-major over (h, w)."""
     return torch.cat([batch["direction"], batch["rgb"], batch["depth"][..., None]], dim=-1).reshape(-1, 7)
@@ -88,12 +96,23 @@ class FusedMappingMixin:
             return torch.rand(n_rays, fs.S).to(self.device)           # the reference's CPU draw (scene_rep.py:381)
         return None
 
+    def _map_guard(self):
+        """Held while this agent's map is being updated: a peer's fetch (dist.ModelExchange) is served between updates
+        only -- at the keyframe boundaries where the reference writes the checkpoint its peers read
+        (mneslam_mp.py:294-315) -- and every loop below leaves with the fused step's streams joined (``fs.check()``)."""
+        exchange = getattr(self.slam, "model_exchange", None)
+        return exchange.lock if exchange is not None else _NoGuard()
+
     # ---------------------------------------------------------------- the two replaced loops
     def mapping_optimize(self, batch, poses):
         """``mapping.iters`` iterations over `sample` global keyframe rays + the current frame's share
         (reference: mp_slam/mapper.py:118-162); ``poses`` [N,4,4] c2w, the current frame's pose last."""
         if self.compute != "fused":
             return super().mapping_optimize(batch, poses)
+        with self._map_guard():
+            return self._mapping_optimize_fused(batch, poses)
+
+    def _mapping_optimize_fused(self, batch, poses):
         cfg, store = self.config["mapping"], self.video.keyframe
         self.map_optimizer.zero_grad()
         n_kf, per_kf = len(store.frame_ids), store.num_rays_to_save
@@ -121,18 +140,19 @@ class FusedMappingMixin:
             raise ValueError("First frame mapping must be the first frame!")
         self.model.train()
         H, W, n = self.slam.dataset.H, self.slam.dataset.W, self.config["mapping"]["sample"]
-        fs = self._fused_step(n)
-        cur = frame_ray_table(batch).to(self.device, torch.float32).contiguous()
-        pose = batch["c2w"].to(self.device).reshape(1, 4, 4).to(torch.float32).contiguous()
-        for it in range(n_iters):
-            pick = None
-            if self.sampler == "host":
-                flat = self.slam.select_samples(H, W, n)
-                # the reference turns a flat draw into (h, w) = (flat % H, flat // H)  (mp_slam/mapper.py:76-77)
-                pick = ((flat % H) * W + torch.div(flat, H, rounding_mode="trunc")).to(self.device)
-            fs.step(None, 0, 1, cur, pose, 0, n, idx_cur=pick, u=self._host_jitter(n, fs), prefetch=it + 1 < n_iters)
-        fs.check()
-        self.last_losses = fs.loss_dict()
+        with self._map_guard():
+            fs = self._fused_step(n)
+            cur = frame_ray_table(batch).to(self.device, torch.float32).contiguous()
+            pose = batch["c2w"].to(self.device).reshape(1, 4, 4).to(torch.float32).contiguous()
+            for it in range(n_iters):
+                pick = None
+                if self.sampler == "host":
+                    flat = self.slam.select_samples(H, W, n)
+                    # the reference turns a flat draw into (h, w) = (flat % H, flat // H)  (mp_slam/mapper.py:76-77)
+                    pick = ((flat % H) * W + torch.div(flat, H, rounding_mode="trunc")).to(self.device)
+                fs.step(None, 0, 1, cur, pose, 0, n, idx_cur=pick, u=self._host_jitter(n, fs), prefetch=it + 1 < n_iters)
+            fs.check()
+            self.last_losses = fs.loss_dict()
         return super().first_frame_mapping(batch, 0)
 
     # ---------------------------------------------------------------- N2: loop-closure loops on the same kernels
@@ -240,7 +260,8 @@ class FusedMappingMixin:
         per_kf = max(n // num_expanded_kfs, floor) if num_expanded_kfs > 0 else n
         pool = self.dataset.rays_d.reshape(-1, 3)
         if self.compute == "fused" and expanded_foreign_kfs_for_distill:
-            return self._distillation_fused(expanded_foreign_kfs_for_distill, per_kf, pool)
+            with self._map_guard():
+                return self._distillation_fused(expanded_foreign_kfs_for_distill, per_kf, pool)
         for _ in range(cfg["mapping"]["distill_iters"]):
             pieces = []
             for kf in expanded_foreign_kfs_for_distill:

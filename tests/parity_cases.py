@@ -189,6 +189,12 @@ def check_mapping3(name, one_grid, co, seed, device, compute="autograd", scatter
     poses = torch.stack([f["c2w"] for f in frames]).to(device)
     random.seed(seed + 1)
     torch.manual_seed(seed + 1)
+    if compute == "fused":
+        # the step is sized for the largest batch the loop can ask for, the batches here are smaller: whatever the decoder
+        # update sums must have been written by the iteration itself (zero-filled allocations hide stale slots)
+        fs0 = mapper._fused_step(cfg["mapping"]["sample"] + cfg["mapping"]["min_pixels_cur"])
+        fs0.partials.fill_(float("nan"))
+        fs0.tape.fill_(float("nan"))
     mapper.optimize_map(frames[3], poses)
     for s in range(n_plane_sets(g, "init.")):
         for l in range(2):
@@ -805,6 +811,7 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
         # emulator sees) would go unnoticed otherwise -- the failure mode of the round-2 layout-sensitive kernel
         # (DESIGN.md section 9).  NaN x 0 = NaN: one stale row poisons a whole gradient matrix.
         fs.tape.fill_(float("nan"))
+        fs.partials.fill_(float("nan"))                  # likewise every partial weight gradient the decoder update sums
     ag.step()                                            # the iteration under test
     fs.synchronize()
     if dev.type == "cuda":

@@ -227,6 +227,37 @@ def _exchange_worker(rank, world, port, ret):
     assert tuple(got[0].shape) != tuple(next(iter(model.all_planes[0])).shape)       # the peer's own lattice, not ours
     assert all(p.dtype == (torch.float16 if other == 1 else torch.float32) for p in got)
     assert slam.model_exchange.served == 0 or slam.model_exchange.served == 1
+    # A fetch that arrives while the mapper is INSIDE an update (the guard the fused loops hold) is answered after it:
+    # the peer never sees planes of one iteration next to the decoder of another.
+    import time
+    dist.barrier()
+    if rank == 0:
+        with mapper._map_guard():
+            dist.barrier()                                           # rank 1 sends its request now
+            time.sleep(0.5)
+            with torch.no_grad():
+                for lst in model.all_planes:
+                    for p in lst:
+                        p.add_(1.0)
+                for w in model.decoder.parameters():
+                    w.add_(0.5)
+        dist.barrier()
+        with torch.no_grad():                                        # back to the published map (the file comparison below)
+            for lst in model.all_planes:
+                for p in lst:
+                    p.sub_(1.0)
+            for w in model.decoder.parameters():
+                w.sub_(0.5)
+    else:
+        dist.barrier()
+        mapper.load_foreign_model(0)
+        for a, b in zip(got, [p for lst in shared.all_planes for p in lst]):
+            assert torch.equal(a + 1.0, b), "served a half-updated map"
+        for a, b in zip(got_dec, shared.decoder.parameters()):
+            assert torch.equal(a + 0.5, b)
+        dist.barrier()
+    dist.barrier()
+    n_served = slam.model_exchange.served
     # the same map through the file, with the exchange switched off
     slam.model_exchange, ex = None, slam.model_exchange
     ck2 = mapper.load_foreign_model(other)
@@ -238,8 +269,8 @@ def _exchange_worker(rank, world, port, ret):
     assert torch.equal(got_bound, shared.bound.cpu().float()) and torch.equal(got_bb.double(), shared.bounding_box.cpu().double())
     # the fetched map is usable as a teacher: a no-grad render runs on it (emulated kernels)
     dist.barrier()
-    assert ex.served == 1
-    ex.stop()
+    assert ex.served == n_served == (2 if rank == 0 else 1)
+    ex.stop()                                                        # collective
     dist.barrier()
     open(ret + f".ok{rank}", "w").write("ok")
     dist.destroy_process_group()
