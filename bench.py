@@ -34,7 +34,8 @@ from mneslam_amd.fused import FusedStep, HashFusedStep  # noqa: E402
 from mneslam_amd.model.scene_rep import JointEncoding  # noqa: E402
 from mneslam_amd.model.scene_rep_hash import HashJointEncoding  # noqa: E402
 
-PMC_JSON = "r04_pmc_traffic.json"      # committed counter passes of this round's kernels (profiles/r04_pmc.sh)
+PMC_PREFIX = "r04"                      # committed counter passes the line's `traffic` figures come from (profiles/r04_pmc.sh)
+PMC_JSON = PMC_PREFIX + "_pmc_traffic.json"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -65,6 +66,11 @@ def parse_args():
                          "middle of a run shorter than 50 steps): a step with its 12 event records is ~60 us longer")
     ap.add_argument("--share-decoder", action="store_true",
                     help="EXTENSION: all-reduce (mean) the decoder gradient over agents each iteration (RCCL)")
+    ap.add_argument("--split", action="store_true",
+                    help="EXTENSION, BASELINE configs[2..4] as worded (--gpus N > 1, --config apartment | scannet | indoor): the N "
+                         "agents map ONE scene -- rank r takes the r-th slab of it (0.5 m overlap with its neighbours, one "
+                         "lattice), the overlap rectangles' plane gradients are exchanged (RCCL point-to-point) and the "
+                         "decoder is shared (all-reduce) every iteration")
     ap.add_argument("--no-variants", dest="variants", action="store_false",
                     help="skip the short runs of the other section-8d workloads reported in the line's `variants` object")
     ap.add_argument("--rays", type=int, default=None, help="with --small: global rays per iteration (functional runs)")
@@ -79,14 +85,16 @@ class Agent:
     """One mapping agent: scene model + optimizer + device-resident keyframe rays."""
 
     def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused", scatter="binned", share_decoder=False,
-                 overlap=True, graph=None):
+                 overlap=True, graph=None, peers_of=None, model_seed=None):
+        """peers_of (split scenes): callable(model) -> FusedStep ``overlap_peers`` (collective: every rank calls it once its
+        model exists); model_seed: the SAME decoder initialisation on every agent of a shared decoder."""
         self.cfg, self.device, self.path = cfg, device, path
         cam = synthetic.camera_from_config(cfg)          # office0: 680x1200, fx=fy=600, cx=599, cy=339
         if small:
             cam = dict(H=68, W=120, fx=60.0, fy=60.0, cx=59.0, cy=33.0)
         self.H, self.W = cam["H"], cam["W"]
         room = synthetic.room_from_config(cfg)           # office0: [[-2.2,2.6],[-3.4,2.1],[-1.4,2.0]]
-        if small:
+        if small and peers_of is None:
             room = [[-0.8, 0.8], [-1.0, 0.9], [-0.6, 0.7]]
         random.seed(seed)
         torch.manual_seed(seed)
@@ -103,8 +111,11 @@ class Agent:
         self.poses = torch.stack([f["c2w"] for f in frames]).to(device)          # [n_kf+1,4,4]; last = current
         bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64, device=device)
         self.hash = cfg.get("scene_encoding") == "hash"
+        if model_seed is not None:
+            torch.manual_seed(model_seed)
         self.model = (HashJointEncoding if self.hash else JointEncoding)(cfg, bb).to(device).train()
         self.model.jitter_rng = "device"
+        peers = peers_of(self.model) if peers_of is not None else None     # (collective; fills the shared cells in place)
         self.opt = slam_glue.create_optimizer(self.model, cfg)
         self.n_cur = max(cfg["mapping"]["sample"] // n_keyframes, cfg["mapping"]["min_pixels_cur"])
         self.n_plane_params = (self.model.embed_fn.params.numel() if self.hash
@@ -119,7 +130,7 @@ class Agent:
             self.fused.seed = seed
         elif path == "fused":
             self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device,
-                                   scatter=scatter, shared_decoder=share_decoder, use_graph=graph,
+                                   scatter=scatter, shared_decoder=share_decoder, use_graph=graph, overlap_peers=peers,
                                    overlap=overlap and os.environ.get("MNE_NO_OVERLAP", "0") != "1")
             self.fused.seed = seed
 
@@ -236,14 +247,16 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0, batch=None):
                       f"{torch.__version__}, {cores} threads"}
 
 
-def bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, mdist):
-    """N1: JointEncoding.render_img on whole frames -- one no-grad launch sequence per frame with exact early ray
-    termination.  One step = the reference's per-keyframe pair: a depth-guided render (n_range_d + n_samples_d samples
-    per ray) and a free render (training.n_samples)."""
-    for _ in range(args.pretrain):
-        agent.step()                                     # mapping iterations in front of the renders: the SDF needs a surface
-    torch.cuda.synchronize()
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector rate (MI355X_MICROARCH.md)
+
+
+def render_img_measure(agent, cfg, device, n_pairs, n_warm):
+    """N1 (SURVEY 8f): JointEncoding.render_img on whole frames -- one no-grad launch sequence per frame with exact early ray
+    termination.  One step = the reference's per-keyframe pair (mneslam_mp.py:498,516): a depth-guided render (n_range_d +
+    n_samples_d samples per ray) and a free render (training.n_samples).  Returns the record without the rate's
+    normalisation over ranks: (seconds for n_pairs pairs, record dict)."""
     m = agent.model
+    was_training = m.training
     m.eval()
     cam = synthetic.camera_from_config(cfg)
     cfg_cam_backup = dict(cfg["cam"])
@@ -256,31 +269,61 @@ def bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, m
     n_rays = cam["H"] * cam["W"]
     pts = n_rays * ((tr["n_range_d"] + tr["n_samples_d"]) + (tr["n_samples"] if has_free else 0))
 
-    def pair():
-        d1, c1 = m.render_img(c2w, device, gt_depth=gt)
+    def pair(stats=None):
+        d1, c1 = m.render_img(c2w, device, gt_depth=gt, stats=stats)
         if has_free:
-            m.render_img(c2w, device, gt_depth=None)
+            m.render_img(c2w, device, gt_depth=None, stats=stats)
         return d1
 
-    for _ in range(max(args.warmup // 10, 1)):
+    for _ in range(n_warm):
         pair()
-    steps = max(args.steps // 20, 3)
-    barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(n_pairs):
         d1 = pair()
-    barrier()
-    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, device)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
+    stats = {}
+    pair(stats)                                          # one more, untimed: the samples the early termination really decodes
     cfg["cam"].update(cfg_cam_backup)
+    if was_training:
+        m.train()
+    d = cfg["decoder"]
+    hid, hidc = d["hidden_dim"], d["hidden_dim_color"]
+    cin = 48 + (0 if cfg["grid"]["oneGrid"] else 64) + d["geo_feat_dim"]
+    flop_per_sample = 2.0 * (hid * 112 + 16 * hid + hidc * cin + 3 * hidc)       # the two bias-free 2-layer MLPs (model/decoder.py:110-175)
+    flops = flop_per_sample * stats["decoded_samples"]
+    rec = {"frame": f"{cam['W']}x{cam['H']}", "rays_per_frame": n_rays, "nominal_point_queries_per_pair": pts,
+           "decoded_samples_per_pair": stats["decoded_samples"], "early_ray_termination": True,
+           "depth_l1_vs_gt": float((d1.float() - gt)[gt > 0].abs().mean()),
+           "roofline": {"kernel": "ray_kernel<..., 0> (inline tri-plane gather + OneBlob + MLP forward + compositing, early termination)",
+                        "bound": "mfma_f32", "flops_per_pair": flops, "flop_per_decoded_sample": flop_per_sample,
+                        "achieved": flops / (own / n_pairs) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (own / n_pairs) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                        "note": "useful MLP flops of the decoded samples only; the kernel's own time is dominated by the inline "
+                                "gather's dependent load rounds and the OneBlob, not by the matrix pipe (DESIGN.md 3.6)"}}
+    return own, rec
+
+
+def bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, mdist):
+    """--mode render_img: the N1 record as the line's metric (see render_img_measure)."""
+    for _ in range(args.pretrain):
+        agent.step()                                     # mapping iterations in front of the renders: the SDF needs a surface
+    torch.cuda.synchronize()
+    steps, warm = max(args.steps // 20, 3), max(args.warmup // 10, 1)
+    barrier()
+    own, rec = render_img_measure(agent, cfg, device, steps, warm)
+    barrier()
+    elapsed = mdist.max_over_ranks(own, device)
     if rank == 0:
+        roof = rec.pop("roofline")
         print(json.dumps({
             "metric": "full-frame renders (render_img pairs) / sec", "value": world * steps / elapsed, "unit": "frame pairs/s",
-            "n_gpus": world, "steps": steps, "warmup": max(args.warmup // 10, 1), "ms_per_step": 1e3 * elapsed / steps,
+            "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload + "_render_img", "frame": f"{cam['W']}x{cam['H']}", "rays_per_frame": n_rays,
-                       "nominal_point_queries_per_step": pts, "early_ray_termination": True},
-            "nominal_Mpts_per_s": world * steps * pts / elapsed / 1e6,
-            "depth_l1_vs_gt": float((d1.float() - gt)[gt > 0].abs().mean())}), flush=True)
+            "config": dict({"workload": workload + "_render_img", "pretrain_iterations": args.pretrain}, **rec),
+            "nominal_Mpts_per_s": world * steps * rec["nominal_point_queries_per_pair"] / elapsed / 1e6,
+            "roofline": roof}), flush=True)
 
 
 def account(cfg, agent, avg_ms):
@@ -369,9 +412,9 @@ def pmc_traffic(tag, needle):
     ``tag`` (profiles/r04_pmc_traffic_<tag>.json, profiles/r04_pmc.sh; the hash grid: r04_hash_pmc_traffic.json, per launch)."""
     try:
         if tag == "office0_hash":
-            per_k = json.load(open(os.path.join(REPO, "profiles", "r04_hash_pmc_traffic.json")))["per_kernel_hbm_bytes"]
+            per_k = json.load(open(os.path.join(REPO, "profiles", f"{PMC_PREFIX}_hash_pmc_traffic.json")))["per_kernel_hbm_bytes"]
         else:
-            per_k = json.load(open(os.path.join(REPO, "profiles", f"r04_pmc_traffic_{tag}.json")))["per_kernel_hbm_bytes_per_iteration"]
+            per_k = json.load(open(os.path.join(REPO, "profiles", f"{PMC_PREFIX}_pmc_traffic_{tag}.json")))["per_kernel_hbm_bytes_per_iteration"]
         return sum(v for k, v in per_k.items() if needle in k) or None
     except (OSError, KeyError, ValueError):
         return None
@@ -414,7 +457,9 @@ def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, bloc
     if graph is not None:
         out["kernel_timing"] = "eager iterations of the same agent (events cannot be recorded inside a replayed graph)"
     needle = {"adam": "tile_adam_kernel", "hash_scatter": "hash_slice_adam_kernel", "hash_gather": "hash_gather_kernel"}.get(acc["dom"], acc["dom"])
-    out["traffic"] = pmc_traffic(name[:-len("_graph")] if (graph and name and name.endswith("_graph")) else name, needle) if name else None
+    tag = name[:-len("_graph")] if (graph and name and name.endswith("_graph")) else name
+    out["traffic"] = pmc_traffic(tag, needle) if name else None
+    out["traffic_source"] = (f"profiles/{PMC_PREFIX}_hash_pmc_traffic.json" if tag == "office0_hash" else f"profiles/{PMC_PREFIX}_pmc_traffic_{tag}.json") if out["traffic"] else None
     out["traffic_frac"] = (out["traffic"] / (acc["dom_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (out["traffic"] and acc["dom_ms"] > 0) else None
     it_bytes = acc["alg"].get("iteration", acc["alg"].get("adam", 0.0) + acc["alg"].get("render", 0.0))
     out["iteration_algorithmic_bytes"] = it_bytes
@@ -422,6 +467,134 @@ def run_variant(config, hidden, device, keyframes, budget_s=1.5, warmup=30, bloc
     del agent
     torch.cuda.empty_cache()
     return out
+
+
+def split_peers(rank, world, device):
+    """peers_of callback of a split scene: the ranks exchange their planes' geometry, the lower neighbour's values of the
+    shared node rectangles are copied into the upper one's planes (shared cells start equal, and stay bit-equal: both add the
+    same two gradient shares, tile_adam_kernel<2>), and the neighbours come back as FusedStep's overlap_peers."""
+    import torch.distributed as dist
+    from mneslam_amd import dist as mdist
+
+    def peers_of(model):
+        geo = mdist.plane_geometry(model)
+        geos = [None] * world
+        dist.all_gather_object(geos, geo)
+        flat = [p for lst in model.all_planes for p in lst]
+        for lower in range(world - 1):                       # startup only: pair after pair
+            upper = lower + 1
+            if rank not in (lower, upper):
+                continue
+            for p, (shape, bnd, axes), (pshape, pbnd, _) in zip(flat, geo, geos[upper if rank == lower else lower]):
+                sl = mdist.overlap_slices(bnd, pbnd, shape, pshape, axes)
+                if sl is None:
+                    continue
+                (ys, xs), _ = sl
+                buf = p.data[:, :, ys, xs].contiguous()
+                if rank == lower:
+                    dist.send(buf, upper)
+                else:
+                    dist.recv(buf, lower)
+                    p.data[:, :, ys, xs] = buf
+        return [(r, geos[r]) for r in (rank - 1, rank + 1) if 0 <= r < world]
+    return peers_of
+
+
+# BASELINE configs[2..4] by agent count: "apartment split into 2 agents", "scene0000 split 4-way", "INS Indoor 8-agent"
+AS_WORDED = {2: "apartment", 4: "scannet", 8: "indoor"}
+
+
+def make_split_agent(config, rank, world, device, keyframes, small=False, rays=None):
+    """Agent ``rank`` of the scene ``config`` split over ``world`` agents (configs.split_agent_config): its slab of the scene
+    on the common lattice, the neighbours as overlap peers, one decoder shared by all.  Collective."""
+    make_cfg, workload = configs.WORKLOADS[config]
+    cfg = make_cfg()
+    if small:
+        cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
+        cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
+        if rays:
+            cfg["mapping"]["sample"] = rays
+            cfg["mapping"]["min_pixels_cur"] = min(cfg["mapping"]["min_pixels_cur"], max(rays // 4, 1))
+    else:
+        cfg["mapping"]["bound"] = [list(b) for b in configs.SCENE_BOUNDS[config]]       # the WHOLE scene, then this rank's slab
+    cfg, axis, slabs = configs.split_agent_config(cfg, world, rank)
+    agent = Agent(cfg, device, seed=rank, n_keyframes=keyframes, small=small, share_decoder=True,
+                  peers_of=split_peers(rank, world, device), model_seed=1234)
+    return agent, cfg, {"axis": "xyz"[axis], "slabs": slabs, "workload": workload + f"_scene_split{world}"}
+
+
+def multi_agent_side_records(args, cfg, rank, world, device, barrier, out):
+    """N > 1 side records of the metric's line (which runs N independent agents, the reference's own decomposition):
+      share_decoder  the same workload with ONE decoder shared by the agents (all-reduce of its weight gradients per iteration);
+      as_worded      BASELINE configs[2] / [3] / [4] as worded for this agent count -- one scene split into N overlapping slabs on
+                     one lattice, overlap-rectangle plane gradients exchanged with the neighbours (RCCL point-to-point) + the
+                     shared decoder.
+    Collective code that has never run on more than one GPU before the driver's first multi-GPU lease: a watchdog prints the
+    metric's line (``out``, rank 0) with what is there and leaves if a record does not come back -- a side record must never
+    cost the line."""
+    import signal
+    import torch.distributed as dist
+    from mneslam_amd import dist as mdist
+    side = {}
+
+    def give_up(signum, frame):
+        if rank == 0:
+            side.setdefault("error", "a multi-agent side record did not return within its time limit")
+            out["variants"] = side
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    signal.signal(signal.SIGALRM, give_up)
+    signal.alarm(int(os.environ.get("MNE_SIDE_RECORD_LIMIT_S", "240")))
+
+    def timed(agent, n_var, warm):
+        for _ in range(warm):
+            agent.step()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(n_var):
+            agent.step(None, prefetch=i + 1 < n_var)
+        barrier()
+        own = time.perf_counter() - t1
+        return own, mdist.max_over_ranks(own, device)
+
+    n_var, warm = max(min(args.steps, 200), 1), min(args.warmup, 10)
+    try:
+        shared = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter,
+                       share_decoder=True, overlap=not args.no_overlap, graph=None)
+        _, el = timed(shared, n_var, warm)
+        side["share_decoder"] = {"value": world * n_var / el, "unit": "it/s", "ms_per_step": 1e3 * el / n_var, "steps": n_var,
+                                 "collective": "all-reduce of the decoder's weight gradients every iteration ("
+                                               + str(dist.get_backend()) + "), planes private to each agent"}
+        del shared
+    except Exception as e:    # noqa: BLE001
+        side["share_decoder"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if args.path == "fused" and args.scatter == "binned":
+        name = AS_WORDED.get(world, "apartment")
+        try:
+            if device.type == "cuda":
+                torch.cuda.empty_cache()
+            agent, scfg, info = make_split_agent(name, rank, world, device, args.keyframes, small=args.small, rays=args.rays)
+            own, el = timed(agent, n_var, warm)
+            psnr, l1 = agent.quality()
+            rows = [None] * world
+            dist.all_gather_object(rows, {"rank": rank, "it_per_s": n_var / own, "plane_params": agent.n_plane_params,
+                                          "overlap_exchange_bytes_per_iter": 4 * 2 * sum(t.numel() for t in agent.fused.ov_send),
+                                          "psnr_last_iter": psnr, "depth_l1_last_iter": l1})
+            S = scfg["training"]["n_range_d"] + scfg["training"]["n_samples_d"]
+            side["as_worded"] = {
+                "baseline_config": {2: "configs[2]", 4: "configs[3]", 8: "configs[4]"}.get(world, "configs[2] (its scene, this agent count)"),
+                "workload": info["workload"], "value": world * n_var / el, "unit": "it/s", "ms_per_step": 1e3 * el / n_var, "steps": n_var,
+                "rays_per_iter": scfg["mapping"]["sample"] + agent.n_cur, "samples_per_ray": S,
+                "parallelism": f"ONE scene ({name}) split into {world} slabs along {info['axis']} (0.5 m overlap, one lattice): "
+                               "overlap-rectangle plane gradients exchanged point-to-point with the neighbours + decoder-gradient "
+                               "all-reduce, every iteration (" + str(dist.get_backend()) + ")",
+                "exchange_bytes_per_iter_all_ranks": sum(r["overlap_exchange_bytes_per_iter"] for r in rows) + world * 4 * agent.n_dec_params,
+                "slab_bounds": info["slabs"], "per_rank": rows}
+            del agent
+        except Exception as e:    # noqa: BLE001
+            side["as_worded"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    signal.alarm(0)
+    return side
 
 
 def spawn_ranks(n):
@@ -473,8 +646,15 @@ def main():
     if args.small:
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
-    agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter,
-                  share_decoder=args.share_decoder, overlap=not args.no_overlap, graph=args.graph)
+    split = None
+    if args.split:
+        if world < 2 or args.config not in configs.SCENE_BOUNDS or args.path != "fused" or args.scatter != "binned" or args.graph:
+            raise SystemExit("--split: --gpus N > 1, --config " + " | ".join(sorted(configs.SCENE_BOUNDS)) + ", the fused binned path")
+        agent, cfg, split = make_split_agent(args.config, rank, world, device, args.keyframes, small=args.small, rays=args.rays)
+        workload, args.share_decoder = split["workload"], True
+    else:
+        agent = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter,
+                      share_decoder=args.share_decoder, overlap=not args.no_overlap, graph=args.graph)
 
     def barrier():
         if world > 1:
@@ -497,32 +677,20 @@ def main():
         agent.step(timers if i % every == every // 2 else None, prefetch=i + 1 < args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     elapsed = mdist.max_over_ranks(elapsed, device)
     avg_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timers.items()}
     psnr, depth_l1 = agent.quality()
-    multi = None
-    if world > 1 and args.variants and not args.share_decoder and args.mode != "render_img":
-        # N > 1: the same workload with the one data-path collective this build has -- the agents share ONE decoder and all-reduce
-        # its weight gradients every iteration (RCCL; EXTENSION, mneslam_amd/dist.py) -- as a side record of the line.  Collective:
-        # every rank runs it; a failure must not cost the metric's line, and must fail on every rank alike.
-        try:
-            shared = Agent(cfg, device, seed=rank, n_keyframes=args.keyframes, small=args.small, path=args.path, scatter=args.scatter,
-                           share_decoder=True, overlap=not args.no_overlap, graph=None)
-            n_var = max(min(args.steps, 200), 1)
-            for _ in range(min(args.warmup, 10)):
-                shared.step()
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(n_var):
-                shared.step(None, prefetch=i + 1 < n_var)
-            barrier()
-            el = mdist.max_over_ranks(time.perf_counter() - t1, device)
-            multi = {"share_decoder": {"value": world * n_var / el, "unit": "it/s", "ms_per_step": 1e3 * el / n_var, "steps": n_var,
-                                       "collective": "all-reduce of the decoder's weight gradients every iteration ("
-                                                     + str(dist.get_backend()) + "), planes private to each agent"}}
-            del shared
-        except Exception as e:    # noqa: BLE001
-            multi = {"share_decoder": {"error": f"{type(e).__name__}: {e}"[:300]}}
+    per_rank = None
+    if world > 1:
+        per_rank = [None] * world
+        f = agent.fused
+        dist.all_gather_object(per_rank, {
+            "rank": rank, "it_per_s": args.steps / own_elapsed, "plane_params": agent.n_plane_params,
+            "overlap_exchange_bytes_per_iter": (4 * 2 * sum(t.numel() for t in f.ov_send)) if (f is not None and f.tile_overlap is not None) else 0,
+            "psnr_last_iter": psnr, "depth_l1_last_iter": depth_l1})
+    agent_dec_params = agent.n_dec_params
+    out = None
     if rank == 0:
         acc = account(cfg, agent, avg_ms)
         alg, kern, dom, dom_ms, achieved = acc["alg"], acc["kern"], acc["dom"], acc["dom_ms"], acc["achieved"]
@@ -555,11 +723,16 @@ def main():
                        "ranks_seen": ranks_seen, "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "plane_dtype": cfg["grid"].get("plane_dtype", "fp32"), "launch": ("hipGraph replay (" + args.graph + ")") if args.graph else "eager",
                        "encoding": "hash grid (parity unpinned: tinycudann is not in the reference tree)" if agent.hash else "tri-planes (as wired)",
-                       "parallelism": f"agent-per-gpu x{world}, " + ("decoder-gradient all-reduce (extension)" if args.share_decoder
+                       "parallelism": (f"ONE scene ({args.config}) split into {world} slabs along {split['axis']} (0.5 m overlap, one lattice), "
+                                       f"agent-per-gpu x{world}: overlap-rectangle plane gradients exchanged point-to-point with the "
+                                       "neighbours + decoder-gradient all-reduce, every iteration (extension)") if split else
+                                      f"agent-per-gpu x{world}, " + ("decoder-gradient all-reduce (extension)" if args.share_decoder
                                                                      else "no data-path collective")},
             "psnr_last_iter": psnr, "depth_l1_last_iter": depth_l1,
             "roofline": {"kernel": kern[dom], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("profiles/" + PMC_JSON + " (committed rocprofv3 --pmc passes of this workload; a profiler "
+                                            "cannot sit inside the timed loop)") if traffic else None,
                          "algorithmic_bytes_per_launch": alg.get(dom, 0.0), "avg_launch_ms": dom_ms,
                          "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms > 0) else None,
                          "mfma_busy": mfma_busy,
@@ -581,6 +754,38 @@ def main():
             del agent
             torch.cuda.empty_cache()
             out["variants"] = {}
+            try:                          # N1 on the record: the two full-frame renders of a keyframe, on a map of 100 iterations
+                ragent = Agent(cfg, device, seed=0, n_keyframes=args.keyframes)
+                for _ in range(100):
+                    ragent.step()
+                torch.cuda.synchronize()
+                own, rec = render_img_measure(ragent, cfg, device, n_pairs=5, n_warm=1)
+                out["variants"]["render_img"] = dict({"workload": workload + "_render_img", "pretrain_iterations": 100,
+                                                      "value": 5 / own, "unit": "frame pairs/s", "ms_per_pair": 1e3 * own / 5}, **rec)
+                del ragent
+                torch.cuda.empty_cache()
+            except Exception as e:    # noqa: BLE001
+                out["variants"]["render_img"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:        # the reference's first_frame_mapping: mapping.first_iters (500) iterations on ONE frame, from a fresh map
+                fagent = Agent(cfg, device, seed=1, n_keyframes=1)
+                n_first, n_ray = cfg["mapping"]["first_iters"], cfg["mapping"]["sample"]
+                pose = fagent.poses[-1:].contiguous()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(n_first):
+                    fagent.fused.step(None, 0, 1, fagent.cur_rays, pose, 0, n_ray, prefetch=i + 1 < n_first)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t1
+                fagent.fused.check()
+                out["variants"]["first_frame_mapping"] = {
+                    "workload": workload + "_first_frame", "iterations": n_first, "rays_per_iter": n_ray, "value": n_first / el, "unit": "it/s",
+                    "total_ms": 1e3 * el, "psnr_last_iter": float(fagent.fused.losses[7].item()),
+                    "note": "mp_slam/mapper.py:52-89: every iteration on the first frame's rays, untrained map at the start (the adaptive "
+                            "schedule decodes every sample a priori until the SDF has sign changes)"}
+                del fagent
+                torch.cuda.empty_cache()
+            except Exception as e:    # noqa: BLE001
+                out["variants"]["first_frame_mapping"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             for name, c, h, gr in VARIANTS:
                 if c == args.config and (h or args.hidden) == args.hidden and gr == args.graph:
                     continue
@@ -588,8 +793,17 @@ def main():
                     out["variants"][name] = run_variant(c, h, device, args.keyframes, graph=gr, name=name)
                 except Exception as e:    # noqa: BLE001
                     out["variants"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if multi:
-            out["variants"] = multi
+        if per_rank:
+            out["per_rank"] = per_rank
+            if split:
+                out["config"]["slab_bounds"] = split["slabs"]
+                out["config"]["exchange_bytes_per_iter_all_ranks"] = (sum(r["overlap_exchange_bytes_per_iter"] for r in per_rank)
+                                                                      + world * 4 * agent_dec_params)
+    if world > 1 and args.variants and not args.share_decoder and not split and args.mode != "render_img":
+        side = multi_agent_side_records(args, cfg, rank, world, device, barrier, out if rank == 0 else None)
+        if rank == 0:
+            out["variants"] = side
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -164,6 +164,47 @@ WORKLOADS = {
 }
 
 
+# ---- EXTENSION: BASELINE configs[2..4] as worded -- ONE scene split over N agents (mneslam_amd/dist.py) ----
+# the scene each multi-agent workload covers as a whole: the union of the reference's per-agent bounds
+SCENE_BOUNDS = {
+    "apartment": [[-2.8, 8.2], [-1.1, 9.0], [-2.5, 1.3]],          # apart1_agent1.yaml U apart1_agent2.yaml
+    "scannet": [[-0.1, 8.6], [-0.1, 8.9], [-0.3, 3.3]],            # scene0000.yaml
+    "indoor": [[-6.2, 56.4], [-15.8, 0.0], [-2.0, 4.5]],           # indoor.yaml:169-173, bound_0 U .. U bound_3
+}
+
+
+def split_agent_config(cfg, n_agents, rank, overlap=0.5, axis=None):
+    """Agent ``rank`` of ``n_agents`` mapping ONE scene (``cfg["mapping"]["bound"]`` = the whole scene): slabs along the
+    scene's longest axis that overlap their neighbours by about ``overlap`` metres (the reference's agents overlap too:
+    mp_slam/mapper.py:491-509, configs/Indoor/indoor.yaml:169-173), all on ONE lattice -- every slab edge on a multiple of
+    the coarsest plane cell from the scene's lower corner, ``planes_res.lattice`` for exact node spacing -- so that the
+    cells two neighbours both hold coincide and their gradients can be exchanged (FusedStep(overlap_peers=...)).
+    Returns (agent config, slab axis, [extended bound of every agent])."""
+    from . import dist as mdist
+    cfg = copy.deepcopy(cfg)
+    res = [cfg["planes_res"]["coarse"], cfg["planes_res"]["fine"]]
+    if not cfg["grid"]["oneGrid"]:
+        res += [cfg["c_planes_res"]["coarse"], cfg["c_planes_res"]["fine"]]
+    cell = max(res)
+    for r in res:
+        if abs(cell / r - round(cell / r)) > 1e-6:
+            raise ValueError(f"plane resolutions {res} do not nest: no common lattice")
+    scene = [[float(lo), float(hi)] for lo, hi in cfg["mapping"]["bound"]]
+    ext = [[lo, lo + -(-(hi - lo) // cell) * cell] for lo, hi in scene]          # whole cells per axis
+    ext = [[lo, lo + round((hi - lo) / cell) * cell] for lo, hi in ext]
+    if axis is None:
+        axis = max(range(3), key=lambda k: ext[k][1] - ext[k][0])
+    slabs = mdist.aligned_agent_bounds(ext, n_agents, axis, overlap, cell)
+    lo_hi = slabs[rank]
+    # raw bound whose extension by load_bound (scene_rep.py:72-83: (int(len / bd) + 1) * bd) is exactly the slab
+    cfg["mapping"]["bound"] = [[lo, hi - 0.5 * cell] for lo, hi in lo_hi]
+    room = [[lo + min(0.3, 0.2 * (hi - lo)), hi - 0.5 * cell - min(0.3, 0.2 * (hi - lo))] for lo, hi in lo_hi]
+    cfg["mapping"]["marching_cubes_bound"] = room
+    cfg["planes_res"]["bound_dividable"] = cell
+    cfg["planes_res"]["lattice"] = True
+    return cfg, axis, slabs
+
+
 def small_test_config(one_grid=True, is_co_sdf=False, n_samples_d=32, n_range_d=11, depth_trunc=100.0):
     """The reduced configuration of the golden fixtures (tests/golden/make_golden.py::small_config)."""
     cfg = replica_office0()

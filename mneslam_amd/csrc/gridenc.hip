@@ -516,8 +516,10 @@ __global__ __launch_bounds__(HASH_BIN_THREADS) void hash_bin_kernel(GridArgs a) 
                     xv[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
                 }
                 x[j] = make_float4(xv[0], xv[1], xv[2], z);
-                const float mj = fmaxf(fabsf(g[j].x), fabsf(g[j].y));
-                m = fmaxf(m, (mj <= 3.0e38f) ? mj : __uint_as_float(0x7f800000u));       // NaN / Inf gradient -> +Inf: poisons the level
+                // NaN / Inf in EITHER component -> +Inf: poisons the level (fmaxf drops a NaN operand, so each is tested by itself)
+                const float ax = fabsf(g[j].x), ay = fabsf(g[j].y);
+                const float mj = (ax <= 3.0e38f && ay <= 3.0e38f) ? fmaxf(ax, ay) : __uint_as_float(0x7f800000u);
+                m = fmaxf(m, mj);
             }
         }
     }
@@ -627,7 +629,7 @@ __device__ __forceinline__ unsigned long long hash_fix(float v, double scale) {
 
 #define HASH_SLICE_UNROLL 4
 __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(GridArgs a) {
-    __shared__ unsigned long long acc[HASH_SLICE * 2];               // fixed-point gradient of this slice (32 KiB)
+    __shared__ unsigned long long acc[HASH_SLICE * 2];               // fixed-point gradient of this slice (2 x 8 B x 1024 entries = 16 KiB)
     __shared__ unsigned cstart[HASH_MAX_CHUNKS + 1];                 // prefix of the chunks' record counts (this slice, this part)
     __shared__ unsigned cbase[HASH_MAX_CHUNKS];                      //   ... and where each chunk's records of this slice begin
     __shared__ float wmaxs[HASH_SLICE_THREADS / 64];

@@ -195,7 +195,8 @@ class FusedStep:
         self.partials = e(self.lib.mne_wgrad_partial_floats(C.byref(self.scene)))
         self.dec_grad = e(self.lib.mne_decoder_param_floats(C.byref(self.scene)))
         co = config["is_co_sdf"] if is_co_sdf is None else is_co_sdf
-        self.loss_w = torch.tensor(slam_glue.loss_weight_vector(config, co) + [0.0], device=dev, dtype=f32)
+        self._loss_w_host = slam_glue.loss_weight_vector(config, co) + [0.0]
+        self.loss_w = torch.tensor(self._loss_w_host, device=dev, dtype=f32)
         self.tables = hip_path.linspace_tables(config, True, dev)
         w_sdf0, w_sdf1, w_col0, w_col1 = self.dec_w
         n0, n1, n2 = w_col0.numel(), w_col1.numel(), w_sdf0.numel()
@@ -373,8 +374,13 @@ class FusedStep:
         ptrs = tuple(p.data_ptr() for p in self.planes) + tuple(w.data_ptr() for w in self.dec_w)
         ptrs += tuple(self.opt._state(p)[k].data_ptr() for p in list(self.planes) + list(self.dec_w)
                       for k in ("exp_avg", "exp_avg_sq"))
+        # kernel arguments the capture bakes in: a changed learning rate / eps / weight decay / betas of a param group or
+        # changed loss weights must record a new graph, not replay the old values
+        hyper = tuple((float(g["lr"]), float(g["eps"]), float(g["weight_decay"]), tuple(map(float, g["betas"])))
+                      for g in self.opt.param_groups)
         return (None if kf_rays is None else kf_rays.data_ptr(), int(n_kf_rays), int(n_save), cur_rays.data_ptr(),
-                cur_rays.shape[0], poses.data_ptr(), poses.shape[0], int(n_global), int(n_cur), ptrs)
+                cur_rays.shape[0], poses.data_ptr(), poses.shape[0], int(n_global), int(n_cur), ptrs, hyper,
+                tuple(self._loss_w_host))
 
     def _make_clock(self, R, n_table=8192):
         groups = self.opt.param_groups
@@ -454,6 +460,14 @@ class FusedStep:
         return {"graph": g, "clock": clock, "t0": t0, "iter_dev": None, "step_dev": None, "packed_for": None,
                 "keep": (self.clk_iter, self.clk_step, self.clk_table)}
 
+    def _clock_covers(self, rec, step_next):
+        """The bias-correction table of a recorded graph holds ``n_table`` steps; beyond it the kernel clamps, which is exact
+        only once 1 - beta^n has rounded to 1 for both betas (true for (0.9, 0.99) at 8192, not for e.g. beta2 = 0.9999)."""
+        ck = rec["clock"]
+        if step_next <= ck.n_table:
+            return True
+        return (1.0 - ck.beta1 ** ck.n_table) == 1.0 and (1.0 - ck.beta2 ** ck.n_table) == 1.0
+
     def _replay(self, rec):
         """Launch the recorded iteration; the device clock is first brought in line with the host's counters when
         eager steps ran in between."""
@@ -505,7 +519,8 @@ class FusedStep:
                     self._graphs.clear()
                 self.synchronize()
                 rec = self._graphs[gkey] = self._record((kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)) or False
-            if rec:
+            steps_now = {self.opt._state(p)["step"] for p in list(self.planes) + list(self.dec_w)}
+            if rec and len(steps_now) == 1 and self._clock_covers(rec, steps_now.pop() + 1):   # else: this step runs eagerly
                 self._replay(rec)
                 self._prefetched = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
                 return
@@ -774,6 +789,7 @@ class HashFusedStep(FusedStep):
         key = self._batch_key(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur)
         if host_batch or self._prefetched != key:
             self._sample_batch(kf_rays, n_kf_rays, n_save, cur_rays, poses, n_global, n_cur, idx_global, idx_cur, u, st)
+            self._gathered = None                                   # a re-drawn batch: rows gathered for the prefetched one are stale
         self._prefetched = None
         sc, gc = C.byref(self.scene), C.byref(self.grid_cfg)
         ti = self.iteration & 1

@@ -149,6 +149,8 @@ class RenderFunction(torch.autograd.Function):
             _lib.check(lib.mne_loss_finalize(R, S, _lib.ptr(ray_sums), _lib.ptr(counts), _lib.ptr(losses), st),
                        "mne_loss_finalize")
         ctx.info, ctx.S, ctx.want_losses = info, S, want_losses
+        if any(p.dtype == torch.float16 for p in planes):
+            ctx.plane_params = list(planes)       # half-precision planes: backward leaves their fp32 gradient sums on these objects
         ctx.save_for_backward(rays_o_c, rays_d_c, tgt_rgb, tgt_d, z_vals, raw, counts, ray_counts, packed, *params)
         ctx.mark_non_differentiable(disp, acc, var, z_vals, raw)
         return rgb, depth, disp, acc, var, z_vals, raw, losses
@@ -208,6 +210,17 @@ class RenderFunction(torch.autograd.Function):
         g_col1 = dgrad[n0:n0 + n1].view_as(w_col1)
         g_sdf0 = dgrad[n0 + n1:n0 + n1 + n2].view_as(w_sdf0)
         g_sdf1 = dgrad[n0 + n1 + n2:].view_as(w_sdf1)
+        if grads is not None:
+            for g, p in zip(grads, getattr(ctx, "plane_params", None) or planes):     # (the caller's own tensor objects)
+                if p.dtype == torch.float16:
+                    # autograd wants the parameter's dtype; the fp32 sums are kept beside it for the optimizer (FusedAdam reads
+                    # ``grad32``, accumulated over backward calls like .grad, cleared by zero_grad): a cast to fp16 flushes a
+                    # mean-reduced plane gradient to zero below ~3e-8
+                    acc = getattr(p, "grad32", None)
+                    if acc is None or acc.shape != g.shape or acc.device != g.device:
+                        p.grad32 = g.clone()
+                    else:
+                        acc.add_(g)
         return (None, None, d_o if ctx.needs_input_grad[2] else None, d_d if ctx.needs_input_grad[3] else None,
                 None, None, None, None,
                 *([g if g.dtype == p.dtype else g.to(p.dtype) for g, p in zip(grads, planes)] if grads is not None else [None] * n_planes),
@@ -215,11 +228,13 @@ class RenderFunction(torch.autograd.Function):
 
 
 @torch.no_grad()
-def render_maps(info, tables, rays_o, rays_d, target_d, u, seed_offset, planes, dec_w, early_termination=True):
+def render_maps(info, tables, rays_o, rays_d, target_d, u, seed_offset, planes, dec_w, early_termination=True, stats=None):
     """No-grad rendering of any number of rays in one launch sequence (no autograd node, no tape, no backward
     workspace): mne_sample_z + mne_pack_decoder + mne_render_forward, by default with exact early ray termination --
     a ray's samples are decoded only up to the last one that can influence its maps.  Returns rgb [R,3], depth, disp,
-    acc, depth_var [R].  What ``render_img`` / teacher renders / visualisation use."""
+    acc, depth_var [R].  What ``render_img`` / teacher renders / visualisation use.
+    ``stats`` (measurement only: a dict; costs a fill of the scratch and a host sync): ``decoded_samples`` / ``nominal_samples``
+    are ADDED to it -- the samples the exact early termination really decoded (their ``raw`` entries are the ones written)."""
     lib = _lib.load()
     dev, st = rays_o.device, _lib.stream_for(rays_o)
     rc = info["render_cfg"]
@@ -242,11 +257,17 @@ def render_maps(info, tables, rays_o, rays_d, target_d, u, seed_offset, planes, 
     rgb, depth = torch.empty(R, 3, **opts), torch.empty(R, **opts)
     disp, acc, var = torch.empty(R, **opts), torch.empty(R, **opts), torch.empty(R, **opts)
     raw = torch.empty(R, S, 4, **opts)                  # scratch under early termination
+    if stats is not None:
+        raw.fill_(float("nan"))
     _lib.check(lib.mne_render_forward(C.byref(sc), C.byref(rc), R, S, _lib.ptr(rays_o_c), _lib.ptr(rays_d_c), None,
                                       _lib.ptr(tgt_d), _lib.ptr(z_vals), _lib.ptr(packed), _lib.ptr(rgb), _lib.ptr(depth),
                                       _lib.ptr(disp), _lib.ptr(acc), _lib.ptr(var), _lib.ptr(raw), None,
                                       _lib.ptr(ray_counts) if early_termination else None,
                                       _lib.RENDER_EARLY_TERMINATION if early_termination else 0, st), "mne_render_forward")
+    if stats is not None:
+        sdf = raw[..., 3]
+        stats["decoded_samples"] = stats.get("decoded_samples", 0) + int((sdf == sdf).sum().item())
+        stats["nominal_samples"] = stats.get("nominal_samples", 0) + R * S
     return rgb, depth, disp, acc, var
 
 

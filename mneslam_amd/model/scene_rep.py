@@ -53,8 +53,13 @@ class JointEncoding(nn.Module):
     def _init_planes(self, resolutions, c_dim):
         xyz_len = self.bound[:, 1] - self.bound[:, 0]
         planes_xy, planes_xz, planes_yz = [], [], []
+        # EXTENSION (multi-agent overlap exchange, mneslam_amd/dist.py): ``planes_res.lattice: true`` puts the nodes at EXACTLY
+        # ``res`` apart (round(len / res) + 1 nodes per axis; the extended bound is then a whole number of cells when
+        # ``bound_dividable`` is a multiple of ``res``), so that agents whose bounds start on a common lattice share its nodes.
+        # The reference's int(len / res) nodes (scene_rep.py:98-100) give a spacing that depends on the agent's own extent.
+        lattice = bool(self.config["planes_res"].get("lattice", False))
         for res in resolutions:
-            gs = list(map(int, (xyz_len / res).tolist()))
+            gs = [int(round(v / res)) + 1 for v in xyz_len.tolist()] if lattice else list(map(int, (xyz_len / res).tolist()))
             gs[0], gs[2] = gs[2], gs[0]
             # same CPU draws, in the same order and logical shape, as scene_rep.py:107-109
             planes_xy.append(torch.empty([1, c_dim, *gs[1:]]).normal_(mean=0, std=0.01))
@@ -185,7 +190,7 @@ class JointEncoding(nn.Module):
         self._philox_offset += (R * S + 3) // 4
         return None, so
 
-    def render_maps(self, rays_o, rays_d, target_d=None, u=None):
+    def render_maps(self, rays_o, rays_d, target_d=None, u=None, stats=None):
         """No-grad fast path of ``render_rays`` for any number of rays at once: {rgb, depth, disp_map, acc_map,
         depth_var} (no z_vals / raw: with exact early ray termination the samples behind a ray's surface are never
         decoded).  Same sampling, same maps as ``render_rays``."""
@@ -200,10 +205,11 @@ class JointEncoding(nn.Module):
             u, seed_offset = self._jitter(rays_o.shape[0], S, rays_o)
         planes = [p if p.device == dev else p.to(dev) for p in self._flat_planes()]
         rgb, depth, disp, acc, var = hip_path.render_maps(self._info(), hip_path.linspace_tables(self.config, has_d, dev), rays_o,
-                                                          rays_d, target_d, u, seed_offset, planes, self.decoder.hip_weights())
+                                                          rays_d, target_d, u, seed_offset, planes, self.decoder.hip_weights(),
+                                                          stats=stats)
         return {"rgb": rgb, "depth": depth, "disp_map": disp, "acc_map": acc, "depth_var": var}
 
-    def render_img(self, c2w, device, gt_depth=None):
+    def render_img(self, c2w, device, gt_depth=None, stats=None):
         """reference: scene_rep.py:422-473 (depth is returned as float64, A20).  The reference walks the image in
         ``ray_batch_size`` = 4096-ray chunks through ``render_rays``; here the whole frame (816 k rays on Replica) is
         ONE no-grad launch sequence (``render_chunk_rays`` bounds the scratch for very large frames).  With
@@ -227,7 +233,8 @@ class JointEncoding(nn.Module):
                     # the reference's draws: one torch.rand(chunk, S) per 4096-ray chunk, in order
                     u = torch.cat([torch.rand(min(self.ray_batch_size, sl.stop - j), S)
                                    for j in range(sl.start, sl.stop, self.ray_batch_size)], 0).to(device)
-                ret = self.render_maps(rays_o[sl], rays_d[sl], None if gt_depth is None else gt_depth[sl], u=u)
+                ret = self.render_maps(rays_o[sl], rays_d[sl], None if gt_depth is None else gt_depth[sl], u=u,
+                                       **({"stats": stats} if stats is not None else {}))
                 depths.append(ret["depth"].double())
                 colors.append(ret["rgb"])
             return torch.cat(depths, 0).reshape(H, W), torch.cat(colors, 0).reshape(H, W, 3)

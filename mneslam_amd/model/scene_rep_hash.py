@@ -73,7 +73,9 @@ class HashJointEncoding(JointEncoding):
         return hip_path.HashRenderFunction.apply(self._info(), self.embed_fn.cfg, tables, rays_o, rays_d, target_rgb, target_d, u,
                                                  seed_offset, self.embed_fn.params, *self.decoder.hip_weights())
 
-    def render_maps(self, rays_o, rays_d, target_d=None, u=None):
+    def render_maps(self, rays_o, rays_d, target_d=None, u=None, stats=None):
+        if stats is not None:
+            raise NotImplementedError("decoded-sample statistics are kept for the tri-plane render only")
         dev = rays_o.device
         has_d = target_d is not None
         if not has_d and not self.config["training"].get("n_samples"):

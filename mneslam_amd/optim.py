@@ -48,6 +48,12 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad if zero_grad_buffers is None else zero_grad_buffers.get(p)   # explicit map: only those params
                 if g is None:
                     continue
+                if zero_grad_buffers is None and p.dtype == torch.float16 and getattr(p, "grad32", None) is not None:
+                    # half-precision plane: autograd's .grad has the parameter's dtype, and a mean-reduced plane gradient
+                    # sits below fp16's range (flushes to zero below ~3e-8; Adam is scale-free, so those would be lost
+                    # updates).  The render node leaves the fp32 sum beside it (hip_path.RenderFunction.backward): that is
+                    # what the update consumes.
+                    g = p.grad32
                 if p.dtype not in (torch.float32, torch.float16):
                     raise TypeError("FusedAdam supports float32 parameters (and float16 planes: fp32 gradient and moments)")
                 if not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)):
@@ -86,4 +92,17 @@ class FusedAdam(torch.optim.Optimizer):
             _lib.check(lib.mne_adam_step(arr, len(chunk), 1 if zero_grad else 0,
                                          C.byref(clock) if clock is not None else None, _lib.stream_for(chunk[0][1])),
                        "mne_adam_step")
+        if zero_grad and grad_buffers is None:
+            # the kernel zeroed the buffers it was given: for a half-precision plane that is the fp32 side sum (or a temporary
+            # fp32 copy of .grad), not autograd's fp16 .grad itself
+            for _, p in segs:
+                if p.dtype == torch.float16 and p.grad is not None:
+                    p.grad.zero_()
         return loss
+
+    def zero_grad(self, set_to_none=True):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if getattr(p, "grad32", None) is not None:
+                    p.grad32 = None                      # the fp32 gradient sum of a half-precision plane (see ``segments``)
+        return super().zero_grad(set_to_none=set_to_none)

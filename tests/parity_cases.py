@@ -694,7 +694,7 @@ def check_distillation(device, compute="autograd"):
         assert_close(p.detach().cpu(), q.detach(), rtol=1e-3, atol=1e-4, what=n)
 
 
-def check_fused_vs_autograd(device, hidden=64, one_grid=False, co=True, seed=31, iters=3):
+def check_fused_vs_autograd(device, hidden=64, one_grid=False, co=True, seed=31, iters=3, plane_dtype="fp32"):
     """Decoder shapes without golden fixtures (2x64, the class defaults BASELINE.json quotes): the fused step must
     reach the parameters of the drop-in autograd path (itself pinned against the oracle by
     check_oracle_random_scene) from the same state with the same host-drawn batches."""
@@ -708,6 +708,10 @@ def check_fused_vs_autograd(device, hidden=64, one_grid=False, co=True, seed=31,
         cfg = configs.small_test_config(one_grid=one_grid, is_co_sdf=co)
         cfg["decoder"]["hidden_dim"] = cfg["decoder"]["hidden_dim_color"] = hidden
         cfg["mapping"].update(sample=64, min_pixels_cur=10, iters=iters, n_pixels=0.25)
+        # plane_dtype "fp16" (EXTENSION): the autograd path hands autograd fp16 gradients but the optimizer consumes the fp32
+        # sums the render node leaves beside them (``grad32``) -- mean-reduced plane gradients are below fp16's range, a cast
+        # would lose those updates (ADAM is scale-free) and the two paths would part
+        cfg["grid"]["plane_dtype"] = plane_dtype
         torch.manual_seed(seed)
         m = JointEncoding(cfg, torch.from_numpy(g["bounding_box"]).to(device))
         m.device = torch.device(device)
@@ -730,12 +734,17 @@ def check_fused_vs_autograd(device, hidden=64, one_grid=False, co=True, seed=31,
         poses = torch.stack([f["c2w"] for f in frames]).to(device)
         random.seed(seed + 1)
         torch.manual_seed(seed + 1)
+        start = [p.detach().cpu().clone() for lst in m.all_planes for p in lst]
         mapper.optimize_map(frames[3], poses)
-        finals.append([p.detach().cpu().clone() for lst in m.all_planes for p in lst] +
+        finals.append([p.detach().cpu().float().clone() for lst in m.all_planes for p in lst] +
                       [p.detach().cpu().clone() for p in m.decoder.parameters()])
+        if plane_dtype == "fp16":
+            assert all(p.dtype == torch.float16 for lst in m.all_planes for p in lst)
+            moved = sum(int((a.float() != b.float()).sum()) for a, b in zip(start, finals[-1]))
+            assert moved > 1000, "half-precision planes did not train"
     for k, (a, b) in enumerate(zip(*finals)):
         assert torch.isfinite(a).all()
-        assert_close(b, a, rtol=1e-3, atol=1e-4, what=f"tensor {k}: fused vs autograd path")
+        assert_close(b, a, rtol=1e-3, atol=1e-4 if plane_dtype == "fp32" else 3e-4, what=f"tensor {k}: fused vs autograd path")
     assert not torch.equal(finals[0][-1], torch.zeros_like(finals[0][-1]))
 
 
@@ -1446,7 +1455,7 @@ def lattice_config(rank):
     return cfg, room
 
 
-def run_overlap_agent(rank, device, comm):
+def run_overlap_agent(rank, device, comm, geometry="lattice"):
     """One of two agents on one lattice: FusedStep (binned plane update, overlap_peers + shared_decoder) against an oracle
     agent with the exchange written out in tensor ops -- plane gradients summed over the node rectangles both agents hold,
     decoder gradient averaged, then Adam.  Equal by construction to ONE model over the union lattice trained on the union
@@ -1455,7 +1464,16 @@ def run_overlap_agent(rank, device, comm):
     two agents' objects by rank (gloo processes on the CPU, threads of one process on the GPU)."""
     from mneslam_amd import dist as mdist, synthetic
     from mneslam_amd.fused import FusedStep
-    cfg, room = lattice_config(rank)
+    if geometry == "apartment":
+        # BASELINE configs[2] as worded, at its full size: the Replica apartment scene split into two overlapping slabs on one
+        # lattice (configs.split_agent_config: what bench.py --split / its as_worded side record run), ~60 M plane parameters each
+        base = configs.WORKLOADS["apartment"][0]()
+        base["mapping"]["bound"] = [list(b) for b in configs.SCENE_BOUNDS["apartment"]]
+        cfg, axis, _ = configs.split_agent_config(base, 2, rank)
+        assert axis == 0
+        room = cfg["mapping"]["marching_cubes_bound"]
+    else:
+        cfg, room = lattice_config(rank)
     bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
     with getattr(comm, "lock", contextlib.nullcontext()):        # (threads of one process share the global generator)
         torch.manual_seed(11)                                    # the same decoder on both agents

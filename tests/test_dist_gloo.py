@@ -283,13 +283,15 @@ def test_two_agents_map_exchange_through_load_foreign_model(tmp_path):
     assert os.path.exists(ret + ".ok0") and os.path.exists(ret + ".ok1")
 
 
-@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+@pytest.mark.parametrize("launcher", ["torchrun", "self", "split"])
 def test_bench_launcher_dry_run_two_ranks(tmp_path, launcher):
     """The driver's multi-GPU command line, as written in the task contract, on two ranks over gloo with the kernels in the
     host emulator: rendezvous, one agent per rank, warm-up, barrier-bracketed timed steps, max over ranks, decoder-gradient
     all-reduce, ONE JSON line from rank 0.  (Functional only: 16 + 4 rays on a tiny scene.)  launcher = "self": plain
     ``python bench.py --gpus 2`` -- bench.py starts its two ranks itself, as the reference's launcher starts its agents
-    (multi_agents.py:43-52)."""
+    (multi_agents.py:43-52).  launcher = "split": ``python bench.py --gpus 2 --config apartment --split`` -- BASELINE
+    configs[2] as worded: ONE scene, two overlapping slabs on one lattice, overlap-rectangle gradient exchange + shared decoder
+    in the timed line; the "self" line carries the same thing as its ``variants.as_worded`` side record."""
     import json
     import subprocess
     sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
@@ -302,7 +304,8 @@ def test_bench_launcher_dry_run_two_ranks(tmp_path, launcher):
     # launcher "self" runs the metric's line with private decoders and lets bench.py add its N > 1 side record (the same
     # workload with the decoder-gradient all-reduce); "torchrun" puts the all-reduce into the timed line itself
     cmd = pre + [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"] \
-        + (["--share-decoder"] if launcher == "torchrun" else []) + ["--small", "--rays", "16", "--keyframes", "2"]
+        + (["--share-decoder"] if launcher == "torchrun" else ["--config", "apartment", "--split"] if launcher == "split" else []) \
+        + ["--small", "--rays", "16", "--keyframes", "2"]
     env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -313,9 +316,18 @@ def test_bench_launcher_dry_run_two_ranks(tmp_path, launcher):
     assert d["config"]["agents"] == 2 and "DRY RUN" in d["data"]
     if launcher == "torchrun":
         assert "all-reduce" in d["config"]["parallelism"] and "variants" not in d
+    elif launcher == "split":
+        assert "overlap-rectangle" in d["config"]["parallelism"] and "all-reduce" in d["config"]["parallelism"] and "variants" not in d
+        assert d["config"]["workload"].endswith("_scene_split2_SMALL") and len(d["config"]["slab_bounds"]) == 2
+        assert len(d["per_rank"]) == 2 and all(r["overlap_exchange_bytes_per_iter"] > 0 and r["it_per_s"] > 0 for r in d["per_rank"])
+        assert d["config"]["exchange_bytes_per_iter_all_ranks"] > sum(r["overlap_exchange_bytes_per_iter"] for r in d["per_rank"])
     else:
         assert "no data-path collective" in d["config"]["parallelism"]
         side = d["variants"]["share_decoder"]
         assert side.get("value", 0) > 0 and "all-reduce" in side["collective"], side
+        worded = d["variants"]["as_worded"]
+        assert worded.get("value", 0) > 0 and worded["baseline_config"] == "configs[2]" and "overlap-rectangle" in worded["parallelism"], worded
+        assert len(worded["per_rank"]) == 2 and all(r["overlap_exchange_bytes_per_iter"] > 0 for r in worded["per_rank"])
+        assert len(d["per_rank"]) == 2
     assert d["config"]["ranks_seen"] == 2 and d["config"]["collective_backend"] == "gloo"
     assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # whole-job rate = all agents' steps / time

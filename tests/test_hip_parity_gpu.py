@@ -129,6 +129,11 @@ def test_fused_step_matches_autograd_path(hidden, one_grid, co):
     pc.check_fused_vs_autograd(DEV, hidden=hidden, one_grid=one_grid, co=co)
 
 
+def test_fp16_planes_autograd_path_matches_fused_path():
+    """Half-precision plane storage on the drop-in (autograd) path: the fp32 gradient sums reach the optimizer (``grad32``)."""
+    pc.check_fused_vs_autograd(DEV, hidden=32, one_grid=True, co=False, plane_dtype="fp16")
+
+
 @pytest.mark.parametrize("compute,absolute", [("autograd", False), ("fused", False), ("fused", True), ("fused", "quat")])
 def test_loop_closure_pose_alignment(compute, absolute):
     pc.check_pose_alignment(DEV, compute, absolute)
@@ -568,8 +573,10 @@ def test_forced_split_lists_and_capped_ray_lds(monkeypatch):
 # 8e on real hardware as far as one GPU allows: the multi-agent forms of the plane update (tile_adam_kernel<1>, <2>),
 # two agents = two threads of this process on the same device, the exchange done by device-to-device copies
 # ------------------------------------------------------------------------------------------------------------
-def test_two_agents_binned_overlap_on_one_device(monkeypatch):
-    """parity_cases.run_overlap_agent with both agents on cuda:0: mne_tile_grad_export / mne_tile_adam_shared on the GPU,
+@pytest.mark.parametrize("geometry", ["lattice", "apartment"])
+def test_two_agents_binned_overlap_on_one_device(monkeypatch, geometry):
+    """geometry "apartment": BASELINE configs[2] as worded at full plane size (the two slabs bench.py --split gives its ranks).
+    parity_cases.run_overlap_agent with both agents on cuda:0: mne_tile_grad_export / mne_tile_adam_shared on the GPU,
     FusedStep(overlap_peers, shared_decoder) on its two streams; what torch.distributed would carry (the send / recv
     buffers of the shared cells, the decoder-gradient mean) is copied between the agents' buffers under a barrier."""
     import threading
@@ -611,7 +618,7 @@ def test_two_agents_binned_overlap_on_one_device(monkeypatch):
         local.rank = rank
         try:
             with torch.cuda.device(0):
-                pc.run_overlap_agent(rank, DEV, comm)
+                pc.run_overlap_agent(rank, DEV, comm, geometry=geometry)
         except BaseException as e:          # noqa: BLE001 -- reported by the main thread
             errors.append((rank, e))
             bar.abort()

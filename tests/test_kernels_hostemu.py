@@ -162,6 +162,11 @@ def test_fused_step_matches_autograd_path_2x64_colorplanes():
     pc.check_fused_vs_autograd(DEV, hidden=64, one_grid=False, co=True, iters=2)
 
 
+def test_fp16_planes_autograd_path_matches_fused_path():
+    """Half-precision plane storage on the drop-in (autograd) path: fp32 gradient sums reach the optimizer (``grad32``)."""
+    pc.check_fused_vs_autograd(DEV, hidden=32, one_grid=True, co=False, plane_dtype="fp16")
+
+
 @pytest.mark.parametrize("one_grid", [True, False])
 def test_random_scene_2x64_vs_oracle(one_grid):
     """2x64 decoders (ALDS / global A tables, fused 2x64 weight-gradient kernel) against the oracle's autograd"""
