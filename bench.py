@@ -115,6 +115,13 @@ class Agent:
             torch.manual_seed(model_seed)
         self.model = (HashJointEncoding if self.hash else JointEncoding)(cfg, bb).to(device).train()
         self.model.jitter_rng = "device"
+        if share_decoder:
+            # ONE decoder shared by the agents starts as ONE decoder: rank 0's initialisation (collective; every rank of a
+            # shared-decoder run builds its agent at the same point)
+            import torch.distributed as tdist
+            if tdist.is_initialized() and tdist.get_world_size() > 1:
+                for w in self.model.decoder.parameters():
+                    tdist.broadcast(w.data, 0)
         peers = peers_of(self.model) if peers_of is not None else None     # (collective; fills the shared cells in place)
         self.opt = slam_glue.create_optimizer(self.model, cfg)
         self.n_cur = max(cfg["mapping"]["sample"] // n_keyframes, cfg["mapping"]["min_pixels_cur"])

@@ -39,6 +39,8 @@ enum { MNE_L_RGB = 0, MNE_L_DEPTH = 1, MNE_L_CO_SDF = 2, MNE_L_CO_FS = 3, MNE_L_
 enum { MNE_C_VALID = 0, MNE_C_E_FRONT = 1, MNE_C_E_CENTER = 2, MNE_C_E_TAIL = 3, MNE_C_CO_FS = 4,
        MNE_C_CO_SDF = 5,
        MNE_C_NEED = 6,   /* per-ray only: leading samples that can carry a loss term (z <= target depth + truncation) */
+       MNE_C_TILE0 = 7,  /* per-ray only: exclusive prefix over the rays of their a-priori 32-sample tile counts (clamp(ceil(
+                          * MNE_C_NEED / 32), 1, tiles per ray)): the render calls deal the decode's tile tasks evenly from it */
        MNE_N_COUNT = 8 };
 
 typedef struct mne_plane {

@@ -646,18 +646,22 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     const uint32_t n_ent = size - lo < HASH_SLICE ? size - lo : HASH_SLICE;
     const bool dense = hash_level_dense(a, level);
     const int n_chunks = a.n_chunks;
-    // the offsets of this slice's records in every chunk of this part (a split level: every n_part-th chunk), requested
-    // before anything else (one round trip)
+    // the offsets of this slice's records in every chunk of this part (a split level: every n_part-th chunk) of the first
+    // group of HASH_MAX_CHUNKS chunks, requested before anything else (one round trip); a batch of more than
+    // HASH_MAX_CHUNKS * HASH_CHUNK = 512 K rows (INS Indoor's 2150 x 1045, or 8192 rays x 128) comes in further groups
     unsigned r0[HASH_MAX_CHUNKS / HASH_SLICE_THREADS], r1[HASH_MAX_CHUNKS / HASH_SLICE_THREADS];
+    auto fetch_offsets = [&](int cg) {
 #pragma unroll
-    for (int j = 0; j < HASH_MAX_CHUNKS / HASH_SLICE_THREADS; ++j) {
-        r0[j] = r1[j] = 0u;
-        const int c = tid + j * HASH_SLICE_THREADS;
-        if (c < n_chunks && c % n_part == part) {
-            const unsigned* so = a.seg_off + a.seg_level[level] + (size_t)c * (ns + 1) + slice;
-            r0[j] = so[0]; r1[j] = so[1];
+        for (int j = 0; j < HASH_MAX_CHUNKS / HASH_SLICE_THREADS; ++j) {
+            r0[j] = r1[j] = 0u;
+            const int c = cg + tid + j * HASH_SLICE_THREADS;
+            if (c < n_chunks && c % n_part == part) {
+                const unsigned* so = a.seg_off + a.seg_level[level] + (size_t)c * (ns + 1) + slice;
+                r0[j] = so[0]; r1[j] = so[1];
+            }
         }
-    }
+    };
+    fetch_offsets(0);
     for (int i = tid; i < HASH_SLICE * 2; i += HASH_SLICE_THREADS) acc[i] = 0ull;
     // the level's fixed-point scale: max |d(feature)| over the chunks' maxima (every workgroup of the level computes the
     // same value; (slice 0, part 0) publishes it for hash_finish_kernel)
@@ -675,67 +679,74 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     const double scale = bad ? 0.0 : ldexp(1.0, HASH_FIX_BITS - ge);
     const double inv = bad ? (double)__uint_as_float(0x7fc00000u) : ldexp(1.0, ge - HASH_FIX_BITS);
     if (blockIdx.x == 0 || (slice == 0 && part == 0)) { if (tid == 0) a.gscale[level] = inv; }
-    // exclusive scan of the chunks' record counts, then a flat walk over this slice's records of ALL its chunks (each chunk's
-    // are contiguous): one more round trip whatever the count
-#pragma unroll
-    for (int j = 0; j < HASH_MAX_CHUNKS / HASH_SLICE_THREADS; ++j) {
-        cbase[tid + j * HASH_SLICE_THREADS] = r0[j];
-        cstart[tid + j * HASH_SLICE_THREADS] = r1[j] - r0[j];
-    }
-    __syncthreads();
-    if (tid < 64) {                                                  // HASH_MAX_CHUNKS counts, 8 per lane of one wave
-        constexpr int PER = HASH_MAX_CHUNKS / 64;
-        unsigned v[PER], sum = 0;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) { v[q] = cstart[tid * PER + q]; sum += v[q]; }
-        unsigned inc = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const unsigned u = __shfl_up(inc, d); if (tid >= d) inc += u; }
-        unsigned ex = inc - sum;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) { cstart[tid * PER + q] = ex; ex += v[q]; }
-        if (tid == 63) cstart[HASH_MAX_CHUNKS] = ex;
-    }
-    __syncthreads();
-    const unsigned total = cstart[HASH_MAX_CHUNKS];
     const HashRecord* rec0 = (const HashRecord*)a.records + (size_t)level * a.n_chunks * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
-    for (unsigned i0 = 0; i0 < total; i0 += HASH_SLICE_THREADS * HASH_SLICE_UNROLL) {
-        float4 rw[HASH_SLICE_UNROLL];
-        bool in[HASH_SLICE_UNROLL];
-#pragma unroll
-        for (int q = 0; q < HASH_SLICE_UNROLL; ++q) {
-            const unsigned i = i0 + q * HASH_SLICE_THREADS + tid;
-            in[q] = i < total;
-            rw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in[q]) {
-                int c = 0;                                           // chunk of flat record i: last c with cstart[c] <= i
-#pragma unroll
-                for (int st = HASH_MAX_CHUNKS / 2; st >= 1; st >>= 1)
-                    if (c + st < n_chunks && cstart[c + st] <= i) c += st;
-                rw[q] = *(const float4*)(rec0 + (size_t)c * (HASH_CHUNK * HASH_REC_PER_ROW) + cbase[c] + (i - cstart[c]));
-            }
+    for (int cg = 0; cg < n_chunks; cg += HASH_MAX_CHUNKS) {
+        if (cg > 0) {
+            __syncthreads();                                         // the previous group's walk has read cstart / cbase
+            fetch_offsets(cg);
         }
+        const int n_here = n_chunks - cg < HASH_MAX_CHUNKS ? n_chunks - cg : HASH_MAX_CHUNKS;
+        // exclusive scan of the chunks' record counts, then a flat walk over this slice's records of ALL chunks of the group
+        // (each chunk's are contiguous): one more round trip whatever the count
 #pragma unroll
-        for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
-            if (in[q]) {
-                const unsigned rm = __float_as_uint(rw[q].x), r = rm & 0xffffffu, mask = rm >> 24;
-                float xv[3];
+        for (int j = 0; j < HASH_MAX_CHUNKS / HASH_SLICE_THREADS; ++j) {
+            cbase[tid + j * HASH_SLICE_THREADS] = r0[j];
+            cstart[tid + j * HASH_SLICE_THREADS] = r1[j] - r0[j];
+        }
+        __syncthreads();
+        if (tid < 64) {                                              // HASH_MAX_CHUNKS counts, 8 per lane of one wave
+            constexpr int PER = HASH_MAX_CHUNKS / 64;
+            unsigned v[PER], sum = 0;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const float p = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * rw[q].y;      // scene_rep.py:384 (as the bin kernel)
-                    xv[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
+            for (int q = 0; q < PER; ++q) { v[q] = cstart[tid * PER + q]; sum += v[q]; }
+            unsigned inc = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const unsigned u = __shfl_up(inc, d); if (tid >= d) inc += u; }
+            unsigned ex = inc - sum;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { cstart[tid * PER + q] = ex; ex += v[q]; }
+            if (tid == 63) cstart[HASH_MAX_CHUNKS] = ex;
+        }
+        __syncthreads();
+        const unsigned total = cstart[HASH_MAX_CHUNKS];
+        for (unsigned i0 = 0; i0 < total; i0 += HASH_SLICE_THREADS * HASH_SLICE_UNROLL) {
+            float4 rw[HASH_SLICE_UNROLL];
+            bool in[HASH_SLICE_UNROLL];
+#pragma unroll
+            for (int q = 0; q < HASH_SLICE_UNROLL; ++q) {
+                const unsigned i = i0 + q * HASH_SLICE_THREADS + tid;
+                in[q] = i < total;
+                rw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in[q]) {
+                    int c = 0;                                       // chunk (within the group) of flat record i: last c with cstart[c] <= i
+#pragma unroll
+                    for (int st = HASH_MAX_CHUNKS / 2; st >= 1; st >>= 1)
+                        if (c + st < n_here && cstart[c + st] <= i) c += st;
+                    rw[q] = *(const float4*)(rec0 + (size_t)(cg + c) * (HASH_CHUNK * HASH_REC_PER_ROW) + cbase[c] + (i - cstart[c]));
                 }
-                HashCorners cn;
-                hash_corners(a, level, make_float4(xv[0], xv[1], xv[2], 0.0f), dense, cn);
-                const float gx = rw[q].z, gy = rw[q].w;
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if ((mask >> c) & 1u) {                          // the corners of this record: inside [lo, lo + n_ent) by construction
-                        const uint32_t e = cn.idx[c] - lo;
-                        atomicAdd(&acc[2 * e], hash_fix(cn.w[c] * gx, scale));
-                        atomicAdd(&acc[2 * e + 1], hash_fix(cn.w[c] * gy, scale));
-                    }
             }
+#pragma unroll
+            for (int q = 0; q < HASH_SLICE_UNROLL; ++q)
+                if (in[q]) {
+                    const unsigned rm = __float_as_uint(rw[q].x), r = rm & 0xffffffu, mask = rm >> 24;
+                    float xv[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const float p = a.rays_o[r * 3 + d] + a.rays_d[r * 3 + d] * rw[q].y;      // scene_rep.py:384 (as the bin kernel)
+                        xv[d] = unit_coord(p, a.bb_lo[d], a.bb_hi[d], a.bb_is_f64 != 0);
+                    }
+                    HashCorners cn;
+                    hash_corners(a, level, make_float4(xv[0], xv[1], xv[2], 0.0f), dense, cn);
+                    const float gx = rw[q].z, gy = rw[q].w;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if ((mask >> c) & 1u) {                      // the corners of this record: inside [lo, lo + n_ent) by construction
+                            const uint32_t e = cn.idx[c] - lo;
+                            atomicAdd(&acc[2 * e], hash_fix(cn.w[c] * gx, scale));
+                            atomicAdd(&acc[2 * e + 1], hash_fix(cn.w[c] * gy, scale));
+                        }
+                }
+        }
     }
     __syncthreads();
     if (n_part > 1) {                                                // a split level's partial sums -> the 64-bit scratch (exact)
@@ -812,7 +823,7 @@ int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st, void* event_af
     if (a.R <= 0) return 0;
     for (int l = 0; l < a.n_levels; ++l)
         if (hash_slices_of(a, l) > HASH_MAX_SLICES) return -7;
-    if (a.n_chunks > HASH_MAX_CHUNKS || a.R >= (1 << 24)) return -7;                    // (a slice workgroup scans its chunks' counts in one pass: <= 512 K rows)
+    if (a.R >= (1 << 24)) return -7;                                                     // (a record carries its ray in 24 bits)
     MNE_LAUNCH(hash_bin_kernel, (unsigned)(a.n_chunks * a.n_levels), HASH_BIN_THREADS, 0, st, a);
     if (event_after_bin) (void)hipEventRecord((hipEvent_t)event_after_bin, st);
     MNE_LAUNCH(hash_slice_adam_kernel, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, 0, st, a);

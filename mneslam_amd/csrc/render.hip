@@ -138,6 +138,31 @@ __device__ __forceinline__ void counts_reduce_block(const ZArgs& a, int (*part)[
         __syncthreads();
     }
     if (t < MNE_N_COUNT) a.counts[t] = part[0][t];
+    // Exclusive prefix of the rays' a-priori tile counts -> slot 7 of every ray's counts (decode_kernel hands its tile tasks
+    // out from it, balanced over the waves): thread t takes a contiguous block of rays, the blocks' sums are scanned in LDS.
+    __syncthreads();
+    const int ntile = (a.S + 31) / 32, per = (a.R + 255) / 256;
+    const int r0 = t * per < a.R ? t * per : a.R, r1 = r0 + per < a.R ? r0 + per : a.R;
+    int mine = 0;
+    for (int r = r0; r < r1; ++r) {
+        const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
+        const int tl = (need + 31) / 32;
+        mine += tl < 1 ? 1 : (tl > ntile ? ntile : tl);
+    }
+    part[t][0] = mine;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < 256; ++k) { const int v = part[k][0]; part[k][0] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[t][0];
+    for (int r = r0; r < r1; ++r) {
+        const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
+        const int tl = (need + 31) / 32;
+        a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_TILE0] = run;
+        run += tl < 1 ? 1 : (tl > ntile ? ntile : tl);
+    }
 }
 
 __global__ __launch_bounds__(256) void counts_reduce_kernel(ZArgs a) {
@@ -334,6 +359,9 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
 #ifndef DECODE_WPB
 #define DECODE_WPB 8
 #endif
+#ifndef MNE_DECODE_BALANCED
+#define MNE_DECODE_BALANCED 1   // decode_kernel: the rays' real tiles dealt evenly to the waves (0: fixed stride over the (tile, ray) slots)
+#endif
 // -----------------------------------------------------------------------------------------------
 // gather_kernel: tri-plane features of the a-priori samples straight into their tape rows.  The gather is a chain of
 // dependent load rounds; inside decode_kernel (12 waves per CU, LDS- and register-bound) it took 21 of the 34 us a tile
@@ -371,7 +399,7 @@ __global__ __launch_bounds__(256) void gather_kernel(RenderArgs a, int chunks_pe
 // extension is SERIAL in one wave (34 us per tile); INS Indoor has 33 tiles per ray and rays that cross empty space:
 // unbounded 606 it/s, 4 tiles 791, 2 tiles 828, 1 tile 846; office0 / ScanNet within noise (profiles/r02_resolver_ext.txt).
 template <int HID, int HIDC, bool CP, bool ALDS, int WPB>
-__global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre) {
+__global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre, int sched) {
     typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
     constexpr int TAB_FLOATS = ALDS ? T::FWD_STEPS * 64 : 0;
@@ -399,11 +427,35 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre)
     // skipped tasks (tiles beyond a ray's prefix) cluster at the end and the real ones spread evenly over the waves.
     // List mode (second pass): the REMAINING tiles of the rays the training kernel deferred.
     const int n_rays = a.ray_list ? *a.ray_list_count : a.R;
-    const long long ntask_l = (long long)n_rays * ntile;
+    // BALANCED schedule (sched != 0; first pass of a depth-guided batch in the prefix schedule): about half of the (tile, ray)
+    // slots are tiles beyond their ray's a-priori prefix, and with a fixed stride over the slots some waves get four real
+    // tiles and others two -- the launch takes as long as its busiest wave (70 us for 2.4 tiles of 12.6 us per wave on
+    // average, profiles/r05_decode_balance.txt).  The exclusive prefix of the rays' tile counts (slot MNE_C_TILE0 of ray_counts, left
+    // by the batch preparation) is staged in LDS and wave w decodes the real tiles w, w + W, ...: tile g belongs to the ray
+    // found by a binary search, every wave gets the same number of tiles +- 1.  (A device-side queue over the slots was
+    // measured first: 8600 returning atomics on one address made the launch 126 us instead of 70.)
+    const bool balanced = sched != 0 && !a.ray_list && a.ray_counts && !(a.adapt && a.adapt[0]);
+    int* tstart = (int*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wpb * tile_wave_lds_bytes(NSETS));
+    long long ntask_l = (long long)n_rays * ntile;
+    if (balanced) {
+        for (int r = threadIdx.x; r < a.R; r += blockDim.x) tstart[r] = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_TILE0];
+        __syncthreads();
+        ntask_l = tstart[a.R - 1] + apriori_tiles(a, a.R - 1, ntile);
+    }
     for (long long task = (long long)blockIdx.x * wpb + wv; task < ntask_l; task += (long long)gridDim.x * wpb) {
-        const int c = (int)(task / n_rays);
-        const int r = a.ray_list ? a.ray_list[(int)(task % n_rays)] : (int)(task % n_rays);
-        if (a.ray_list ? (c < (a.dec_tiles ? a.dec_tiles[r] : prefix_tiles(a, r, ntile))) : (c >= prefix_tiles(a, r, ntile))) continue;
+        int c, r;
+        if (balanced) {
+            int lo = 0, hi = a.R - 1;                              // last ray whose first tile is <= task
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (tstart[mid] <= (int)task) lo = mid; else hi = mid - 1;
+            }
+            r = lo; c = (int)task - tstart[lo];
+        } else {
+            c = (int)(task / n_rays);
+            r = a.ray_list ? a.ray_list[(int)(task % n_rays)] : (int)(task % n_rays);
+            if (a.ray_list ? (c < (a.dec_tiles ? a.dec_tiles[r] : prefix_tiles(a, r, ntile))) : (c >= prefix_tiles(a, r, ntile))) continue;
+        }
         float pnv[3], u[3];
         uint2 relu;
         // The wave that decodes the LAST a-priori tile of a ray extends the prefix on the spot while the ray is visibly
@@ -1429,14 +1481,19 @@ static int launch_decode(RenderArgs d, hipStream_t st, const RenderHost& host, b
     const size_t tab = table_bytes<HID, HIDC, CP>(0);
     const int wpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(CP ? 2 : 1), DECODE_WPB);
     if (wpb < 1) return -4;
-    const size_t lds = tab + (size_t)wpb * tile_wave_lds_bytes(CP ? 2 : 1);
+    size_t lds = tab + (size_t)wpb * tile_wave_lds_bytes(CP ? 2 : 1);
+    // balanced tile schedule (see decode_kernel): needs the tile-count prefix of mne_sample_z / mne_sample_batch and room for
+    // it in LDS; the adaptive "decode everything" state is checked on the device
+    const size_t sched_bytes = align16((size_t)d.R * sizeof(int));
+    const int sched = (MNE_DECODE_BALANCED && d.ray_counts && !d.ray_list && lds + sched_bytes <= MNE_LDS_MAX) ? 1 : 0;
+    if (sched) lds += sched_bytes;
     const long long ntask = (long long)d.R * ((d.S + TILE - 1) / TILE);
     long long grid = (ntask + wpb - 1) / wpb;
     if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
     if (d.ray_list && grid > MNE_LIST_PASS_BLOCKS) grid = MNE_LIST_PASS_BLOCKS;      // deferred pass: see MNE_LIST_PASS_BLOCKS
     // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
     if (lds > 64 * 1024) MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB>), MNE_LDS_MAX);
-    MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB>), (unsigned)grid, 64 * wpb, lds, st, d, pre ? 1 : 0);
+    MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB>), (unsigned)grid, 64 * wpb, lds, st, d, pre ? 1 : 0, sched);
     return 0;
 }
 

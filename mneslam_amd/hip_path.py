@@ -521,9 +521,19 @@ class PoseAlignment:
         self.S = lib.mne_num_samples(C.byref(self.rc), 0)
         S = self.S
         self.tables = linspace_tables(cfg, False, dev)
-        self.planes = [p.detach() for p in model._flat_planes()]
         self.dec_w = [w.detach() for w in model.decoder.hip_weights()]
-        self.scene = scene_struct(self.info, self.planes, self.dec_w)
+        # hash / dense grid model (HashJointEncoding): the grid's features are caller-supplied rows of the *_features entry
+        # points, its share of the ray gradients comes from mne_hash_ray_grad -- the loop is nine launches instead of six,
+        # still no autograd graph, no allocation, no host sync (mp_slam/mapper.py:388-408 on the hash wiring)
+        self.grid = getattr(model, "embed_fn", None)
+        if self.grid is not None:
+            self.planes = []
+            self.scene = _hash_scene(self.info, self.dec_w)
+            self.table = self.grid.params.detach()
+            self.feats = torch.zeros(n * S, 64, **f)           # the grid fills the first n_levels * 2 columns of the 64-wide slot
+        else:
+            self.planes = [p.detach() for p in model._flat_planes()]
+            self.scene = scene_struct(self.info, self.planes, self.dec_w)
         self.packed = torch.empty(lib.mne_packed_decoder_floats(C.byref(self.scene)), **f)
         n_rot = rot0.shape[-1]
         self.rot, self.trans = rot0.detach().reshape(n_rot).to(**f).clone(), trans0.detach().reshape(3).to(**f).clone()
@@ -540,6 +550,8 @@ class PoseAlignment:
         self.partials = torch.empty((n + 255) // 256, **f)
         self.d_o, self.d_d = torch.empty(n, 3, **f), torch.empty(n, 3, **f)
         self.tape = torch.empty(n * S, lib.mne_tape_row_floats(C.byref(self.scene)), **f)
+        if self.grid is not None:
+            self.tape[:, :64].zero_()                          # feature columns the grid does not fill must read as zero
         self.tape_rows = torch.zeros(1, device=dev, dtype=torch.int32)
         self.ray_tiles = torch.empty(n, device=dev, dtype=torch.int32)
         self.ws_bytes = lib.mne_render_workspace_bytes(n, S)
@@ -569,17 +581,36 @@ class PoseAlignment:
         u_c = _f32c(u, "u") if u is not None else None
         _lib.check(lib.mne_sample_z(rc, n, None, P(u_c), P(self.tables), seed_offset[0], seed_offset[1], P(self.z), P(self.counts),
                                     None, None, st), "mne_sample_z")
-        _lib.check(lib.mne_render_forward(sc, rc, n, S, P(self.rays_o), P(self.rays_d), None, None, P(self.z), P(self.packed),
-                                          P(self.rgb), P(self.depth), P(self.aux[0]), P(self.aux[1]), P(self.aux[2]), P(self.raw),
-                                          None, None, 0, st), "mne_render_forward")
+        if self.grid is not None:
+            gc = C.byref(self.grid.cfg)
+            _lib.check(lib.mne_hash_features(gc, sc, n, S, P(self.rays_o), P(self.rays_d), P(self.z), P(self.table), P(self.feats), st),
+                       "mne_hash_features")
+            _lib.check(lib.mne_render_forward_features(sc, rc, n, S, P(self.rays_o), P(self.rays_d), None, None, P(self.z),
+                                                       P(self.packed), P(self.feats), P(self.rgb), P(self.depth), P(self.aux[0]),
+                                                       P(self.aux[1]), P(self.aux[2]), P(self.raw), None, None, 0, st),
+                       "mne_render_forward_features")
+        else:
+            _lib.check(lib.mne_render_forward(sc, rc, n, S, P(self.rays_o), P(self.rays_d), None, None, P(self.z), P(self.packed),
+                                              P(self.rgb), P(self.depth), P(self.aux[0]), P(self.aux[1]), P(self.aux[2]), P(self.raw),
+                                              None, None, 0, st), "mne_render_forward")
         _lib.check(lib.mne_pose_loss(n, P(self.rgb), P(self.depth), P(self.want_rgb), P(self.want_depth), self.w[0], self.w[1],
                                      P(self.d_rgb), P(self.d_depth), P(self.partials), st), "mne_pose_loss")
         self.d_o.zero_()
         self.d_d.zero_()
-        _lib.check(lib.mne_render_backward(sc, rc, n, S, P(self.rays_o), P(self.rays_d), None, None, P(self.z), None,
-                                           P(self.packed), P(self.raw), None, P(self.d_rgb), P(self.d_depth), P(self.tape), n * S,
-                                           P(self.tape_rows), P(self.ray_tiles), P(self.d_o), P(self.d_d), P(self.ws),
-                                           self.ws_bytes, st), "mne_render_backward")
+        if self.grid is not None:
+            _lib.check(lib.mne_hash_gather(gc, sc, n, S, P(self.rays_o), P(self.rays_d), P(self.z), None, P(self.table), P(self.tape), st),
+                       "mne_hash_gather")
+            _lib.check(lib.mne_render_backward_features(sc, rc, n, S, P(self.rays_o), P(self.rays_d), None, None, P(self.z), None,
+                                                        P(self.packed), P(self.raw), None, P(self.d_rgb), P(self.d_depth), P(self.tape),
+                                                        n * S, P(self.tape_rows), P(self.ray_tiles), P(self.d_o), P(self.d_d), P(self.ws),
+                                                        self.ws_bytes, st), "mne_render_backward_features")
+            _lib.check(lib.mne_hash_ray_grad(gc, sc, n, S, P(self.rays_o), P(self.rays_d), P(self.z), P(self.table), P(self.tape),
+                                             P(self.ray_tiles), P(self.d_o), P(self.d_d), st), "mne_hash_ray_grad")     # + the grid's share
+        else:
+            _lib.check(lib.mne_render_backward(sc, rc, n, S, P(self.rays_o), P(self.rays_d), None, None, P(self.z), None,
+                                               P(self.packed), P(self.raw), None, P(self.d_rgb), P(self.d_depth), P(self.tape), n * S,
+                                               P(self.tape_rows), P(self.ray_tiles), P(self.d_o), P(self.d_d), P(self.ws),
+                                               self.ws_bytes, st), "mne_render_backward")
         _lib.check(lib.mne_pose_update(C.byref(self.ps), n, P(self.dirs), P(self.d_o), P(self.d_d), P(self.partials), st),
                    "mne_pose_update")
 

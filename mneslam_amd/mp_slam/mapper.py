@@ -214,8 +214,8 @@ class FusedMappingMixin:
         from .. import hip_path
         if steps < 1 or not isinstance(pose_opt, torch.optim.Adam) or len(pose_opt.param_groups) != 2:
             return None
-        if not getattr(model, "all_planes", None):           # ray gradients need the plane encoding (HashJointEncoding has none)
-            return None
+        if not getattr(model, "all_planes", None) and getattr(model, "embed_fn", None) is None:
+            return None                                       # neither the plane encoding nor the hash / dense grid
         g_rot, g_trans = pose_opt.param_groups
         same = all(g_rot[k] == g_trans[k] for k in ("betas", "eps")) and not any(
             g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or g.get("capturable")

@@ -603,10 +603,11 @@ def check_pose_alignment(device, compute="autograd", absolute=False):
     assert not torch.allclose(rel_h, base @ torch.inverse(target0))     # the pose moved
 
 
-def check_pose_alignment_hash(device):
+def check_pose_alignment_hash(device, compute="fused"):
     """The same loop on the hash-grid model (R13 through the grid: OneBlob share from the render backward + trilinear-weight
-    share from mne_hash_ray_grad): Mapper.optimize_relative_pose with the host's own autograd loop -- the device loop of
-    csrc/pose.hip belongs to the plane encoding -- against the loop driven by the oracle's autograd."""
+    share from mne_hash_ray_grad): Mapper.optimize_relative_pose against the loop driven by the oracle's autograd --
+    compute "fused": the DEVICE loop (hip_path.PoseAlignment on caller-supplied grid features: nine launches per iteration,
+    round 5), "autograd": the host's own autograd loop through HashRenderFunction."""
     cfg = hash_test_config(hash_size=12, hidden=32, desired_resolution=128)
     cfg["mapping"]["loop_iters"] = 3
     cfg["training"]["n_samples"] = 40
@@ -624,11 +625,11 @@ def check_pose_alignment_hash(device):
                                      dataset=None, video=None, get_pose_param_optim=None, matrix_from_tensor=None)
         pose = _PoseSLAM()
         slam.get_pose_param_optim, slam.matrix_from_tensor = pose.get_pose_param_optim, pose.matrix_from_tensor
-        mp = Mapper(cfg, slam, compute="fused" if kind == "hip" else "autograd")
+        mp = Mapper(cfg, slam, compute=compute if kind == "hip" else "autograd")
         torch.manual_seed(11)
         rel, best = mp.optimize_relative_pose(base.clone(), target0.clone(), model, model, rays_d_cam_batch=cam_dirs.clone())
         if kind == "hip":
-            assert mp.last_pose_loop == "host"
+            assert mp.last_pose_loop == ("device" if compute == "fused" else "host")
         results.append((rel.detach().cpu(), best))
     (rel_h, best_h), (rel_o, best_o) = results
     assert best_h == best_h and abs(best_h - best_o) <= 1e-3 * abs(best_o) + 1e-7, (best_h, best_o)
@@ -982,6 +983,42 @@ def check_hash_update_bit_reproducible(device, cfg, n_keyframes=3, seed=5, warm_
         for name, a, b in zip(("table", "exp_avg", "exp_avg_sq"), (tb, mm, vv), want):
             assert torch.equal(a, b), f"repeat {k}: {name} differs from the pipeline's result in {int((a != b).sum())} entries"
     return {"moved": int((want[0] != table0).sum()), "R": R, "S": S}
+
+
+def check_hash_large_batch(device, cfg, n_keyframes=4, seed=7, steps=2):
+    """A batch of more than 512 K tape rows (HASH_MAX_CHUNKS chunks of 1024: the slice kernel then walks its records in
+    several chunk groups; round 5 -- INS Indoor's 2150 x 1045 or an 8192-ray batch did not run on the hash encoding before).
+    Size-independent check: the table update by slice-binned exact LDS sums against the other implementation of the same
+    update -- run-reduced global float atomics into a gradient buffer + the streaming Adam kernel (MNE_HASH_UPDATE=atomics) --
+    on the same device-drawn batches from the same state."""
+    import bench
+    dev = torch.device(device)
+    tables = []
+    for update in ("slices", "atomics"):
+        old = os.environ.get("MNE_HASH_UPDATE")
+        os.environ["MNE_HASH_UPDATE"] = update
+        try:
+            ag = bench.Agent(cfg, dev, seed=seed, n_keyframes=n_keyframes, path="fused")
+        finally:
+            if old is None:
+                os.environ.pop("MNE_HASH_UPDATE", None)
+            else:
+                os.environ["MNE_HASH_UPDATE"] = old
+        assert ag.fused.table_update == update
+        rows = ag.fused.R * ag.fused.S
+        for _ in range(steps):
+            ag.step()
+        ag.fused.synchronize()
+        torch.cuda.synchronize() if dev.type == "cuda" else None
+        tables.append((ag.model.embed_fn.params.detach().cpu().clone(), ag.opt.param_groups, float(ag.fused.losses[7])))
+        del ag
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+    (t_s, groups, psnr_s), (t_a, _, psnr_a) = tables
+    assert torch.isfinite(t_s).all() and abs(psnr_s - psnr_a) < 1e-3 * abs(psnr_a) + 1e-4
+    lr = next(g["lr"] for g in groups if any(p.numel() == t_s.numel() for p in g["params"]))
+    mean, frac = adam_agreement(t_s, t_a, lr, "table", "slice update vs atomics update")
+    return {"rows": rows, "mean_over_lr": mean, "outliers": frac}
 
 
 def check_hash_fused_step_vs_oracle(device, cfg, n_keyframes=3, seed=5, warm_steps=0, small=True):
@@ -1478,6 +1515,10 @@ def run_overlap_agent(rank, device, comm, geometry="lattice"):
     with getattr(comm, "lock", contextlib.nullcontext()):        # (threads of one process share the global generator)
         torch.manual_seed(11)                                    # the same decoder on both agents
         model = JointEncoding(cfg, bb).to(device).train()
+    # one decoder for both agents: the planes' draws come first in the constructor and the two slabs need not have the same
+    # number of nodes, so the seed alone does not give equal decoders -- agent 0's initialisation is the common one
+    dec0 = comm.all_gather({k: v.detach().cpu().clone() for k, v in model.decoder.state_dict().items()})[0]
+    model.decoder.load_state_dict({k: v.to(device) for k, v in dec0.items()})
     geo = mdist.plane_geometry(model)
     peer_geo = comm.all_gather(geo)[1 - rank]
     # planes = windows of one field over the union lattice (same seed on both ranks), so shared cells start equal

@@ -443,9 +443,19 @@ def test_dense_grid_scene_api_vs_oracle():
     pc.check_hash_scene_api(DEV, cfg, n_rays=200)
 
 
-def test_loop_closure_pose_alignment_on_the_hash_model():
+@pytest.mark.parametrize("compute", ["fused", "autograd"])
+def test_loop_closure_pose_alignment_on_the_hash_model(compute):
     """R13 on the north-star encoding: the pose loop of loop closure differentiates the hash-grid render w.r.t. its rays."""
-    pc.check_pose_alignment_hash(DEV)
+    pc.check_pose_alignment_hash(DEV, compute)
+
+
+def test_hash_iteration_on_more_than_512k_rows():
+    """8192 rays x 128 samples = 1.1 M tape rows on the headline hash grid (T = 2^19, 2x64): the slice kernel's chunk groups."""
+    from mneslam_amd import configs
+    cfg = configs.bench_office0_hash()
+    cfg["mapping"]["sample"] = 8192
+    out = pc.check_hash_large_batch(DEV, cfg)
+    assert out["rows"] > (1 << 20)
 
 
 def test_hash_grid_training_learns():
@@ -620,7 +630,8 @@ def test_two_agents_binned_overlap_on_one_device(monkeypatch, geometry):
             with torch.cuda.device(0):
                 pc.run_overlap_agent(rank, DEV, comm, geometry=geometry)
         except BaseException as e:          # noqa: BLE001 -- reported by the main thread
-            errors.append((rank, e))
+            import traceback
+            errors.append((rank, e, traceback.format_exc()[-1500:]))
             bar.abort()
     threads = [threading.Thread(target=agent, args=(r,)) for r in range(2)]
     for t in threads:

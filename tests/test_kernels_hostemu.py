@@ -129,8 +129,9 @@ def test_loop_closure_pose_alignment(compute, absolute):
     pc.check_pose_alignment(DEV, compute, absolute)
 
 
-def test_loop_closure_pose_alignment_on_the_hash_model():
-    pc.check_pose_alignment_hash(DEV)
+@pytest.mark.parametrize("compute", ["fused", "autograd"])
+def test_loop_closure_pose_alignment_on_the_hash_model(compute):
+    pc.check_pose_alignment_hash(DEV, compute)
 
 
 def test_pose_alignment_falls_back_for_other_parameterisations():
