@@ -188,7 +188,7 @@ class Agent:
         return float(ret["psnr"].detach()[0]), float(l1)
 
 
-def cpu_baseline(cfg, n_keyframes, iters, seed=0, batch=None):
+def cpu_baseline(cfg, n_keyframes, iters, seed=0, batch=None, cores=None):
     """The oracle (CPU restatement of the reference's PyTorch path; checker code, reported baseline
     only) timed on this box's host cores on the same workload shape -- with ``batch`` = (rays_o, rays_d, rgb, depth, z_vals)
     on the very batch the device drew in its last timed iteration."""
@@ -199,7 +199,8 @@ def cpu_baseline(cfg, n_keyframes, iters, seed=0, batch=None):
         host_cores_usable = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         host_cores_usable = host_cores
-    cores = min(host_cores_usable, 32)        # more threads only add contention on the scatter-heavy backward
+    # 32 threads: more only add contention on the scatter-heavy backward (profiles/r05_cpu_threads.txt: 32 / 64 / 128 threads)
+    cores = min(host_cores_usable, 32) if cores is None else int(cores)
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(seed)
     bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)

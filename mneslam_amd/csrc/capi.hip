@@ -332,6 +332,8 @@ static int render_fused(bool ext_feat, const GridArgs* ext_grid, const mne_scene
     RenderHost host;
     host.ext_grid = ext_grid;
     if (const char* c = std::getenv("MNE_HOT_LDS_SAMPLES")) a.lds_samples = std::atoi(c);      // tests force the two-pass split on small S
+    if (const char* c = std::getenv("MNE_HEAVY_NTILE")) a.heavy_ntile = std::atoi(c);          // ... and the heavy-ray list (< 0: off)
+    if (const char* c = std::getenv("MNE_HEAVY_TILES")) a.heavy_min = std::atoi(c);
     if (opts) {
         if (opts->n_timing_events < 0 || opts->n_timing_events > 6 || (opts->n_timing_events > 0 && !opts->timing_events))
             return fail(-1, "mne_fused_opts: timing_events holds 0..6 event handles");

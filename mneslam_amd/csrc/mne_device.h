@@ -186,11 +186,10 @@ __device__ __forceinline__ float4 plane_row4(const mne_plane_t& pl, int e) {
     return *(const float4*)((const float*)pl.data + e);
 }
 
-template <int NSETS, bool F16>
+template <int NSETS, bool F16, int NLV = MNE_GATHER_INFLIGHT / 12>       // NLV: levels loaded together (12 corner rows each)
 __device__ __forceinline__ void gather_slot_t(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
     const int kmine = cg < 6 ? cg : cg - 6;                        // this lane's plane: k = lvl * 3 + ori
     const int lvl_m = kmine >= 3 ? 1 : 0, ori_m = kmine - 3 * lvl_m;
-    constexpr int NLV = MNE_GATHER_INFLIGHT / 12;                   // levels loaded together
 #pragma unroll
     for (int set = 0; set < NSETS; ++set) {
         int Hm = sc.plane[set][0][0].h, Wm = sc.plane[set][0][0].w;
@@ -246,19 +245,21 @@ __device__ __forceinline__ void gather_slot_t(const mne_scene_t& sc, float px, f
     }
 }
 
-template <int NSETS>
+template <int NSETS, int NLV = MNE_GATHER_INFLIGHT / 12>
 __device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
-    if (sc.plane_f16) gather_slot_t<NSETS, true>(sc, px, py, pz, cg, out, set_stride);       // (uniform over the launch)
-    else gather_slot_t<NSETS, false>(sc, px, py, pz, cg, out, set_stride);
+    if (sc.plane_f16) gather_slot_t<NSETS, true, NLV>(sc, px, py, pz, cg, out, set_stride);       // (uniform over the launch)
+    else gather_slot_t<NSETS, false, NLV>(sc, px, py, pz, cg, out, set_stride);
 }
 
-template <int NSETS, int NPTS>
+// (NLV = 2 -- both levels' 24 corner rows requested together -- was measured for the gathers INSIDE the tile kernels, where the
+// registers are free: no effect on the deferred decode, the resolver's extension tile or render_img, profiles/r05_inline_gather_levels.txt)
+template <int NSETS, int NPTS, int NLV = 1>
 __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane) {
     const int cg = lane & 7;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 8; ++it) {
         const int slot = it * 8 + (lane >> 3);
-        gather_slot<NSETS>(sc, pn[slot * 4 + 0], pn[slot * 4 + 1], pn[slot * 4 + 2], cg, feat + slot * MNE_FS, NPTS * MNE_FS);
+        gather_slot<NSETS, NLV>(sc, pn[slot * 4 + 0], pn[slot * 4 + 1], pn[slot * 4 + 2], cg, feat + slot * MNE_FS, NPTS * MNE_FS);
     }
 }
 

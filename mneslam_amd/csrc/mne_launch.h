@@ -97,6 +97,13 @@ struct RenderArgs {
     int* adapt;                 // optional [4] device words: [0] = decode every sample a priori in this call, [1] = rays the a-priori
                                 // prefix did / would not resolve (mne_fused_opts_t::adapt_state)
     TileBins bins;              // bins.lists != NULL: binned scatter instead of atomics into plane[].grad
+    // rays with more than heavy_min backward tiles (0 = never): the training kernel lists them with their gradient constants,
+    // heavy_bwd_kernel walks their tiles tile-parallel (render.hip)
+    int heavy_min;              // (in: 0 = the build's default, MNE_HEAVY_TILES)
+    int heavy_ntile;            // the heavy list exists for rays of more than this many tiles (0 = default MNE_HEAVY_NTILE, < 0 = never)
+    int* heavy_list;            // [R]
+    int* heavy_count;           // [1]
+    float* heavy_rec;           // [R][8]: denom, z_lim, Aq, g_dep | g_rgb[3], decoded samples (int bits)
 };
 
 // host-side extras of one training render (never part of a kernel argument block)

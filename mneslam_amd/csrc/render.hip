@@ -138,30 +138,29 @@ __device__ __forceinline__ void counts_reduce_block(const ZArgs& a, int (*part)[
         __syncthreads();
     }
     if (t < MNE_N_COUNT) a.counts[t] = part[0][t];
-    // Exclusive prefix of the rays' a-priori tile counts -> slot 7 of every ray's counts (decode_kernel hands its tile tasks
-    // out from it, balanced over the waves): thread t takes a contiguous block of rays, the blocks' sums are scanned in LDS.
+    // Exclusive prefix of the rays' a-priori tile counts -> slot MNE_C_TILE0 of every ray's counts (decode_kernel deals its
+    // tile tasks out from it, evenly over the waves): 256 rays per round, wave scan + the four waves' sums through LDS.
     __syncthreads();
-    const int ntile = (a.S + 31) / 32, per = (a.R + 255) / 256;
-    const int r0 = t * per < a.R ? t * per : a.R, r1 = r0 + per < a.R ? r0 + per : a.R;
-    int mine = 0;
-    for (int r = r0; r < r1; ++r) {
-        const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
-        const int tl = (need + 31) / 32;
-        mine += tl < 1 ? 1 : (tl > ntile ? ntile : tl);
-    }
-    part[t][0] = mine;
-    __syncthreads();
-    if (t == 0) {
-        int run = 0;
-        for (int k = 0; k < 256; ++k) { const int v = part[k][0]; part[k][0] = run; run += v; }
-    }
-    __syncthreads();
-    int run = part[t][0];
-    for (int r = r0; r < r1; ++r) {
-        const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
-        const int tl = (need + 31) / 32;
-        a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_TILE0] = run;
-        run += tl < 1 ? 1 : (tl > ntile ? ntile : tl);
+    const int ntile = (a.S + 31) / 32, lane = t & 63, wave = t >> 6;
+    int base = 0;
+    for (int r0 = 0; r0 < a.R; r0 += 256) {
+        const int r = r0 + t;
+        int v = 0;
+        if (r < a.R) {
+            const int tl = (a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED] + 31) / 32;
+            v = tl < 1 ? 1 : (tl > ntile ? ntile : tl);
+        }
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+        if (lane == 63) part[0][wave] = inc;
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int sw = part[0][w]; woff += w < wave ? sw : 0; total += sw; }
+        if (r < a.R) a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_TILE0] = base + woff + inc - v;
+        base += total;
+        __syncthreads();
     }
 }
 
@@ -410,6 +409,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
         if (a.bins.spill_count) *a.bins.spill_count = 0;
         if (a.defer_count) *a.defer_count = 0;
         if (a.long_count) *a.long_count = 0;
+        if (a.heavy_count) *a.heavy_count = 0;
     }
     if (a.ray_list && *a.ray_list_count == 0) return;      // second pass with nothing deferred (the usual case)
     if (ALDS) {                                            // stage the A tables: the only block-wide step
@@ -670,6 +670,122 @@ __device__ __forceinline__ unsigned run_meta(int w_, int lane) {
 // spilled 0.4-6 KiB per lane at 8 waves; it serves the 100-iteration pose loops of loop closure, not the mapping iteration)
 #define RAY_WPB(HID, CP, MODE) ((MODE) == 4 ? (((HID) == 64 && (CP)) ? MNE_HOT64CP_WPB : MAX_WPB_HOT) : (MODE) == 3 ? 4 : MAX_WPB_RAY)
 
+// One 32-sample tile of the TRAINING backward of ray r (tile c, samples [32 c, 32 c + 32) of the ray's Dn decoded ones): loss
+// and compositing gradients of every sample from the ray's constants G -> MFMA backward chain from the saved ReLU masks ->
+// backward half of the tape rows (d(pre-activations) for the decoder's weight gradients, d(feature) rows for the plane / table
+// update).  zsrc / rawsrc: the ray's z samples and raw (r,g,b,sdf) rows -- the wave's LDS copies in ray_kernel, global memory
+// in heavy_bwd_kernel.  pn / feat: the wave's LDS rows; atab: the backward tables (step BIAS onwards).
+template <int HID, int HIDC, bool CP, int BIAS, bool GTAB>
+__device__ __forceinline__ void hot_backward_tile(const RenderArgs& a, int r, int c, int Dn, const RayGrad& G, float td,
+                                                  const float (&ro)[3], const float (&rd)[3], const float (&cf)[MNE_N_LOSS],
+                                                  bool use_e, bool use_co, const float* zsrc, const float* rawsrc, int lane,
+                                                  float* pn, float* feat, const float* atab) {
+    typedef DecDims<HID, HIDC, CP> D;
+    constexpr int NT = HID / 32, NTC = HIDC / 32;
+    constexpr bool SEQ = CP, EARLY_DHC = HID == 64;       // see ray_kernel: one set of LDS rows / 32 registers less across the sdf chain
+    const int S = a.S, pt = lane & 31, hf = lane >> 5;
+    const bool has_t = a.target_d != nullptr;
+    const int i = c * TILE + pt;
+    const bool valid = i < Dn;
+    const int ii = valid ? i : Dn - 1;
+    const float z = zsrc[ii];
+    float p[3], pnv[3], u[3];
+    const size_t e = (size_t)r * S + ii;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) p[q] = ro[q] + rd[q] * z;
+    point_coords(a.sc, p, pnv, u);
+    const uint2 mk2 = *(const uint2*)(a.relu_mask + e * 4 + hf * 2);
+    // ---- d(total)/d(raw) of this point (both lanes of the pair compute the same values)
+    const float4 rw = *(const float4*)(rawsrc + 4 * ii);
+    const float s = rw.w;
+    float ds = 0.0f, dc[3] = {0.f, 0.f, 0.f};
+    bool contrib = false;
+    if (valid) {
+        if (z < G.z_lim) {
+            const float pp = sigmoidf_(s / a.trunc_f), qq = sigmoidf_(-s / a.trunc_f);
+            const float wt = pp * qq;
+            const float w = wt / G.denom;
+            const float sg[3] = {sigmoidf_(rw.x), sigmoidf_(rw.y), sigmoidf_(rw.z)};
+            const float dLdw = G.g_rgb[0] * sg[0] + G.g_rgb[1] * sg[1] + G.g_rgb[2] * sg[2] + G.g_dep * z;
+            ds += ((dLdw - G.Aq) / G.denom) * (wt * (qq - pp) / a.trunc_f);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) dc[q] = G.g_rgb[q] * w * (sg[q] * (1.0f - sg[q]));
+        }
+        const SampleMasks mk = sample_masks(z, td, has_t, a);
+        const float e_res = (z + s * a.e_T) - td, c_res = (z + s * a.win_f) - td;
+        if (mk.e_front) ds += cf[MNE_L_E_FS] * (s - 1.0f);
+        if (mk.e_center) ds += cf[MNE_L_E_CENTER] * e_res;
+        if (mk.e_tail) ds += cf[MNE_L_E_TAIL] * e_res;
+        if (mk.co_fs) ds += cf[MNE_L_CO_FS] * (s - 1.0f);
+        if (mk.co_sdf) ds += cf[MNE_L_CO_SDF] * c_res;
+        contrib = sample_contrib(z, G.z_lim, mk, use_e, use_co);
+    }
+    MNE_WAVE_SYNC();                                      // feat rows are about to be overwritten
+    // ---- MFMA backward chain from the saved ReLU masks; d(feature) rows land in this point's LDS rows.
+    // A sample without gradient has ds = dc = 0 and therefore an all-zero backward row.
+    float* frow = feat + pt * MNE_FS;
+    f32x16 dh[NT], dout, dhc[NTC];
+    const bool live = valid && contrib;
+    const unsigned live_rows = (unsigned)__ballot(live && hf == 0), valid_rows = (unsigned)__ballot(valid && hf == 0);
+    float* tape0 = a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW;
+    if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+    if (SEQ || EARLY_DHC) {
+        // colour net first; what it produces leaves for the tape before the sdf net's chain starts, so that its registers
+        // (and, with colour planes, its LDS rows) are free again
+        mlp_backward_color<HID, HIDC, CP, BIAS, GTAB>(mk2.y, ds, dc, atab, lane, dout, dhc, frow);
+        MNE_WAVE_SYNC();
+        if (SEQ) {
+            if (a.ext_feat) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT + MNE_FEAT, valid_rows, lane);
+            else if (a.plane_grads) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT + MNE_FEAT, live_rows, lane);
+            MNE_WAVE_SYNC();
+        }
+        if (EARLY_DHC) {
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) acc_to_row(frow, 32 * t, dhc[t], hf);
+            MNE_WAVE_SYNC();
+            store_rows<HIDC>(feat, tape0, D::ROW, D::T_DHC, valid_rows, lane);
+            MNE_WAVE_SYNC();
+        }
+        mlp_backward_sdf<HID, HIDC, CP, BIAS, GTAB>(mk2.x, atab, lane, dh, dout, frow);
+    } else {
+        mlp_backward_mfma<HID, HIDC, CP, BIAS, GTAB>(mk2.x, mk2.y, ds, dc, atab, lane, dh, dout, dhc, frow, frow);
+    }
+    MNE_WAVE_SYNC();
+    // ---- backward half of the tape rows, staged through the LDS rows (full-line stores, see store_rows)
+    if (a.ext_feat) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT, valid_rows, lane);         // caller-owned encoding: every valid sample
+    else if (a.plane_grads) store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_DFEAT, live_rows, lane);   // the samples that receive gradient
+    MNE_WAVE_SYNC();
+    if (HID == 32 && HIDC == 32) {
+        acc_to_row(frow, 0, dh[0], hf);
+        acc_to_row(frow, 32, dhc[0], hf);
+        MNE_WAVE_SYNC();
+        store_rows<64>(feat, tape0, D::ROW, D::T_DH, valid_rows, lane);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc_to_row(frow, 32 * t, dh[t], hf);
+        MNE_WAVE_SYNC();
+        store_rows<HID>(feat, tape0, D::ROW, D::T_DH, valid_rows, lane);
+        if (!EARLY_DHC) {
+            MNE_WAVE_SYNC();
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) acc_to_row(frow, 32 * t, dhc[t], hf);
+            MNE_WAVE_SYNC();
+            store_rows<HIDC>(feat, tape0, D::ROW, D::T_DHC, valid_rows, lane);
+        }
+    }
+    MNE_WAVE_SYNC();
+    acc_to_row(frow, 0, dout, hf, 8);                     // [dout 16 | dc 4 | pn 4 | pad 8]
+    if (hf == 0) {
+        *(float4*)(frow + 16) = make_float4(dc[0], dc[1], dc[2], 0.0f);
+        *(float4*)(frow + 20) = make_float4(pnv[0], pnv[1], pnv[2], live ? 1.0f : 0.0f);   // pn.w: the sample receives gradient (scatter_kernel)
+    } else {
+        *(float4*)(frow + 24) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)(frow + 28) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    MNE_WAVE_SYNC();
+    store_rows<32>(feat, tape0, D::ROW, D::T_DOUT, valid_rows, lane);
+}
+
 template <int HID, int HIDC, bool CP, bool ALDS, int MODE>
 __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(RenderArgs a) {
     typedef DecDims<HID, HIDC, CP> D;
@@ -806,6 +922,18 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
         if (lane == 0) {
             if (a.ray_tiles) a.ray_tiles[r] = nb;
             if (a.tape_rows && n_contrib) atomicAdd(a.tape_rows, n_contrib);
+        }
+        if (HOT && a.heavy_min > 0 && nb > a.heavy_min) {
+            // A ray with many backward tiles: its tiles go to heavy_bwd_kernel, tile-parallel and evenly dealt, instead of being
+            // walked one after the other by this wave (INS Indoor: up to 33 tiles per ray; the launch was as long as its
+            // longest ray).  What the tiles need of the ray: the gradient constants and the decoded sample count.
+            if (lane == 0) {
+                a.heavy_list[atomicAdd(a.heavy_count, 1)] = r;
+                float4* rec = (float4*)(a.heavy_rec + (size_t)r * 8);
+                rec[0] = make_float4(G.denom, G.z_lim, G.Aq, G.g_dep);
+                rec[1] = make_float4(G.g_rgb[0], G.g_rgb[1], G.g_rgb[2], __uint_as_float((unsigned)Dn));
+            }
+            continue;
         }
         float ray_do[3] = {0.f, 0.f, 0.f}, ray_dd[3] = {0.f, 0.f, 0.f};
         for (int c = 0; c < nb; ++c) {
@@ -965,6 +1093,74 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
 }
 
 // -----------------------------------------------------------------------------------------------
+// heavy_bwd_kernel: the backward tiles of the rays the training kernel put on its heavy list (more than heavy_min tiles:
+// long rays -- INS Indoor samples 1045 points per ray), TILE-parallel: the exclusive prefix of the listed rays' tile counts
+// is built in LDS by every workgroup, wave w takes tiles w, w + W, ... and finds the ray of a tile by binary search (the
+// schedule of decode_kernel).  One wave per ray made the ray launches as long as the longest ray's 10-30 tiles in sequence
+// (Indoor: 134 + 153 + 81 us for the three ray launches of an iteration, profiles/r05_timeline_indoor.txt) while most waves
+// had long finished; here every wave gets the same number of tiles, and no wave carries a ray's raw / z arrays in LDS, so
+// twelve waves fit on a CU whatever S is.
+// -----------------------------------------------------------------------------------------------
+template <int HID, int HIDC, bool CP>
+__global__ __launch_bounds__(64 * RAY_WPB(HID, CP, 4)) void heavy_bwd_kernel(RenderArgs a) {
+    typedef ATab<HID, HIDC, CP> T;
+    constexpr int TAB_FIRST = T::FWD_STEPS, TAB_FLOATS = (T::TOTAL - T::FWD_STEPS) * 64;
+    MNE_DYN_LDS(lds_raw);
+    const int n_heavy = *a.heavy_count;
+    if (n_heavy == 0) return;
+    {
+        float4* dst = (float4*)lds_raw;
+        const float4* src = (const float4*)(a.packed + TAB_FIRST * 64);
+        for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    const float* atab = (const float*)lds_raw;
+    const int wpb = blockDim.x >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int* tstart = (int*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wpb * tile_wave_lds_bytes(1));     // [n_heavy + 1]
+    for (int j = threadIdx.x; j < n_heavy; j += blockDim.x) tstart[j] = a.ray_tiles[a.heavy_list[j]];
+    __syncthreads();
+    if (wv == 0) {                                         // exclusive prefix: lane l scans a contiguous stretch, the wave its 64 sums
+        const int per = (n_heavy + 63) / 64, j0 = lane * per < n_heavy ? lane * per : n_heavy, j1 = j0 + per < n_heavy ? j0 + per : n_heavy;
+        int sum = 0;
+        for (int j = j0; j < j1; ++j) sum += tstart[j];
+        int inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+        int run = inc - sum;
+        for (int j = j0; j < j1; ++j) { const int v = tstart[j]; tstart[j] = run; run += v; }
+        if (lane == 63) tstart[n_heavy] = inc;
+    }
+    __syncthreads();
+    const int total = tstart[n_heavy];
+    float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(1));
+    float* feat = pn + TILE * 4;
+    const bool has_t = a.target_d != nullptr;
+    float cf[MNE_N_LOSS];
+#pragma unroll
+    for (int q = 0; q < MNE_N_LOSS; ++q) cf[q] = a.coef ? a.coef[q] : 0.0f;
+    const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
+    const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
+    for (int task = blockIdx.x * wpb + wv; task < total; task += gridDim.x * wpb) {
+        int lo = 0, hi = n_heavy - 1;                      // last listed ray whose first tile is <= task
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tstart[mid] <= task) lo = mid; else hi = mid - 1;
+        }
+        const int r = a.heavy_list[lo], c = task - tstart[lo];
+        const float4 g0 = *(const float4*)(a.heavy_rec + (size_t)r * 8), g1 = *(const float4*)(a.heavy_rec + (size_t)r * 8 + 4);
+        RayGrad G;
+        G.denom = g0.x; G.z_lim = g0.y; G.Aq = g0.z; G.g_dep = g0.w;
+        G.g_rgb[0] = g1.x; G.g_rgb[1] = g1.y; G.g_rgb[2] = g1.z;
+        const int Dn = (int)__float_as_uint(g1.w);
+        const float td = has_t ? a.target_d[r] : 0.0f;
+        float ro[3], rd[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { ro[q] = a.rays_o[r * 3 + q]; rd[q] = a.rays_d[r * 3 + q]; }
+        hot_backward_tile<HID, HIDC, CP, TAB_FIRST, false>(a, r, c, Dn, G, td, ro, rd, cf, use_e, use_co, a.z_vals + (size_t)r * a.S,
+                                                           a.raw + (size_t)r * a.S * 4, lane, pn, feat, atab);
+    }
+}
+
+// -----------------------------------------------------------------------------------------------
 // List appends of the binned plane update (tile_adam.hip).
 // append_tile: the 32 samples of one (ray, tile) held by a wave, lane = (sample, plane level): every sample that receives
 // gradient (`live`) is appended to the list of every 16x16-cell plane tile its 2x2 footprints touch.
@@ -1067,6 +1263,12 @@ __device__ __forceinline__ int first_crossing_g(const float* raw_ray, int D, int
 //       adaptive-schedule word adapt[0], which the LAST ray launch of the render call rewrites for the next call while pass 0
 //       may still be running (prefix_tiles() reads it: bin_kernel therefore calls it only for list passes, where it returns
 //       ntile before looking at adapt, and without dec_tiles).
+#ifndef BIN_WPR
+#define BIN_WPR 4               // waves of a workgroup that share one ray's tiles (1, 2 or 4)
+#endif
+#ifndef BIN_WG_PER_CU
+#define BIN_WG_PER_CU 8         // grid cap of the appends (x 4 waves = every wave slot); long-ray batches: one workgroup per CU
+#endif
 template <bool CP>
 __global__ __launch_bounds__(256) void bin_kernel(RenderArgs a) {
     constexpr int NSETS = CP ? 2 : 1;
@@ -1081,7 +1283,13 @@ __global__ __launch_bounds__(256) void bin_kernel(RenderArgs a) {
     const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
     const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
     const int n_items = a.ray_list ? *a.ray_list_count : a.R;
-    for (int item = blockIdx.x * 4 + wv; item < n_items; item += gridDim.x * 4) {
+    // BIN_WPR waves share a ray: each derives the ray's first sign change / render window itself (a few loads) and takes
+    // every BIN_WPR-th decoded tile.  With one wave per ray the kernel was as long as the longest ray's walk -- a chain of
+    // atomic round trips per tile: 72 us on office0 (<= 4 tiles per ray), 176 us on ScanNet, 249 us on INS Indoor (up to 33
+    // tiles per ray) -- beside a ray kernel that needs the same time or less (profiles/r05_bin_waves_per_ray.txt).
+    constexpr int RPB = 4 / BIN_WPR;                                   // rays per workgroup
+    const int wr = wv / BIN_WPR, wt = wv % BIN_WPR;
+    for (int item = blockIdx.x * RPB + wr; item < n_items; item += gridDim.x * RPB) {
         const int r = a.ray_list ? a.ray_list[item] : item;
         const float td = has_t ? a.target_d[r] : 0.0f;
         const float* zr = a.z_vals + (size_t)r * S;
@@ -1099,7 +1307,7 @@ __global__ __launch_bounds__(256) void bin_kernel(RenderArgs a) {
         // therefore starts at a different tile of its own and wraps around, which spreads those reservations over the
         // kernel's run time instead of queueing them all at its start.
         const int c0 = (int)((unsigned)r % (unsigned)t_dec);
-        for (int k = 0; k < t_dec; ++k) {
+        for (int k = wt; k < t_dec; k += BIN_WPR) {
             const int c = c0 + k < t_dec ? c0 + k : c0 + k - t_dec;
             const int i = c * TILE + pt;
             const bool valid = i < Dn;
@@ -1379,7 +1587,7 @@ static int fit_waves(size_t tab, size_t per_wave, int max_wpb) {
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 // backward workspace: ReLU masks [R*S][4] u32 | deferred-ray list [R] | its length [1]
 size_t mne_render_workspace(int R, int S) {
-    return align16((size_t)R * S * 4 * sizeof(unsigned)) + 3 * align16((size_t)R * sizeof(int)) + 32;
+    return align16((size_t)R * S * 4 * sizeof(unsigned)) + 4 * align16((size_t)R * sizeof(int)) + align16((size_t)R * 8 * sizeof(float)) + 32;
 }
 static void carve_workspace(RenderArgs& a, void* ws) {
     unsigned char* p = (unsigned char*)ws;
@@ -1387,7 +1595,10 @@ static void carve_workspace(RenderArgs& a, void* ws) {
     a.defer_list = (int*)p; p += align16((size_t)a.R * sizeof(int));
     a.dec_tiles = (int*)p; p += align16((size_t)a.R * sizeof(int));
     a.long_list = (int*)p; p += align16((size_t)a.R * sizeof(int));
+    a.heavy_list = (int*)p; p += align16((size_t)a.R * sizeof(int));
+    a.heavy_rec = (float*)p; p += align16((size_t)a.R * 8 * sizeof(float));
     a.defer_count = (int*)p;
+    a.heavy_count = (int*)(p + 8);
     a.long_count = (int*)(p + 16);
 }
 
@@ -1463,6 +1674,25 @@ static inline void mark(const RenderHost& h, int i, hipStream_t st) {
 #define MNE_LIST_PASS_BLOCKS 64
 #endif
 
+#ifndef MNE_HEAVY_NTILE
+#define MNE_HEAVY_NTILE 8       // rays of more than this many 32-sample tiles: the heavy list exists
+#endif
+#ifndef MNE_HEAVY_TILES
+#define MNE_HEAVY_TILES 2       // ... and takes the rays with more than this many backward tiles (0: never)
+#endif
+template <int HID, int HIDC, bool CP>
+static int launch_heavy(const RenderArgs& a, hipStream_t st) {
+    typedef ATab<HID, HIDC, CP> T;
+    const size_t tab = (size_t)(T::TOTAL - T::FWD_STEPS) * 64 * sizeof(float);
+    const size_t sched = align16((size_t)(a.R + 1) * sizeof(int));
+    const int wpb = fit_waves<HID, HIDC, CP>(tab + sched, tile_wave_lds_bytes(1), RAY_WPB(HID, CP, 4));
+    if (wpb < 1) return -4;
+    const size_t lds = tab + (size_t)wpb * tile_wave_lds_bytes(1) + sched;
+    if (lds > 64 * 1024) MNE_SET_MAX_LDS((heavy_bwd_kernel<HID, HIDC, CP>), MNE_LDS_MAX);
+    MNE_LAUNCH((heavy_bwd_kernel<HID, HIDC, CP>), MNE_NUM_CU, 64 * wpb, lds, st, a);
+    return 0;
+}
+
 // pre = true: the a-priori tiles' plane features are gathered by gather_kernel first (needs the tape)
 template <int HID, int HIDC, bool CP>
 static int launch_decode(RenderArgs d, hipStream_t st, const RenderHost& host, bool pre = false) {
@@ -1503,8 +1733,15 @@ template <bool CP>
 static int launch_bin(RenderArgs b, int pass, hipStream_t st) {
     if (pass) { b.ray_list = b.defer_list; b.ray_list_count = b.defer_count; }
     else { b.ray_list = nullptr; b.ray_list_count = nullptr; }
-    long long grid = ((long long)b.R + 3) / 4;
-    if (grid > MNE_NUM_CU * 8) grid = MNE_NUM_CU * 8;
+    constexpr int rpb = 4 / BIN_WPR;
+    long long grid = ((long long)b.R + rpb - 1) / rpb;
+    // The appends are bound by the returning atomics, not by the number of waves -- and pass 0 runs BESIDE the ray kernels,
+    // which need wave slots of their own: with every slot of the chip taken by this kernel (2048 workgroups) INS Indoor's
+    // long-ray pass sat waiting until the appends had drained (profiles/r05_timeline_indoor_heavy.txt).
+    // (measured, profiles/r05_bin_grid_cap.txt: Indoor 1074-1094 it/s with 8 workgroups per CU, 1135 with one; office0 prefers
+    // the full grid -- its appends are as long as its ray kernel, 2113-2129 vs 2020 it/s)
+    const int per_cu = (b.S + TILE - 1) / TILE > MNE_HEAVY_NTILE ? 1 : BIN_WG_PER_CU;
+    if (grid > (long long)MNE_NUM_CU * per_cu) grid = (long long)MNE_NUM_CU * per_cu;
     if (pass && grid > MNE_LIST_PASS_BLOCKS) grid = MNE_LIST_PASS_BLOCKS;
     MNE_LAUNCH((bin_kernel<CP>), (unsigned)grid, 256, 0, st, b);
     return 0;
@@ -1569,6 +1806,13 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         // full kernel, driven by the deferred list (a handful of workgroups that leave at once when the list is empty)
         mark(host, 2, st);
         if (host.ev_after_decode) (void)hipEventRecord((hipEvent_t)host.ev_after_decode, st);      // the caller's bin pass 0 may start
+        // long rays (more than MNE_HEAVY_NTILE tiles per ray, e.g. INS Indoor's 33): a ray with more than MNE_HEAVY_TILES
+        // backward tiles is only composited by the ray kernels; heavy_bwd_kernel walks the listed rays' tiles afterwards
+        {
+            const int ntile_min = a.heavy_ntile > 0 ? a.heavy_ntile : MNE_HEAVY_NTILE;       // (tests lower both on small S)
+            const int tiles = a.heavy_min > 0 ? a.heavy_min : MNE_HEAVY_TILES;
+            a.heavy_min = (tiles > 0 && (a.S + TILE - 1) / TILE > ntile_min && a.heavy_ntile >= 0) ? tiles : 0;
+        }
         if (int rc = launch_ray<HID, HIDC, CP, 4>(a, st)) return rc;
         if (ray_lds_cap(a) < a.S) {        // long rays: those whose decoded prefix exceeded the first pass's LDS, same kernel sized for S
             RenderArgs l = a;
@@ -1586,6 +1830,8 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         launch_decode<HID, HIDC, CP>(d, st, host);         // their remaining tiles, tile-parallel
         d.adapt_update = 1;                                // the last ray launch of the call decides the next call's schedule
         if (int rc = launch_ray<HID, HIDC, CP, 4>(d, st, MNE_LIST_PASS_BLOCKS / 2)) return rc;    // the same lean kernel: now every listed ray resolves
+        if (a.heavy_min)
+            if (int rc = launch_heavy<HID, HIDC, CP>(a, st)) return rc;
         mark(host, 4, st);
         if (a.bins.lists) {                                // list appends: the resolved rays' (pass 0) here unless the host runs
             if (!host.external_bin) launch_bin<CP>(a, 0, st);   // them beside the backward (mne_tile_bin on a second stream);

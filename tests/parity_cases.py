@@ -930,7 +930,7 @@ def check_fused_step_vs_oracle(device, cfg, n_keyframes=4, seed=3, warm_steps=0,
     if fs.bins is not None:                # (the deferred-list length of the call sits in the render workspace, behind the lists)
         import struct
         a16 = lambda x: (x + 15) & ~15
-        off_cnt = a16(R * S * 16) + 3 * a16(R * 4)
+        off_cnt = a16(R * S * 16) + 4 * a16(R * 4) + a16(R * 32)      # masks | deferred, decoded-tile, long, heavy lists | heavy records
         n_defer = struct.unpack("i", bytes(cpu(fs.ws)[off_cnt:off_cnt + 4].tolist()))[0]
     return {"R": R, "S": S, "contributing": int(fs.tape_rows.item()), "adam_stats": stats, "deferred_rays": n_defer,
             "rgb_l1": float((rgb - ret["rgb"].detach()).abs().mean()), "depth_l1": float((depth - ret["depth"].detach()).abs().mean())}

@@ -336,3 +336,18 @@ def test_bench_path_step_with_capped_ray_lds(monkeypatch):
     monkeypatch.setenv("MNE_HOT_LDS_SAMPLES", "16")
     out = pc.check_fused_step_vs_oracle(DEV, _tiny_bench_cfg(), n_keyframes=3, seed=2, small=True, impl="explicit")
     assert out["contributing"] > 0
+
+
+@pytest.mark.parametrize("capped", [False, True])
+def test_bench_path_step_with_heavy_ray_list(monkeypatch, capped):
+    """Rays with many backward tiles leave them to heavy_bwd_kernel (tile-parallel; INS Indoor: 33 tiles per ray).  Forced here
+    on S = 111 (4 tiles): every ray with more than ONE backward tile goes to the heavy list -- from the first ray pass, from the
+    long-ray pass (capped: 48 samples of a ray in LDS) and from the deferred pass alike."""
+    monkeypatch.setenv("MNE_HEAVY_NTILE", "1")
+    monkeypatch.setenv("MNE_HEAVY_TILES", "1")
+    if capped:
+        monkeypatch.setenv("MNE_HOT_LDS_SAMPLES", "48")
+    cfg = _tiny_bench_cfg()
+    cfg["training"]["n_samples_d"], cfg["training"]["n_range_d"] = 100, 11
+    out = pc.check_fused_step_vs_oracle(DEV, cfg, n_keyframes=3, seed=2, small=True, impl="explicit")
+    assert out["contributing"] > 0
