@@ -1172,6 +1172,13 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, 4)) void heavy_bwd_kernel(Ren
 // atomics (one per run of samples in the same list; ~60 us of same-address serialisation on the tiles around the camera
 // centres, profiles/r03_bin_ablation.txt) sat on the critical path of every ray.
 // -----------------------------------------------------------------------------------------------
+#ifdef BIN_XCD_EXPERIMENT
+__device__ __forceinline__ int bin_xcc_id() {
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7;
+}
+#endif
 template <int NSETS>
 __device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&pnv)[3], bool live, size_t e, int lane, int hf) {
 #pragma unroll 1
@@ -1214,7 +1221,11 @@ __device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&p
 #pragma unroll
         for (int q = 0; q < NJ * 4; ++q) {
             first_slot[q] = 0;
+#ifdef BIN_XCD_EXPERIMENT      // timing experiment only (results are wrong): one cursor per (list, XCD)
+            if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q] * 8 + bin_xcc_id(), (int)(meta[q] >> 16));
+#else
             if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q], (int)(meta[q] >> 16));
+#endif
         }
         const unsigned trow = (unsigned)e;                 // tape row of this sample
 #pragma unroll
