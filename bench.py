@@ -308,8 +308,8 @@ def render_img_measure(agent, cfg, device, n_pairs, n_warm):
                         "bound": "mfma_f32", "flops_per_pair": flops, "flop_per_decoded_sample": flop_per_sample,
                         "achieved": flops / (own / n_pairs) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (own / n_pairs) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                        "note": "useful MLP flops of the decoded samples only; the kernel's own time is dominated by the inline "
-                                "gather's dependent load rounds and the OneBlob, not by the matrix pipe (DESIGN.md 3.6)"}}
+                        "note": "useful MLP flops of the decoded samples only; the kernel is not bound by the matrix pipe (nor by the "
+                                "number of load rounds of its inline gather: DESIGN.md 3.6)"}}
     return own, rec
 
 
@@ -762,18 +762,16 @@ def main():
             del agent
             torch.cuda.empty_cache()
             out["variants"] = {}
-            try:                          # N1 on the record: the two full-frame renders of a keyframe, on a map of 100 iterations
-                ragent = Agent(cfg, device, seed=0, n_keyframes=args.keyframes)
-                for _ in range(100):
-                    ragent.step()
-                torch.cuda.synchronize()
-                own, rec = render_img_measure(ragent, cfg, device, n_pairs=5, n_warm=1)
-                out["variants"]["render_img"] = dict({"workload": workload + "_render_img", "pretrain_iterations": 100,
-                                                      "value": 5 / own, "unit": "frame pairs/s", "ms_per_pair": 1e3 * own / 5}, **rec)
-                del ragent
-                torch.cuda.empty_cache()
-            except Exception as e:    # noqa: BLE001
-                out["variants"]["render_img"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            for name, c, h, gr in VARIANTS:
+                if c == args.config and (h or args.hidden) == args.hidden and gr == args.graph:
+                    continue
+                try:                      # a side record must never cost the metric's line
+                    out["variants"][name] = run_variant(c, h, device, args.keyframes, graph=gr, name=name)
+                except Exception as e:    # noqa: BLE001
+                    out["variants"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # (render_img comes LAST: the full-frame renders allocate and free several GB of scratch, and workloads measured after them
+            # in the same process ran 20-25 % slower than stand-alone -- INS Indoor 830 vs 1110 it/s, office0 with fp16 storage 1716 vs
+            # 1964, first_frame_mapping 1580 vs 1950 -- in positions that changed with the order of the records)
             try:        # the reference's first_frame_mapping: mapping.first_iters (500) iterations on ONE frame, from a fresh map
                 fagent = Agent(cfg, device, seed=1, n_keyframes=1)
                 n_first, n_ray = cfg["mapping"]["first_iters"], cfg["mapping"]["sample"]
@@ -794,13 +792,18 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:    # noqa: BLE001
                 out["variants"]["first_frame_mapping"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            for name, c, h, gr in VARIANTS:
-                if c == args.config and (h or args.hidden) == args.hidden and gr == args.graph:
-                    continue
-                try:                      # a side record must never cost the metric's line
-                    out["variants"][name] = run_variant(c, h, device, args.keyframes, graph=gr, name=name)
-                except Exception as e:    # noqa: BLE001
-                    out["variants"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:                          # N1 on the record: the two full-frame renders of a keyframe, on a map of 100 iterations
+                ragent = Agent(cfg, device, seed=0, n_keyframes=args.keyframes)
+                for _ in range(100):
+                    ragent.step()
+                torch.cuda.synchronize()
+                own, rec = render_img_measure(ragent, cfg, device, n_pairs=5, n_warm=1)
+                out["variants"]["render_img"] = dict({"workload": workload + "_render_img", "pretrain_iterations": 100,
+                                                      "value": 5 / own, "unit": "frame pairs/s", "ms_per_pair": 1e3 * own / 5}, **rec)
+                del ragent
+                torch.cuda.empty_cache()
+            except Exception as e:    # noqa: BLE001
+                out["variants"]["render_img"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if per_rank:
             out["per_rank"] = per_rank
             if split:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MNE_ABI_VERSION 6
+#define MNE_ABI_VERSION 7
 
 /* orientation index of a plane triple, as in JointEncoding.all_planes (scene_rep.py:117) */
 enum { MNE_XY = 0, MNE_XZ = 1, MNE_YZ = 2 };
@@ -96,7 +96,10 @@ typedef struct mne_render_cfg {
  * mne_tile_adam call leaves counts zeroed again; mne_render_fused zeroes *spill_count itself). */
 typedef struct mne_tile_bins {
     uint32_t* lists;       /* [mne_tile_list_entries()][8] = [mne_tile_count()][cap][8] with one capacity: tape row, packed local corner, 4 weights, tile id, 0 (32-byte entries) */
-    int32_t* counts;       /* [mne_tile_count()] */
+    int32_t* counts;       /* [mne_tile_count()][mne_tile_list_segments()]: ABI 7 -- every list is cut into mne_tile_list_segments() = 8 equal
+                            * segments, one per XCD of the MI355X, each with its own cursor (the appending waves of an XCD use their own:
+                            * returning atomics on one address retire one after the other).  A list's capacity is rounded down to a
+                            * multiple of the segment count. */
     uint32_t* spill;       /* [spill_cap][8] overflow entries (same layout) */
     int32_t* spill_count;  /* [1] */
     int32_t* order;        /* [mne_tile_count()] scratch: tile processing order (heaviest first) */
@@ -376,6 +379,7 @@ int mne_tile_bin(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_ra
  * (mneslam_mp.py:459-469) with no gradient buffer and no global atomics.  opt[] has 6*n_sets entries.
  * Entries reference tape rows (ray * n_samples + sample). */
 size_t mne_tile_count(const mne_scene_t* scene);
+int mne_tile_list_segments(void);     /* cursors per tile list (8) */
 /* Entries `bins->lists` must hold for this scene with bins->cap / bins->plane_cap (0 on invalid arguments). */
 size_t mne_tile_list_entries(const mne_scene_t* scene, const mne_tile_bins_t* bins);
 /* Processing order of the tiles for the next mne_tile_adam call (bins->order): longest lists first, so the

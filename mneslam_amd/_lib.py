@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmneslam_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 N_LOSS = 8
 N_COUNT = 8
 C_NEED = 6
@@ -53,6 +53,7 @@ class TileBins(C.Structure):
                 ("plane_cap", C.c_int32 * 12)]
 
 
+LIST_SEGMENTS = 8              # cursors per tile list (re-read from mne_tile_list_segments() at load time)
 TILE_SPLIT_PARTS = 2048
 TILE_ORDER_SNAPSHOT = 20480
 MAX_OVERLAP_PEERS = 2
@@ -150,6 +151,7 @@ _PROTOS = {
     "mne_tile_bin": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 7
                      + [C.POINTER(TileBins), C.c_void_p, C.c_size_t, C.c_int, C.POINTER(FusedOpts), C.c_void_p]),
     "mne_tile_count": (C.c_size_t, [C.POINTER(Scene)]),
+    "mne_tile_list_segments": (C.c_int, []),
     "mne_tile_list_entries": (C.c_size_t, [C.POINTER(Scene), C.POINTER(TileBins)]),
     "mne_sizeof_tile_overlap": (C.c_size_t, []),
     "mne_sizeof_pose_state": (C.c_size_t, []),
@@ -212,6 +214,8 @@ def load(path=None):
             fn.restype, fn.argtypes = res, args
         if lib.mne_abi_version() != ABI_VERSION:
             raise RuntimeError("libmneslam_hip ABI version mismatch")
+        global LIST_SEGMENTS
+        LIST_SEGMENTS = int(lib.mne_tile_list_segments())      # (8 in the shipped build; experiment builds may differ)
         for fn, st in ((lib.mne_sizeof_scene, Scene), (lib.mne_sizeof_render_cfg, RenderCfg),
                        (lib.mne_sizeof_adam_seg, AdamSeg), (lib.mne_sizeof_tile_bins, TileBins),
                        (lib.mne_sizeof_plane_opt, PlaneOpt), (lib.mne_sizeof_clock, Clock),

@@ -216,7 +216,8 @@ size_t mne_render_workspace_bytes(int n_rays, int n_samples) {
 static size_t list_layout(const mne_scene_t& sc, const mne_tile_bins_t* bins, TileBins& out) {
     long long off = 0;
     for (int p = 0; p < MNE_MAX_PLANES; ++p) {
-        const int cap = (p < sc.n_sets * 6 && bins->plane_cap[p] > 0) ? bins->plane_cap[p] : bins->cap;
+        int cap = (p < sc.n_sets * 6 && bins->plane_cap[p] > 0) ? bins->plane_cap[p] : bins->cap;
+        cap = cap < MNE_LIST_SEGMENTS ? MNE_LIST_SEGMENTS : cap - cap % MNE_LIST_SEGMENTS;      // MNE_LIST_SEGMENTS equal segments per list
         out.pcap[p] = cap;
         out.list_off[p] = off - (long long)out.tile_base[p] * cap;
         off += (long long)(out.tile_base[p + 1] - out.tile_base[p]) * cap;
@@ -400,6 +401,8 @@ int mne_tile_bin(const mne_scene_t* scene, const mne_render_cfg_t* cfg, int n_ra
     mne_launch_bin(a, pass, workspace, (hipStream_t)stream);
     return check_launch("tile_bin");
 }
+
+int mne_tile_list_segments(void) { return MNE_LIST_SEGMENTS; }
 
 size_t mne_tile_count(const mne_scene_t* scene) {
     if (!scene || (scene->n_sets != 1 && scene->n_sets != 2)) return 0;

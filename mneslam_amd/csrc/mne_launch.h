@@ -32,9 +32,17 @@ struct ZArgs {
 #define MNE_ENTRY_WORDS 8       // list / spill entry (32 B): tape row | (lx+1)|(ly+1)<<8 | 4 bilinear weights | tile id | 0
 #define MNE_SPILL_WORDS 8
 
+// Every tile list is cut into MNE_LIST_SEGMENTS = 8 segments, one per XCD, each with its own cursor: the waves of one XCD
+// append to their own segment.  Returning atomics on ONE address retire one after the other at ~12 ns each
+// (profiles/r05_xcd_atomics.txt) and every ray of a keyframe passes through the few tiles around its camera centre; eight
+// cursors per list divide that queue by eight (bin_kernel 68 -> 50 us on office0, 153 -> 108 on ScanNet, 268 -> 160 on INS
+// Indoor in the timing experiment, profiles/r05_bin_xcd_experiment.txt).
+#ifndef MNE_LIST_SEGMENTS
+#define MNE_LIST_SEGMENTS 8
+#endif
 struct TileBins {
-    unsigned* lists;          // [n_tiles][cap][MNE_ENTRY_WORDS]
-    int* counts;              // [n_tiles] cursors (reset by tile_adam_kernel)
+    unsigned* lists;          // [n_tiles][MNE_LIST_SEGMENTS][cap / MNE_LIST_SEGMENTS][MNE_ENTRY_WORDS]
+    int* counts;              // [n_tiles][MNE_LIST_SEGMENTS] cursors (reset by tile_adam_kernel)
     unsigned* spill;          // [spill_cap][MNE_SPILL_WORDS] overflow entries
     int* spill_count;
     int* order;               // [n_tiles] processing order of tile_adam_kernel (heaviest lists first)

@@ -37,6 +37,12 @@ static __device__ __forceinline__ int mne_bcast8(int v, int k) {
     }
 }
 static __device__ __forceinline__ float mne_bcast8(float v, int k) { return __int_as_float(mne_bcast8(__float_as_int(v), k)); }
+// The XCD (accelerator complex die, 0..7 on MI355X) this wave runs on: hardware register XCC_ID.
+static __device__ __forceinline__ int mne_xcc_id() {
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7;
+}
 // LDS hand-off between the lanes of ONE wave (each wave owns a private LDS region): DS operations of
 // a wave complete in issue order, so draining lgkmcnt and pinning the compiler's order is enough --
 // no s_barrier, the four waves of a workgroup never wait for each other.

@@ -1172,13 +1172,6 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, 4)) void heavy_bwd_kernel(Ren
 // atomics (one per run of samples in the same list; ~60 us of same-address serialisation on the tiles around the camera
 // centres, profiles/r03_bin_ablation.txt) sat on the critical path of every ray.
 // -----------------------------------------------------------------------------------------------
-#ifdef BIN_XCD_EXPERIMENT
-__device__ __forceinline__ int bin_xcc_id() {
-    int v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 7;
-}
-#endif
 template <int NSETS>
 __device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&pnv)[3], bool live, size_t e, int lane, int hf) {
 #pragma unroll 1
@@ -1218,14 +1211,12 @@ __device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&p
             pcap[j] = a.bins.pcap[pidx]; loff[j] = a.bins.list_off[pidx];
         }
         int first_slot[NJ * 4];
+        const int xcc = mne_xcc_id();
 #pragma unroll
         for (int q = 0; q < NJ * 4; ++q) {
             first_slot[q] = 0;
-#ifdef BIN_XCD_EXPERIMENT      // timing experiment only (results are wrong): one cursor per (list, XCD)
-            if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q] * 8 + bin_xcc_id(), (int)(meta[q] >> 16));
-#else
-            if (want[q] >= 0 && (int)(meta[q] & 255u) == lane) first_slot[q] = atomicAdd(a.bins.counts + want[q], (int)(meta[q] >> 16));
-#endif
+            if (want[q] >= 0 && (int)(meta[q] & 255u) == lane)
+                first_slot[q] = atomicAdd(a.bins.counts + want[q] * MNE_LIST_SEGMENTS + xcc, (int)(meta[q] >> 16));      // this XCD's segment of the list
         }
         const unsigned trow = (unsigned)e;                 // tape row of this sample
 #pragma unroll
@@ -1234,7 +1225,8 @@ __device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&p
             if (want[eq] >= 0) {
                 const int slot = f0 + (int)((meta[eq] >> 8) & 255u);
                 unsigned* dst = nullptr;
-                if (slot < pcap[eq >> 2]) dst = a.bins.lists + (size_t)(loff[eq >> 2] + (long long)want[eq] * pcap[eq >> 2] + slot) * MNE_ENTRY_WORDS;
+                const int seg_cap = pcap[eq >> 2] / MNE_LIST_SEGMENTS;
+                if (slot < seg_cap) dst = a.bins.lists + (size_t)(loff[eq >> 2] + (long long)want[eq] * pcap[eq >> 2] + (long long)xcc * seg_cap + slot) * MNE_ENTRY_WORDS;
                 else {
                     const int sp = atomicAdd(a.bins.spill_count, 1);
                     if (sp < a.bins.spill_cap) dst = a.bins.spill + (size_t)sp * MNE_ENTRY_WORDS;

@@ -91,7 +91,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
     // then cut into a few more parts than its in-list entries need, which is harmless; finding the plane of every tile
     // here cost 8 us of this latency-critical kernel.)
     auto length0 = [&](int t) {
-        const int c = a.bins.counts[t];
+        int c = 0;                                                   // the list's segments, one per XCD
+#pragma unroll
+        for (int x = 0; x < MNE_LIST_SEGMENTS; ++x) c += a.bins.counts[(size_t)t * MNE_LIST_SEGMENTS + x];
         if (!a.prev_counts) return c;
         const int p = a.prev_counts[t];
         return c > p ? c : p;
@@ -189,7 +191,25 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     const mne_plane_t& pl = a.sc.plane[set][(pidx % 6) / 2][lvl];
     const int local = tile - a.bins.tile_base[pidx];
     const int tx0 = local % a.bins.ntx[pidx], ty0 = local / a.bins.ntx[pidx];
-    const int cnt = a.bins.counts[tile];
+    // the list's MNE_LIST_SEGMENTS segments (one per XCD, appended to by that XCD's waves): cursor of each, entries it holds
+    // (a cursor beyond the segment's capacity = the rest of its entries went to the spill area), start of each in the flat
+    // entry numbering of the list
+    const int cap = a.bins.pcap[pidx], seg_cap = cap / MNE_LIST_SEGMENTS;
+    int seg_start[MNE_LIST_SEGMENTS + 1];
+    int cnt = 0;
+    bool overflow = false;
+    {
+        int run = 0;
+#pragma unroll
+        for (int x = 0; x < MNE_LIST_SEGMENTS; ++x) {
+            const int cx = a.bins.counts[(size_t)tile * MNE_LIST_SEGMENTS + x];      // (wave-uniform: scalar loads)
+            seg_start[x] = run;
+            run += cx < seg_cap ? cx : seg_cap;
+            cnt += cx;
+            overflow = overflow || cx > seg_cap;
+        }
+        seg_start[MNE_LIST_SEGMENTS] = run;
+    }
     bool shared_tile = false;                                  // does this tile hold cells of a shared rectangle?
     if constexpr (OV != 0) {
         for (int k = 0; k < ov.n_peers; ++k) {
@@ -213,10 +233,9 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
     }
     if (!empty)
         for (int i = tid; i < TILE_CELLS * MNE_C / 4; i += TILE_THREADS) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int cap = a.bins.pcap[pidx];
-    const int n_list = cnt < cap ? cnt : cap;
+    const int n_list = seg_start[MNE_LIST_SEGMENTS];
     int n_spill = 0;
-    if (cnt > cap) {                     // only a tile whose list overflowed has entries in the spill area
+    if (overflow) {                      // only a tile with an overflowed segment has entries in the spill area
         const int ns = *a.bins.spill_count;
         n_spill = ns < a.bins.spill_cap ? ns : a.bins.spill_cap;
     }
@@ -247,7 +266,16 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
         if (tid < PASS_ENTRIES) {
             unsigned row = 0xffffffffu;
             const unsigned* ent = nullptr;
-            if (e < e_hi && e < n_list) ent = lst + (size_t)e * MNE_ENTRY_WORDS;
+            if (e < e_hi && e < n_list) {
+                int x = 0, s0 = 0;                                       // segment of flat entry e and the segment's first entry
+#pragma unroll                                                          // (static register indices only)
+                for (int k = 1; k < MNE_LIST_SEGMENTS; ++k) {
+                    const bool ge = e >= seg_start[k];
+                    x += ge ? 1 : 0;
+                    s0 = ge ? seg_start[k] : s0;
+                }
+                ent = lst + ((size_t)x * seg_cap + (size_t)(e - s0)) * MNE_ENTRY_WORDS;
+            }
             else if (e < e_hi) ent = a.bins.spill + (size_t)(e - n_list) * MNE_ENTRY_WORDS;
             if (ent) {
                 const uint4 e0 = *(const uint4*)ent, e1 = *(const uint4*)(ent + 4);      // one 32-byte entry
@@ -445,10 +473,8 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             *(float4*)(o.m + offmv) = m; *(float4*)(o.v + offmv) = v;
         }
     }
-    if (tid == 0) {
-        if (a.prev_counts) a.prev_counts[tile] = cnt;
-        a.bins.counts[tile] = 0;                                               // ready for the next iteration
-    }
+    if (tid == 0 && a.prev_counts) a.prev_counts[tile] = cnt;
+    if (tid < MNE_LIST_SEGMENTS) a.bins.counts[(size_t)tile * MNE_LIST_SEGMENTS + tid] = 0;      // ready for the next iteration
 }
 
 void mne_tile_geometry(const mne_scene_t& sc, TileBins& b) {

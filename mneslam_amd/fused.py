@@ -113,8 +113,8 @@ class FusedStep:
             n_entries = self.lib.mne_tile_list_entries(C.byref(self.scene), C.byref(b))
             # (only the counters need to start at zero: an entry is read after it was written)
             self.tile_lists = torch.empty(n_entries, 8, device=dev, dtype=torch.int32)
-            self._xcd_exp = os.environ.get("MNE_BIN_XCD_EXPERIMENT", "0") == "1"       # (timing experiment, profiles/r05_bin_xcd.sh)
-            self.tile_counts = torch.zeros(n_tiles * (8 if self._xcd_exp else 1), device=dev, dtype=torch.int32)
+            # one cursor per (list, XCD): every list is cut into LIST_SEGMENTS segments (csrc/mne_launch.h)
+            self.tile_counts = torch.zeros(n_tiles * _lib.LIST_SEGMENTS, device=dev, dtype=torch.int32)
             if spill_capacity is None:
                 # worst case: every sample appends to 4 tiles of every plane and every entry overflows its list --
                 # then nothing can ever be dropped (small scenes put >4096 samples into most tiles; office0 none)
@@ -540,8 +540,6 @@ class FusedStep:
         if self._planes_pending:                                  # previous step's plane update (side stream)
             main.wait_event(ev[1])
             self._planes_pending = False
-        if self.bins is not None and getattr(self, "_xcd_exp", False):
-            self.tile_counts.zero_()
         e0 = self._mark("render")
         opts, marks = self._render_opts(main)
         _lib.check(lib.mne_render_fused(C.byref(self.scene), C.byref(self.rc), R, S, P(self.rays_o), P(self.rays_d),

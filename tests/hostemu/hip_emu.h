@@ -273,6 +273,7 @@ typedef const float* mne_cptr;
 
 #define MNE_WAVE_SYNC() hipemu::wave_sync()
 #define MNE_SCHED_BARRIER() do { } while (0)
+inline int mne_xcc_id() { return (int)(blockIdx.x & 7u); }          // workgroups go round the XCDs
 #define MNE_LDS_MAX (160 * 1024)
 #define MNE_DRAIN_STORES() do { } while (0)
 #define MNE_FENCE_RELEASE_AGENT() std::atomic_thread_fence(std::memory_order_seq_cst)

@@ -71,9 +71,13 @@ def test_argument_validation_without_gpu(lib_path):
     sc.plane[0][0][0].h, sc.plane[0][0][0].w = 40, 33                    # 3 x 3 tiles; the other planes are empty
     bins = _lib.TileBins()
     bins.cap = 100
-    assert lib.mne_tile_list_entries(ctypes.byref(sc), ctypes.byref(bins)) == 9 * 100
+    # (ABI 7: a list = mne_tile_list_segments() equal segments, one per XCD: capacities are rounded down to a multiple of it, at least one entry each)
+    assert lib.mne_tile_list_segments() == _lib.LIST_SEGMENTS == 8
+    assert lib.mne_tile_list_entries(ctypes.byref(sc), ctypes.byref(bins)) == 9 * 96
     bins.plane_cap[0] = 7
-    assert lib.mne_tile_list_entries(ctypes.byref(sc), ctypes.byref(bins)) == 9 * 7
+    assert lib.mne_tile_list_entries(ctypes.byref(sc), ctypes.byref(bins)) == 9 * 8
+    bins.plane_cap[0] = 50
+    assert lib.mne_tile_list_entries(ctypes.byref(sc), ctypes.byref(bins)) == 9 * 48
     bins.plane_cap[0] = -1
     assert lib.mne_tile_list_entries(ctypes.byref(sc), ctypes.byref(bins)) == 0
     ov = _lib.TileOverlap()

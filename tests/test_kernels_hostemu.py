@@ -297,8 +297,17 @@ def test_tile_order_with_more_tiles_than_registers(hw, monkeypatch):
     split_scratch = torch.zeros(4)                               # (only its presence matters to tile_order)
     split_state = torch.zeros(n_tiles + 1, dtype=torch.int32)
     prev = torch.zeros(n_tiles, dtype=torch.int32)
+    # a list's length is the sum of its segments' cursors (one per XCD): spread every length unevenly over the eight
+    seg = torch.zeros(n_tiles, _lib.LIST_SEGMENTS, dtype=torch.int32)
+    rest = counts.clone()
+    for x in range(_lib.LIST_SEGMENTS - 1):
+        part = (rest.float() * torch.rand(n_tiles, generator=gen) * 0.4).to(torch.int32)
+        seg[:, x], rest = part, rest - part
+    seg[:, -1] = rest
+    assert torch.equal(seg.sum(1).to(torch.int32), counts)
+    seg = seg.contiguous()
     b = _lib.TileBins()
-    b.counts, b.order, b.cap, b.spill_cap = counts.data_ptr(), order.data_ptr(), 4096, 0
+    b.counts, b.order, b.cap, b.spill_cap = seg.data_ptr(), order.data_ptr(), 4096, 0
     b.split_scratch, b.split_state, b.prev_counts = split_scratch.data_ptr(), split_state.data_ptr(), prev.data_ptr()
     _lib.check(lib.mne_tile_order(C.byref(sc), C.byref(b), None), "mne_tile_order")
     n_items = int(split_state[n_tiles])
