@@ -1211,7 +1211,9 @@ __device__ __forceinline__ void append_tile(const RenderArgs& a, const float (&p
             pcap[j] = a.bins.pcap[pidx]; loff[j] = a.bins.list_off[pidx];
         }
         int first_slot[NJ * 4];
-        const int xcc = mne_xcc_id();
+        // this wave's segment of every list: its XCD (more than eight segments: the workgroup index picks among the XCD's)
+        const int xcc = MNE_LIST_SEGMENTS > 8 ? mne_xcc_id() + 8 * (int)((blockIdx.x >> 3) % (MNE_LIST_SEGMENTS / 8 > 0 ? MNE_LIST_SEGMENTS / 8 : 1))
+                                              : mne_xcc_id() % MNE_LIST_SEGMENTS;
 #pragma unroll
         for (int q = 0; q < NJ * 4; ++q) {
             first_slot[q] = 0;
