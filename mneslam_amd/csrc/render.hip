@@ -937,6 +937,10 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
         }
         float ray_do[3] = {0.f, 0.f, 0.f}, ray_dd[3] = {0.f, 0.f, 0.f};
         for (int c = 0; c < nb; ++c) {
+            if constexpr (HOT) {                                  // the training kernel's tile body (shared with heavy_bwd_kernel)
+                hot_backward_tile<HID, HIDC, CP, BIAS, !ALDS>(a, r, c, Dn, G, td, ro, rd, cf, use_e, use_co, zr, raws, lane, pn, feat, atab);
+                continue;
+            }
             const int i = c * TILE + pt;
             const bool valid = i < Dn;
             const int ii = valid ? i : Dn - 1;
