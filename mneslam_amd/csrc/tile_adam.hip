@@ -92,8 +92,13 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(TileAdamArgs a, int n_
     // here cost 8 us of this latency-critical kernel.)
     auto length0 = [&](int t) {
         int c = 0;                                                   // the list's segments, one per XCD
+#if MNE_LIST_SEGMENTS == 8
+        const int4 c0 = *(const int4*)(a.bins.counts + (size_t)t * 8), c1 = *(const int4*)(a.bins.counts + (size_t)t * 8 + 4);      // two loads, not eight
+        c = (c0.x + c0.y + c0.z + c0.w) + (c1.x + c1.y + c1.z + c1.w);
+#else
 #pragma unroll
         for (int x = 0; x < MNE_LIST_SEGMENTS; ++x) c += a.bins.counts[(size_t)t * MNE_LIST_SEGMENTS + x];
+#endif
         if (!a.prev_counts) return c;
         const int p = a.prev_counts[t];
         return c > p ? c : p;
