@@ -266,6 +266,8 @@ def render_img_measure(agent, cfg, device, n_pairs, n_warm):
     m = agent.model
     was_training = m.training
     m.eval()
+    if os.environ.get("MNE_RENDER_PATCH_ORDER") == "0":       # (A/B of the Z-order ray walk of render_img, profiles/r05_render_img.sh)
+        m.render_patch_order = False
     cam = synthetic.camera_from_config(cfg)
     cfg_cam_backup = dict(cfg["cam"])
     cfg["cam"].update(cam, crop_edge=0)                  # render_img reads the camera from the config

@@ -164,6 +164,7 @@ static int render_forward(const float* features, const mne_scene_t* scene, const
     a.ray_counts = early ? ray_counts : nullptr;
     a.prefix_default = early ? 1 : (1 << 30);
     if (features) { a.ext_feat = 1; a.ext_rows = features; a.ext_stride = 64; }
+    if (const char* c = std::getenv("MNE_FRAME_MIN_TILES")) a.frame_min_tiles = std::atoi(c);      // tests run the pipelined frame decode on small batches
     if (int rc = mne_launch_render(a, early ? 1 : 0, nullptr, RenderHost{}, (hipStream_t)stream)) return fail(rc, "unsupported scene configuration");
     return check_launch("render_forward");
 }

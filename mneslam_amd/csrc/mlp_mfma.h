@@ -195,14 +195,15 @@ __device__ __forceinline__ void oneblob_half(const float u[3], int h, float (&po
 }
 
 // frow / cfrow: LDS feature rows of this lane's POINT (64 floats each); the lane reads its level half.
+// Two halves -- the sdf net (needs frow) and the colour net (needs cfrow, pos and the sdf net's out) -- so that a forward-only
+// caller can keep ONE set of feature rows in LDS and gather the colour planes between the two (decode_tile<..., SEQF>).
 template <int HID, int HIDC, bool CP, bool GTAB = false>
-__device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float* cfrow, const float (&pos)[24],
-                                                 const float* atab, int lane, MlpState<HID, HIDC>& S) {
+__device__ __forceinline__ void mlp_forward_sdf(const float* frow, const float (&pos)[24], const float* atab, int lane,
+                                                MlpState<HID, HIDC>& S) {
     typedef ATab<HID, HIDC, CP> T;
     const int h = lane >> 5;
     const ATabRef<GTAB> A(atab, lane);
     const float* fh = frow + h * 32;
-    const float* ch = cfrow + h * 32;
 #pragma unroll
     for (int t = 0; t < T::NT; ++t) {
         f32x16 acc;
@@ -230,6 +231,15 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float*
         for (int s = 0; s < 16 * T::NT; ++s) acc = MNE_MFMA(A.at(T::OFF_L2 + s), S.h[s >> 4][s & 15], acc);
         S.out = acc;
     }
+}
+
+template <int HID, int HIDC, bool CP, bool GTAB = false>
+__device__ __forceinline__ void mlp_forward_color(const float* cfrow, const float (&pos)[24], const float* atab, int lane,
+                                                  MlpState<HID, HIDC>& S) {
+    typedef ATab<HID, HIDC, CP> T;
+    const int h = lane >> 5;
+    const ATabRef<GTAB> A(atab, lane);
+    const float* ch = cfrow + h * 32;
 #pragma unroll
     for (int t = 0; t < T::NTC; ++t) {
         f32x16 acc;
@@ -262,6 +272,13 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float*
         for (int s = 0; s < 16 * T::NTC; ++s) acc = MNE_MFMA(A.at(T::OFF_C2 + s), S.hc[s >> 4][s & 15], acc);
         S.rgb = acc;
     }
+}
+
+template <int HID, int HIDC, bool CP, bool GTAB = false>
+__device__ __forceinline__ void mlp_forward_mfma(const float* frow, const float* cfrow, const float (&pos)[24],
+                                                 const float* atab, int lane, MlpState<HID, HIDC>& S) {
+    mlp_forward_sdf<HID, HIDC, CP, GTAB>(frow, pos, atab, lane, S);
+    mlp_forward_color<HID, HIDC, CP, GTAB>(cfrow, pos, atab, lane, S);
 }
 
 // ReLU pattern of this lane's hidden rows: bit (16 t + e) = (S.h[t][e] > 0), same for hc.  Saved by the forward

@@ -166,6 +166,9 @@ __device__ __forceinline__ void oneblob8(float x, int base, float* out /*8*/, bo
 #ifndef MNE_GATHER_INFLIGHT
 #define MNE_GATHER_INFLIGHT 12
 #endif
+#ifndef MNE_INLINE_GATHER_NLV
+#define MNE_INLINE_GATHER_NLV 1     // levels requested together by the gathers INSIDE the tile kernels (gather_chunk)
+#endif
 // Tri-plane features of ONE point for the 8 lanes that share it (cg = lane & 7: float4 chunk of the 128-B rows); the
 // blended rows go to out + set * set_stride + level * 32 + cg * 4 (LDS row or tape row).
 // Four channels of one corner row at element offset e: planes are stored in fp32, or -- mne_scene_t.plane_f16, uniform over
@@ -186,12 +189,12 @@ __device__ __forceinline__ float4 plane_row4(const mne_plane_t& pl, int e) {
     return *(const float4*)((const float*)pl.data + e);
 }
 
-template <int NSETS, bool F16, int NLV = MNE_GATHER_INFLIGHT / 12>       // NLV: levels loaded together (12 corner rows each)
-__device__ __forceinline__ void gather_slot_t(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
+template <int NSETS, bool F16, int NLV = MNE_GATHER_INFLIGHT / 12, int SET0 = 0>       // NLV: levels loaded together (12 corner rows each)
+__device__ __forceinline__ void gather_slot_t(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {   // plane sets SET0 .. SET0 + NSETS - 1
     const int kmine = cg < 6 ? cg : cg - 6;                        // this lane's plane: k = lvl * 3 + ori
     const int lvl_m = kmine >= 3 ? 1 : 0, ori_m = kmine - 3 * lvl_m;
 #pragma unroll
-    for (int set = 0; set < NSETS; ++set) {
+    for (int set = SET0; set < SET0 + NSETS; ++set) {
         int Hm = sc.plane[set][0][0].h, Wm = sc.plane[set][0][0].w;
 #pragma unroll
         for (int k = 1; k < 6; ++k) {
@@ -239,27 +242,27 @@ __device__ __forceinline__ void gather_slot_t(const mne_scene_t& sc, float px, f
                     }
                     sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;       // xy + xz + yz
                 }
-                *(float4*)(out + set * set_stride + (l0 + lv) * MNE_C + cg * 4) = sum;
+                *(float4*)(out + (set - SET0) * set_stride + (l0 + lv) * MNE_C + cg * 4) = sum;
             }
         }
     }
 }
 
-template <int NSETS, int NLV = MNE_GATHER_INFLIGHT / 12>
+template <int NSETS, int NLV = MNE_GATHER_INFLIGHT / 12, int SET0 = 0>
 __device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
-    if (sc.plane_f16) gather_slot_t<NSETS, true, NLV>(sc, px, py, pz, cg, out, set_stride);       // (uniform over the launch)
-    else gather_slot_t<NSETS, false, NLV>(sc, px, py, pz, cg, out, set_stride);
+    if (sc.plane_f16) gather_slot_t<NSETS, true, NLV, SET0>(sc, px, py, pz, cg, out, set_stride);       // (uniform over the launch)
+    else gather_slot_t<NSETS, false, NLV, SET0>(sc, px, py, pz, cg, out, set_stride);
 }
 
 // (NLV = 2 -- both levels' 24 corner rows requested together -- was measured for the gathers INSIDE the tile kernels, where the
 // registers are free: no effect on the deferred decode, the resolver's extension tile or render_img, profiles/r05_inline_gather_levels.txt)
-template <int NSETS, int NPTS, int NLV = 1>
+template <int NSETS, int NPTS, int NLV = 1, int SET0 = 0>
 __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane) {
     const int cg = lane & 7;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 8; ++it) {
         const int slot = it * 8 + (lane >> 3);
-        gather_slot<NSETS, NLV>(sc, pn[slot * 4 + 0], pn[slot * 4 + 1], pn[slot * 4 + 2], cg, feat + slot * MNE_FS, NPTS * MNE_FS);
+        gather_slot<NSETS, NLV, SET0>(sc, pn[slot * 4 + 0], pn[slot * 4 + 1], pn[slot * 4 + 2], cg, feat + slot * MNE_FS, NPTS * MNE_FS);
     }
 }
 

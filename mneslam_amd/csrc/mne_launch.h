@@ -84,6 +84,7 @@ struct RenderArgs {
     int ext_stride;
     const int* ray_counts;      // [R][MNE_N_COUNT] from sample_z (slot MNE_C_NEED = a-priori sample count)
     int prefix_default;         // ray_counts == NULL: a-priori tiles of every ray (ntile = decode everything, 1 = on demand only)
+    int frame_min_tiles;         // (host only) forward decode: rays per wave from which decode_frame_kernel is used (0: build default, < 0: always; tests)
     const float *coef, *g_rgb, *g_depth;
     float* tape;                // [R*S][ROW]; NULL = forward only
     int tape_row, tape_tx, tape_tcf;   // gather_kernel: row length and the columns of the two feature blocks

@@ -123,12 +123,21 @@ __global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
     sample_z_ray(a, r, a.has_d ? a.target_d[r] : 0.0f, lane, tab, tab + ((n_tab + 3) & ~3) + w * ((S + 3) & ~3));
 }
 
-// sum of the per-ray mask counts: all 256 threads of ONE workgroup
+// Batches of more rays than this (whole frames: 816 k rays) neither fit the balanced decode schedule (its tile-count prefix of
+// every ray sits in LDS) nor a one-workgroup reduction: their counts are summed by many workgroups (integer atomics) and slot
+// MNE_C_TILE0 is left unwritten -- launch_decode applies the same bound.  (Round 5 first ran the one-workgroup form on frames:
+// 3.3 ms of a 22 ms depth-guided render, profiles/r05_render_img_counts.txt.)
+#ifndef MNE_BALANCED_MAX_RAYS
+#define MNE_BALANCED_MAX_RAYS 16384
+#endif
+// sum of the per-ray mask counts: all 256 threads of ONE workgroup (gridDim.x == 1), or this workgroup's stripe of the rays
+// added to a.counts (zeroed by the launcher)
 __device__ __forceinline__ void counts_reduce_block(const ZArgs& a, int (*part)[MNE_N_COUNT]) {
     const int t = threadIdx.x;
+    const bool striped = gridDim.x > 1;
     int acc[MNE_N_COUNT];
     for (int k = 0; k < MNE_N_COUNT; ++k) acc[k] = 0;
-    for (int r = t; r < a.R; r += 256)
+    for (long long r = (long long)blockIdx.x * 256 + t; r < a.R; r += (long long)gridDim.x * 256)
         for (int k = 0; k < MNE_N_COUNT; ++k) acc[k] += a.ray_counts[(size_t)r * MNE_N_COUNT + k];
     for (int k = 0; k < MNE_N_COUNT; ++k) part[t][k] = acc[k];
     __syncthreads();
@@ -137,7 +146,12 @@ __device__ __forceinline__ void counts_reduce_block(const ZArgs& a, int (*part)[
             for (int k = 0; k < MNE_N_COUNT; ++k) part[t][k] += part[t + st][k];
         __syncthreads();
     }
+    if (striped) {
+        if (t < MNE_N_COUNT && t != MNE_C_TILE0 && part[0][t]) atomicAdd(a.counts + t, part[0][t]);
+        return;
+    }
     if (t < MNE_N_COUNT) a.counts[t] = part[0][t];
+    if (a.R > MNE_BALANCED_MAX_RAYS) return;
     // Exclusive prefix of the rays' a-priori tile counts -> slot MNE_C_TILE0 of every ray's counts (decode_kernel deals its
     // tile tasks out from it, evenly over the waves): 256 rays per round, wave scan + the four waves' sums through LDS.
     __syncthreads();
@@ -257,7 +271,11 @@ __device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntil
 // of this lane's point (valid lanes); pnv/u are its coordinates, relu its mask words.
 // PRE: the plane features of the tile are already in the tape rows (gather_kernel): they are loaded back into the LDS
 // rows with one batch of coalesced loads instead of being gathered here (8 dependent rounds of corner-row loads).
-template <int HID, int HIDC, bool CP, bool GTAB = false>
+// SEQF (forward-only launches of a model with colour planes: no tape, no pre-gathered rows): `feat` is ONE set of 32 rows -- the
+// geometry planes are gathered, the sdf net runs, then the colour planes are gathered into the same rows for the colour net.
+// Same operations on the same values; what it buys is LDS: 9.2 instead of 17.9 KB per wave, i.e. 8 waves per CU beside the
+// 38.9 KB of tables instead of 6 (decode_kernel) / 5 (ray_kernel<..., 0> at 256 samples per ray) -- render_img, DESIGN.md 3.6.
+template <int HID, int HIDC, bool CP, bool GTAB = false, bool SEQF = false>
 __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c, int lane, float* pn, float* feat,
                                               const float* atab, float (&pnv)[3], float (&u)[3], uint2& relu, bool PRE = false) {
     typedef DecDims<HID, HIDC, CP> D;
@@ -275,6 +293,31 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     const unsigned live = n_here >= TILE ? 0xffffffffu : ((1u << n_here) - 1u);
     float* tape0 = a.tape ? a.tape + ((size_t)r * S + (size_t)c * TILE) * D::ROW : nullptr;
     MNE_WAVE_SYNC();                                       // earlier LDS reads of this wave are done
+    if constexpr (SEQF) {
+        static_assert(CP, "SEQF: the one-set form exists for models with colour planes");
+        if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
+        MNE_WAVE_SYNC();
+        gather_chunk<1, TILE, MNE_INLINE_GATHER_NLV, 0>(a.sc, pn, feat, lane);
+        MNE_WAVE_SYNC();
+        const float* row = feat + pt * MNE_FS;
+        float pos[24];
+        oneblob_half<!(HID == 64 && CP)>(u, hf, pos);
+        MlpState<HID, HIDC> st;
+        mlp_forward_sdf<HID, HIDC, CP, GTAB>(row, pos, atab, lane, st);
+        MNE_WAVE_SYNC();                                   // every lane has read its geometry row
+        gather_chunk<1, TILE, MNE_INLINE_GATHER_NLV, 1>(a.sc, pn, feat, lane);
+        MNE_WAVE_SYNC();
+        mlp_forward_color<HID, HIDC, CP, GTAB>(row, pos, atab, lane, st);
+        const float4 rw = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.out[0]);
+        relu = make_uint2(0u, 0u);
+        if (a.relu_mask) relu_masks<HID, HIDC>(st, relu.x, relu.y);
+        if (valid) {
+            const size_t e = (size_t)r * S + i;
+            if (a.raw && hf == 0) *(float4*)(a.raw + e * 4) = rw;
+            if (a.relu_mask) *(uint2*)(a.relu_mask + e * 4 + hf * 2) = relu;
+        }
+        return rw;
+    }
     // Pre-gathered rows, 2x32 decoders (registers to spare): the row loads are issued here and land in LDS only after the
     // OneBlob below (3 us of VALU work that does not depend on them) -- 2 us of load latency per tile off the chain.
     constexpr bool OVERLAP = HID == 32 && HIDC == 32;
@@ -296,7 +339,7 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     } else {
         if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
         MNE_WAVE_SYNC();
-        gather_chunk<NSETS, TILE>(a.sc, pn, feat, lane);
+        gather_chunk<NSETS, TILE, MNE_INLINE_GATHER_NLV>(a.sc, pn, feat, lane);
         MNE_WAVE_SYNC();
         if (tape0) {                                       // plane features: straight from the gathered rows
             store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
@@ -358,6 +401,22 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
 #ifndef DECODE_WPB
 #define DECODE_WPB 8
 #endif
+// Persistent tile kernels walk their tasks with a grid stride; consecutive tasks are consecutive rays -- in a frame render
+// neighbouring pixels, whose samples fall into the same plane cells.  Workgroups are dealt to the 8 XCDs round robin, so with
+// the plain stride every XCD (own L2) sees every 8th group of rays and fetches the same plane lines as its neighbours.
+// xcd_block() renumbers the workgroups so that the 32 workgroups of one XCD take ADJACENT task groups: one contiguous run of
+// rays per XCD and round.  (grid a multiple of 8 only; any other grid keeps its numbering.)
+#ifndef MNE_XCD_TASK_MAP
+#define MNE_XCD_TASK_MAP 1
+#endif
+__device__ __forceinline__ int xcd_block() {
+    const int b = blockIdx.x, g = gridDim.x;
+    if (!MNE_XCD_TASK_MAP || (g & 7)) return b;
+    return (b & 7) * (g >> 3) + (b >> 3);
+}
+#ifndef MNE_SEQ_FORWARD
+#define MNE_SEQ_FORWARD 1       // forward-only launches with colour planes: one set of LDS feature rows per wave (decode_tile<..., SEQF>)
+#endif
 #ifndef MNE_DECODE_BALANCED
 #define MNE_DECODE_BALANCED 1   // decode_kernel: the rays' real tiles dealt evenly to the waves (0: fixed stride over the (tile, ray) slots)
 #endif
@@ -397,10 +456,10 @@ __global__ __launch_bounds__(256) void gather_kernel(RenderArgs a, int chunks_pe
 // Tiles the resolver wave may decode beyond a ray's a-priori prefix before it leaves the rest to the deferred pass: the
 // extension is SERIAL in one wave (34 us per tile); INS Indoor has 33 tiles per ray and rays that cross empty space:
 // unbounded 606 it/s, 4 tiles 791, 2 tiles 828, 1 tile 846; office0 / ScanNet within noise (profiles/r02_resolver_ext.txt).
-template <int HID, int HIDC, bool CP, bool ALDS, int WPB>
+template <int HID, int HIDC, bool CP, bool ALDS, int WPB, bool SEQF = false>
 __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre, int sched) {
     typedef ATab<HID, HIDC, CP> T;
-    constexpr int NSETS = CP ? 2 : 1;
+    constexpr int NSETS = (CP && !SEQF) ? 2 : 1;           // sets of LDS feature rows per wave
     constexpr int TAB_FLOATS = ALDS ? T::FWD_STEPS * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     const int wpb = blockDim.x >> 6;
@@ -442,7 +501,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
         __syncthreads();
         ntask_l = tstart[a.R - 1] + apriori_tiles(a, a.R - 1, ntile);
     }
-    for (long long task = (long long)blockIdx.x * wpb + wv; task < ntask_l; task += (long long)gridDim.x * wpb) {
+    for (long long task = (long long)xcd_block() * wpb + wv; task < ntask_l; task += (long long)gridDim.x * wpb) {
         int c, r;
         if (balanced) {
             int lo = 0, hi = a.R - 1;                              // last ray whose first tile is <= task
@@ -468,7 +527,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
         float z_lim = 0.0f, s_carry = 0.0f;
         const float* zr = a.z_vals + (size_t)r * a.S;
         while (true) {
-            const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, cc, lane, pn, feat, atab, pnv, u, relu, pre_now);
+            const float4 rw = decode_tile<HID, HIDC, CP, !ALDS, SEQF>(a, r, cc, lane, pn, feat, atab, pnv, u, relu, pre_now);
             if (!resolver) break;
             const int i0 = cc * TILE, n_in = a.S - i0 < TILE ? a.S - i0 : TILE;
             const float s_me = rw.w;                                   // valid on lanes < 32 (rows 0..3 of the result)
@@ -488,6 +547,138 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
             pre_now = a.ext_feat != 0;                                 // tiles beyond the prefix were not pre-gathered
         }
         if (resolver && lane == 0) a.dec_tiles[r] = cc + 1;
+    }
+}
+
+// -----------------------------------------------------------------------------------------------
+// decode_frame_kernel: the forward-only decode of whole frames (render_img) -- decode_kernel without its tape, ReLU-mask,
+// resolver and pre-gathered-row paths, for 2x32 decoders without colour planes (what the frame renders of the default scene use).
+//
+// What bounds decode_kernel on a frame (profiles/r05_render_img_experiments.txt, r05_render_sq_counters.txt): per 32-sample tile
+// a wave issues 120 dependent MFMAs (64 cycles each), ~1750 VALU and ~270 LDS instructions and waits 54 % of its cycles; the
+// matrix pipe is 43 % busy at two waves per SIMD.  Not HBM: a Z-order ray walk cut the plane fetches 4x and changed nothing.
+// Overlapping the chain of tile k with the gather of tile k + 1 inside ONE wave was built and measured (patches/
+// r05_decode_pipe_kernel.patch): nothing at equal occupancy -- fillers between the MFMAs of one accumulator chain cost the chain
+// its back-to-back issue.  What does pay is a third wave per SIMD, and that is a matter of registers: without the training-side
+// code the tile needs 124 instead of 189, so 12 waves per CU (LDS: 30.7 KB of tables + 12 x 9.2 KB) instead of 8: -14 % per
+// launch; 14 waves (the LDS limit; uneven over the SIMDs) are slower again.
+// Same operations on the same values in the same order as decode_tile: bit-equal results.
+// -----------------------------------------------------------------------------------------------
+#ifndef MNE_DECODE_FRAME
+#define MNE_DECODE_FRAME 1
+#endif
+#ifndef MNE_FRAME_WPB
+#define MNE_FRAME_WPB 12        // waves per workgroup (= the register budget: 512 / ceil(waves / 4) = 168 per lane)
+#endif
+#ifndef MNE_FRAME_MIN_TILES
+#define MNE_FRAME_MIN_TILES 8   // launches with fewer rays per wave than this stay with decode_kernel (balanced schedule, fewer waves to fill)
+#endif
+
+struct FrameTile {
+    float4 x[8];            // this lane's half of its point's feature row
+    float pos[24];
+    f32x16 acc, h, out, hc;
+};
+
+// MFMA number M (0..119) of the forward chain of mlp_forward_sdf + mlp_forward_color for <32, 32, no colour planes>
+template <int M>
+__device__ __forceinline__ void frame_mfma(FrameTile& s, const ATabRef<false>& A) {
+    typedef ATab<32, 32, false> T;
+    if constexpr (M == 0 || M == 56 || M == 72 || M == 104) s.acc = f32x16_zero();
+    if constexpr (M < 32) {
+        const float4 q = s.x[M / 4];
+        s.acc = MNE_MFMA(A.at(T::OFF_L1 + M), (M % 4 == 0 ? q.x : M % 4 == 1 ? q.y : M % 4 == 2 ? q.z : q.w), s.acc);
+    } else if constexpr (M < 56) {
+        s.acc = MNE_MFMA(A.at(T::OFF_L1 + M), s.pos[M - 32], s.acc);
+        if constexpr (M == 55) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s.h[e] = fmaxf(s.acc[e], 0.0f);
+        }
+    } else if constexpr (M < 72) {
+        s.acc = MNE_MFMA(A.at(T::OFF_L2 + (M - 56)), s.h[M - 56], s.acc);
+        if constexpr (M == 71) s.out = s.acc;
+    } else if constexpr (M < 96) {
+        s.acc = MNE_MFMA(A.at(T::OFF_C1 + (M - 72)), s.pos[M - 72], s.acc);
+    } else if constexpr (M < 104) {
+        s.acc = MNE_MFMA(A.at(T::OFF_C1 + 24 + (M - 96)), s.out[M - 96], s.acc);
+        if constexpr (M == 103) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s.hc[e] = fmaxf(s.acc[e], 0.0f);
+        }
+    } else {
+        s.acc = MNE_MFMA(A.at(T::OFF_C2 + (M - 104)), s.hc[M - 104], s.acc);
+    }
+}
+template <int M0, int M1>
+__device__ __forceinline__ void frame_mfma_range(FrameTile& s, const ATabRef<false>& A) {
+    if constexpr (M0 < M1) {
+        frame_mfma<M0>(s, A);
+        frame_mfma_range<M0 + 1, M1>(s, A);
+    }
+}
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void decode_frame_kernel(RenderArgs a, int sched) {
+    typedef ATab<32, 32, false> T;
+    constexpr int TAB_FLOATS = T::FWD_STEPS * 64;
+    MNE_DYN_LDS(lds_raw);
+    const int wpb = blockDim.x >> 6;
+    {
+        float4* dst = (float4*)lds_raw;
+        const float4* src = (const float4*)a.packed;
+        for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+    const float* atab = (const float*)lds_raw;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pt = lane & 31, hf = lane >> 5;
+    const int S = a.S, ntile = (S + TILE - 1) / TILE;
+    float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(1));
+    float* feat = pn + TILE * 4;
+    const int n_rays = a.R;
+    const bool balanced = sched != 0 && a.ray_counts && !(a.adapt && a.adapt[0]);
+    int* tstart = (int*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wpb * tile_wave_lds_bytes(1));
+    long long ntask_l = (long long)n_rays * ntile;
+    if (balanced) {
+        for (int r = threadIdx.x; r < a.R; r += blockDim.x) tstart[r] = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_TILE0];
+        __syncthreads();
+        ntask_l = tstart[a.R - 1] + apriori_tiles(a, a.R - 1, ntile);
+    }
+    const ATabRef<false> A(atab, lane);
+    FrameTile st;
+    // decode_kernel's two schedules over the (tile, ray) tasks: tiles of the rays' a-priori prefixes only
+    for (long long task = (long long)xcd_block() * wpb + wv; task < ntask_l; task += (long long)gridDim.x * wpb) {
+        int c, r;
+        if (balanced) {
+            int lo = 0, hi = a.R - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (tstart[mid] <= (int)task) lo = mid; else hi = mid - 1;
+            }
+            r = lo; c = (int)task - tstart[lo];
+        } else {
+            c = (int)(task / n_rays);
+            r = (int)(task % n_rays);
+            if (c >= prefix_tiles(a, r, ntile)) continue;
+        }
+        const int i = c * TILE + pt;
+        const float z = a.z_vals[(size_t)r * S + (i < S ? i : S - 1)];
+        float p[3], pnv[3], u[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = a.rays_o[r * 3 + k] + a.rays_d[r * 3 + k] * z;      // scene_rep.py:384
+        point_coords(a.sc, p, pnv, u);
+        MNE_WAVE_SYNC();                                       // the previous tile's LDS reads are done
+        *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);       // (both lanes of a point store the same value)
+        MNE_WAVE_SYNC();
+        gather_chunk<1, TILE, MNE_INLINE_GATHER_NLV>(a.sc, pn, feat, lane);
+        MNE_WAVE_SYNC();
+        oneblob_half<true>(u, hf, st.pos);
+        const float* frow = feat + pt * MNE_FS + hf * 32;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st.x[q] = *(const float4*)(frow + 4 * q);
+        frame_mfma_range<0, 120>(st, A);
+        // rows 0..3 of the colour result and row 0 of the sdf result live in the lower half
+        if (i < S && hf == 0) *(float4*)(a.raw + ((size_t)r * S + i) * 4) = make_float4(st.acc[0], st.acc[1], st.acc[2], st.out[0]);
     }
 }
 
@@ -825,10 +1016,11 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
     // the tape before the sdf net's rows are produced -- so that more waves fit beside the tables (ScanNet: 6 -> 11 per CU,
     // i.e. all 2150 rays in one round instead of two).
     constexpr bool SEQ = HOT && CP;
+    constexpr bool SEQF = MNE_SEQ_FORWARD && MODE == 0 && CP;       // forward only: one set of rows, the two nets' gathers in turn (decode_tile)
     // 2x64 decoders: d(hidden) of the colour net is written to the tape before the sdf net's backward (32 registers less
     // across its chain); not with ray gradients, which need both nets' d(hidden) for the OneBlob input gradient
     constexpr bool EARLY_DHC = HID == 64 && BWD && !RAYGRAD;
-    constexpr int LSETS = SEQ ? 1 : NSETS;
+    constexpr int LSETS = (SEQ || SEQF) ? 1 : NSETS;
     const size_t wave_bytes = (size_t)Spad * 5 * sizeof(float) + tile_wave_lds_bytes(LSETS, RAYGRAD);
     unsigned char* my = lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * wave_bytes;
     float* raws = (float*)my;                                     // [Spad][4]
@@ -845,7 +1037,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
     const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
     const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
     const int n_items = a.ray_list ? *a.ray_list_count : a.R;
-    for (int item = blockIdx.x * wpb + wv; item < n_items; item += gridDim.x * wpb) {
+    for (int item = (MODE == 0 ? xcd_block() : (int)blockIdx.x) * wpb + wv; item < n_items; item += gridDim.x * wpb) {
         const int r = a.ray_list ? a.ray_list[item] : item;
         const float td = has_t ? a.target_d[r] : 0.0f;
         float ro[3], rd[3];
@@ -881,7 +1073,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
                 // decode the next tile on demand (Dn is a multiple of TILE here)
                 float pnv[3], u[3];
                 uint2 relu;
-                const float4 rw = decode_tile<HID, HIDC, CP, !ALDS>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu, a.ext_feat != 0);
+                const float4 rw = decode_tile<HID, HIDC, CP, !ALDS, SEQF>(a, r, t_dec, lane, pn, feat, atab, pnv, u, relu, a.ext_feat != 0);
                 const int i = t_dec * TILE + pt;
                 if (i < S && hf == 0) *(float4*)(raws + 4 * i) = rw;
                 MNE_WAVE_SYNC();
@@ -1628,7 +1820,12 @@ int mne_launch_sample_z(const ZArgs& a, hipStream_t st) {
     const int n_tab = a.has_d ? a.n_a + 2 * a.n_b : a.S;
     const size_t lds = (size_t)(((n_tab + 3) & ~3) + RAYS_PER_WG * ((a.S + 3) & ~3)) * sizeof(float);
     MNE_LAUNCH(sample_z_kernel, (a.R + RAYS_PER_WG - 1) / RAYS_PER_WG, 256, lds, st, a);
-    if (a.has_d) MNE_LAUNCH(counts_reduce_kernel, 1, 256, 0, st, a);
+    if (a.has_d) {
+        if (a.R > MNE_BALANCED_MAX_RAYS) {                 // whole frames: a stripe of the rays per workgroup
+            (void)hipMemsetAsync(a.counts, 0, MNE_N_COUNT * sizeof(int), st);
+            MNE_LAUNCH(counts_reduce_kernel, MNE_NUM_CU, 256, 0, st, a);
+        } else MNE_LAUNCH(counts_reduce_kernel, 1, 256, 0, st, a);
+    }
     return 0;
 }
 
@@ -1656,7 +1853,7 @@ static int launch_ray(RenderArgs a, hipStream_t st, int max_blocks = MNE_NUM_CU)
     const int cap = ray_lds_cap(a);
     a.lds_samples = (MODE == 4 && !a.ray_list && a.S > cap) ? cap : 0;
     const int L = a.lds_samples ? a.lds_samples : a.S;
-    const size_t per_wave = (size_t)((L + 3) & ~3) * 5 * sizeof(float) + tile_wave_lds_bytes((CP && MODE != 4) ? 2 : 1, MODE == 3);
+    const size_t per_wave = (size_t)((L + 3) & ~3) * 5 * sizeof(float) + tile_wave_lds_bytes((CP && MODE != 4 && !(MNE_SEQ_FORWARD && MODE == 0)) ? 2 : 1, MODE == 3);
     const int wpb = fit_waves<HID, HIDC, CP>(tab, per_wave, RAY_WPB(HID, CP, MODE));
     if (wpb < 1) return -4;
     const size_t lds = tab + (size_t)wpb * per_wave;
@@ -1718,19 +1915,46 @@ static int launch_decode(RenderArgs d, hipStream_t st, const RenderHost& host, b
         mark(host, 1, st);
     }
     const size_t tab = table_bytes<HID, HIDC, CP>(0);
-    const int wpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(CP ? 2 : 1), DECODE_WPB);
+    // forward-only launch of a model with colour planes (no tape to fill, no pre-gathered rows): one set of feature rows per wave
+    const bool seqf = MNE_SEQ_FORWARD && CP && !d.tape && !pre;
+    const int nsets = (CP && !seqf) ? 2 : 1;
+    const int wpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(nsets), DECODE_WPB);
     if (wpb < 1) return -4;
-    size_t lds = tab + (size_t)wpb * tile_wave_lds_bytes(CP ? 2 : 1);
+    size_t lds = tab + (size_t)wpb * tile_wave_lds_bytes(nsets);
     // balanced tile schedule (see decode_kernel): needs the tile-count prefix of mne_sample_z / mne_sample_batch and room for
     // it in LDS; the adaptive "decode everything" state is checked on the device
     const size_t sched_bytes = align16((size_t)d.R * sizeof(int));
-    const int sched = (MNE_DECODE_BALANCED && d.ray_counts && !d.ray_list && lds + sched_bytes <= MNE_LDS_MAX) ? 1 : 0;
+    const int sched = (MNE_DECODE_BALANCED && d.ray_counts && !d.ray_list && d.R <= MNE_BALANCED_MAX_RAYS && lds + sched_bytes <= MNE_LDS_MAX) ? 1 : 0;
     if (sched) lds += sched_bytes;
     const long long ntask = (long long)d.R * ((d.S + TILE - 1) / TILE);
     long long grid = (ntask + wpb - 1) / wpb;
     if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
     if (d.ray_list && grid > MNE_LIST_PASS_BLOCKS) grid = MNE_LIST_PASS_BLOCKS;      // deferred pass: see MNE_LIST_PASS_BLOCKS
     // gfx950 has 160 KiB of LDS per CU; above 64 KiB HIP wants an opt-in
+    if constexpr (MNE_DECODE_FRAME && HID == 32 && HIDC == 32 && !CP) {
+        // whole frames (forward only, a priori prefix, no caller-supplied features): the lean kernel at 12 waves per CU
+        const int fwpb = fit_waves<HID, HIDC, CP>(tab, tile_wave_lds_bytes(1), MNE_FRAME_WPB);
+        const int min_tiles = d.frame_min_tiles > 0 ? d.frame_min_tiles : d.frame_min_tiles < 0 ? 0 : MNE_FRAME_MIN_TILES;
+        const bool frame = fwpb >= 1 && !d.tape && !pre && !d.relu_mask && !d.dec_tiles && !d.ray_list && !d.ext_feat && d.raw &&
+                           (long long)d.R >= (long long)MNE_NUM_CU * fwpb * min_tiles;
+        if (frame) {
+            size_t flds = tab + (size_t)fwpb * tile_wave_lds_bytes(1);
+            const int fsched = (sched && flds + sched_bytes <= MNE_LDS_MAX) ? 1 : 0;
+            if (fsched) flds += sched_bytes;
+            long long fgrid = (ntask + fwpb - 1) / fwpb;
+            if (fgrid > MNE_NUM_CU) fgrid = MNE_NUM_CU;
+            if (flds > 64 * 1024) MNE_SET_MAX_LDS((decode_frame_kernel<MNE_FRAME_WPB>), MNE_LDS_MAX);
+            MNE_LAUNCH((decode_frame_kernel<MNE_FRAME_WPB>), (unsigned)fgrid, 64 * fwpb, flds, st, d, fsched);
+            return 0;
+        }
+    }
+    if constexpr (CP) {
+        if (seqf) {
+            if (lds > 64 * 1024) MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB, true>), MNE_LDS_MAX);
+            MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB, true>), (unsigned)grid, 64 * wpb, lds, st, d, 0, sched);
+            return 0;
+        }
+    }
     if (lds > 64 * 1024) MNE_SET_MAX_LDS((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB>), MNE_LDS_MAX);
     MNE_LAUNCH((decode_kernel<HID, HIDC, CP, W::ALDS, DECODE_WPB>), (unsigned)grid, 64 * wpb, lds, st, d, pre ? 1 : 0, sched);
     return 0;

@@ -224,6 +224,18 @@ class JointEncoding(nn.Module):
             n = rays_d.shape[0]
             tr = self.config["training"]
             S = (tr["n_range_d"] + tr["n_samples_d"]) if gt_depth is not None else tr.get("n_samples")
+            # Ray order inside the launch: pixels along a Z-order curve instead of row by row, so that the 8 rays a workgroup
+            # decodes at a time are a 4 x 2 pixel patch and the 256 rays of an XCD's workgroups a 16 x 16 one -- their samples
+            # fall into the same 1-2 cm plane cells, whose corner rows then come from L1 / L2 instead of from HBM (the frame
+            # kernels are bound by exactly those fetches: DESIGN.md 3.6).  Per-ray results do not depend on the order; the
+            # device jitter is keyed by the position in the launch, so a pixel gets a different (equally distributed) draw.
+            # Not with the reference's CPU draws (torch_cpu): those are consumed in image order, chunk by chunk.
+            order = None
+            if getattr(self, "render_patch_order", True) and not (tr["perturb"] > 0.0 and self.jitter_rng == "torch_cpu" and S):
+                order = self._pixel_order(H, W, device)
+                rays_o, rays_d = rays_o[order], rays_d[order]
+                if gt_depth is not None:
+                    gt_depth = gt_depth[order]
             depths, colors = [], []
             step = getattr(self, "render_chunk_rays", 1 << 20)
             for i in range(0, n, step):
@@ -237,7 +249,24 @@ class JointEncoding(nn.Module):
                                        **({"stats": stats} if stats is not None else {}))
                 depths.append(ret["depth"].double())
                 colors.append(ret["rgb"])
-            return torch.cat(depths, 0).reshape(H, W), torch.cat(colors, 0).reshape(H, W, 3)
+            depth, color = torch.cat(depths, 0), torch.cat(colors, 0)
+            if order is not None:
+                depth, color = torch.empty_like(depth).index_copy_(0, order, depth), torch.empty_like(color).index_copy_(0, order, color)
+            return depth.reshape(H, W), color.reshape(H, W, 3)
+
+    def _pixel_order(self, H, W, device):
+        """Pixel indices (row-major y * W + x) of an H x W frame sorted along the Z-order (Morton) curve: any aligned run of
+        8 / 64 / 256 consecutive entries is a 4 x 2 / 8 x 8 / 16 x 16 pixel block (cut at the frame's edges).  Cached."""
+        key = (H, W, str(device))
+        cache = self.__dict__.setdefault("_pixel_order_cache", {})
+        if key not in cache:
+            y, x = torch.meshgrid(torch.arange(H, dtype=torch.int64), torch.arange(W, dtype=torch.int64), indexing="ij")
+            code = torch.zeros(H, W, dtype=torch.int64)
+            for b in range(16):
+                code |= ((x >> b) & 1) << (2 * b)
+                code |= ((y >> b) & 1) << (2 * b + 1)
+            cache[key] = torch.argsort(code.reshape(-1), stable=True).to(device)
+        return cache[key]
 
     # ------------------------------------------------------------------ point queries (forward only)
     def _query(self, pts, **kw):

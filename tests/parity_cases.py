@@ -1185,6 +1185,10 @@ def check_device_clock(device):
     assert lib.mne_adam_step(arr, 1, 0, C.byref(bad), st) < 0 and b"betas" in lib.mne_last_error()
 
 
+def U5f(ro, cfg, device):
+    return torch.rand(ro.shape[0], cfg["training"]["n_samples"], generator=torch.Generator().manual_seed(8)).to(device)
+
+
 def check_render_maps_fast_path(device):
     """N1: the no-grad fast path (one launch sequence, exact early ray termination) gives the maps of render_rays --
     without depth guidance against the reference's golden render, with depth guidance against the full render of the
@@ -1207,6 +1211,40 @@ def check_render_maps_fast_path(device):
     fast = m2.render_maps(ro, rd, target_d=dd, u=U2)
     assert torch.equal(full[0].detach(), fast["rgb"]) and torch.equal(full[1].detach(), fast["depth"])
     assert torch.equal(full[3].detach(), fast["acc_map"])
+    # colour planes: the forward-only kernels keep ONE set of feature rows in LDS and gather the two plane sets in turn
+    # (decode_tile<..., SEQF>) -- same bits as the training-form decode behind _render, with and without depth guidance
+    g4 = load_golden("fwd_colorplanes")
+    cfg4 = configs.small_test_config(**FWD_CASES["fwd_colorplanes"])
+    m4 = model_from_golden(g4, cfg4, device).eval()
+    ro4, rd4, _, dd4, U4 = to_dev(fixture_inputs(g4), device)
+    full4 = m4._render(ro4, rd4, None, dd4, u=U4)
+    fast4 = m4.render_maps(ro4, rd4, target_d=dd4, u=U4)
+    assert torch.equal(full4[0].detach(), fast4["rgb"]) and torch.equal(full4[1].detach(), fast4["depth"])
+    assert torch.equal(full4[3].detach(), fast4["acc_map"])
+    S_free = cfg4["training"]["n_samples"]
+    U5 = torch.rand(ro4.shape[0], S_free, generator=torch.Generator().manual_seed(8)).to(device)
+    full5 = m4._render(ro4, rd4, None, None, u=U5)
+    fast5 = m4.render_maps(ro4, rd4, target_d=None, u=U5)
+    assert torch.equal(full5[0].detach(), fast5["rgb"]) and torch.equal(full5[1].detach(), fast5["depth"])
+    # the frame decode kernel (decode_frame_kernel: one plane set, 2x32 decoders, whole frames only) forced onto
+    # these small batches: same bits as decode_kernel, with and without depth guidance, fp32 and half-precision planes
+    import os
+    for f16 in (False, True):
+        m6 = model_from_golden(g2, cfg, device).eval()
+        if f16:
+            for lst in m6.all_planes:
+                for k in range(len(lst)):
+                    lst[k] = lst[k].half()
+        outs = {}
+        for mode in ("1000000", "-1"):
+            os.environ["MNE_FRAME_MIN_TILES"] = mode
+            try:
+                outs[mode] = (m6.render_maps(ro, rd, target_d=dd, u=U2), m6.render_maps(ro, rd, target_d=None, u=U5f(ro, cfg, device)))
+            finally:
+                del os.environ["MNE_FRAME_MIN_TILES"]
+        for a_, b_ in zip(outs["1000000"], outs["-1"]):
+            for k in ("rgb", "depth", "acc_map", "depth_var", "disp_map"):
+                assert torch.equal(a_[k], b_[k]), f"frame decode kernel differs ({k}, f16={f16})"
     # whole frame through render_img: chunked like the reference vs one launch sequence
     cfg3 = configs.small_test_config()
     cfg3["cam"].update(H=12, W=16, fx=16.0, fy=16.0, cx=8.0, cy=6.0, crop_edge=0)
@@ -1221,6 +1259,25 @@ def check_render_maps_fast_path(device):
     d_b, c_b = m3.render_img(c2w.to(device), device, gt_depth=None)
     assert d_a.dtype == torch.float64 and d_a.shape == (12, 16) and c_a.shape == (12, 16, 3)
     assert torch.equal(d_a, d_b) and torch.equal(c_a, c_b)
+    # production form (device jitter): the frame's rays are walked along a Z-order curve (4 x 2 pixel patches per workgroup);
+    # per-pixel results do not depend on the order -- without jitter the image is the same bit for bit, chunked or not
+    cfg5 = configs.small_test_config()
+    cfg5["cam"].update(H=13, W=18, fx=16.0, fy=16.0, cx=9.0, cy=6.5, crop_edge=0)
+    cfg5["training"]["perturb"] = 0
+    m5 = model_from_golden(g, cfg5, device).eval()
+    m5.jitter_rng = "device"
+    gt5 = (1.0 + 0.05 * torch.arange(13 * 18, dtype=torch.float32).reshape(13, 18) % 1.7).to(device)
+    for gtd in (None, gt5):
+        d_on, c_on = m5.render_img(c2w.to(device), device, gt_depth=gtd)
+        m5.render_chunk_rays = 100
+        d_ch, c_ch = m5.render_img(c2w.to(device), device, gt_depth=gtd)
+        m5.render_patch_order = False
+        d_off, c_off = m5.render_img(c2w.to(device), device, gt_depth=gtd)
+        m5.render_patch_order, m5.render_chunk_rays = True, 1 << 20
+        assert torch.equal(d_on, d_off) and torch.equal(c_on, c_off) and torch.equal(d_on, d_ch) and torch.equal(c_on, c_ch)
+    order = m5._pixel_order(13, 18, "cpu")
+    assert sorted(order.tolist()) == list(range(13 * 18))
+    assert sorted(order[:8].tolist()) == [0, 1, 2, 3, 18, 19, 20, 21]          # a 4 x 2 patch
     # and equal to the reference's own chunk loop over render_rays (same CPU jitter draws, same order)
     from mneslam_amd.model.utils import get_rays
     ro3, rd3 = get_rays(12, 16, 16.0, 16.0, 8.0, 6.0, c2w.to(device), device)
@@ -1588,3 +1645,36 @@ def run_overlap_agent(rank, device, comm, geometry="lattice"):
     dec = torch.cat([cpu(p).reshape(-1) for p in model.decoder.parameters()])
     both = comm.all_gather(dec)
     assert torch.equal(both[0], both[1])
+
+
+def check_sample_z_frame_counts(device, R=20011):
+    """mne_sample_z on a batch larger than MNE_BALANCED_MAX_RAYS (whole frames): the mask counts are summed by many workgroups;
+    they must equal the sum of the per-ray counts."""
+    import ctypes as C
+    from mneslam_amd import hip_path, _lib
+    lib = _lib.load()
+    dev = torch.device(device)
+    cfg = configs.small_test_config()
+    rc = hip_path.render_cfg_struct(cfg)
+    S = lib.mne_num_samples(C.byref(rc), 1)
+    tables = hip_path.linspace_tables(cfg, True, dev)
+    g = torch.Generator().manual_seed(4)
+    d = (torch.rand(R, generator=g) * 4.0).to(dev)
+    d[::7] = 0.0                                           # rays without depth
+    P = _lib.ptr
+
+    def run(lo, hi):
+        n = hi - lo
+        z = torch.empty(n, S, device=dev)
+        cnt = torch.full((8,), -1, dtype=torch.int32, device=dev)
+        rcnt = torch.zeros(n, 8, dtype=torch.int32, device=dev)
+        dd = d[lo:hi].contiguous()
+        _lib.check(lib.mne_sample_z(C.byref(rc), n, P(dd), None, P(tables), 5, lo * S // 4 * 4, P(z), P(cnt), P(rcnt), None,
+                                    _lib.stream_for(z)), "mne_sample_z")
+        return cnt.cpu().long(), rcnt.cpu().long()
+
+    cnt, rcnt = run(0, R)
+    keep = list(range(7))                                  # slot 7 (MNE_C_TILE0) is per-ray scratch of the balanced decode schedule
+    assert torch.equal(cnt[keep], rcnt.sum(0)[keep]), (cnt, rcnt.sum(0))
+    cnt1, rcnt1 = run(0, 4096)                             # a batch below the bound: the one-workgroup form, same contract
+    assert torch.equal(cnt1[keep], rcnt1.sum(0)[keep]) and torch.equal(rcnt1[:, keep], rcnt[:4096, keep])

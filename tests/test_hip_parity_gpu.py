@@ -639,3 +639,8 @@ def test_two_agents_binned_overlap_on_one_device(monkeypatch, geometry):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_sample_z_frame_sized_batch_counts():
+    """whole-frame batches: the striped counts reduction of mne_sample_z"""
+    pc.check_sample_z_frame_counts(DEV)

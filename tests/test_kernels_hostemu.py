@@ -360,3 +360,8 @@ def test_bench_path_step_with_heavy_ray_list(monkeypatch, capped):
     cfg["training"]["n_samples_d"], cfg["training"]["n_range_d"] = 100, 11
     out = pc.check_fused_step_vs_oracle(DEV, cfg, n_keyframes=3, seed=2, small=True, impl="explicit")
     assert out["contributing"] > 0
+
+
+def test_sample_z_frame_sized_batch_counts():
+    """whole-frame batches: the striped counts reduction of mne_sample_z"""
+    pc.check_sample_z_frame_counts(DEV)
