@@ -40,7 +40,9 @@ enum { MNE_C_VALID = 0, MNE_C_E_FRONT = 1, MNE_C_E_CENTER = 2, MNE_C_E_TAIL = 3,
        MNE_C_CO_SDF = 5,
        MNE_C_NEED = 6,   /* per-ray only: leading samples that can carry a loss term (z <= target depth + truncation) */
        MNE_C_TILE0 = 7,  /* per-ray only: exclusive prefix over the rays of their a-priori 32-sample tile counts (clamp(ceil(
-                          * MNE_C_NEED / 32), 1, tiles per ray)): the render calls deal the decode's tile tasks evenly from it */
+                          * MNE_C_NEED / 32), 1, tiles per ray)): the render calls deal the decode's tile tasks evenly from it.
+                          * Written for batches of at most 16384 rays (whole frames are summed by many workgroups and decoded with
+                          * the fixed-stride schedule) */
        MNE_N_COUNT = 8 };
 
 typedef struct mne_plane {
