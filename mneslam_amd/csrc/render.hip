@@ -617,6 +617,33 @@ __device__ __forceinline__ void frame_mfma_range(FrameTile& s, const ATabRef<fal
     }
 }
 
+// One 32-sample tile of ray r, forward only, by the calling wave: normalised points -> inline gather into the wave's LDS rows -> OneBlob
+// -> the bare MFMA chain.  Returns (r, g, b, sdf) of this lane's sample (rows 0..3 of the colour result and row 0 of the sdf result
+// live in the lower half-wave) and stores it to a.raw.
+__device__ __forceinline__ float4 frame_tile(const RenderArgs& a, int r, int c, int lane, float* pn, float* feat, const ATabRef<false>& A,
+                                             FrameTile& st) {
+    const int S = a.S, pt = lane & 31, hf = lane >> 5;
+    const int i = c * TILE + pt;
+    const float z = a.z_vals[(size_t)r * S + (i < S ? i : S - 1)];
+    float p[3], pnv[3], u[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = a.rays_o[r * 3 + k] + a.rays_d[r * 3 + k] * z;      // scene_rep.py:384
+    point_coords(a.sc, p, pnv, u);
+    MNE_WAVE_SYNC();                                       // the previous tile's LDS reads are done
+    *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);       // (both lanes of a point store the same value)
+    MNE_WAVE_SYNC();
+    gather_chunk<1, TILE, MNE_INLINE_GATHER_NLV>(a.sc, pn, feat, lane);
+    MNE_WAVE_SYNC();
+    oneblob_half<true>(u, hf, st.pos);
+    const float* frow = feat + pt * MNE_FS + hf * 32;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st.x[q] = *(const float4*)(frow + 4 * q);
+    frame_mfma_range<0, 120>(st, A);
+    const float4 rw = make_float4(st.acc[0], st.acc[1], st.acc[2], st.out[0]);
+    if (i < S && hf == 0) *(float4*)(a.raw + ((size_t)r * S + i) * 4) = rw;
+    return rw;
+}
+
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void decode_frame_kernel(RenderArgs a, int sched) {
     typedef ATab<32, 32, false> T;
@@ -631,7 +658,6 @@ __global__ __launch_bounds__(64 * WPB) void decode_frame_kernel(RenderArgs a, in
     }
     const float* atab = (const float*)lds_raw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int pt = lane & 31, hf = lane >> 5;
     const int S = a.S, ntile = (S + TILE - 1) / TILE;
     float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(1));
     float* feat = pn + TILE * 4;
@@ -661,24 +687,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_frame_kernel(RenderArgs a, in
             r = (int)(task % n_rays);
             if (c >= prefix_tiles(a, r, ntile)) continue;
         }
-        const int i = c * TILE + pt;
-        const float z = a.z_vals[(size_t)r * S + (i < S ? i : S - 1)];
-        float p[3], pnv[3], u[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = a.rays_o[r * 3 + k] + a.rays_d[r * 3 + k] * z;      // scene_rep.py:384
-        point_coords(a.sc, p, pnv, u);
-        MNE_WAVE_SYNC();                                       // the previous tile's LDS reads are done
-        *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);       // (both lanes of a point store the same value)
-        MNE_WAVE_SYNC();
-        gather_chunk<1, TILE, MNE_INLINE_GATHER_NLV>(a.sc, pn, feat, lane);
-        MNE_WAVE_SYNC();
-        oneblob_half<true>(u, hf, st.pos);
-        const float* frow = feat + pt * MNE_FS + hf * 32;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) st.x[q] = *(const float4*)(frow + 4 * q);
-        frame_mfma_range<0, 120>(st, A);
-        // rows 0..3 of the colour result and row 0 of the sdf result live in the lower half
-        if (i < S && hf == 0) *(float4*)(a.raw + ((size_t)r * S + i) * 4) = make_float4(st.acc[0], st.acc[1], st.acc[2], st.out[0]);
+        frame_tile(a, r, c, lane, pn, feat, A, st);
     }
 }
 
@@ -975,6 +984,72 @@ __device__ __forceinline__ void hot_backward_tile(const RenderArgs& a, int r, in
     }
     MNE_WAVE_SYNC();
     store_rows<32>(feat, tape0, D::ROW, D::T_DOUT, valid_rows, lane);
+}
+
+// first adjacent sign change among samples [from, D) of a ray whose sdf values sit in `sdf` (LDS); -1 when none
+__device__ __forceinline__ int first_crossing_s(const float* sdf, int from, int D, int lane) {
+    for (int base = from; base < D - 1; base += MNE_WAVE) {
+        const int i = base + lane;
+        const bool cr = (i < D - 1) && (sdf[i + 1] * sdf[i] < 0.0f);
+        const unsigned long long m = __ballot(cr);
+        if (m) return base + __ffsll(m) - 1;
+    }
+    return -1;
+}
+
+// ray_frame_kernel: ray_kernel<32, 32, no colour planes, MODE 0> of whole frames -- resolve every ray from its a-priori prefix, decoding
+// further tiles on demand (frame_tile), then composite.  What differs is the LDS: ray_kernel keeps a ray's raw rows and z samples in
+// LDS (20 B per sample: 5 KB of the 14.3 KB per wave at 256 samples), which holds it at 8 waves per CU; here only the sdf values stay in
+// LDS (the sign-change search), the compositing reads the raw rows back from global memory -- written by the decode launch and by this
+// very wave (L1 is write-through and shared by the workgroup: a drain of the wave's stores is all the hand-off needs) -- and z from
+// global memory: 10.2 KB per wave, 12 waves per CU.  Same values through the same compositing code: bit-equal maps.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void ray_frame_kernel(RenderArgs a) {
+    typedef ATab<32, 32, false> T;
+    constexpr int TAB_FLOATS = T::FWD_STEPS * 64;
+    MNE_DYN_LDS(lds_raw);
+    const int wpb = blockDim.x >> 6;
+    {
+        float4* dst = (float4*)lds_raw;
+        const float4* src = (const float4*)a.packed;
+        for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+    const float* atab = (const float*)lds_raw;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pt = lane & 31, hf = lane >> 5;
+    const int S = a.S, ntile = (S + TILE - 1) / TILE;
+    const size_t wave_bytes = tile_wave_lds_bytes(1) + (size_t)((S + 3) & ~3) * sizeof(float);
+    float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * wave_bytes);
+    float* feat = pn + TILE * 4;
+    float* sdf = feat + TILE * MNE_FS;                            // [Spad] this ray's sdf values
+    const ATabRef<false> A(atab, lane);
+    FrameTile st;
+    for (int r = xcd_block() * wpb + wv; r < a.R; r += gridDim.x * wpb) {
+        const float* zsrc = a.z_vals + (size_t)r * S;
+        const float* rawsrc = a.raw + (size_t)r * S * 4;
+        int t_dec = prefix_tiles(a, r, ntile);                   // tiles the decode launch wrote
+        int Dn = t_dec * TILE < S ? t_dec * TILE : S;
+        MNE_WAVE_SYNC();                                          // previous ray's LDS reads are done
+        for (int i = lane; i < Dn; i += MNE_WAVE) sdf[i] = rawsrc[4 * i + 3];
+        MNE_WAVE_SYNC();
+        int first = -1, from = 0;
+        while (true) {
+            if (first < 0) first = first_crossing_s(sdf, from, Dn, lane);
+            if (ray_resolved(zsrc, first, Dn, S, a.win_f)) break;
+            const float4 rw = frame_tile(a, r, t_dec, lane, pn, feat, A, st);      // (Dn is a multiple of TILE here)
+            const int i = t_dec * TILE + pt;
+            if (i < S && hf == 0) sdf[i] = rw.w;
+            MNE_WAVE_SYNC();
+            from = Dn > 0 ? Dn - 1 : 0;
+            ++t_dec;
+            Dn = t_dec * TILE < S ? t_dec * TILE : S;
+        }
+        MNE_DRAIN_STORES();                                       // this wave's raw rows have left for L1 / L2 before its lanes read them back
+        MNE_WAVE_SYNC();
+        RayGrad G;
+        composite_ray<false>(a, r, lane, rawsrc, zsrc, Dn, first < 0 ? 0 : first, G);
+    }
 }
 
 template <int HID, int HIDC, bool CP, bool ALDS, int MODE>
@@ -2033,7 +2108,25 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         MNE_LAUNCH(composite_kernel, (a.R + 3) / 4, 256, clds, st, a);
         return 0;
     }
-    if (mode == 1) return launch_ray<HID, HIDC, CP, 0>(a, st);
+    if (mode == 1) {
+        if constexpr (MNE_DECODE_FRAME && HID == 32 && HIDC == 32 && !CP) {
+            // whole frames: the lean kernel at 12 waves per CU (see ray_frame_kernel)
+            const size_t tab = table_bytes<HID, HIDC, CP>(0);
+            const size_t per_wave = tile_wave_lds_bytes(1) + (size_t)((a.S + 3) & ~3) * sizeof(float);
+            const int wpb = fit_waves<HID, HIDC, CP>(tab, per_wave, MNE_FRAME_WPB);
+            const int min_tiles = a.frame_min_tiles > 0 ? a.frame_min_tiles : a.frame_min_tiles < 0 ? 0 : MNE_FRAME_MIN_TILES;
+            if (wpb >= 1 && !a.raw_in && !a.ext_feat && a.raw && !a.ray_list && !a.dec_tiles &&
+                (long long)a.R >= (long long)MNE_NUM_CU * wpb * min_tiles) {
+                const size_t lds = tab + (size_t)wpb * per_wave;
+                long long grid = ((long long)a.R + wpb - 1) / wpb;
+                if (grid > MNE_NUM_CU) grid = MNE_NUM_CU;
+                if (lds > 64 * 1024) MNE_SET_MAX_LDS((ray_frame_kernel<MNE_FRAME_WPB>), MNE_LDS_MAX);
+                MNE_LAUNCH((ray_frame_kernel<MNE_FRAME_WPB>), (unsigned)grid, 64 * wpb, lds, st, a);
+                return 0;
+            }
+        }
+        return launch_ray<HID, HIDC, CP, 0>(a, st);
+    }
     if (mode == 2) {
         // training: every ray in the lean kernel; the few it cannot resolve from the decoded prefix are finished by the
         // full kernel, driven by the deferred list (a handful of workgroups that leave at once when the list is empty)
