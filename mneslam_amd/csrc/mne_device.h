@@ -183,13 +183,35 @@ __device__ __forceinline__ uint2 float4_to_half4(float4 v) {                  //
     r.h[0] = (_Float16)v.x; r.h[1] = (_Float16)v.y; r.h[2] = (_Float16)v.z; r.h[3] = (_Float16)v.w;
     return r.u;
 }
-template <bool F16>
+// MNE_PLANE_BUFFER_LOADS: the corner rows through BUFFER loads -- the plane's base in a (wave-uniform) resource descriptor, the
+// element offset as one 32-bit VGPR: one VALU instruction of address arithmetic per load instead of three (add, sign extension,
+// 64-bit shift-add).  Same bytes loaded.  The frame kernels are bound by what their waves ISSUE: render_img 36.2 -> 34.7 ms
+// per frame pair; the mapping iteration +0.3 % (office0) / +0.8 % (ScanNet) / 0 (INS Indoor), profiles/r05_buffer_loads.txt.
+// Opt-in per call site (BUF): gather_kernel and the frame kernels; the tile kernels of the largest decoder have no register to spare
+// for the descriptors (decode_kernel<64, 64, colour planes> spilled 12 B per lane with it).
+#ifndef MNE_PLANE_BUFFER_LOADS
+#define MNE_PLANE_BUFFER_LOADS 1
+#endif
+template <bool F16, bool BUF = false>
 __device__ __forceinline__ float4 plane_row4(const mne_plane_t& pl, int e) {
+#if MNE_PLANE_BUFFER_LOADS && !defined(MNE_HOST_EMU)
+  if constexpr (BUF) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pl.data, 0, 0x7fffffff, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    if (F16) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, e * 2, 0, 0);
+        return half4_to_float4(make_uint2(v.x, v.y));
+    }
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, e * 4, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
+#endif
     if (F16) return half4_to_float4(*(const uint2*)((const _Float16*)pl.data + e));
     return *(const float4*)((const float*)pl.data + e);
 }
 
-template <int NSETS, bool F16, int NLV = MNE_GATHER_INFLIGHT / 12, int SET0 = 0>       // NLV: levels loaded together (12 corner rows each)
+template <int NSETS, bool F16, int NLV = MNE_GATHER_INFLIGHT / 12, int SET0 = 0, bool BUF = false>       // NLV: levels loaded together (12 corner rows each)
 __device__ __forceinline__ void gather_slot_t(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {   // plane sets SET0 .. SET0 + NSETS - 1
     const int kmine = cg < 6 ? cg : cg - 6;                        // this lane's plane: k = lvl * 3 + ori
     const int lvl_m = kmine >= 3 ? 1 : 0, ori_m = kmine - 3 * lvl_m;
@@ -224,7 +246,7 @@ __device__ __forceinline__ void gather_slot_t(const mne_scene_t& sc, float px, f
                 const int k = l0 * 3 + j;
                 const mne_plane_t& pl = sc.plane[set][k % 3][k / 3];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[j][q] = plane_row4<F16>(pl, cg * 4 + off[j][q]);
+                for (int q = 0; q < 4; ++q) v[j][q] = plane_row4<F16, BUF>(pl, cg * 4 + off[j][q]);
             }
             MNE_SCHED_BARRIER();
 #pragma unroll
@@ -248,21 +270,21 @@ __device__ __forceinline__ void gather_slot_t(const mne_scene_t& sc, float px, f
     }
 }
 
-template <int NSETS, int NLV = MNE_GATHER_INFLIGHT / 12, int SET0 = 0>
+template <int NSETS, int NLV = MNE_GATHER_INFLIGHT / 12, int SET0 = 0, bool BUF = false>
 __device__ __forceinline__ void gather_slot(const mne_scene_t& sc, float px, float py, float pz, int cg, float* out, int set_stride) {
-    if (sc.plane_f16) gather_slot_t<NSETS, true, NLV, SET0>(sc, px, py, pz, cg, out, set_stride);       // (uniform over the launch)
-    else gather_slot_t<NSETS, false, NLV, SET0>(sc, px, py, pz, cg, out, set_stride);
+    if (sc.plane_f16) gather_slot_t<NSETS, true, NLV, SET0, BUF>(sc, px, py, pz, cg, out, set_stride);       // (uniform over the launch)
+    else gather_slot_t<NSETS, false, NLV, SET0, BUF>(sc, px, py, pz, cg, out, set_stride);
 }
 
 // (NLV = 2 -- both levels' 24 corner rows requested together -- was measured for the gathers INSIDE the tile kernels, where the
 // registers are free: no effect on the deferred decode, the resolver's extension tile or render_img, profiles/r05_inline_gather_levels.txt)
-template <int NSETS, int NPTS, int NLV = 1, int SET0 = 0>
+template <int NSETS, int NPTS, int NLV = 1, int SET0 = 0, bool BUF = false>
 __device__ __forceinline__ void gather_chunk(const mne_scene_t& sc, const float* pn, float* feat, int lane) {
     const int cg = lane & 7;
 #pragma unroll 1
     for (int it = 0; it < NPTS / 8; ++it) {
         const int slot = it * 8 + (lane >> 3);
-        gather_slot<NSETS, NLV, SET0>(sc, pn[slot * 4 + 0], pn[slot * 4 + 1], pn[slot * 4 + 2], cg, feat + slot * MNE_FS, NPTS * MNE_FS);
+        gather_slot<NSETS, NLV, SET0, BUF>(sc, pn[slot * 4 + 0], pn[slot * 4 + 1], pn[slot * 4 + 2], cg, feat + slot * MNE_FS, NPTS * MNE_FS);
     }
 }
 

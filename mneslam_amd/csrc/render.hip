@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void gather_kernel(RenderArgs a, int chunks_pe
     }
     float* row = a.tape + ((size_t)r * S + ii) * a.tape_row + a.tape_tx;
     // rows of samples beyond S (last chunk of a ray) are computed on the clamped sample and written twice: harmless
-    gather_slot_t<NSETS, F16>(a.sc, pnv[0], pnv[1], pnv[2], lane & 7, row, a.tape_tcf - a.tape_tx);
+    gather_slot_t<NSETS, F16, MNE_GATHER_INFLIGHT / 12, 0, true>(a.sc, pnv[0], pnv[1], pnv[2], lane & 7, row, a.tape_tcf - a.tape_tx);
 }
 
 // WPB: waves per workgroup the kernel is compiled for (12 for the fused gather+MLP form: latency hiding matters most;
@@ -632,7 +632,7 @@ __device__ __forceinline__ float4 frame_tile(const RenderArgs& a, int r, int c, 
     MNE_WAVE_SYNC();                                       // the previous tile's LDS reads are done
     *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);       // (both lanes of a point store the same value)
     MNE_WAVE_SYNC();
-    gather_chunk<1, TILE, MNE_INLINE_GATHER_NLV>(a.sc, pn, feat, lane);
+    gather_chunk<1, TILE, MNE_INLINE_GATHER_NLV, 0, true>(a.sc, pn, feat, lane);
     MNE_WAVE_SYNC();
     oneblob_half<true>(u, hf, st.pos);
     const float* frow = feat + pt * MNE_FS + hf * 32;
