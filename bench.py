@@ -306,12 +306,12 @@ def render_img_measure(agent, cfg, device, n_pairs, n_warm):
     rec = {"frame": f"{cam['W']}x{cam['H']}", "rays_per_frame": n_rays, "nominal_point_queries_per_pair": pts,
            "decoded_samples_per_pair": stats["decoded_samples"], "early_ray_termination": True,
            "depth_l1_vs_gt": float((d1.float() - gt)[gt > 0].abs().mean()),
-           "roofline": {"kernel": "ray_kernel<..., 0> (inline tri-plane gather + OneBlob + MLP forward + compositing, early termination)",
+           "roofline": {"kernel": "decode_frame_kernel + ray_frame_kernel (inline tri-plane gather + OneBlob + MLP forward + compositing, early termination)",
                         "bound": "mfma_f32", "flops_per_pair": flops, "flop_per_decoded_sample": flop_per_sample,
                         "achieved": flops / (own / n_pairs) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (own / n_pairs) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                        "note": "useful MLP flops of the decoded samples only; the kernel is not bound by the matrix pipe (nor by the "
-                                "number of load rounds of its inline gather: DESIGN.md 3.6)"}}
+                        "note": "useful MLP flops of the decoded samples only; the kernels are bound by what their waves issue (120 dependent "
+                                "MFMAs + ~1500 VALU per 32-sample tile), not by HBM or the matrix pipe: DESIGN.md 3.6"}}
     return own, rec
 
 

@@ -7,6 +7,9 @@ timeout 900 python bench.py > gpurun_out/r05_bench_default.json 2> gpurun_out/r0
 : > gpurun_out/r05_bench_driver_form.json
 for k in 1 2 3; do timeout 600 python bench.py --steps 20 --warmup 5 --cpu-iters 0 --no-variants 2>/dev/null | tail -1 >> gpurun_out/r05_bench_driver_form.json; done
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r05_bench_driver_form_torchrun.json
+cd /tmp; rm -rf /tmp/ks_f; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ks_f -o k -- python $OLDPWD/bench.py --no-variants --cpu-iters 0 --steps 100 --warmup 20 > /dev/null 2>&1
+python $OLDPWD/profiles/summarize_rocprof_db.py $(find /tmp/ks_f -name '*.db' | head -1) > $OLDPWD/gpurun_out/r05_kernel_stats_office0_final.txt 2>&1; head -16 $OLDPWD/gpurun_out/r05_kernel_stats_office0_final.txt | cut -c1-150
+cd $OLDPWD
 python - <<'PY'
 import json
 d = json.loads(open('gpurun_out/r05_bench_default.json').read().strip().splitlines()[-1])
