@@ -51,6 +51,36 @@
 #ifndef TILE_MIN_WAVES
 #define TILE_MIN_WAVES 4        // waves per SIMD the register allocation must allow: 2 workgroups of 8 waves per CU (LDS-limited)
 #endif
+// Cache policy of the Adam sweep's streams (bit mask: 1 = m / v stores, 2 = m / v loads, 4 = p loads, 8 = p stores nontemporal).  The moments are
+// touched once per iteration and by nothing else; the parameters are read again by the next iteration's gather.  Measured
+// (profiles/r05_adam_nt.txt; the kernel itself hardly changes, the kernels around it find more of their data in cache): moments
+// nontemporal (3) office0 2233 -> 2267 it/s, ScanNet 1209 -> 1218, INS Indoor within noise; + parameter stores (11) the same;
+// + parameter loads (15) loses it again.
+#ifndef MNE_ADAM_NT
+#define MNE_ADAM_NT 3
+#endif
+typedef float mne_f4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+#ifndef MNE_HOST_EMU
+    if constexpr (NT) {
+        const mne_f4 v = __builtin_nontemporal_load((const mne_f4*)p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+#endif
+    return *(const float4*)p;
+}
+template <bool NT>
+__device__ __forceinline__ void nt_store4(float* p, float4 v) {
+#ifndef MNE_HOST_EMU
+    if constexpr (NT) {
+        mne_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_nontemporal_store(t, (mne_f4*)p);
+        return;
+    }
+#endif
+    *(float4*)p = v;
+}
 #ifndef TILE_EMPTY_FAST
 #define TILE_EMPTY_FAST 1
 #endif
@@ -451,8 +481,8 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             const size_t off = ((size_t)gy * pl.w + gx) * MNE_C + ch4 * 4;
             const size_t offmv = off;    // (moments stored tile-major were measured: no DRAM-locality effect, profiles/r02_tile_adam_variants.txt)
             // parameters: fp32, or half precision (mne_scene_t.plane_f16: p32 = float(p16) -> Adam in fp32 -> round to nearest)
-            float4 p = f16 ? half4_to_float4(*(const uint2*)((const _Float16*)pl.data + off)) : *(const float4*)((const float*)pl.data + off);
-            float4 m = *(float4*)(o.m + offmv), v = *(float4*)(o.v + offmv);
+            float4 p = f16 ? half4_to_float4(*(const uint2*)((const _Float16*)pl.data + off)) : nt_load4<(MNE_ADAM_NT & 4) != 0>((const float*)pl.data + off);
+            float4 m = nt_load4<(MNE_ADAM_NT & 2) != 0>(o.m + offmv), v = nt_load4<(MNE_ADAM_NT & 2) != 0>(o.v + offmv);
             float4 gg = empty ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)g)[i4];
             if constexpr (OV == 2) {
                 if (shared_tile) {
@@ -474,8 +504,8 @@ __global__ __launch_bounds__(TILE_THREADS, TILE_MIN_WAVES) void tile_adam_kernel
             adam_elem(p.x, gg.x, m.x, v.x, o); adam_elem(p.y, gg.y, m.y, v.y, o);
             adam_elem(p.z, gg.z, m.z, v.z, o); adam_elem(p.w, gg.w, m.w, v.w, o);
             if (f16) *(uint2*)((_Float16*)pl.data + off) = float4_to_half4(p);
-            else *(float4*)((float*)pl.data + off) = p;
-            *(float4*)(o.m + offmv) = m; *(float4*)(o.v + offmv) = v;
+            else nt_store4<(MNE_ADAM_NT & 8) != 0>((float*)pl.data + off, p);
+            nt_store4<(MNE_ADAM_NT & 1) != 0>(o.m + offmv, m); nt_store4<(MNE_ADAM_NT & 1) != 0>(o.v + offmv, v);
         }
     }
     if (tid == 0 && a.prev_counts) a.prev_counts[tile] = cnt;
