@@ -1245,6 +1245,23 @@ def check_render_maps_fast_path(device):
         for a_, b_ in zip(outs["1000000"], outs["-1"]):
             for k in ("rgb", "depth", "acc_map", "depth_var", "disp_map"):
                 assert torch.equal(a_[k], b_[k]), f"frame decode kernel differs ({k}, f16={f16})"
+    # ... and on rays of several tiles whose sample count is no multiple of 32 (150 free samples: five tiles, the on-demand kernel
+    # walks up to four of them per ray; the raw rows of a tile then share cache lines with the next tile's)
+    cfg7 = configs.small_test_config()
+    cfg7["training"]["n_samples"] = 150
+    m7 = model_from_golden(g2, cfg7, device).eval()
+    U7 = torch.rand(ro.shape[0], 150, generator=torch.Generator().manual_seed(9)).to(device)
+    outs7 = {}
+    for mode in ("1000000", "-1"):
+        os.environ["MNE_FRAME_MIN_TILES"] = mode
+        try:
+            outs7[mode] = m7.render_maps(ro, rd, target_d=None, u=U7)
+        finally:
+            del os.environ["MNE_FRAME_MIN_TILES"]
+    full7 = m7._render(ro, rd, None, None, u=U7)
+    for k in ("rgb", "depth", "acc_map", "depth_var", "disp_map"):
+        assert torch.equal(outs7["1000000"][k], outs7["-1"][k]), f"frame kernels differ on 150-sample rays ({k})"
+    assert torch.equal(full7[0].detach(), outs7["-1"]["rgb"]) and torch.equal(full7[1].detach(), outs7["-1"]["depth"])
     # whole frame through render_img: chunked like the reference vs one launch sequence
     cfg3 = configs.small_test_config()
     cfg3["cam"].update(H=12, W=16, fx=16.0, fy=16.0, cx=8.0, cy=6.0, crop_edge=0)
