@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void sample_z_kernel(ZArgs a) {
 // Batches of more rays than this (whole frames: 816 k rays) neither fit the balanced decode schedule (its tile-count prefix of
 // every ray sits in LDS) nor a one-workgroup reduction: their counts are summed by many workgroups (integer atomics) and slot
 // MNE_C_TILE0 is left unwritten -- launch_decode applies the same bound.  (Round 5 first ran the one-workgroup form on frames:
-// 3.3 ms of a 22 ms depth-guided render, profiles/r05_render_img_counts.txt.)
+// 3.3 ms of a 22 ms depth-guided render, profiles/r05_render_img_experiments.txt.)
 #ifndef MNE_BALANCED_MAX_RAYS
 #define MNE_BALANCED_MAX_RAYS 16384
 #endif
@@ -405,7 +405,9 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
 // neighbouring pixels, whose samples fall into the same plane cells.  Workgroups are dealt to the 8 XCDs round robin, so with
 // the plain stride every XCD (own L2) sees every 8th group of rays and fetches the same plane lines as its neighbours.
 // xcd_block() renumbers the workgroups so that the 32 workgroups of one XCD take ADJACENT task groups: one contiguous run of
-// rays per XCD and round.  (grid a multiple of 8 only; any other grid keeps its numbering.)
+// rays per XCD and round.  (grid a multiple of 8 only; any other grid keeps its numbering.)  Measured on frames: 39.66 vs 39.65 ms
+// per pair, i.e. nothing by itself -- the frame kernels are not bound by their fetches; kept because it is what lets the Z-order ray
+// walk of render_img keep an XCD's rays in one 16 x 16 pixel patch (HBM traffic of the frame kernels / 4).
 #ifndef MNE_XCD_TASK_MAP
 #define MNE_XCD_TASK_MAP 1
 #endif
