@@ -57,9 +57,9 @@ def test_shipped_build_is_clean(variant):
     assert len(names) > 60
     hot = [k for n, k in names.items() if any(t in n for t in ("gather_kernel", "decode_kernel", "bin_kernel", "tile_adam_kernel",
                                                                 "tile_order_kernel", "wgrad_fused", "adam_kernel", "sample_z_kernel", "heavy_bwd_kernel",
-                                                                "sample_rays"))
+                                                                "sample_rays", "decode_frame_kernel", "ray_frame_kernel"))
            or ("ray_kernel" in n and n.endswith("ELi4EEv10RenderArgs"))]
-    assert len(hot) >= 19
+    assert len(hot) >= 21
     for k in hot:
         assert k["scratch"] == 0 and k.get("vgpr_spill", 0) == 0, f"{k['kernel']} uses {k['scratch']} B of scratch per lane"
     # the weight-gradient kernels share CUs with the plane update (tile_adam_kernel: 2 workgroups of 8 waves per CU): at
