@@ -85,7 +85,7 @@ class Agent:
     """One mapping agent: scene model + optimizer + device-resident keyframe rays."""
 
     def __init__(self, cfg, device, seed, n_keyframes, small=False, path="fused", scatter="binned", share_decoder=False,
-                 overlap=True, graph=None, peers_of=None, model_seed=None):
+                 overlap=True, graph=None, peers_of=None, model_seed=None, overlap_group_axis=None):
         """peers_of (split scenes): callable(model) -> FusedStep ``overlap_peers`` (collective: every rank calls it once its
         model exists); model_seed: the SAME decoder initialisation on every agent of a shared decoder."""
         self.cfg, self.device, self.path = cfg, device, path
@@ -138,6 +138,7 @@ class Agent:
         elif path == "fused":
             self.fused = FusedStep(self.model, self.opt, cfg, cfg["mapping"]["sample"] + self.n_cur, device,
                                    scatter=scatter, shared_decoder=share_decoder, use_graph=graph, overlap_peers=peers,
+                                   overlap_group_axis=overlap_group_axis if peers else None,
                                    overlap=overlap and os.environ.get("MNE_NO_OVERLAP", "0") != "1")
             self.fused.seed = seed
 
@@ -522,14 +523,17 @@ def make_split_agent(config, rank, world, device, keyframes, small=False, rays=N
     if small:
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
+        cfg["c_planes_res"] = {"coarse": 0.2, "fine": 0.1}       # (colour planes, ScanNet: resolutions that nest with the geometry planes')
         if rays:
             cfg["mapping"]["sample"] = rays
             cfg["mapping"]["min_pixels_cur"] = min(cfg["mapping"]["min_pixels_cur"], max(rays // 4, 1))
     else:
         cfg["mapping"]["bound"] = [list(b) for b in configs.SCENE_BOUNDS[config]]       # the WHOLE scene, then this rank's slab
     cfg, axis, slabs = configs.split_agent_config(cfg, world, rank)
+    # more than two agents: the planes that do not contain the slab axis are held by every agent -- their gradient is the sum over
+    # ALL agents (one all-reduce), not pairwise with the neighbours (FusedStep(overlap_group_axis))
     agent = Agent(cfg, device, seed=rank, n_keyframes=keyframes, small=small, share_decoder=True,
-                  peers_of=split_peers(rank, world, device), model_seed=1234)
+                  peers_of=split_peers(rank, world, device), model_seed=1234, overlap_group_axis=axis if world > 2 else None)
     return agent, cfg, {"axis": "xyz"[axis], "slabs": slabs, "workload": workload + f"_scene_split{world}"}
 
 
@@ -596,8 +600,9 @@ def multi_agent_side_records(args, cfg, rank, world, device, barrier, out):
                 "workload": info["workload"], "value": world * n_var / el, "unit": "it/s", "ms_per_step": 1e3 * el / n_var, "steps": n_var,
                 "rays_per_iter": scfg["mapping"]["sample"] + agent.n_cur, "samples_per_ray": S,
                 "parallelism": f"ONE scene ({name}) split into {world} slabs along {info['axis']} (0.5 m overlap, one lattice): "
-                               "overlap-rectangle plane gradients exchanged point-to-point with the neighbours + decoder-gradient "
-                               "all-reduce, every iteration (" + str(dist.get_backend()) + ")",
+                               "overlap-rectangle plane gradients exchanged point-to-point with the neighbours"
+                               + (", gradients of the planes without the slab axis all-reduced over all agents" if world > 2 else "")
+                               + " + decoder-gradient all-reduce, every iteration (" + str(dist.get_backend()) + ")",
                 "exchange_bytes_per_iter_all_ranks": sum(r["overlap_exchange_bytes_per_iter"] for r in rows) + world * 4 * agent.n_dec_params,
                 "slab_bounds": info["slabs"], "per_rank": rows}
             del agent
@@ -656,6 +661,7 @@ def main():
     if args.small:
         cfg["mapping"]["bound"] = [[-1.0, 1.0], [-1.2, 1.1], [-0.8, 0.9]]
         cfg["planes_res"] = {"coarse": 0.1, "fine": 0.05, "bound_dividable": 0.1}
+        cfg["c_planes_res"] = {"coarse": 0.2, "fine": 0.1}
     split = None
     if args.split:
         if world < 2 or args.config not in configs.SCENE_BOUNDS or args.path != "fused" or args.scatter != "binned" or args.graph:
@@ -735,7 +741,9 @@ def main():
                        "encoding": "hash grid (parity unpinned: tinycudann is not in the reference tree)" if agent.hash else "tri-planes (as wired)",
                        "parallelism": (f"ONE scene ({args.config}) split into {world} slabs along {split['axis']} (0.5 m overlap, one lattice), "
                                        f"agent-per-gpu x{world}: overlap-rectangle plane gradients exchanged point-to-point with the "
-                                       "neighbours + decoder-gradient all-reduce, every iteration (extension)") if split else
+                                       "neighbours" + (", gradients of the planes without the slab axis all-reduced over all agents"
+                                                       if world > 2 else "")
+                                       + " + decoder-gradient all-reduce, every iteration (extension)") if split else
                                       f"agent-per-gpu x{world}, " + ("decoder-gradient all-reduce (extension)" if args.share_decoder
                                                                      else "no data-path collective")},
             "psnr_last_iter": psnr, "depth_l1_last_iter": depth_l1,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MNE_ABI_VERSION 7
+#define MNE_ABI_VERSION 8
 
 /* orientation index of a plane triple, as in JointEncoding.all_planes (scene_rep.py:117) */
 enum { MNE_XY = 0, MNE_XZ = 1, MNE_YZ = 2 };
@@ -398,8 +398,13 @@ int mne_tile_adam(const mne_scene_t* scene, const mne_plane_opt_t* opt, const fl
  * (mne_tile_overlap_floats() in total).
  *   mne_tile_order -> mne_tile_grad_export (send[k] filled) -> exchange with the peers (one message each way per peer)
  *   -> mne_tile_adam_shared (= mne_tile_adam where a shared cell's gradient is send[k] + recv[k]: the agents add the same
- *      two numbers, so cells that start equal stay bit-equal on both). */
-#define MNE_MAX_OVERLAP_PEERS 2
+ *      two numbers, so cells that start equal stay bit-equal on both).
+ * ABI 8: three slots -- an agent of a chain of slabs has two neighbours, and the planes that do NOT contain the slab axis (yz for
+ * slabs along x) are held as a whole by EVERY agent: with more than two agents their gradient must be the sum over ALL agents
+ * (pairwise sums would give the middle agent g0 + g1 + g2 and its neighbours g0 + g1 / g1 + g2: the copies drift apart).  The caller
+ * gives such planes a slot of their own (rectangle = the whole plane), all-reduces send[k] into recv[k] and zeroes send[k]
+ * (mneslam_amd/dist.py::allreduce_sum_into): every agent then applies the same total. */
+#define MNE_MAX_OVERLAP_PEERS 3
 typedef struct mne_tile_overlap {
     int32_t n_peers, reserved;
     struct { int32_t x0, y0, x1, y1; } rect[MNE_MAX_OVERLAP_PEERS][12];

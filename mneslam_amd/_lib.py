@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmneslam_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 N_LOSS = 8
 N_COUNT = 8
 C_NEED = 6
@@ -56,7 +56,7 @@ class TileBins(C.Structure):
 LIST_SEGMENTS = 8              # cursors per tile list (re-read from mne_tile_list_segments() at load time)
 TILE_SPLIT_PARTS = 2048
 TILE_ORDER_SNAPSHOT = 20480
-MAX_OVERLAP_PEERS = 2
+MAX_OVERLAP_PEERS = 3
 
 
 class OverlapRect(C.Structure):

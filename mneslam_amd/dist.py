@@ -292,6 +292,16 @@ def exchange_buffers(peers, send, recv):
         w.wait()
 
 
+def allreduce_sum_into(send, recv):
+    """Group slot of the binned overlap exchange (more than two agents, FusedStep(overlap_group_axis=...)): ``recv`` = the sum of
+    every agent's ``send`` (one all-reduce: reduce-scatter + all-gather over the xGMI links on GPUs; every rank receives the same
+    bits), ``send`` zeroed -- mne_tile_adam_shared adds send + recv, i.e. exactly the total, on every agent."""
+    recv.copy_(send)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(recv, op=dist.ReduceOp.SUM)
+    send.zero_()
+
+
 def plane_geometry(model):
     """((H, W), extended bound as [3][2] floats, plane axes) for every plane of ``model`` in all_planes order."""
     bound = [[float(lo), float(hi)] for lo, hi in torch.as_tensor(model.bound).cpu()]

@@ -31,7 +31,7 @@ class FusedStep:
 
     def __init__(self, model, optimizer, config, n_rays, device, is_co_sdf=None, scatter="binned",
                  tile_capacity=None, spill_capacity=None, shared_decoder=False, overlap=True, overlap_peers=None,
-                 use_graph=None):
+                 use_graph=None, overlap_group_axis=None):
         """scatter="binned": plane gradients are accumulated per 16x16-cell tile in LDS and Adam is applied
         in the same kernel (csrc/tile_adam.hip; no gradient buffers).  scatter="atomics": global
         atomic adds into persistent gradient buffers + the streaming Adam kernel.
@@ -50,8 +50,17 @@ class FusedStep:
         # way per peer -- mne_tile_grad_export / mne_tile_adam_shared; atomics path: slices of the gradient buffers)
         self.overlap_peers = list(overlap_peers or [])
         self.tile_overlap = None
-        if len(self.overlap_peers) > _lib.MAX_OVERLAP_PEERS and scatter != "atomics":
-            raise ValueError(f"the binned plane update exchanges with at most {_lib.MAX_OVERLAP_PEERS} peers (slabs along one axis)")
+        # EXTENSION, more than two agents in a chain of slabs along ``overlap_group_axis``: the planes that do not contain that
+        # axis (yz for slabs along x) are held as a whole by EVERY agent, so their gradient is summed over ALL agents (one
+        # all-reduce per iteration, dist.allreduce_sum_into) instead of pairwise with the neighbours -- pairwise sums would
+        # leave the middle agent with g0 + g1 + g2 and its neighbours with g0 + g1 / g1 + g2.  None: every plane pairwise
+        # (two agents).
+        self.overlap_group_axis = overlap_group_axis
+        if overlap_group_axis is not None and (scatter != "binned" or not self.overlap_peers):
+            raise ValueError("overlap_group_axis belongs to the binned plane update with overlap_peers")
+        n_slots = len(self.overlap_peers) + (1 if overlap_group_axis is not None else 0)
+        if n_slots > _lib.MAX_OVERLAP_PEERS and scatter != "atomics":
+            raise ValueError(f"the binned plane update exchanges with at most two neighbours (slabs along one axis) + the group")
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("the fused mapping step needs mneslam_amd.optim.FusedAdam "
                             "(slam_glue.create_optimizer builds it with the reference's groups)")
@@ -150,15 +159,25 @@ class FusedStep:
             if self.overlap_peers:
                 from . import dist as mdist
                 ov = _lib.TileOverlap()
-                ov.n_peers = len(self.overlap_peers)
+                n_nb, gax = len(self.overlap_peers), self.overlap_group_axis
+                ov.n_peers = n_nb + (1 if gax is not None else 0)
                 geo = mdist.plane_geometry(model)
                 for k, (peer, peer_geo) in enumerate(self.overlap_peers):
                     for pi, ((shape, bound, axes), (pshape, pbound, _)) in enumerate(zip(geo, peer_geo)):
+                        if gax is not None and gax not in axes:          # held by every agent: the group slot below
+                            if tuple(shape) != tuple(pshape) or any(abs(bound[a][q] - pbound[a][q]) > 1e-6 for a in axes for q in (0, 1)):
+                                raise ValueError(f"plane {pi} does not contain the slab axis but differs between the agents")
+                            continue
                         sl = mdist.overlap_slices(bound, pbound, shape, pshape, axes)
                         if sl is not None:
                             (ys, xs), _ = sl
                             r = ov.rect[k][pi]
                             r.x0, r.x1, r.y0, r.y1 = xs.start, xs.stop, ys.start, ys.stop
+                if gax is not None:
+                    for pi, (shape, bound, axes) in enumerate(geo):
+                        if gax not in axes:
+                            r = ov.rect[n_nb][pi]
+                            r.x0, r.x1, r.y0, r.y1 = 0, shape[1], 0, shape[0]
                 self.ov_send, self.ov_recv = [], []
                 for k in range(ov.n_peers):
                     n = self.lib.mne_tile_overlap_floats(C.byref(self.scene), C.byref(ov), k)
@@ -589,7 +608,10 @@ class FusedStep:
                 _lib.check(lib.mne_tile_grad_export(C.byref(self.scene), P(self.tape), C.byref(self.bins),
                                                     C.byref(self.tile_overlap), st2), "mne_tile_grad_export")
                 with torch.cuda.stream(side) if side is not None else _null_ctx():
-                    mdist.exchange_buffers([peer for peer, _ in self.overlap_peers], self.ov_send, self.ov_recv)
+                    n_nb = len(self.overlap_peers)
+                    mdist.exchange_buffers([peer for peer, _ in self.overlap_peers], self.ov_send[:n_nb], self.ov_recv[:n_nb])
+                    if self.overlap_group_axis is not None:     # planes every agent holds: the total over all agents
+                        mdist.allreduce_sum_into(self.ov_send[n_nb], self.ov_recv[n_nb])
                 _lib.check(lib.mne_tile_adam_shared(C.byref(self.scene), self.plane_opt, P(self.tape), C.byref(self.bins),
                                                     C.byref(self.tile_overlap), None, st2), "mne_tile_adam_shared")
             else:

@@ -1556,8 +1556,9 @@ def check_checkpoint_handoff(device, tmp_dir):
 # EXTENSION: two agents on one lattice, binned plane update, shared cells + shared decoder
 # --------------------------------------------------------------------------------------------------------------
 def lattice_config(rank):
-    """Two slabs along x whose planes sit on ONE lattice on both levels: extended x length 2.4 m with 13 / 25 nodes
-    (spacing 0.2 / 0.1 m), agent 1 shifted by 1.4 m = 7 coarse / 14 fine nodes; y and z extents are the agents' common ones."""
+    """Slabs along x whose planes sit on ONE lattice on both levels: extended x length 2.4 m with 13 / 25 nodes
+    (spacing 0.2 / 0.1 m), agent r shifted by r * 1.4 m = 7 coarse / 14 fine nodes (neighbours share 1.0 m, agents two apart
+    nothing); y and z extents are the agents' common ones."""
     cfg = configs.small_test_config(one_grid=True, is_co_sdf=False, n_samples_d=21, n_range_d=11)
     x0 = -1.0 + 1.4 * rank
     cfg["mapping"]["bound"] = [[x0, x0 + 2.3], [-1.2, 1.1], [-0.8, 0.9]]             # extended by bound_dividable to 2.4 / 2.4 / 1.8
@@ -1566,55 +1567,77 @@ def lattice_config(rank):
     return cfg, room
 
 
-def run_overlap_agent(rank, device, comm, geometry="lattice"):
-    """One of two agents on one lattice: FusedStep (binned plane update, overlap_peers + shared_decoder) against an oracle
-    agent with the exchange written out in tensor ops -- plane gradients summed over the node rectangles both agents hold,
-    decoder gradient averaged, then Adam.  Equal by construction to ONE model over the union lattice trained on the union
-    batch wherever the cells are shared.  Checks, over two iterations: every plane and decoder parameter against the oracle
-    agent, and the shared cells and the decoder bit-equal between the two HIP agents.  ``comm.all_gather(obj)`` -> the
-    two agents' objects by rank (gloo processes on the CPU, threads of one process on the GPU)."""
+def run_overlap_agent(rank, device, comm, geometry="lattice", world=2):
+    """One of ``world`` agents in a chain of overlapping slabs on one lattice: FusedStep (binned plane update, overlap_peers =
+    its one or two neighbours + shared_decoder) against an oracle agent with the exchange written out in tensor ops -- plane
+    gradients summed over the node rectangles neighbours both hold, decoder gradient averaged over all agents, then Adam.
+    Equal by construction to ONE model over the union lattice trained on the union batch wherever cells are shared.  Checks,
+    over two iterations: every plane and decoder parameter against the oracle agent, and the shared cells and the decoder
+    bit-equal between the HIP agents.  ``comm.all_gather(obj)`` -> the agents' objects by rank (gloo processes on the CPU,
+    threads of one process on the GPU).  An INTERIOR agent (world >= 3) runs mne_tile_grad_export / mne_tile_adam_shared with
+    two rectangles per plane and exchanges with both neighbours in one step (mp_slam/mapper.py:491-509: an agent's bound
+    intersects those of the agents on either side; configs/Indoor/indoor.yaml:169-173)."""
     from mneslam_amd import dist as mdist, synthetic
     from mneslam_amd.fused import FusedStep
-    if geometry == "apartment":
-        # BASELINE configs[2] as worded, at its full size: the Replica apartment scene split into two overlapping slabs on one
-        # lattice (configs.split_agent_config: what bench.py --split / its as_worded side record run), ~60 M plane parameters each
-        base = configs.WORKLOADS["apartment"][0]()
-        base["mapping"]["bound"] = [list(b) for b in configs.SCENE_BOUNDS["apartment"]]
-        cfg, axis, _ = configs.split_agent_config(base, 2, rank)
-        assert axis == 0
+    if geometry in ("apartment", "scannet"):
+        # BASELINE configs[2] / configs[3] as worded, at full size: the Replica apartment scene split into two / ScanNet
+        # scene0000 (colour planes) split into four overlapping slabs on one lattice (configs.split_agent_config: what
+        # bench.py --split / its as_worded side record run)
+        base = configs.WORKLOADS[geometry][0]()
+        base["mapping"]["bound"] = [list(b) for b in configs.SCENE_BOUNDS[geometry]]
+        cfg, axis, _ = configs.split_agent_config(base, world, rank)
         room = cfg["mapping"]["marching_cubes_bound"]
     else:
         cfg, room = lattice_config(rank)
     bb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float64)
     with getattr(comm, "lock", contextlib.nullcontext()):        # (threads of one process share the global generator)
-        torch.manual_seed(11)                                    # the same decoder on both agents
+        torch.manual_seed(11)                                    # the same decoder on all agents
         model = JointEncoding(cfg, bb).to(device).train()
-    # one decoder for both agents: the planes' draws come first in the constructor and the two slabs need not have the same
+    # one decoder for all agents: the planes' draws come first in the constructor and the slabs need not have the same
     # number of nodes, so the seed alone does not give equal decoders -- agent 0's initialisation is the common one
     dec0 = comm.all_gather({k: v.detach().cpu().clone() for k, v in model.decoder.state_dict().items()})[0]
     model.decoder.load_state_dict({k: v.to(device) for k, v in dec0.items()})
     geo = mdist.plane_geometry(model)
-    peer_geo = comm.all_gather(geo)[1 - rank]
-    # planes = windows of one field over the union lattice (same seed on both ranks), so shared cells start equal
+    all_geo = comm.all_gather(geo)
+    nbs = [r for r in (rank - 1, rank + 1) if 0 <= r < world]
+    # planes = windows of one field over the union lattice (same seed on all ranks), so shared cells start equal.  Node
+    # offset of every agent on the union lattice, from the overlap of consecutive agents: off[a+1] = off[a] + start(a) - start(a+1)
     flat = [p for lst in model.all_planes for p in lst]
-    rects = []
-    for k, (p, (shape, bnd, axes), (pshape, pbnd, _)) in enumerate(zip(flat, geo, peer_geo)):
-        (ys, xs), (pys, pxs) = mdist.overlap_slices(bnd, pbnd, shape, pshape, axes)
-        rects.append(((ys, xs), (pys, pxs)))
-        off = (xs.start - pxs.start) if rank == 1 else 0        # this agent's first node on the union lattice (x only)
-        if axes[0] != 0:
-            assert xs == slice(0, shape[1]) and ys == slice(0, shape[0])          # yz planes: shared as a whole
-        shift = pxs.start if rank == 0 else 0                    # union width = own + peer - shared
-        width = shape[1] + pshape[1] - (xs.stop - xs.start)
-        field = 0.05 * torch.randn(1, p.shape[1], shape[0], width, generator=torch.Generator().manual_seed(100 + k))
-        start = 0 if (rank == 0 or axes[0] != 0) else width - shape[1]
+    rects = {nb: [] for nb in nbs}
+    for k, p in enumerate(flat):
+        off = [(0, 0)]
+        for a in range(world - 1):
+            (sa, ba, axa), (sb, bb_, _) = all_geo[a][k], all_geo[a + 1][k]
+            (ys, xs), (pys, pxs) = mdist.overlap_slices(ba, bb_, sa, sb, axa)
+            off.append((off[a][0] + ys.start - pys.start, off[a][1] + xs.start - pxs.start))
+        hu = max(o[0] + all_geo[a][k][0][0] for a, o in enumerate(off))
+        wu = max(o[1] + all_geo[a][k][0][1] for a, o in enumerate(off))
+        shape = geo[k][0]
+        field = 0.05 * torch.randn(1, p.shape[1], hu, wu, generator=torch.Generator().manual_seed(100 + k))
+        oy, ox = off[rank]
         with torch.no_grad():
-            p.copy_(field[..., start:start + shape[1]].to(device))
-        del off, shift
+            p.copy_(field[..., oy:oy + shape[0], ox:ox + shape[1]].to(device))
+        del field
+        for nb in nbs:
+            (sh, bnd, axes), (psh, pbnd, _) = geo[k], all_geo[nb][k]
+            rects[nb].append(mdist.overlap_slices(bnd, pbnd, sh, psh, axes))
+    if world > 2 and 0 < rank < world - 1:                        # the two rectangles of an interior agent do not meet
+        for (sh, _, axes), ra, rb in zip(geo, rects[nbs[0]], rects[nbs[1]]):
+            (ya, xa), (yb, xb) = ra[0], rb[0]
+            whole = ya == yb == slice(0, sh[0]) and xa == xb == slice(0, sh[1])        # (a plane without the slab axis: every agent's)
+            assert whole or ya.stop <= yb.start or yb.stop <= ya.start or xa.stop <= xb.start or xb.stop <= xa.start
     opt = slam_glue.create_optimizer(model, cfg)
+    flat = [p for lst in model.all_planes for p in lst]          # (now the nn.Parameters the optimizer's groups hold)
     n_rays = 40
-    fs = FusedStep(model, opt, cfg, n_rays, device, scatter="binned", shared_decoder=True, overlap_peers=[(1 - rank, peer_geo)])
-    assert fs.tile_overlap is not None and fs.ov_send[0].numel() > 32 * 25
+    # more than two agents: the planes without the slab axis are held by EVERY agent and take the sum over all agents
+    gax = None
+    if world > 2:
+        gax = axis if geometry in ("apartment", "scannet") else 0
+    group = [gax is not None and gax not in g[2] for g in geo]
+    fs = FusedStep(model, opt, cfg, n_rays, device, scatter="binned", shared_decoder=True,
+                   overlap_peers=[(nb, all_geo[nb]) for nb in nbs], overlap_group_axis=gax)
+    assert fs.tile_overlap is not None and fs.tile_overlap.n_peers == len(nbs) + (gax is not None)
+    assert all(s.numel() > 32 * 25 for s in fs.ov_send)
     H, W = 34, 60
     frames = synthetic.make_frames(2, H, W, 30.0, 30.0, 29.5, 16.5, room, seed=3 + rank)
     fr = frames[1]
@@ -1638,30 +1661,43 @@ def run_overlap_agent(rank, device, comm, geometry="lattice"):
         oopt.zero_grad()
         r = sc.forward(cpu(fs.rays_o), cpu(fs.rays_d), cpu(fs.tgt_rgb), cpu(fs.tgt_d)[:, None], impl="grid_sample",
                        z_vals=cpu(fs.z_vals))
-        omap.loss_from_ret(cfg, r, is_co_sdf=False).backward()
-        mine = [p.grad.clone() for p in sc.plane_list()]
+        omap.loss_from_ret(cfg, r, is_co_sdf=cfg["is_co_sdf"]).backward()
+        # what each neighbour needs of this agent's plane gradients: its window of the shared rectangle (not whole planes)
+        mine = {nb: [None if grp else p.grad[:, :, ys, xs].clone() for p, ((ys, xs), _), grp in zip(sc.plane_list(), rects[nb], group)]
+                for nb in nbs}
+        mine["all"] = [p.grad.clone() if grp else None for p, grp in zip(sc.plane_list(), group)]
         theirs = comm.all_gather(mine)
         with torch.no_grad():
-            for p, g_peer, ((ys, xs), (pys, pxs)) in zip(sc.plane_list(), theirs[1 - rank], rects):
-                p.grad[:, :, ys, xs] += g_peer[:, :, pys, pxs]
+            for nb in nbs:
+                for p, g_peer, ((ys, xs), _), grp in zip(sc.plane_list(), theirs[nb][rank], rects[nb], group):
+                    if not grp:
+                        p.grad[:, :, ys, xs] += g_peer
+            for k, (p, grp) in enumerate(zip(sc.plane_list(), group)):
+                if grp:
+                    p.grad.copy_(sum((t["all"][k] for t in theirs[1:]), theirs[0]["all"][k].clone()))
             for w in sc.decoder_list():
                 gs = comm.all_gather(w.grad.clone())
-                w.grad.copy_((gs[0] + gs[1]) / 2)
+                w.grad.copy_(sum(gs[1:], gs[0]) / world)
         oopt.step()
         for k, (p, ref) in enumerate(zip(flat, sc.plane_list())):
-            adam_agreement(cpu(p), ref.detach(), opt.param_groups[1]["lr"], "plane", f"iteration {it} plane {k}")
+            lr = fs.group_of[p]["lr"]
+            adam_agreement(cpu(p), ref.detach(), lr, "plane", f"agent {rank} iteration {it} plane {k}")
         for w_hip, w_ref in zip(model.decoder.parameters(), sc.decoder_list()):
-            adam_agreement(cpu(w_hip), w_ref.detach(), opt.param_groups[0]["lr"], "decoder", f"iteration {it}: decoder")
-    # the exchange carried something: the shared cells' first moments hold the peer's share too
-    ex = fs.ov_recv[0]
-    assert float(ex.abs().max()) > 0
-    # shared cells are bit-equal on the two agents (a + b == b + a; same moments, same step), the rest is not
-    for k, (p, ((ys, xs), (pys, pxs))) in enumerate(zip(flat, rects)):
-        both = comm.all_gather(cpu(p)[:, :, ys, xs].clone())
-        assert torch.equal(both[0], both[1]), f"plane {k}: shared cells differ between the agents"
+            adam_agreement(cpu(w_hip), w_ref.detach(), opt.param_groups[0]["lr"], "decoder", f"agent {rank} iteration {it}: decoder")
+    # the exchange carried something: the shared cells' first moments hold the peers' share too
+    assert all(float(ex.abs().max()) > 0 for ex in fs.ov_recv)
+    # shared cells are bit-equal on neighbouring agents (a + b == b + a; same moments, same step), the rest is not
+    win = comm.all_gather({nb: [cpu(p)[:, :, ys, xs].clone() for p, ((ys, xs), _) in zip(flat, rects[nb])] for nb in nbs})
+    for nb in nbs:
+        for k, (a, b) in enumerate(zip(win[rank][nb], win[nb][rank])):
+            assert torch.equal(a, b), f"plane {k}: cells shared by agents {rank} and {nb} differ"
+    if gax is not None:                                           # planes every agent holds: one copy, bit for bit, on all of them
+        every = comm.all_gather([cpu(p) if grp else None for p, grp in zip(flat, group)])
+        for k, grp in enumerate(group):
+            assert not grp or all(torch.equal(every[0][k], e[k]) for e in every[1:]), f"plane {k} (held by every agent) drifted apart"
     dec = torch.cat([cpu(p).reshape(-1) for p in model.decoder.parameters()])
     both = comm.all_gather(dec)
-    assert torch.equal(both[0], both[1])
+    assert all(torch.equal(both[0], d) for d in both[1:])
 
 
 def check_sample_z_frame_counts(device, R=20011):

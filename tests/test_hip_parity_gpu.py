@@ -583,15 +583,18 @@ def test_forced_split_lists_and_capped_ray_lds(monkeypatch):
 # 8e on real hardware as far as one GPU allows: the multi-agent forms of the plane update (tile_adam_kernel<1>, <2>),
 # two agents = two threads of this process on the same device, the exchange done by device-to-device copies
 # ------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("geometry", ["lattice", "apartment"])
-def test_two_agents_binned_overlap_on_one_device(monkeypatch, geometry):
-    """geometry "apartment": BASELINE configs[2] as worded at full plane size (the two slabs bench.py --split gives its ranks).
-    parity_cases.run_overlap_agent with both agents on cuda:0: mne_tile_grad_export / mne_tile_adam_shared on the GPU,
+@pytest.mark.parametrize("geometry,world", [("lattice", 2), ("apartment", 2), ("lattice", 3), ("scannet", 4)])
+def test_two_agents_binned_overlap_on_one_device(monkeypatch, geometry, world):
+    """geometry "apartment": BASELINE configs[2] as worded at full plane size (the two slabs bench.py --split gives its ranks);
+    "scannet", 4 agents: configs[3] as worded -- ScanNet scene0000 with colour planes split 4-way, agents 1 and 2 INTERIOR (two
+    neighbours each: two rectangles per plane in mne_tile_grad_export / mne_tile_adam_shared); "lattice", 3: the
+    small chain with one interior agent.
+    parity_cases.run_overlap_agent with all agents on cuda:0: mne_tile_grad_export / mne_tile_adam_shared on the GPU,
     FusedStep(overlap_peers, shared_decoder) on its two streams; what torch.distributed would carry (the send / recv
     buffers of the shared cells, the decoder-gradient mean) is copied between the agents' buffers under a barrier."""
     import threading
     from mneslam_amd import dist as mdist
-    bar, slots, local = threading.Barrier(2), [None, None], threading.local()
+    bar, slots, local = threading.Barrier(world), [None] * world, threading.local()
 
     class ThreadComm:
         lock = threading.Lock()
@@ -606,34 +609,45 @@ def test_two_agents_binned_overlap_on_one_device(monkeypatch, geometry):
 
     def exchange(peers, send, recv):
         torch.cuda.current_stream().synchronize()                 # my export has finished
-        theirs = comm.all_gather(send)[1 - local.rank]
-        for r, s in zip(recv, theirs):
-            r.copy_(s)
+        everyone = comm.all_gather((list(peers), send))
+        for k, peer in enumerate(peers):                          # what the peer exported for ME
+            their_peers, their_send = everyone[peer]
+            recv[k].copy_(their_send[their_peers.index(local.rank)])
         torch.cuda.current_stream().synchronize()
-        bar.wait()                                                # the peer has read my send buffers
+        bar.wait()                                                # the peers have read my send buffers
 
     def allreduce_mean(buf):
         torch.cuda.current_stream().synchronize()
-        both = comm.all_gather(buf)
-        mean = (both[0] + both[1]) / 2
+        every = comm.all_gather(buf)
+        mean = sum(every[1:], every[0].clone()) / world
         torch.cuda.current_stream().synchronize()
         bar.wait()
         buf.copy_(mean)
         return buf
+
+    def allreduce_sum_into(send, recv):
+        torch.cuda.current_stream().synchronize()
+        every = comm.all_gather(send)
+        total = sum(every[1:], every[0].clone())                  # (rank order: the same bits on every agent)
+        recv.copy_(total)
+        torch.cuda.current_stream().synchronize()
+        bar.wait()                                                # everyone has read my send buffer
+        send.zero_()
     monkeypatch.setattr(mdist, "exchange_buffers", exchange)
     monkeypatch.setattr(mdist, "allreduce_mean_", allreduce_mean)
+    monkeypatch.setattr(mdist, "allreduce_sum_into", allreduce_sum_into)
     errors = []
 
     def agent(rank):
         local.rank = rank
         try:
             with torch.cuda.device(0):
-                pc.run_overlap_agent(rank, DEV, comm, geometry=geometry)
+                pc.run_overlap_agent(rank, DEV, comm, geometry=geometry, world=world)
         except BaseException as e:          # noqa: BLE001 -- reported by the main thread
             import traceback
             errors.append((rank, e, traceback.format_exc()[-1500:]))
             bar.abort()
-    threads = [threading.Thread(target=agent, args=(r,)) for r in range(2)]
+    threads = [threading.Thread(target=agent, args=(r,)) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
