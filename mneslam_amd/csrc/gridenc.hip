@@ -628,6 +628,12 @@ __device__ __forceinline__ unsigned long long hash_fix(float v, double scale) {
 }
 
 #define HASH_SLICE_UNROLL 4
+// GROUPS: the batch has more than HASH_MAX_CHUNKS chunks (> 512 K rows: INS Indoor's 2150 x 1045, 8192 rays x 128) and the
+// records come in several groups of chunks.  A template parameter, not a run-time loop bound: the loop around the record walk
+// that round 5 added for such batches cost the headline shape (272 chunks, one group) 47 us of this kernel -- 164.6 -> 211.9 us,
+// profiles/r04_hash_kernel_stats.txt vs r05_hash_kernel_stats.txt -- with the group loop compiled away it is the
+// round-4 code again.
+template <bool GROUPS>
 __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(GridArgs a) {
     __shared__ unsigned long long acc[HASH_SLICE * 2];               // fixed-point gradient of this slice (2 x 8 B x 1024 entries = 16 KiB)
     __shared__ unsigned cstart[HASH_MAX_CHUNKS + 1];                 // prefix of the chunks' record counts (this slice, this part)
@@ -680,12 +686,12 @@ __global__ __launch_bounds__(HASH_SLICE_THREADS) void hash_slice_adam_kernel(Gri
     const double inv = bad ? (double)__uint_as_float(0x7fc00000u) : ldexp(1.0, ge - HASH_FIX_BITS);
     if (blockIdx.x == 0 || (slice == 0 && part == 0)) { if (tid == 0) a.gscale[level] = inv; }
     const HashRecord* rec0 = (const HashRecord*)a.records + (size_t)level * a.n_chunks * (size_t)(HASH_CHUNK * HASH_REC_PER_ROW);
-    for (int cg = 0; cg < n_chunks; cg += HASH_MAX_CHUNKS) {
-        if (cg > 0) {
+    for (int cg = 0; cg < (GROUPS ? n_chunks : 1); cg += HASH_MAX_CHUNKS) {
+        if (GROUPS && cg > 0) {
             __syncthreads();                                         // the previous group's walk has read cstart / cbase
             fetch_offsets(cg);
         }
-        const int n_here = n_chunks - cg < HASH_MAX_CHUNKS ? n_chunks - cg : HASH_MAX_CHUNKS;
+        const int n_here = !GROUPS ? n_chunks : (n_chunks - cg < HASH_MAX_CHUNKS ? n_chunks - cg : HASH_MAX_CHUNKS);
         // exclusive scan of the chunks' record counts, then a flat walk over this slice's records of ALL chunks of the group
         // (each chunk's are contiguous): one more round trip whatever the count
 #pragma unroll
@@ -826,7 +832,8 @@ int mne_launch_hash_slice_adam(const GridArgs& a, hipStream_t st, void* event_af
     if (a.R >= (1 << 24)) return -7;                                                     // (a record carries its ray in 24 bits)
     MNE_LAUNCH(hash_bin_kernel, (unsigned)(a.n_chunks * a.n_levels), HASH_BIN_THREADS, 0, st, a);
     if (event_after_bin) (void)hipEventRecord((hipEvent_t)event_after_bin, st);
-    MNE_LAUNCH(hash_slice_adam_kernel, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, 0, st, a);
+    if (a.n_chunks > HASH_MAX_CHUNKS) MNE_LAUNCH(hash_slice_adam_kernel<true>, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, 0, st, a);
+    else MNE_LAUNCH(hash_slice_adam_kernel<false>, (unsigned)mne_hash_slice_count(a), HASH_SLICE_THREADS, 0, st, a);
     const unsigned n_split = mne_hash_scratch_entries(a);
     if (n_split) MNE_LAUNCH(hash_finish_kernel, (n_split + 255) / 256, 256, 0, st, a, n_split);
     return 0;
