@@ -42,7 +42,11 @@ enum { MNE_C_VALID = 0, MNE_C_E_FRONT = 1, MNE_C_E_CENTER = 2, MNE_C_E_TAIL = 3,
        MNE_C_TILE0 = 7,  /* per-ray only: exclusive prefix over the rays of their a-priori 32-sample tile counts (clamp(ceil(
                           * MNE_C_NEED / 32), 1, tiles per ray)): the render calls deal the decode's tile tasks evenly from it.
                           * Written for batches of at most 16384 rays (whole frames are summed by many workgroups and decoded with
-                          * the fixed-stride schedule) */
+                          * the fixed-stride schedule).  CONTRACT of every render call that takes `ray_counts` (mne_render_forward /
+                          * _backward / _fused and their _features forms): the prefix is the one mne_sample_z / mne_sample_batch wrote
+                          * for EXACTLY the call's n_rays rays (slot of ray 0 == 0).  A sub-range of a larger batch, or counts filled
+                          * by the caller, fail that test on the device and are decoded with the fixed-stride schedule instead (same
+                          * results, a few us slower) -- never out of bounds. */
        MNE_N_COUNT = 8 };
 
 typedef struct mne_plane {
@@ -101,7 +105,13 @@ typedef struct mne_tile_bins {
     int32_t* counts;       /* [mne_tile_count()][mne_tile_list_segments()]: ABI 7 -- every list is cut into mne_tile_list_segments() = 8 equal
                             * segments, one per XCD of the MI355X, each with its own cursor (the appending waves of an XCD use their own:
                             * returning atomics on one address retire one after the other).  A list's capacity is rounded down to a
-                            * multiple of the segment count. */
+                            * multiple of the segment count.  A SEGMENT that is full overflows to the spill area even while its
+                            * list's other segments have room (entries appended by fewer than 8 XCDs -- a launch of fewer than 8
+                            * workgroups -- use cap * k / 8 of a list): overflow stays exact (the spill area is walked by every
+                            * overflowing tile: slower, not wrong), entries beyond a caller-chosen spill_cap are COUNTED in `dropped`
+                            * (FusedStep.check() raises on it) -- size caps for the per-segment share, or keep the default worst-case
+                            * spill area.  The segment of a wave comes from the hardware register XCC_ID (gfx94x / gfx950: this
+                            * library is built for gfx950 only). */
     uint32_t* spill;       /* [spill_cap][8] overflow entries (same layout) */
     int32_t* spill_count;  /* [1] */
     int32_t* order;        /* [mne_tile_count()] scratch: tile processing order (heaviest first) */

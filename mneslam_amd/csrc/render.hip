@@ -495,13 +495,18 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
     // by the batch preparation) is staged in LDS and wave w decodes the real tiles w, w + W, ...: tile g belongs to the ray
     // found by a binary search, every wave gets the same number of tiles +- 1.  (A device-side queue over the slots was
     // measured first: 8600 returning atomics on one address made the launch 126 us instead of 70.)
-    const bool balanced = sched != 0 && !a.ray_list && a.ray_counts && !(a.adapt && a.adapt[0]);
+    bool balanced = sched != 0 && !a.ray_list && a.ray_counts && !(a.adapt && a.adapt[0]);
     int* tstart = (int*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wpb * tile_wave_lds_bytes(NSETS));
     long long ntask_l = (long long)n_rays * ntile;
     if (balanced) {
         for (int r = threadIdx.x; r < a.R; r += blockDim.x) tstart[r] = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_TILE0];
         __syncthreads();
-        ntask_l = tstart[a.R - 1] + apriori_tiles(a, a.R - 1, ntile);
+        // The prefix must be THIS call's: written by mne_sample_z / mne_sample_batch for exactly these R rays, starting at 0.
+        // A caller that renders a sub-range of a larger batch (pointer offset into ray_counts) or fills the counts itself has
+        // another start or total: the fixed-stride schedule then (workgroup-uniform, every thread reads the same words).
+        const long long total = (long long)tstart[a.R - 1] + apriori_tiles(a, a.R - 1, ntile);
+        if (tstart[0] != 0 || total < a.R || total > (long long)a.R * ntile) balanced = false;
+        else ntask_l = total;
     }
     for (long long task = (long long)xcd_block() * wpb + wv; task < ntask_l; task += (long long)gridDim.x * wpb) {
         int c, r;
@@ -664,13 +669,15 @@ __global__ __launch_bounds__(64 * WPB) void decode_frame_kernel(RenderArgs a, in
     float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(1));
     float* feat = pn + TILE * 4;
     const int n_rays = a.R;
-    const bool balanced = sched != 0 && a.ray_counts && !(a.adapt && a.adapt[0]);
+    bool balanced = sched != 0 && a.ray_counts && !(a.adapt && a.adapt[0]);
     int* tstart = (int*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wpb * tile_wave_lds_bytes(1));
     long long ntask_l = (long long)n_rays * ntile;
     if (balanced) {
         for (int r = threadIdx.x; r < a.R; r += blockDim.x) tstart[r] = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_TILE0];
         __syncthreads();
-        ntask_l = tstart[a.R - 1] + apriori_tiles(a, a.R - 1, ntile);
+        const long long total = (long long)tstart[a.R - 1] + apriori_tiles(a, a.R - 1, ntile);       // (a foreign prefix: see decode_kernel)
+        if (tstart[0] != 0 || total < a.R || total > (long long)a.R * ntile) balanced = false;
+        else ntask_l = total;
     }
     const ATabRef<false> A(atab, lane);
     FrameTile st;

@@ -143,8 +143,14 @@ class ModelExchange:
     def _data(self, sender, receiver):
         return self.data_up if sender < receiver else self.data_down
 
-    def start(self):
+    def start(self, producer_stream=None):
+        """``producer_stream``: the HIP stream the mapping thread enqueues its map updates on (default: the current stream
+        of the thread that calls ``start`` -- a mapper working on another stream passes its own)."""
         import threading
+        if self.device.type == "cuda":
+            self.producer_stream = producer_stream if producer_stream is not None else torch.cuda.current_stream(self.device)
+        if self.world == 1:
+            return self                  # nobody to serve: no thread (gloo has no send-to-self that could ever stop it)
         if self._thread is None:
             self._thread = threading.Thread(target=self.serve, name=f"mne-model-exchange-{self.rank}", daemon=True)
             self._thread.start()

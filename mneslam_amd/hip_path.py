@@ -150,7 +150,8 @@ class RenderFunction(torch.autograd.Function):
                        "mne_loss_finalize")
         ctx.info, ctx.S, ctx.want_losses = info, S, want_losses
         if any(p.dtype == torch.float16 for p in planes):
-            ctx.plane_params = list(planes)       # half-precision planes: backward leaves their fp32 gradient sums on these objects
+            # half-precision planes: backward leaves their fp32 gradient sums on the parameter objects the caller names
+            ctx.plane_params = list(info.get("plane_owners") or planes)
         ctx.save_for_backward(rays_o_c, rays_d_c, tgt_rgb, tgt_d, z_vals, raw, counts, ray_counts, packed, *params)
         ctx.mark_non_differentiable(disp, acc, var, z_vals, raw)
         return rgb, depth, disp, acc, var, z_vals, raw, losses

@@ -147,7 +147,12 @@ class JointEncoding(nn.Module):
     def _render(self, rays_o, rays_d, target_rgb, target_d, u=None):
         info = self._info()
         dev = rays_o.device
-        planes = [hip_path.as_channels_last(p if p.device == dev else p.to(dev)) for p in self._flat_planes()]
+        owners = self._flat_planes()
+        planes = [hip_path.as_channels_last(p if p.device == dev else p.to(dev)) for p in owners]
+        if any(p.dtype == torch.float16 for p in owners):
+            # half-precision planes: the backward leaves the fp32 gradient sums (``grad32``) on the PARAMETERS themselves -- a plane
+            # that is not channels_last or not on the render device reaches the node as a temporary copy
+            info = dict(info, plane_owners=owners)
         dec_w = self.decoder.hip_weights()
         has_d = target_d is not None
         if not has_d and not self.config["training"].get("n_samples"):

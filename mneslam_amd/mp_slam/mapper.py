@@ -71,6 +71,13 @@ class FusedMappingMixin:
             cache.clear()                            # release the previous scratch before allocating the new one
             fs = cache[key] = FusedStep(self.model, self.map_optimizer, self.config, cap, self.device,
                                         scatter=self.scatter, **self.fused_kwargs)
+            # The loops below run under ``_map_guard`` (the exchange's lock, also taken by the service thread that answers a
+            # peer's fetch).  A step that itself waits for the peers -- decoder all-reduce, overlap exchange -- under that lock
+            # can deadlock: A sits in fetch(B), B's service waits for B's lock, B's mapper holds it inside an all-reduce that
+            # waits for A.  bench.py --split drives such steps directly, without an exchange; here they are refused.
+            if getattr(self.slam, "model_exchange", None) is not None and (fs.shared_decoder or fs.overlap_peers):
+                raise RuntimeError("a FusedStep with per-iteration collectives (shared_decoder / overlap_peers) must not run "
+                                   "under the ModelExchange lock: serve fetches from a snapshot or drop the exchange")
         return fs
 
     def _device_ray_db(self, store):

@@ -45,15 +45,20 @@ class FusedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
+                if p.grad is None and getattr(p, "grad32", None) is not None:
+                    p.grad32 = None              # .grad was dropped by someone else's zero_grad: the fp32 sum beside it is stale
                 g = p.grad if zero_grad_buffers is None else zero_grad_buffers.get(p)   # explicit map: only those params
                 if g is None:
                     continue
-                if zero_grad_buffers is None and p.dtype == torch.float16 and getattr(p, "grad32", None) is not None:
+                if zero_grad_buffers is None and p.dtype == torch.float16:
                     # half-precision plane: autograd's .grad has the parameter's dtype, and a mean-reduced plane gradient
                     # sits below fp16's range (flushes to zero below ~3e-8; Adam is scale-free, so those would be lost
                     # updates).  The render node leaves the fp32 sum beside it (hip_path.RenderFunction.backward): that is
-                    # what the update consumes.
-                    g = p.grad32
+                    # what the update consumes.  Without it the step would silently run on the flushed fp16 gradient: refused.
+                    if getattr(p, "grad32", None) is None:
+                        raise RuntimeError("a half-precision plane has .grad but no fp32 gradient sum (grad32): its gradient did not "
+                                           "come from this package's render node")
+                    g = p.grad32 if p.grad32.device == p.device else p.grad32.to(p.device)
                 if p.dtype not in (torch.float32, torch.float16):
                     raise TypeError("FusedAdam supports float32 parameters (and float16 planes: fp32 gradient and moments)")
                 if not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)):

@@ -99,6 +99,42 @@ int main() {
             else printf("value     stream write / wait value calls failed\n");
         } else printf("value     hipMallocSignalMemory allocation failed\n");
     }
+    // a wait for an event that fired long ago: A(s1), [s2: short kernel + record, done while A spins], s1 waits for it, B(s1)
+    {
+        long long short_ticks = ticks / 20;
+        double t0 = now_us();
+        for (int i = 0; i < N; ++i) {
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s2, short_ticks, sink);
+            CHECK(hipEventRecord(ev[i], s2));
+            launch(s1, 0);
+            CHECK(hipStreamWaitEvent(s1, ev[i], 0));
+            launch(s1, 0);
+        }
+        CHECK(hipStreamSynchronize(s1));
+        CHECK(hipStreamSynchronize(s2));
+        report("satisfied", now_us() - t0, N);
+    }
+    // the fused step's shape: chain C on s1 (A -> B), helper H on s2 that starts after A (event) and ends before B would (shorter),
+    // B waits for H: A(40) -> [H(20) on s2] ; B after A and H.  Critical path if hops were free: A + B.
+    {
+        long long half = ticks / 2;
+        double t0 = now_us();
+        for (int i = 0; i < N; ++i) {
+            launch(s1, 0);                                        // A
+            CHECK(hipEventRecord(ev[2 * i], s1));
+            CHECK(hipStreamWaitEvent(s2, ev[2 * i], 0));
+            hipLaunchKernelGGL(spin_kernel, dim3(64), dim3(64), 0, s2, half, sink);      // H (20 us) beside A2
+            CHECK(hipEventRecord(ev[2 * i + 1], s2));
+            launch(s1, 0);                                        // A2 (40 us), same queue as A
+            CHECK(hipStreamWaitEvent(s1, ev[2 * i + 1], 0));      // H finished ~20 us ago
+            launch(s1, 0);                                        // B
+        }
+        CHECK(hipStreamSynchronize(s1));
+        CHECK(hipStreamSynchronize(s2));
+        const double t = (now_us() - t0) / N;
+        printf("sidecar   %8.1f us per round (A, A2, B of %.0f us in one queue = %.0f; helper of %.0f us beside A2, joined before B)\n", t, spin_us,
+               3 * spin_us, spin_us / 2);
+    }
     // three kernels, the middle one any-order, a barrier kernel behind: A[B] B[any] C[B] -- C must wait for both
     {
         double t0 = now_us();
