@@ -316,6 +316,41 @@ def render_img_measure(agent, cfg, device, n_pairs, n_warm):
     return own, rec
 
 
+def pose_alignment_measure(agent, cfg, device, n_iters=None):
+    """Row R13 / N2 on the record: the pose-alignment loop of loop closure (mp_slam/mapper.py:362-412) as the device
+    loop runs it -- ``mapping.loop_iters`` (100) iterations of rays-from-parameters -> z samples -> render forward -> loss -> render
+    backward WITH RAY GRADIENTS (ray_kernel<..., 3>) -> analytic Jacobian + Adam on the six pose parameters, ``mapping.sample`` rays x
+    ``training.n_samples`` uniform samples, the teacher's maps rendered by the same model from the true pose, the start pose 5 cm and
+    ~1.7 degrees off.  No autograd graph, no host synchronisation inside the loop."""
+    from mneslam_amd import hip_path
+    model, n = agent.model, cfg["mapping"]["sample"]
+    steps = cfg["mapping"]["loop_iters"] if n_iters is None else n_iters
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dirs = agent.cur_rays[torch.randint(0, agent.cur_rays.shape[0], (n,), generator=g).to(device), :3].contiguous()
+    base = agent.poses[0]
+    with torch.no_grad():
+        rays_d = torch.sum(dirs[:, None, :] * base[:3, :3], -1)
+        teacher = model.render_rays(base[:3, 3].expand(n, 3).contiguous(), rays_d, target_d=None)
+    want_rgb, want_depth = teacher["rgb"].detach(), teacher["depth"].detach()
+    rot0 = torch.tensor([0.03, 0.0, 0.0], device=device)                 # axis-angle relative to the true rotation
+    trans0 = base[:3, 3] + torch.tensor([0.05, 0.0, 0.0], device=device)
+    pa = hip_path.PoseAlignment(model, dirs, want_rgb, want_depth, rot0, trans0, base[:3, :3].contiguous().cpu(), 1e-3, 1e-3,
+                                (0.9, 0.999), 1e-8, cfg["training"]["rgb_weight"], cfg["training"]["depth_weight"])
+    for k in range(3):                                                    # warm-up (first launches of these instantiations)
+        pa.step(seed_offset=(7, k * ((pa.n * pa.S + 3) // 4)))
+    torch.cuda.synchronize()
+    first = float(pa.last_loss[0])
+    t0 = time.perf_counter()
+    for k in range(steps):
+        pa.step(seed_offset=(7, (k + 3) * ((pa.n * pa.S + 3) // 4)))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"iterations": steps, "rays": n, "samples_per_ray": pa.S, "total_ms": 1e3 * el, "ms_per_iteration": 1e3 * el / steps,
+            "loss_start": first, "loss_best": float(pa.best_loss[0]), "loss_last": float(pa.last_loss[0]),
+            "launches_per_iteration": 6, "kernels": "mne_pose_rays, mne_sample_z, mne_render_forward, mne_pose_loss, "
+            "mne_render_backward (ray gradients: ray_kernel<..., 3>), mne_pose_update"}
+
+
 def bench_render_img(args, cfg, workload, agent, device, rank, world, barrier, mdist):
     """--mode render_img: the N1 record as the line's metric (see render_img_measure)."""
     for _ in range(args.pretrain):
@@ -807,6 +842,11 @@ def main():
                 for _ in range(100):
                     ragent.step()
                 torch.cuda.synchronize()
+                try:                      # R13 / N2: loop closure's pose alignment on the same (trained) map, before the frames' scratch
+                    out["variants"]["pose_alignment"] = dict({"workload": workload + "_pose_alignment"},
+                                                             **pose_alignment_measure(ragent, cfg, device))
+                except Exception as e:    # noqa: BLE001
+                    out["variants"]["pose_alignment"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 own, rec = render_img_measure(ragent, cfg, device, n_pairs=5, n_warm=1)
                 out["variants"]["render_img"] = dict({"workload": workload + "_render_img", "pretrain_iterations": 100,
                                                       "value": 5 / own, "unit": "frame pairs/s", "ms_per_pair": 1e3 * own / 5}, **rec)
