@@ -386,12 +386,12 @@ __device__ __forceinline__ void mlp_backward_mfma(unsigned mh, unsigned mhc, flo
 
 // d(total)/d(OneBlob channel) rows of this lane's point -> LDS row dprow[0..63] (48 used): both nets'
 // first layers, chained into one accumulator per 32-row tile.  Ray-gradient variant only.
-template <int HID, int HIDC, bool CP, bool GTAB = false>
+template <int HID, int HIDC, bool CP, int BIAS = 0, bool GTAB = false>
 __device__ __forceinline__ void mlp_backward_dpos(const f32x16 (&dh)[HID / 32], const f32x16 (&dhc)[HIDC / 32],
                                                   const float* atab, int lane, float* dprow) {
     typedef ATab<HID, HIDC, CP> T;
     const int h = lane >> 5;
-    const ATabRef<GTAB> A(atab, lane);
+    const ATabRef<GTAB, BIAS> A(atab, lane);                   // atab starts at table step BIAS (as in the other backward chains)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         f32x16 acc;

@@ -94,6 +94,8 @@ struct RenderArgs {
     unsigned* relu_mask;        // [R*S][4]: per lane half (h mask, hc mask)
     int* ray_tiles;             // [R] number of leading 32-sample tiles of each ray whose tape rows are complete
     int* dec_tiles;             // [R] leading tiles of each ray decode_kernel really decoded (a-priori prefix + its extension)
+    const int* tile_need;       // [R] backward of an earlier forward call: tiles of each ray whose tape rows the backward walks
+                                // (tile_need_kernel): the decode makes exactly these, tile-parallel (NULL: the a-priori prefix)
     int* defer_list;            // [R] rays the training kernel could not resolve from the decoded prefix
     int* defer_count;           // [1]
     int* long_list;             // [R] rays whose decoded prefix exceeds the first pass's LDS sample cap (long rays only)

@@ -259,6 +259,7 @@ __device__ __forceinline__ int apriori_tiles(const RenderArgs& a, int r, int nti
 }
 __device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntile, bool listed = false) {
     if (listed) return ntile;                    // second pass over the deferred rays: everything is decoded
+    if (a.tile_need) return a.tile_need[r];      // backward of an earlier forward call: the tiles its backward will walk
     if (!a.ray_counts) return a.prefix_default < ntile ? a.prefix_default : ntile;
     if (a.adapt && a.adapt[0]) return ntile;     // adaptive schedule, mode 1: most rays would be deferred -> decode everything a priori
     const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
         // unresolved: no sign change from this tile on, or the truncation window behind the sign change runs past the
         // tile.  (A heuristic that saves a second pass: ray_kernel checks the whole prefix exactly and defers whatever
         // is still unresolved.)  dec_tiles[r] = tiles decoded in the end.  One decode_tile call site for both uses.
-        const bool resolver = a.dec_tiles && a.ray_counts && !a.ray_list && c == prefix_tiles(a, r, ntile) - 1;
+        const bool resolver = a.dec_tiles && a.ray_counts && !a.ray_list && !a.tile_need && c == prefix_tiles(a, r, ntile) - 1;
         int cc = c;
         bool found = false, have_carry = false, pre_now = pre != 0 || a.ext_feat != 0;   // ext_feat: every row's features are the caller's
         float z_lim = 0.0f, s_carry = 0.0f;
@@ -877,7 +878,8 @@ __device__ __forceinline__ unsigned run_meta(int w_, int lane) {
 // waves per workgroup a ray_kernel instantiation is compiled for (= its register budget: 512 / ceil(waves / 4) per lane)
 // (MODE 3, ray gradients: 4 waves = the whole register file of a SIMD per wave -- its extra d(OneBlob) / d(coordinate) stages
 // spilled 0.4-6 KiB per lane at 8 waves; it serves the 100-iteration pose loops of loop closure, not the mapping iteration)
-#define RAY_WPB(HID, CP, MODE) ((MODE) == 4 ? (((HID) == 64 && (CP)) ? MNE_HOT64CP_WPB : MAX_WPB_HOT) : (MODE) == 3 ? 4 : MAX_WPB_RAY)
+// (MODE 2, the autograd path's backward: the training kernel's tile body and tables since round 6, so its shape as well)
+#define RAY_WPB(HID, CP, MODE) (((MODE) == 4 || (MODE) == 2) ? (((HID) == 64 && (CP)) ? MNE_HOT64CP_WPB : MAX_WPB_HOT) : (MODE) == 3 ? 4 : MAX_WPB_RAY)
 
 // One 32-sample tile of the TRAINING backward of ray r (tile c, samples [32 c, 32 c + 32) of the ray's Dn decoded ones): loss
 // and compositing gradients of every sample from the ray's constants G -> MFMA backward chain from the saved ReLU masks ->
@@ -1067,9 +1069,10 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
     typedef ATab<HID, HIDC, CP> T;
     constexpr int NSETS = CP ? 2 : 1;
     constexpr int NT = HID / 32, NTC = HIDC / 32;
-    constexpr bool HOT = MODE == 4, BWD = MODE >= 1, RAYGRAD = MODE == 3, LATE_DECODE = MODE == 2 || MODE == 3;
-    // A tables in LDS: everything the mode needs; the training kernel stages only the backward steps
-    constexpr int TAB_FIRST = HOT ? T::FWD_STEPS : 0;
+    constexpr bool HOT = MODE == 4, BWD = MODE >= 1, RAYGRAD = MODE == 3;
+    // A tables in LDS: everything the mode needs; the backward modes stage only the backward steps (round 6: none of them
+    // decodes any more -- tile_need_kernel + the decode launch make every tape row MODE 2 / 3 walk)
+    constexpr int TAB_FIRST = BWD ? T::FWD_STEPS : 0;
     constexpr int TAB_LAST = RAYGRAD ? T::TOTAL_RAYGRAD : BWD ? T::TOTAL : T::FWD_STEPS;
     constexpr int TAB_FLOATS = ALDS ? (TAB_LAST - TAB_FIRST) * 64 : 0;
     MNE_DYN_LDS(lds_raw);
@@ -1153,7 +1156,8 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             if (first < 0) first = first_crossing(raws, from, Dn, lane);
             if (ray_resolved(zr, first, Dn, S, a.win_f)) break;
             if (HOT) { deferred = true; break; }
-            if (!HOT) {
+            if constexpr (BWD) break;                             // MODE 2 / 3: raw of the forward call, all S samples: always resolved above
+            if constexpr (MODE == 0) {
                 // decode the next tile on demand (Dn is a multiple of TILE here)
                 float pnv[3], u[3];
                 uint2 relu;
@@ -1213,7 +1217,8 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
         }
         float ray_do[3] = {0.f, 0.f, 0.f}, ray_dd[3] = {0.f, 0.f, 0.f};
         for (int c = 0; c < nb; ++c) {
-            if constexpr (HOT) {                                  // the training kernel's tile body (shared with heavy_bwd_kernel)
+            if constexpr (HOT || MODE == 2) {                     // the training kernel's tile body (shared with heavy_bwd_kernel);
+                // MODE 2 -- the autograd path's backward -- is the same tile without the ray-gradient stages below
                 hot_backward_tile<HID, HIDC, CP, BIAS, !ALDS>(a, r, c, Dn, G, td, ro, rd, cf, use_e, use_co, zr, raws, lane, pn, feat, atab);
                 continue;
             }
@@ -1224,15 +1229,13 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
             float p[3], pnv[3], u[3];
             const size_t e = (size_t)r * S + ii;
             uint2 mk2;
-            if (LATE_DECODE && c >= t_dec) {                      // tape rows of this tile are missing: decode it now
-                decode_tile<HID, HIDC, CP, !ALDS>(a, r, c, lane, pn, feat, atab, pnv, u, mk2, a.ext_feat != 0);
-                t_dec = c + 1;
-            } else {
+            // (MODE 2 / 3, the backward of an earlier forward call: the tape rows and ReLU masks of every tile walked here were
+            // made by the decode launch -- tile_need_kernel told it which; until round 6 tiles beyond the a-priori prefix were
+            // decoded HERE, which put the forward chain's registers on top of the backward's: 20-240 B of scratch per lane)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) p[q] = ro[q] + rd[q] * z;
-                point_coords(a.sc, p, pnv, u);
-                mk2 = *(const uint2*)(a.relu_mask + e * 4 + hf * 2);
-            }
+            for (int q = 0; q < 3; ++q) p[q] = ro[q] + rd[q] * z;
+            point_coords(a.sc, p, pnv, u);
+            mk2 = *(const uint2*)(a.relu_mask + e * 4 + hf * 2);
             // ---- d(total)/d(raw) of this point (both lanes of the pair compute the same values)
             const float4 rw = *(const float4*)(raws + 4 * ii);
             const float s = rw.w;
@@ -1294,7 +1297,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
                 // d(total)/d(point) = through the OneBlob input + through the bilinear plane coordinates; every
                 // point of the tile belongs to this ray: summed over the wave, stored once at the end
                 float* dprow = dposL + pt * 64;
-                mlp_backward_dpos<HID, HIDC, CP, !ALDS>(dh, dhc, atab, lane, dprow);
+                mlp_backward_dpos<HID, HIDC, CP, BIAS, !ALDS>(dh, dhc, atab, lane, dprow);
                 MNE_WAVE_SYNC();
                 // (a caller-owned encoding -- hash / dense grid -- differentiates its own features: mne_hash_ray_grad adds
                 // that part from the d(feature) rows this kernel leaves in the tape; here only the OneBlob input's share)
@@ -1537,6 +1540,38 @@ __device__ __forceinline__ int first_crossing_g(const float* raw_ray, int D, int
         if (m) return base + __ffsll(m) - 1;
     }
     return -1;
+}
+
+// tile_need_kernel: backward of an EARLIER forward call (mne_render_backward: the autograd path, the pose loops of loop
+// closure) -- which tiles of every ray will the backward walk?  Exactly ray_kernel<..., 2 | 3>'s own rule on the forward
+// call's raw: first sign change over all samples (undecoded ones are NaN there and never form a crossing), render window
+// z < z[first] + sc_factor * trunc, loss masks; need[r] = max(a-priori prefix, last contributing tile + 1).  The decode
+// launch then makes the forward half of exactly those tape rows tile-parallel, and the backward kernel carries no decode.
+__global__ __launch_bounds__(256) void tile_need_kernel(RenderArgs a, int* need) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int S = a.S, ntile = (S + TILE - 1) / TILE;
+    const bool has_t = a.target_d != nullptr;
+    const float td = has_t ? a.target_d[r] : 0.0f;
+    const bool use_e = a.coef && (a.coef[MNE_L_E_FS] != 0.f || a.coef[MNE_L_E_CENTER] != 0.f || a.coef[MNE_L_E_TAIL] != 0.f);
+    const bool use_co = a.coef && (a.coef[MNE_L_CO_FS] != 0.f || a.coef[MNE_L_CO_SDF] != 0.f);
+    const float* zr = a.z_vals + (size_t)r * S;
+    const int first = first_crossing_g(a.raw_in + (size_t)r * S * 4, S, lane);
+    const float z_lim = zr[first < 0 ? 0 : first] + a.win_f;
+    int last = -1;
+    for (int base = 0; base < S; base += MNE_WAVE) {
+        const int i = base + lane;
+        bool f = false;
+        if (i < S) {
+            const float z = zr[i];
+            f = sample_contrib(z, z_lim, sample_masks(z, td, has_t, a), use_e, use_co);
+        }
+        const unsigned long long m = __ballot(f);
+        if (m) last = base + 63 - __clzll(m);
+    }
+    const int nb = last < 0 ? 0 : last / TILE + 1;
+    const int t0 = prefix_tiles(a, r, ntile);                  // (a.tile_need is NULL in this launch: the a-priori prefix)
+    if (lane == 0) need[r] = nb > t0 ? nb : t0;
 }
 
 // INVARIANTS of pass 0 running on another stream beside the backward kernels and the deferred pass (exercised by
@@ -1928,9 +1963,10 @@ static int launch_ray(RenderArgs a, hipStream_t st, int max_blocks = MNE_NUM_CU)
     typedef ATab<HID, HIDC, CP> T;
     // A tables in LDS: always for the training kernel (backward steps only: at most 46 KiB); the other modes of the
     // largest decoder (2x64 + colour planes: 124 KiB of tables) read them through L2
-    constexpr bool ALDS = W::ALDS || MODE == 4;
+    constexpr bool ALDS = W::ALDS || MODE == 4 || MODE == 2;
     size_t tab = table_bytes<HID, HIDC, CP>(MODE);
-    if (MODE == 4) tab = (size_t)(T::TOTAL - T::FWD_STEPS) * 64 * sizeof(float);
+    if (MODE == 4 || MODE == 2) tab = (size_t)(T::TOTAL - T::FWD_STEPS) * 64 * sizeof(float);
+    else if (MODE == 3 && tab) tab -= (size_t)T::FWD_STEPS * 64 * sizeof(float);
     // Training kernel, first pass: LDS for MNE_HOT_LDS_SAMPLES samples per ray instead of S (INS Indoor: S = 1045 would
     // leave room for 4 waves per CU, i.e. 1024 of 2150 rays at a time); the few rays whose decoded prefix is longer
     // go to the second pass, which is sized for S.
@@ -2008,7 +2044,8 @@ static int launch_decode(RenderArgs d, hipStream_t st, const RenderHost& host, b
     // balanced tile schedule (see decode_kernel): needs the tile-count prefix of mne_sample_z / mne_sample_batch and room for
     // it in LDS; the adaptive "decode everything" state is checked on the device
     const size_t sched_bytes = align16((size_t)d.R * sizeof(int));
-    const int sched = (MNE_DECODE_BALANCED && d.ray_counts && !d.ray_list && d.R <= MNE_BALANCED_MAX_RAYS && lds + sched_bytes <= MNE_LDS_MAX) ? 1 : 0;
+    const int sched = (MNE_DECODE_BALANCED && d.ray_counts && !d.ray_list && !d.tile_need && d.R <= MNE_BALANCED_MAX_RAYS &&
+                       lds + sched_bytes <= MNE_LDS_MAX) ? 1 : 0;
     if (sched) lds += sched_bytes;
     const long long ntask = (long long)d.R * ((d.S + TILE - 1) / TILE);
     long long grid = (ntask + wpb - 1) / wpb;
@@ -2102,6 +2139,11 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         mark(host, 0, st);
         mne_launch_hash_rows(g, 0, st);
         mark(host, 1, st);
+    }
+    if (mode == 3 && a.raw_in) {                           // backward of an earlier forward: the tiles the backward walks, then their decode
+        int* need = a.heavy_list;                          // (workspace array of the training call's heavy-ray list: unused in this mode)
+        MNE_LAUNCH(tile_need_kernel, (unsigned)((a.R + 3) / 4), 256, 0, st, a, need);
+        a.tile_need = need;
     }
     {   // decode: every tile (mode 0), or the a-priori prefix of every ray
         RenderArgs d = a;
