@@ -518,6 +518,19 @@ int mne_query_features(const mne_scene_t* scene, int64_t n_pts, const float* pts
  * x [N][dims] in [0,1] -> out [N][dims*16], layout [dim0 bins | dim1 bins | ...]. */
 int mne_encode_oneblob(int64_t n_pts, int dims, const float* x, float* out, void* stream);
 
+/* ---- the remaining branches of get_encoder (model/encodings.py:48-58, 73-95; ABI 8) -----------
+ * tcnn.Encoding(otype = "Frequency" | "SphericalHarmonics" | "Identity"): never reached by the reference's mapping path
+ * (model/scene_rep.py:157 requests OneBlob); forward + gradient with respect to the input.  Spec and parity status:
+ * oracle/encodings_misc.py (tinycudann is not in the reference tree: parity unpinned).
+ *   frequency: x [N][dims] -> out [N][dims * 2 * n_frequencies], out[dim * 2F + 2f + s] = sin(2^f * pi * x[dim] + s * pi / 2)
+ *   sh       : in [N][3] in [0,1] (direction = 2 in - 1) -> out [N][degree^2], degree 1..4
+ *   identity : out = x * scale + offset */
+int mne_encode_frequency(int64_t n_pts, int dims, int n_frequencies, const float* x, float* out, void* stream);
+int mne_encode_frequency_backward(int64_t n_pts, int dims, int n_frequencies, const float* x, const float* d_out, float* d_x, void* stream);
+int mne_encode_sh(int64_t n_pts, int degree, const float* in, float* out, void* stream);
+int mne_encode_sh_backward(int64_t n_pts, int degree, const float* in, const float* d_out, float* d_in, void* stream);
+int mne_encode_identity(int64_t n_elems, float scale, float offset, const float* x, float* out, void* stream);
+
 /* ---- R14: multiresolution hash / dense grid encoding (tinycudann replacement surface) ------ */
 /* Replaces tcnn.Encoding(otype="HashGrid"/"Grid") as configured by get_encoder (model/encodings.py:
  * 13-46; not executed by the reference's mapping path).  grid_type 0 = Hash, 1 = Dense.  Spec and

@@ -180,6 +180,11 @@ _PROTOS = {
     "mne_grid_encode": (C.c_int, [C.POINTER(GridCfg), C.c_int64] + [C.c_void_p] * 5),
     "mne_grid_encode_backward": (C.c_int, [C.POINTER(GridCfg), C.c_int64] + [C.c_void_p] * 4),
     "mne_encode_oneblob": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_encode_frequency": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_encode_frequency_backward": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_encode_sh": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_encode_sh_backward": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mne_encode_identity": (C.c_int, [C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mne_hash_gather": (C.c_int, [C.POINTER(GridCfg), C.POINTER(Scene), C.c_int, C.c_int] + [C.c_void_p] * 7),
     "mne_render_fused_features": (C.c_int, [C.POINTER(Scene), C.POINTER(RenderCfg), C.c_int, C.c_int] + [C.c_void_p] * 13
                                   + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GridCfg), C.c_void_p,

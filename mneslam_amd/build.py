@@ -25,7 +25,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libmneslam_hip.so")
 FUZZ_DIR = os.path.join(HERE, "_fuzz")
-SOURCES = ["capi.hip", "render.hip", "wgrad.hip", "adam.hip", "sampler.hip", "tile_adam.hip", "gridenc.hip", "pose.hip"]
+SOURCES = ["capi.hip", "render.hip", "wgrad.hip", "adam.hip", "sampler.hip", "tile_adam.hip", "gridenc.hip", "pose.hip", "encodings.hip"]
 HEADERS = ["mne_device.h", "mne_launch.h", "mne_platform.h", "mlp_mfma.h"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]

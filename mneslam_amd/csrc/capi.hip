@@ -708,6 +708,41 @@ int mne_encode_oneblob(int64_t n_pts, int dims, const float* x, float* out, void
     return check_launch("encode_oneblob");
 }
 
+int mne_encode_frequency(int64_t n_pts, int dims, int n_frequencies, const float* x, float* out, void* stream) {
+    if (!x || !out || dims < 1 || n_frequencies < 1 || n_frequencies > 32) return fail(-1, "mne_encode_frequency: bad argument");
+    if (n_pts <= 0) return 0;
+    mne_launch_frequency(n_pts, dims, n_frequencies, x, out, (hipStream_t)stream);
+    return check_launch("encode_frequency");
+}
+
+int mne_encode_frequency_backward(int64_t n_pts, int dims, int n_frequencies, const float* x, const float* d_out, float* d_x, void* stream) {
+    if (!x || !d_out || !d_x || dims < 1 || n_frequencies < 1 || n_frequencies > 32) return fail(-1, "mne_encode_frequency_backward: bad argument");
+    if (n_pts <= 0) return 0;
+    mne_launch_frequency_backward(n_pts, dims, n_frequencies, x, d_out, d_x, (hipStream_t)stream);
+    return check_launch("encode_frequency_backward");
+}
+
+int mne_encode_sh(int64_t n_pts, int degree, const float* in, float* out, void* stream) {
+    if (!in || !out || degree < 1 || degree > 4) return fail(-1, "mne_encode_sh: degree 1..4 (tinycudann goes to 8; the reference asks for 4)");
+    if (n_pts <= 0) return 0;
+    mne_launch_sh(n_pts, degree * degree, in, out, (hipStream_t)stream);
+    return check_launch("encode_sh");
+}
+
+int mne_encode_sh_backward(int64_t n_pts, int degree, const float* in, const float* d_out, float* d_in, void* stream) {
+    if (!in || !d_out || !d_in || degree < 1 || degree > 4) return fail(-1, "mne_encode_sh_backward: degree 1..4");
+    if (n_pts <= 0) return 0;
+    mne_launch_sh_backward(n_pts, degree * degree, in, d_out, d_in, (hipStream_t)stream);
+    return check_launch("encode_sh_backward");
+}
+
+int mne_encode_identity(int64_t n_elems, float scale, float offset, const float* x, float* out, void* stream) {
+    if (!x || !out) return fail(-1, "mne_encode_identity: NULL argument");
+    if (n_elems <= 0) return 0;
+    mne_launch_identity(n_elems, scale, offset, x, out, (hipStream_t)stream);
+    return check_launch("encode_identity");
+}
+
 int mne_query_features(const mne_scene_t* scene, int64_t n_pts, const float* pts, const float* features,
                        const float* packed_decoder, float* raw, float* geo, void* stream) {
     if (int rc = check_scene(scene, false, false)) return rc;

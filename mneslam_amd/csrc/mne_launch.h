@@ -309,6 +309,11 @@ size_t mne_hash_layout(GridArgs& a, int R, int S, void* base);     // fills the 
 size_t mne_render_workspace(int R, int S);
 int mne_launch_query(const QueryArgs& a, hipStream_t st);
 int mne_launch_oneblob(long long n, int dims, const float* x, float* out, hipStream_t st);
+int mne_launch_frequency(long long n, int dims, int F, const float* x, float* out, hipStream_t st);
+int mne_launch_frequency_backward(long long n, int dims, int F, const float* x, const float* dout, float* dx, hipStream_t st);
+int mne_launch_sh(long long n, int n_coef, const float* in, float* out, hipStream_t st);
+int mne_launch_sh_backward(long long n, int n_coef, const float* in, const float* dout, float* din, hipStream_t st);
+int mne_launch_identity(long long n_elems, float scale, float offset, const float* x, float* out, hipStream_t st);
 int mne_launch_loss_finalize(const LossArgs& a, hipStream_t st);
 int mne_launch_loss_coef(const LossArgs& a, hipStream_t st);
 int mne_launch_wgrad(const mne_scene_t& sc, WgradArgs a, int impl, hipStream_t st);

@@ -1,7 +1,8 @@
 """``get_encoder`` -- the reference's encoder factory (model/encodings.py:6-97) without tinycudann.
 
 Only OneBlob is reachable in the reference (model/scene_rep.py:157; the hash-grid call at :160 is
-commented out).  The module returned here has tinycudann's surface (``n_output_dims``, a zero-size
+commented out); every branch of the factory is provided (dense / hash grid, OneBlob, and -- round 6 -- spherical
+harmonics, frequency, identity).  The module returned here has tinycudann's surface (``n_output_dims``, a zero-size
 ``params`` Parameter -> state_dict key ``embedpos_fn.params``) and runs the stand-alone HIP kernel.
 """
 import ctypes as C
@@ -32,6 +33,109 @@ class OneBlobEncoding(nn.Module):
         out = torch.empty(n, d * self.n_bins, device=x.device, dtype=torch.float32)
         _lib.check(lib.mne_encode_oneblob(n, d, _lib.ptr(x), _lib.ptr(out), _lib.stream_for(x)), "mne_encode_oneblob")
         return out
+
+
+class _FrequencyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_frequencies):
+        lib = _lib.load()
+        xc = x.detach().to(torch.float32).contiguous()
+        n, d = xc.shape
+        out = torch.empty(n, d * 2 * n_frequencies, device=xc.device, dtype=torch.float32)
+        _lib.check(lib.mne_encode_frequency(n, d, n_frequencies, _lib.ptr(xc), _lib.ptr(out), _lib.stream_for(xc)), "mne_encode_frequency")
+        ctx.save_for_backward(xc)
+        ctx.F, ctx.dtype = n_frequencies, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (xc,) = ctx.saved_tensors
+        dout = dout.to(torch.float32).contiguous()
+        dx = torch.empty_like(xc)
+        _lib.check(_lib.load().mne_encode_frequency_backward(xc.shape[0], xc.shape[1], ctx.F, _lib.ptr(xc), _lib.ptr(dout),
+                                                             _lib.ptr(dx), _lib.stream_for(xc)), "mne_encode_frequency_backward")
+        return dx.to(ctx.dtype), None
+
+
+class FrequencyEncoding(nn.Module):
+    """tcnn.Encoding(otype="Frequency", n_frequencies=F) replacement (model/encodings.py:73-84); differentiable with respect to
+    its input; spec in oracle/encodings_misc.py (parity unpinned: tinycudann is not part of the reference tree)."""
+
+    def __init__(self, n_input_dims=3, n_frequencies=12):
+        super().__init__()
+        self.n_input_dims, self.n_frequencies = n_input_dims, n_frequencies
+        self.n_output_dims = n_input_dims * 2 * n_frequencies
+        self.params = nn.Parameter(torch.zeros(0, dtype=torch.float32))
+
+    def forward(self, x):
+        return _FrequencyFn.apply(x, self.n_frequencies)
+
+
+class _ShFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, degree):
+        lib = _lib.load()
+        xc = x.detach().to(torch.float32).contiguous()
+        n = xc.shape[0]
+        out = torch.empty(n, degree * degree, device=xc.device, dtype=torch.float32)
+        _lib.check(lib.mne_encode_sh(n, degree, _lib.ptr(xc), _lib.ptr(out), _lib.stream_for(xc)), "mne_encode_sh")
+        ctx.save_for_backward(xc)
+        ctx.degree, ctx.dtype = degree, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (xc,) = ctx.saved_tensors
+        dout = dout.to(torch.float32).contiguous()
+        dx = torch.empty_like(xc)
+        _lib.check(_lib.load().mne_encode_sh_backward(xc.shape[0], ctx.degree, _lib.ptr(xc), _lib.ptr(dout), _lib.ptr(dx),
+                                                      _lib.stream_for(xc)), "mne_encode_sh_backward")
+        return dx.to(ctx.dtype), None
+
+
+class SphericalHarmonicsEncoding(nn.Module):
+    """tcnn.Encoding(otype="SphericalHarmonics", degree=d) replacement (model/encodings.py:48-58): inputs in [0, 1]^3 are
+    directions 2 x - 1, outputs the d^2 real SH coefficients; degrees 1..4 (the reference's factory default is 4)."""
+
+    def __init__(self, n_input_dims=3, degree=4):
+        super().__init__()
+        if n_input_dims != 3:
+            raise ValueError("spherical harmonics encode 3-D directions")
+        if not 1 <= degree <= 4:
+            raise NotImplementedError("the HIP spherical-harmonics kernel covers degrees 1..4 (tinycudann: up to 8)")
+        self.n_input_dims, self.degree, self.n_output_dims = 3, degree, degree * degree
+        self.params = nn.Parameter(torch.zeros(0, dtype=torch.float32))
+
+    def forward(self, x):
+        return _ShFn.apply(x, self.degree)
+
+
+class _IdentityFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, offset):
+        lib = _lib.load()
+        xc = x.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(xc)
+        _lib.check(lib.mne_encode_identity(xc.numel(), scale, offset, _lib.ptr(xc), _lib.ptr(out), _lib.stream_for(xc)), "mne_encode_identity")
+        ctx.scale, ctx.dtype = scale, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return (dout * ctx.scale).to(ctx.dtype), None, None
+
+
+class IdentityEncoding(nn.Module):
+    """tcnn.Encoding(otype="Identity") replacement (model/encodings.py:86-95): out = x * scale + offset (defaults 1, 0)."""
+
+    def __init__(self, n_input_dims=3, scale=1.0, offset=0.0):
+        super().__init__()
+        self.n_input_dims = self.n_output_dims = n_input_dims
+        self.scale, self.offset = float(scale), float(offset)
+        self.params = nn.Parameter(torch.zeros(0, dtype=torch.float32))
+
+    def forward(self, x):
+        return _IdentityFn.apply(x, self.scale, self.offset)
 
 
 class _GridFn(torch.autograd.Function):
@@ -116,6 +220,15 @@ def get_encoder(encoding, input_dim=3, degree=4, n_bins=16, n_frequencies=12, n_
     if "blob" in name:                                    # model/encodings.py:61-71
         embed = OneBlobEncoding(input_dim, n_bins)
         return embed, embed.n_output_dims
-    raise NotImplementedError(
-        f"encoding '{encoding}': the spherical-harmonics / frequency / identity branches of the reference factory "
-        "are never reached by the mapping path (model/scene_rep.py:157 requests OneBlob) and are not provided")
+    # the branches below are never reached by the reference's mapping path (model/scene_rep.py:157 requests OneBlob); they
+    # complete the factory's surface
+    if "spherical" in name:                               # model/encodings.py:48-58
+        embed = SphericalHarmonicsEncoding(input_dim, degree)
+        return embed, embed.n_output_dims
+    if "freq" in name:                                    # model/encodings.py:73-84
+        embed = FrequencyEncoding(input_dim, n_frequencies)
+        return embed, embed.n_output_dims
+    if "identity" in name:                                # model/encodings.py:86-95
+        embed = IdentityEncoding(input_dim)
+        return embed, embed.n_output_dims
+    raise ValueError(f"encoding '{encoding}': not one of the reference factory's names (model/encodings.py:6-97)")

@@ -15,7 +15,7 @@ SAN = os.environ.get("MNE_EMU_SANITIZE", "")
 if SAN:
     OUT = os.path.join(HERE, "_build_" + SAN)
 LIB = os.path.join(OUT, "libmneslam_emu.so")
-SOURCES = ["capi.hip", "render.hip", "wgrad.hip", "adam.hip", "sampler.hip", "tile_adam.hip", "gridenc.hip", "pose.hip"]
+SOURCES = ["capi.hip", "render.hip", "wgrad.hip", "adam.hip", "sampler.hip", "tile_adam.hip", "gridenc.hip", "pose.hip", "encodings.hip"]
 
 
 def _cxx():

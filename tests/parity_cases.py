@@ -307,6 +307,57 @@ def check_oneblob(device):
     assert_close(got, oneblob(xi, 16), rtol=0, atol=0, what="OneBlob inside the box (bit-exact vs spec)")
 
 
+def check_misc_encodings(device):
+    """The remaining branches of the reference's encoder factory (model/encodings.py:48-58, 73-95): spherical harmonics,
+    frequency, identity -- forward and input gradient against the frozen spec (oracle/encodings_misc.py: parity unpinned)."""
+    from mneslam_amd.model.encodings import get_encoder
+    from oracle import encodings_misc as em
+    torch.manual_seed(3)
+    x = torch.cat([torch.rand(300, 3), torch.tensor([[0.0, 1.0, 0.5], [0.25, 0.75, 1.0]])])
+    # ---- frequency (factory default: 12 frequencies)
+    enc, dim = get_encoder("Frequency", n_frequencies=12)
+    assert dim == 72 and enc.n_output_dims == 72 and enc.params.numel() == 0
+    xr = x.clone().to(device).requires_grad_(True)
+    got = enc(xr)
+    xo = x.clone().requires_grad_(True)
+    ref = em.frequency(xo, 12)
+    # sin of arguments up to 2^11 pi: one fp32 ulp of the ARGUMENT is 2.4e-4 there, the device's sinf and torch's agree to ~1e-6 on the same argument
+    assert_close(got.detach().cpu(), ref.detach(), rtol=0, atol=2e-6, what="frequency encoding")
+    g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
+    got.backward(g.to(device))
+    ref.backward(g)
+    assert_close(xr.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-2, what="frequency input gradient")       # (gradients scale with 2^11 pi)
+    enc4, dim4 = get_encoder("frequency", input_dim=2, n_frequencies=4)
+    assert dim4 == 16
+    assert_close(enc4(x[:, :2].contiguous().to(device)).cpu(), em.frequency(x[:, :2], 4), rtol=0, atol=1e-6, what="frequency 2-D")
+    # ---- spherical harmonics (factory default: degree 4)
+    for degree in (4, 2, 1):
+        enc, dim = get_encoder("SphericalHarmonics", degree=degree)
+        assert dim == degree * degree and enc.params.numel() == 0
+        xr = x.clone().to(device).requires_grad_(True)
+        got = enc(xr)
+        xo = x.clone().requires_grad_(True)
+        ref = em.spherical_harmonics(xo, degree)
+        assert_close(got.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-6, what=f"SH degree {degree}")
+        g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(2))
+        got.backward(g.to(device))
+        if degree == 1:                                   # a constant: no gradient
+            assert float(xr.grad.abs().max()) == 0.0
+            continue
+        ref.backward(g)
+        assert_close(xr.grad.cpu(), xo.grad, rtol=1e-5, atol=1e-5, what=f"SH degree {degree} input gradient")
+    # ---- identity
+    enc, dim = get_encoder("Identity")
+    assert dim == 3 and enc.params.numel() == 0
+    xr = x.clone().to(device).requires_grad_(True)
+    got = enc(xr)
+    assert torch.equal(got.detach().cpu(), em.identity(x))
+    got.sum().backward()
+    assert torch.equal(xr.grad.cpu(), torch.ones_like(x))
+    with pytest.raises(ValueError):
+        get_encoder("no-such-encoding")
+
+
 def check_grid_encoding(device, kind="hash"):
     """R14 surface: get_encoder('HashGrid'/'dense') vs the frozen spec (oracle/hashgrid.py): uint32 table
     indices bit-exact, features and parameter gradients to fp32 rounding."""

@@ -36,6 +36,11 @@ def test_oneblob():
     pc.check_oneblob(DEV)
 
 
+def test_spherical_frequency_identity_encodings():
+    """get_encoder('SphericalHarmonics' | 'Frequency' | 'Identity'), model/encodings.py:48-58, 73-95"""
+    pc.check_misc_encodings(DEV)
+
+
 def test_adam():
     pc.check_adam(DEV)
 
