@@ -34,7 +34,7 @@ from mneslam_amd.fused import FusedStep, HashFusedStep  # noqa: E402
 from mneslam_amd.model.scene_rep import JointEncoding  # noqa: E402
 from mneslam_amd.model.scene_rep_hash import HashJointEncoding  # noqa: E402
 
-PMC_PREFIX = "r05"                      # committed counter passes the line's `traffic` figures come from (profiles/r05_pmc.sh)
+PMC_PREFIX = "r06"                      # committed counter passes the line's `traffic` figures come from (profiles/r06_pmc.sh)
 PMC_JSON = PMC_PREFIX + "_pmc_traffic.json"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
