@@ -173,9 +173,9 @@ __device__ __forceinline__ void oneblob_half(const float u[3], int h, float (&po
     // 0 and 1 (its value there is 0.023 outside [0, 1]; checked over 2.2 M fp32 values incl. every value next to the bounds)
     const bool in_f = xf >= 0.015625f && xf <= 0.921875f, in_p = u[1] >= 0.015625f && u[1] <= 0.921875f;
     const bool interior = __ballot(!(in_f && in_p)) == 0ull;        // wave-uniform fast path
-    oneblob16(xf, full, interior);
+    oneblob16<LEAN>(xf, full, interior);
     if constexpr (LEAN) oneblob8(u[1], h * 8, part, interior);
-    else oneblob16(u[1], part, interior);
+    else oneblob16<false>(u[1], part, interior);
     if constexpr (!LEAN) {
 #pragma unroll
         for (int idx = 0; idx < 24; ++idx) {

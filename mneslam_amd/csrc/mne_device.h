@@ -120,15 +120,48 @@ __device__ __forceinline__ float quartic_cdf(float t) {
     return fminf(1.0f, fmaxf(poly, 0.0f));
 }
 
+// Two cumulative values at once (bins b, b + 1): the same fp32 operations on the same inputs as quartic_cdf, element by element
+// (-ffp-contract=off: no fused multiply-add either way), written on float2 so that the multiplies and adds issue as
+// v_pk_mul_f32 / v_pk_add_f32 -- two values per VALU instruction.  Round 6: the OneBlob was ~400 scalar VALU instructions per lane
+// and 32-sample tile (25 cumulative values x 15 operations), a fifth of what a decode wave issues.
+typedef float mne_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mne_f2 quartic_cdf2(mne_f2 t) {
+    const mne_f2 u = t * 16.0f;
+    const mne_f2 u2 = u * u;
+    const mne_f2 u4 = u2 * u2;
+    const mne_f2 poly = (0.9375f * u) * ((1.0f - 0.6666666666666666f * u2) + 0.2f * u4) + 0.5f;
+    mne_f2 r;
+    r.x = fminf(1.0f, fmaxf(poly.x, 0.0f));
+    r.y = fminf(1.0f, fmaxf(poly.y, 0.0f));
+    return r;
+}
+__device__ __forceinline__ mne_f2 oneblob_cum2(float b0, float b1, float x, bool interior) {
+    mne_f2 t;
+    t.x = b0 * 0.0625f - x;
+    t.y = b1 * 0.0625f - x;
+    if (interior) return (quartic_cdf2(t) + 0.0f) + 1.0f;
+    return (quartic_cdf2(t) + quartic_cdf2(t - 1.0f)) + quartic_cdf2(t + 1.0f);
+}
+__device__ __forceinline__ float oneblob_cum1(float b, float x, bool interior) {
+    const float t = b * 0.0625f - x;
+    return interior ? (quartic_cdf(t) + 0.0f) + 1.0f : (quartic_cdf(t) + quartic_cdf(t - 1.0f)) + quartic_cdf(t + 1.0f);
+}
+
 // `interior` (wave-uniform): every lane's x lies in [1/64, 59/64], where the two periodic wrap terms are
 // exactly 0 and 1 (|u| >= 1.25: the clamp saturates with a margin of 0.023), so only the central kernel is evaluated.
+// PACKED = false: the scalar form, for the one kernel without a register to spare for even-aligned pairs (decode of 2x64 + colour planes).
+template <bool PACKED = true>
 __device__ __forceinline__ void oneblob16(float x, float* out /*16*/, bool interior = false) {
     float c[MNE_NB];
+    if constexpr (PACKED) {
 #pragma unroll
-    for (int b = 0; b < MNE_NB; ++b) {
-        float t = (float)b * 0.0625f - x;
-        c[b] = interior ? (quartic_cdf(t) + 0.0f) + 1.0f
-                        : (quartic_cdf(t) + quartic_cdf(t - 1.0f)) + quartic_cdf(t + 1.0f);
+        for (int b = 0; b < MNE_NB; b += 2) {
+            const mne_f2 v = oneblob_cum2((float)b, (float)(b + 1), x, interior);
+            c[b] = v.x; c[b + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < MNE_NB; ++b) c[b] = oneblob_cum1((float)b, x, interior);
     }
 #pragma unroll
     for (int b = 0; b < MNE_NB - 1; ++b) out[b] = c[b + 1] - c[b];
@@ -141,12 +174,11 @@ __device__ __forceinline__ void oneblob16(float x, float* out /*16*/, bool inter
 __device__ __forceinline__ void oneblob8(float x, int base, float* out /*8*/, bool interior = false) {
     float c[9];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const int b = (base + j) & (MNE_NB - 1);              // base = 8: the ninth value is c[0] (periodic wrap, below)
-        float t = (float)b * 0.0625f - x;
-        c[j] = interior ? (quartic_cdf(t) + 0.0f) + 1.0f
-                        : (quartic_cdf(t) + quartic_cdf(t - 1.0f)) + quartic_cdf(t + 1.0f);
+    for (int j = 0; j < 8; j += 2) {                          // base + j + 1 <= 15: no wrap inside a pair
+        const mne_f2 v = oneblob_cum2((float)(base + j), (float)(base + j + 1), x, interior);
+        c[j] = v.x; c[j + 1] = v.y;
     }
+    c[8] = oneblob_cum1((float)((base + 8) & (MNE_NB - 1)), x, interior);     // base = 8: the ninth value is c[0] (periodic wrap, below)
 #pragma unroll
     for (int j = 0; j < 7; ++j) out[j] = c[j + 1] - c[j];
     out[7] = base ? (c[8] + 1.0f) - c[7] : c[8] - c[7];        // bin 15 wraps around: (c[0] + 1) - c[15]

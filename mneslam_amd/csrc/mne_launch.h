@@ -173,6 +173,13 @@ struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, 
 #ifndef MNE_RESOLVER_MAX_EXT
 #define MNE_RESOLVER_MAX_EXT 1
 #endif
+// ... with colour planes: the extension tile's inline gather walks two plane sets (48 corner rows per sample, serial in the
+// one wave), and leaving the unresolved rays to the tile-parallel deferred pass is cheaper (round 6, profiles/r06_resolver_ext_cp.txt:
+// ScanNet scene0000 decode_kernel 121 -> 94 us, 1180 -> 1209 it/s; office0 without colour planes loses 3.5 % that way, INS Indoor +-0)
+#ifndef MNE_RESOLVER_MAX_EXT_CP
+#define MNE_RESOLVER_MAX_EXT_CP 0
+#endif
+template <bool CP> struct ResolverExt { static constexpr int MAX = CP ? MNE_RESOLVER_MAX_EXT_CP : MNE_RESOLVER_MAX_EXT; };
 #define MNE_GRID_MAX_LEVELS 32
 #define MNE_GRID_MAX_F 8
 struct GridArgs {

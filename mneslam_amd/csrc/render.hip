@@ -420,6 +420,9 @@ __device__ __forceinline__ int xcd_block() {
 #ifndef MNE_SEQ_FORWARD
 #define MNE_SEQ_FORWARD 1       // forward-only launches with colour planes: one set of LDS feature rows per wave (decode_tile<..., SEQF>)
 #endif
+#ifndef MNE_WAVE_MAJOR
+#define MNE_WAVE_MAJOR 1        // first-pass tasks / rays of launches on caller-supplied features dealt wave-major over the workgroups (decode_kernel, ray_kernel<..., 4>); 0: workgroup-major everywhere
+#endif
 #ifndef MNE_DECODE_BALANCED
 #define MNE_DECODE_BALANCED 1   // decode_kernel: the rays' real tiles dealt evenly to the waves (0: fixed stride over the (tile, ray) slots)
 #endif
@@ -466,6 +469,9 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
     constexpr int TAB_FLOATS = ALDS ? T::FWD_STEPS * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     const int wpb = blockDim.x >> 6;
+#ifdef DECODE_PROFILE
+    const unsigned long long t_entry = wall_clock64();
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0 && !a.ray_list) {   // counters of this call, reset before any consumer runs
         if (a.tape_rows) *a.tape_rows = 0;
         if (a.bins.spill_count) *a.bins.spill_count = 0;
@@ -483,6 +489,14 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
     const float* atab = ALDS ? (const float*)lds_raw : a.packed;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntile = (a.S + TILE - 1) / TILE;
+#ifdef DECODE_PROFILE       // (profiling builds only, profiles/r06_decode_waves.py: per-wave clock stamps in the tail of the spill area)
+    unsigned long long* prof = (a.bins.spill && !a.ray_list && pre) ? (unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 65536) * MNE_SPILL_WORDS) + (size_t)(blockIdx.x * wpb + wv) * 16 : nullptr;
+    int prof_n = 0, prof_ext = 0;
+#define DEC_STAMP(k) do { if (prof && lane == 0 && (k) < 14) prof[(k)] = wall_clock64(); } while (0)
+    if (prof && lane == 0) prof[0] = t_entry;
+#else
+#define DEC_STAMP(k) do { } while (0)
+#endif
     float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(NSETS));
     float* feat = pn + TILE * 4;
     // persistent waves over the (tile, ray) tasks, TILE-major: the a-priori tiles of all rays come first, so the
@@ -509,8 +523,20 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
         if (tstart[0] != 0 || total < a.R || total > (long long)a.R * ntile) balanced = false;
         else ntask_l = total;
     }
-    for (long long task = (long long)xcd_block() * wpb + wv; task < ntask_l; task += (long long)gridDim.x * wpb) {
+    DEC_STAMP(1);
+    // Task numbering.  The launch is bound by what a SIMD issues -- 7.2 us per tile and SIMD whether two or three waves share it
+    // (profiles/r06_decode_waves.txt) -- and workgroup-major numbering (wave w of workgroup b: tasks b * wpb + w, ...) puts the last,
+    // partial round on the first workgroups only (office0: 4952 tiles on 2048 waves, the 856 third tasks on workgroups 0..106).  Wave-major
+    // numbering (w * gridDim + b) spreads it over all CUs and SIMDs: first-pass decode 60 -> 57 us, ray pass 74 -> 72 us on office0,
+    // 94 -> 86 / 100 -> 93 us on ScanNet -- and the deferred pass behind them, beside the list appends on the other stream, loses the same
+    // time (same-box A/B, profiles/r06_wave_major.txt: office0 +-0, INS Indoor -1..2 %).  It is used where no append kernel runs beside the
+    // ray pass: the hash-grid iteration (caller-supplied features), +1.5 %.
+    for (long long task = (MNE_WAVE_MAJOR && !a.ray_list && a.ext_feat) ? (long long)wv * gridDim.x + xcd_block() : (long long)xcd_block() * wpb + wv; task < ntask_l;
+         task += (long long)gridDim.x * wpb) {
         int c, r;
+#ifdef DECODE_PROFILE
+        DEC_STAMP(2 + 2 * prof_n);
+#endif
         if (balanced) {
             int lo = 0, hi = a.R - 1;                              // last ray whose first tile is <= task
             while (lo < hi) {
@@ -549,12 +575,17 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
             }
             if (cc + 1 >= ntile) break;
             if (found && !(zr[i0 + n_in] < z_lim)) break;              // the window ends before the next tile
-            if (cc - c >= MNE_RESOLVER_MAX_EXT) break;                 // a long unresolved stretch is cheaper tile-parallel (deferred pass)
+            if (cc - c >= ResolverExt<CP>::MAX) break;                 // a long unresolved stretch is cheaper tile-parallel (deferred pass)
             s_carry = __shfl(s_me, n_in - 1); have_carry = true;
             ++cc;
             pre_now = a.ext_feat != 0;                                 // tiles beyond the prefix were not pre-gathered
         }
         if (resolver && lane == 0) a.dec_tiles[r] = cc + 1;
+#ifdef DECODE_PROFILE
+        DEC_STAMP(3 + 2 * prof_n);
+        ++prof_n; prof_ext += cc - c;
+        if (prof && lane == 0) { prof[14] = (unsigned long long)prof_n; prof[15] = (unsigned long long)prof_ext; }
+#endif
     }
 }
 
@@ -1124,7 +1155,11 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
     const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
     const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
     const int n_items = a.ray_list ? *a.ray_list_count : a.R;
-    for (int item = (MODE == 0 ? xcd_block() : (int)blockIdx.x) * wpb + wv; item < n_items; item += gridDim.x * wpb) {
+    // (training with caller-supplied features -- see decode_kernel's task numbering: wave w of workgroup b takes rays w * gridDim + b, ...,
+    // with launch_ray's grid of min(CUs, rays) every CU gets its share of a 2150-ray batch; forward frames keep consecutive rays -- Z-order
+    // neighbours -- in one workgroup)
+    for (int item = ((MODE == 4 && MNE_WAVE_MAJOR && !a.ray_list && a.ext_feat) ? wv * (int)gridDim.x + (int)blockIdx.x : (MODE == 0 ? xcd_block() : (int)blockIdx.x) * wpb + wv); item < n_items;
+         item += gridDim.x * wpb) {
         const int r = a.ray_list ? a.ray_list[item] : item;
         const float td = has_t ? a.target_d[r] : 0.0f;
         float ro[3], rd[3];
@@ -1177,7 +1212,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
         if (HOT && a.adapt && a.adapt[0] && (!a.ray_list || a.list_keeps_prefix)) {
             // mode 1 (every sample was decoded a priori): would the a-priori prefix plus the resolver's extension have
             // resolved this ray?  Feeds the decision to go back to mode 0.
-            int t_ap = apriori_tiles(a, r, ntile) + MNE_RESOLVER_MAX_EXT;
+            int t_ap = apriori_tiles(a, r, ntile) + ResolverExt<CP>::MAX;
             const int D_ap = t_ap * TILE < S ? t_ap * TILE : S;
             const bool resolved = D_ap >= S || (first >= 0 && first + 1 < D_ap && !(zr[D_ap] < zr[first] + a.win_f));
             if (!resolved && lane == 0) atomicAdd(a.adapt + 1, 1);
@@ -1422,7 +1457,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, 4)) void heavy_bwd_kernel(Ren
     for (int q = 0; q < MNE_N_LOSS; ++q) cf[q] = a.coef ? a.coef[q] : 0.0f;
     const bool use_e = cf[MNE_L_E_FS] != 0.f || cf[MNE_L_E_CENTER] != 0.f || cf[MNE_L_E_TAIL] != 0.f;
     const bool use_co = cf[MNE_L_CO_FS] != 0.f || cf[MNE_L_CO_SDF] != 0.f;
-    for (int task = blockIdx.x * wpb + wv; task < total; task += gridDim.x * wpb) {
+    for (int task = (int)blockIdx.x * wpb + wv; task < total; task += gridDim.x * wpb) {      // (wave-major: see decode_kernel)
         int lo = 0, hi = n_heavy - 1;                      // last listed ray whose first tile is <= task
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -1907,7 +1942,7 @@ static int fit_waves(size_t tab, size_t per_wave, int max_wpb) {
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 // backward workspace: ReLU masks [R*S][4] u32 | deferred-ray list [R] | its length [1]
 size_t mne_render_workspace(int R, int S) {
-    return align16((size_t)R * S * 4 * sizeof(unsigned)) + 4 * align16((size_t)R * sizeof(int)) + align16((size_t)R * 8 * sizeof(float)) + 32;
+    return align16((size_t)R * S * 4 * sizeof(unsigned)) + 5 * align16((size_t)R * sizeof(int)) + align16((size_t)R * 8 * sizeof(float)) + 32;
 }
 static void carve_workspace(RenderArgs& a, void* ws) {
     unsigned char* p = (unsigned char*)ws;
@@ -1979,6 +2014,9 @@ static int launch_ray(RenderArgs a, hipStream_t st, int max_blocks = MNE_NUM_CU)
     const size_t lds = tab + (size_t)wpb * per_wave;
     if (lds > 64 * 1024) MNE_SET_MAX_LDS((ray_kernel<HID, HIDC, CP, ALDS, MODE>), MNE_LDS_MAX);
     long long grid = ((long long)a.R + wpb - 1) / wpb;
+#ifndef MNE_HOST_EMU                                        // (the host emulator pays per workgroup: it keeps the dense grid, same item loop)
+    if (MODE == 4 && MNE_WAVE_MAJOR && !a.ray_list && a.ext_feat) grid = a.R;      // training, first pass, caller-supplied features: rays are dealt wave-major over the workgroups (ray_kernel's item loop)
+#endif
     if (grid > max_blocks) grid = max_blocks;
     MNE_LAUNCH((ray_kernel<HID, HIDC, CP, ALDS, MODE>), (unsigned)grid, 64 * wpb, lds, st, a);
     return 0;
