@@ -469,9 +469,6 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
     constexpr int TAB_FLOATS = ALDS ? T::FWD_STEPS * 64 : 0;
     MNE_DYN_LDS(lds_raw);
     const int wpb = blockDim.x >> 6;
-#ifdef DECODE_PROFILE
-    const unsigned long long t_entry = wall_clock64();
-#endif
     if (blockIdx.x == 0 && threadIdx.x == 0 && !a.ray_list) {   // counters of this call, reset before any consumer runs
         if (a.tape_rows) *a.tape_rows = 0;
         if (a.bins.spill_count) *a.bins.spill_count = 0;
@@ -489,14 +486,6 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
     const float* atab = ALDS ? (const float*)lds_raw : a.packed;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntile = (a.S + TILE - 1) / TILE;
-#ifdef DECODE_PROFILE       // (profiling builds only, profiles/r06_decode_waves.py: per-wave clock stamps in the tail of the spill area)
-    unsigned long long* prof = (a.bins.spill && !a.ray_list && pre) ? (unsigned long long*)(a.bins.spill + (size_t)(a.bins.spill_cap - 65536) * MNE_SPILL_WORDS) + (size_t)(blockIdx.x * wpb + wv) * 16 : nullptr;
-    int prof_n = 0, prof_ext = 0;
-#define DEC_STAMP(k) do { if (prof && lane == 0 && (k) < 14) prof[(k)] = wall_clock64(); } while (0)
-    if (prof && lane == 0) prof[0] = t_entry;
-#else
-#define DEC_STAMP(k) do { } while (0)
-#endif
     float* pn = (float*)(lds_raw + (size_t)TAB_FLOATS * sizeof(float) + (size_t)wv * tile_wave_lds_bytes(NSETS));
     float* feat = pn + TILE * 4;
     // persistent waves over the (tile, ray) tasks, TILE-major: the a-priori tiles of all rays come first, so the
@@ -523,7 +512,6 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
         if (tstart[0] != 0 || total < a.R || total > (long long)a.R * ntile) balanced = false;
         else ntask_l = total;
     }
-    DEC_STAMP(1);
     // Task numbering.  The launch is bound by what a SIMD issues -- 7.2 us per tile and SIMD whether two or three waves share it
     // (profiles/r06_decode_waves.txt) -- and workgroup-major numbering (wave w of workgroup b: tasks b * wpb + w, ...) puts the last,
     // partial round on the first workgroups only (office0: 4952 tiles on 2048 waves, the 856 third tasks on workgroups 0..106).  Wave-major
@@ -534,9 +522,6 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
     for (long long task = (MNE_WAVE_MAJOR && !a.ray_list && a.ext_feat) ? (long long)wv * gridDim.x + xcd_block() : (long long)xcd_block() * wpb + wv; task < ntask_l;
          task += (long long)gridDim.x * wpb) {
         int c, r;
-#ifdef DECODE_PROFILE
-        DEC_STAMP(2 + 2 * prof_n);
-#endif
         if (balanced) {
             int lo = 0, hi = a.R - 1;                              // last ray whose first tile is <= task
             while (lo < hi) {
@@ -581,11 +566,6 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
             pre_now = a.ext_feat != 0;                                 // tiles beyond the prefix were not pre-gathered
         }
         if (resolver && lane == 0) a.dec_tiles[r] = cc + 1;
-#ifdef DECODE_PROFILE
-        DEC_STAMP(3 + 2 * prof_n);
-        ++prof_n; prof_ext += cc - c;
-        if (prof && lane == 0) { prof[14] = (unsigned long long)prof_n; prof[15] = (unsigned long long)prof_ext; }
-#endif
     }
 }
 

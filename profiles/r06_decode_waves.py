@@ -1,4 +1,4 @@
-"""decode_kernel by wave (variant build -DDECODE_PROFILE: build.build_variant("decprof", ["-DDECODE_PROFILE"])): when does every wave enter,
+"""decode_kernel by wave (variant build: git apply profiles/patches/r06_decode_wave_stamps.patch, build.build_variant("decprof", ["-DDECODE_PROFILE"]), git apply -R): when does every wave enter,
 finish staging, start / end each of its tile tasks -- where do the 60 us of the first-pass decode go?  100 MHz clock stamps, lane 0 of each
 wave, in the tail of the spill area.  python profiles/r06_decode_waves.py [config]"""
 import os, sys
