@@ -766,7 +766,9 @@ def main():
             "metric": f"mapping iters/sec ({cfg['mapping']['sample']} rays x {S} samples)", "value": world * args.steps / elapsed,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (HOST-EMULATOR DRY RUN of the launcher logic: not a measurement)" if dry else ""),
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (HOST-EMULATOR DRY RUN of the launcher logic: not a measurement)" if dry else "")
+                                                         + (" (RANKS SHARE GPUs over gloo, MNE_SHARE_GPUS=1: functional run of the multi-agent path on the HIP library, not a scaling measurement)"
+                                                            if (world > 1 and device.type == "cuda" and world > torch.cuda.device_count()) else ""),
             "config": {"workload": workload + ("_SMALL" if args.small else ""),
                        "rays_per_iter": R, "samples_per_ray": S, "plane_params": agent.n_plane_params,
                        "decoder_params": agent.n_dec_params, "mlp_hidden": args.hidden, "keyframes": args.keyframes,

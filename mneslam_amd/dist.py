@@ -21,13 +21,24 @@ def init_agents(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
+    n_dev = torch.cuda.device_count() if use_gpu else 0
+    # More ranks on this node than GPUs?  The deployment is one agent per GPU (RCCL refuses two ranks on one device); MNE_SHARE_GPUS=1
+    # lets the ranks share the devices round robin with gloo as the transport (it takes device tensors): a FUNCTIONAL run of the
+    # multi-agent data path on the HIP library -- what a one-GPU box can execute of it (tests/test_hip_parity_gpu.py; bench.py marks
+    # its line).  Every rank of the node takes the same branch (LOCAL_WORLD_SIZE is the launcher's).
+    shared = use_gpu and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > n_dev
+    if shared:
+        if os.environ.get("MNE_SHARE_GPUS", "0") != "1":
+            raise RuntimeError(f"{os.environ.get('LOCAL_WORLD_SIZE', world)} ranks on a node with {n_dev} GPU(s): one rank per GPU "
+                               "(MNE_SHARE_GPUS=1: ranks share devices over gloo, functional runs only)")
+        local = local % n_dev
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        backend = backend or ("nccl" if use_gpu else "gloo")
+        backend = backend or ("gloo" if shared else "nccl" if use_gpu else "gloo")       # (every rank of a node takes the same branch)
         if backend == "nccl":
             dist.init_process_group(backend, device_id=device)
         else:
