@@ -420,6 +420,9 @@ __device__ __forceinline__ int xcd_block() {
 #ifndef MNE_SEQ_FORWARD
 #define MNE_SEQ_FORWARD 1       // forward-only launches with colour planes: one set of LDS feature rows per wave (decode_tile<..., SEQF>)
 #endif
+#ifndef MNE_FUSED_GATHER
+#define MNE_FUSED_GATHER 1      // training launches without colour planes gather inline in decode_kernel (no gather_kernel); see launch_render
+#endif
 #ifndef MNE_WAVE_MAJOR
 #define MNE_WAVE_MAJOR 1        // first-pass tasks / rays of launches on caller-supplied features dealt wave-major over the workgroups (decode_kernel, ray_kernel<..., 4>); 0: workgroup-major everywhere
 #endif
@@ -2167,7 +2170,12 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         RenderArgs d = a;
         if (mode == 0) { d.ray_counts = nullptr; d.prefix_default = 1 << 30; }
         if (mode == 3) d.raw = nullptr;                    // raw of the forward call stays untouched
-        if (int rc = launch_decode<HID, HIDC, CP>(d, st, host, mode >= 2)) return rc;
+        // Training launches: the a-priori tiles' plane features either come pre-gathered (gather_kernel, then decode_kernel<PRE> reads the
+        // rows back) or are gathered INLINE by the decode waves -- north_star's fused sample -> gather -> MLP form.  Round 2 measured the
+        // split form 1.3 % ahead and kept it for everything; on the final tree (corner rows through buffer loads, balanced tile schedule) the
+        // fused form wins without colour planes -- office0 driver form +2 %, apartment +2-4 %, INS Indoor +5 % -- and ties with them (48 corner
+        // rows per sample in one wave): profiles/r06_inline_gather.txt.  MNE_FUSED_GATHER=0 builds the split form everywhere (A/B).
+        if (int rc = launch_decode<HID, HIDC, CP>(d, st, host, mode >= 2 && (CP || !MNE_FUSED_GATHER))) return rc;
     }
     if (mode == 0) {
         const size_t clds = (size_t)4 * ((a.S + 3) & ~3) * 4 * sizeof(float);
