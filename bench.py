@@ -432,13 +432,20 @@ def account(cfg, agent, avg_ms):
                 "deferred_pass": "decode_kernel + ray_kernel over the deferred-ray list",
                 "bin_kernel": "bin_kernel (list appends of the binned plane update)",
                 "render": "whole mne_render_fused call (gather + decode + ray + deferred pass + bin)"}
+        # Fused gather + decode launch (scenes without colour planes since round 6, csrc/render.hip launch_render): no gather_kernel runs
+        # between its two timing marks (a few us of event spacing remain) -- the gather's algorithmic bytes are the decode launch's
+        if "decode_kernel" in avg_ms and avg_ms.get("gather_kernel", 1.0) < 0.02:
+            avg_ms.pop("gather_kernel")
+            alg["decode_kernel"] = alg.pop("gather_kernel")
+            kern["decode_kernel"] = "decode_kernel (fused launch: tri-plane gather inline + OneBlob + MLP)"
+            kern["render"] = "whole mne_render_fused call (fused gather + decode, ray, deferred pass, bin)"
     else:
         alg = {"adam": 32.0 * n_par, "render": (decoded + p_contrib) * G}
         kern = {"adam": "adam_kernel (planes + decoder, one launch)",
                 "render": "whole mne_render_fused call (gather + decode + ray kernels, atomic scatter)"}
     # the dominant KERNEL = the longest live-measured single launch (the bracket around the whole render call is
     # reported beside it, not as a kernel, when its kernels are timed individually)
-    single = {k: v for k, v in avg_ms.items() if not (k == "render" and ("gather_kernel" in avg_ms or agent.hash))}
+    single = {k: v for k, v in avg_ms.items() if not (k == "render" and ("gather_kernel" in avg_ms or "decode_kernel" in avg_ms or agent.hash))}
     dom = max(single, key=single.get) if single else "adam"
     dom_ms = avg_ms.get(dom, 0.0)
     achieved = alg.get(dom, 0.0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
