@@ -317,7 +317,7 @@ int mne_render_backward(const mne_scene_t* scene, const mne_render_cfg_t* cfg, i
  * call is stateless, whatever carries over from one iteration to the next lives in caller-owned device memory. */
 typedef struct mne_fused_opts {
     /* Measurement: up to 6 hipEvent_t handles that THIS call records on its stream -- [0] before the feature gather, [1]
-     * after it, [2] after the prefix decode, [3] after the ray kernel, [4] after the deferred pass, [5] after the list
+     * after it (scenes without colour planes gather inside the decode launch: nothing runs between [0] and [1]), [2] after the prefix decode, [3] after the ray kernel, [4] after the deferred pass, [5] after the list
      * appends (bin_kernel) -- so that bench.py can time the kernels of the call live (HIP events on the launch stream).
      * NULL entries are skipped. */
     void* const* timing_events;
