@@ -243,6 +243,9 @@ __device__ __forceinline__ SampleMasks sample_masks(float z, float d, bool has_t
     return m;
 }
 
+#ifndef MNE_DECODE_WIDE_GATHER
+#define MNE_DECODE_WIDE_GATHER 1  // see decode_tile<..., WIDE>
+#endif
 // per-wave LDS of the tile code: pn[32][4] | feat[NSETS][32][FS]  (+ ray-gradient variant: dpos[32][64] | dpn[32][4])
 __host__ __device__ inline size_t tile_wave_lds_bytes(int nsets, bool raygrad = false) {
     size_t b = (size_t)(TILE * 4 + nsets * TILE * MNE_FS) * sizeof(float);
@@ -276,7 +279,10 @@ __device__ __forceinline__ int prefix_tiles(const RenderArgs& a, int r, int ntil
 // geometry planes are gathered, the sdf net runs, then the colour planes are gathered into the same rows for the colour net.
 // Same operations on the same values; what it buys is LDS: 9.2 instead of 17.9 KB per wave, i.e. 8 waves per CU beside the
 // 38.9 KB of tables instead of 6 (decode_kernel) / 5 (ray_kernel<..., 0> at 256 samples per ray) -- render_img, DESIGN.md 3.6.
-template <int HID, int HIDC, bool CP, bool GTAB = false, bool SEQF = false>
+// WIDE (decode_kernel of 2x32 decoders without colour planes, the fused training launch): the inline gather requests both levels' 24 corner
+// rows together and goes through buffer loads, as gather_kernel does -- the kernel has the registers (249 of 256, no scratch), the other
+// callers of this function do not (round 6, profiles/r06_inline_gather.txt: +1.1 % on office0, nothing elsewhere).
+template <int HID, int HIDC, bool CP, bool GTAB = false, bool SEQF = false, bool WIDE = false>
 __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c, int lane, float* pn, float* feat,
                                               const float* atab, float (&pnv)[3], float (&u)[3], uint2& relu, bool PRE = false) {
     typedef DecDims<HID, HIDC, CP> D;
@@ -340,7 +346,7 @@ __device__ __forceinline__ float4 decode_tile(const RenderArgs& a, int r, int c,
     } else {
         if (hf == 0) *(float4*)(pn + pt * 4) = make_float4(pnv[0], pnv[1], pnv[2], 0.0f);
         MNE_WAVE_SYNC();
-        gather_chunk<NSETS, TILE, MNE_INLINE_GATHER_NLV>(a.sc, pn, feat, lane);
+        gather_chunk<NSETS, TILE, WIDE ? 2 : MNE_INLINE_GATHER_NLV, 0, WIDE>(a.sc, pn, feat, lane);
         MNE_WAVE_SYNC();
         if (tape0) {                                       // plane features: straight from the gathered rows
             store_rows<MNE_FEAT>(feat, tape0, D::ROW, D::T_X, live, lane);
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
         float z_lim = 0.0f, s_carry = 0.0f;
         const float* zr = a.z_vals + (size_t)r * a.S;
         while (true) {
-            const float4 rw = decode_tile<HID, HIDC, CP, !ALDS, SEQF>(a, r, cc, lane, pn, feat, atab, pnv, u, relu, pre_now);
+            const float4 rw = decode_tile<HID, HIDC, CP, !ALDS, SEQF, MNE_DECODE_WIDE_GATHER && HID == 32 && HIDC == 32 && !CP>(a, r, cc, lane, pn, feat, atab, pnv, u, relu, pre_now);
             if (!resolver) break;
             const int i0 = cc * TILE, n_in = a.S - i0 < TILE ? a.S - i0 : TILE;
             const float s_me = rw.w;                                   // valid on lanes < 32 (rows 0..3 of the result)
