@@ -362,49 +362,6 @@ def test_baseline_config_shapes_full_batch_properties(workload):
         assert abs(x - y) <= 1e-3 * abs(y)
 
 
-@pytest.mark.parametrize("form,world", [("self", 2), ("split-scannet", 4), ("split-indoor", 8)])
-def test_multi_agent_processes_share_the_gpu(tmp_path, form, world):
-    """The process-per-agent paths of bench.py as REAL processes on the HIP library (round 6): N ranks share this box's GPU(s) with
-    gloo as the transport (MNE_SHARE_GPUS=1, dist.init_agents: RCCL refuses two ranks on one device) -- rendezvous, barrier-bracketed
-    timing, max over ranks, ONE JSON line; "self": N independent agents + the side records (decoder-gradient all-reduce; BASELINE
-    configs[2] as worded: one scene, two overlapping slabs); "split-*": configs[3] / configs[4] geometry, interior agents exchange the
-    overlap rectangles with TWO neighbours (batch_isend_irecv on device buffers, tile_adam_kernel<1> / <2>) and the planes without the
-    slab axis are reduced over all agents.  Small scenes (functional, a few steps); the full-size runs of the same command lines are
-    recorded in profiles/r06_shared_gpu_ranks.txt.  What this cannot show is RCCL itself and any rate."""
-    import json
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MNE_EMULATED_LIBRARY")}
-    env.update(MNE_SHARE_GPUS="1", PYTHONPATH=repo, MNE_SIDE_RECORD_LIMIT_S="600")
-    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2", "--cpu-iters", "0",
-           "--small", "--rays", "256", "--keyframes", "3"]
-    if form != "self":
-        cmd += ["--split", "--config", form.split("-")[1], "--no-variants"]
-    out = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == world and d["config"]["ranks_seen"] == world and d["config"]["collective_backend"] == "gloo" and d["value"] > 0
-    assert "RANKS SHARE GPUs" in d["data"] and "DRY RUN" not in d["data"]
-    per = d["per_rank"]
-    assert len(per) == world and all(r["it_per_s"] > 0 and math.isfinite(r["psnr_last_iter"]) and math.isfinite(r["depth_l1_last_iter"]) for r in per)
-    if form == "self":
-        assert "no data-path collective" in d["config"]["parallelism"]
-        side = d["variants"]
-        assert side["share_decoder"].get("value", 0) > 0, side
-        worded = side["as_worded"]
-        assert worded.get("value", 0) > 0 and worded["baseline_config"] == "configs[2]", worded
-        assert len(worded["per_rank"]) == 2 and all(r["overlap_exchange_bytes_per_iter"] > 0 and math.isfinite(r["psnr_last_iter"]) for r in worded["per_rank"])
-    else:
-        assert d["config"]["workload"].endswith(f"_scene_split{world}_SMALL") and "all agents" in d["config"]["parallelism"]
-        ends = (per[0]["overlap_exchange_bytes_per_iter"] + per[-1]["overlap_exchange_bytes_per_iter"]) / 2
-        assert ends > 0
-        for r in per[1:-1]:            # two neighbours: more to exchange than an end slab
-            assert 1.2 * ends < r["overlap_exchange_bytes_per_iter"] < 2.5 * ends, [q["overlap_exchange_bytes_per_iter"] for q in per]
-
-
 def test_rccl_branch_single_rank():
     """The RCCL (backend "nccl") branch of the multi-agent plumbing on a real GPU, world size 1: process-group set-up of
     dist.init_agents, a collective on a device tensor, the pose gather and bench.py's timing rule.  (8-GPU runs are the
@@ -706,3 +663,50 @@ def test_two_agents_binned_overlap_on_one_device(monkeypatch, geometry, world):
 def test_sample_z_frame_sized_batch_counts():
     """whole-frame batches: the striped counts reduction of mne_sample_z"""
     pc.check_sample_z_frame_counts(DEV)
+
+
+# (last in the module: N child processes on the device; nothing that initialises RCCL runs behind them)
+@pytest.mark.parametrize("form,world", [("self", 2), ("split-scannet", 4), ("split-indoor", 8)])
+def test_multi_agent_processes_share_the_gpu(tmp_path, form, world):
+    """The process-per-agent paths of bench.py as REAL processes on the HIP library (round 6): N ranks share this box's GPU(s) with
+    gloo as the transport (MNE_SHARE_GPUS=1, dist.init_agents: RCCL refuses two ranks on one device) -- rendezvous, barrier-bracketed
+    timing, max over ranks, ONE JSON line; "self": N independent agents + the side records (decoder-gradient all-reduce; BASELINE
+    configs[2] as worded: one scene, two overlapping slabs); "split-*": configs[3] / configs[4] geometry, interior agents exchange the
+    overlap rectangles with TWO neighbours (batch_isend_irecv on device buffers, tile_adam_kernel<1> / <2>) and the planes without the
+    slab axis are reduced over all agents.  Small scenes (functional, a few steps); the full-size runs of the same command lines are
+    recorded in profiles/r06_shared_gpu_ranks.txt.  What this cannot show is RCCL itself and any rate."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MNE_EMULATED_LIBRARY")}
+    env.update(MNE_SHARE_GPUS="1", PYTHONPATH=repo, MNE_SIDE_RECORD_LIMIT_S="600")
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2", "--cpu-iters", "0",
+           "--small", "--rays", "256", "--keyframes", "3"]
+    if form != "self":
+        cmd += ["--split", "--config", form.split("-")[1], "--no-variants"]
+    out = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    if out.returncode != 0:                    # (one retry: N fresh processes + a TCP rendezvous on a box that has just run the rest of the suite)
+        first = out.stderr[-1500:]
+        out = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, first + "\n---- retry ----\n" + out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["config"]["ranks_seen"] == world and d["config"]["collective_backend"] == "gloo" and d["value"] > 0
+    assert "RANKS SHARE GPUs" in d["data"] and "DRY RUN" not in d["data"]
+    per = d["per_rank"]
+    assert len(per) == world and all(r["it_per_s"] > 0 and math.isfinite(r["psnr_last_iter"]) and math.isfinite(r["depth_l1_last_iter"]) for r in per)
+    if form == "self":
+        assert "no data-path collective" in d["config"]["parallelism"]
+        side = d["variants"]
+        assert side["share_decoder"].get("value", 0) > 0, side
+        worded = side["as_worded"]
+        assert worded.get("value", 0) > 0 and worded["baseline_config"] == "configs[2]", worded
+        assert len(worded["per_rank"]) == 2 and all(r["overlap_exchange_bytes_per_iter"] > 0 and math.isfinite(r["psnr_last_iter"]) for r in worded["per_rank"])
+    else:
+        assert d["config"]["workload"].endswith(f"_scene_split{world}_SMALL") and "all agents" in d["config"]["parallelism"]
+        ends = (per[0]["overlap_exchange_bytes_per_iter"] + per[-1]["overlap_exchange_bytes_per_iter"]) / 2
+        assert ends > 0
+        for r in per[1:-1]:            # two neighbours: more to exchange than an end slab
+            assert 1.2 * ends < r["overlap_exchange_bytes_per_iter"] < 2.5 * ends, [q["overlap_exchange_bytes_per_iter"] for q in per]
