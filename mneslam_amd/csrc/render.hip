@@ -2181,7 +2181,9 @@ static int launch_render(RenderArgs a, int mode, void* workspace, const RenderHo
         // split form 1.3 % ahead and kept it for everything; on the final tree (corner rows through buffer loads, balanced tile schedule) the
         // fused form wins without colour planes -- office0 driver form +2 %, apartment +2-4 %, INS Indoor +5 % -- and ties with them (48 corner
         // rows per sample in one wave): profiles/r06_inline_gather.txt.  MNE_FUSED_GATHER=0 builds the split form everywhere (A/B).
-        if (int rc = launch_decode<HID, HIDC, CP>(d, st, host, mode >= 2 && (CP || !MNE_FUSED_GATHER))) return rc;
+        const bool pre = mode >= 2 && (CP || !MNE_FUSED_GATHER);
+        if (mode == 2 && !pre && !d.ext_feat) { mark(host, 0, st); mark(host, 1, st); }      // (timing marks of the gather that does not run: the decode's bracket starts here)
+        if (int rc = launch_decode<HID, HIDC, CP>(d, st, host, pre)) return rc;
     }
     if (mode == 0) {
         const size_t clds = (size_t)4 * ((a.S + 3) & ~3) * 4 * sizeof(float);
