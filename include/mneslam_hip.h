@@ -565,7 +565,7 @@ int mne_grid_encode_backward(const mne_grid_cfg_t* cfg, int64_t n_pts, const flo
  *   mne_render_fused_features  = mne_render_fused without plane gather / scatter: every decode reads its features from the
  *                                tape (ray_counts as in mne_render_fused: exact early termination).  With grid_cfg + table
  *                                the call does the gather itself and only where rows can be decoded: the a-priori tiles of
- *                                every ray plus the resolver's extension first, the remaining rows of the deferred rays
+ *                                every ray first (round 6: no resolver extension on caller-supplied features), the remaining rows of the deferred rays
  *                                before the second pass (then mne_hash_gather is not needed); NULL, NULL: the caller has
  *                                filled every row; the d(feature) rows of every sample of the first
  *                                ray_tiles[r] tiles of ray r are left in the tape (column mne_tape_dfeat_offset)
@@ -588,7 +588,7 @@ int mne_hash_slice_adam(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int
                         const float* rays_d, const float* z_vals, const float* tape, const int32_t* ray_tiles, float* table,
                         const mne_plane_opt_t* opt, void* workspace, size_t workspace_bytes, void* event_after_bin, void* stream);
 /* ray_counts (optional, the per-ray counts of mne_sample_z): only the rows the exact early termination can decode in its first
- * pass -- the a-priori tiles of every ray plus the resolver's extension; NULL = every row */
+ * pass -- the a-priori tiles of every ray (what the first decode pass of mne_render_fused_features reads); NULL = every row */
 int mne_hash_gather(const mne_grid_cfg_t* cfg, const mne_scene_t* scene, int n_rays, int n_samples, const float* rays_o,
                     const float* rays_d, const float* z_vals, const int32_t* ray_counts, const float* table, float* tape, void* stream);
 /* the grid features of every sample as compact rows: features [R*S][64], columns [0, n_levels*2) written, the rest

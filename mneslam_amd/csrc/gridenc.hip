@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void hash_gather_kernel(GridArgs a) {
         const int ntile = (a.S + 31) / 32;
         const int need = a.ray_counts[(size_t)r * MNE_N_COUNT + MNE_C_NEED];
         int t = (need + 31) / 32;
-        t = (t < 1 ? 1 : (t > ntile ? ntile : t)) + MNE_RESOLVER_MAX_EXT;         // = prefix_tiles() of render.hip + extension
+        t = (t < 1 ? 1 : (t > ntile ? ntile : t)) + MNE_RESOLVER_MAX_EXT_FEAT;    // = prefix_tiles() of render.hip + the extension decode_kernel may take on caller-supplied features
         if (a.ray_list) s_lo = t * 32; else s_hi = t * 32 < a.S ? t * 32 : a.S;
     }
     if (s0 >= s_hi || s0 + 64 <= s_lo) continue;                      // (whole workgroup)

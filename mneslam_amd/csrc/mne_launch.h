@@ -179,6 +179,12 @@ struct PlaneOpt { float* m; float* v; float omb1, b2, omb2, eps, wd, step_size, 
 #ifndef MNE_RESOLVER_MAX_EXT_CP
 #define MNE_RESOLVER_MAX_EXT_CP 0
 #endif
+// ... on caller-supplied features (the hash-grid iteration): every extension tile a ray MIGHT take has to be gathered up front for all rays (mne_hash_gather
+// fills a-priori tiles + extension), 43 % more rows for the few rays that extend; without it the gather is 25 us and the decode 9 us shorter and the deferred pass
+// 28 us longer: +0.9 % (round 6, profiles/r06_resolver_ext_cp.txt)
+#ifndef MNE_RESOLVER_MAX_EXT_FEAT
+#define MNE_RESOLVER_MAX_EXT_FEAT 0
+#endif
 template <bool CP> struct ResolverExt { static constexpr int MAX = CP ? MNE_RESOLVER_MAX_EXT_CP : MNE_RESOLVER_MAX_EXT; };
 #define MNE_GRID_MAX_LEVELS 32
 #define MNE_GRID_MAX_F 8
@@ -212,7 +218,7 @@ struct GridArgs {
     unsigned long long* scratch64;   // fixed-point gradient sums of the levels that are split over several workgroups per slice
     PlaneOpt opt;                // table optimizer state and step constants
     // gather restricted to the rows the exact early termination can decode (inside mne_render_fused_features)
-    const int* ray_counts;       // [R][MNE_N_COUNT]: rows [0, (a-priori tiles + MNE_RESOLVER_MAX_EXT) * 32) of every ray; NULL = all rows
+    const int* ray_counts;       // [R][MNE_N_COUNT]: rows [0, (a-priori tiles + MNE_RESOLVER_MAX_EXT_FEAT) * 32) of every ray; NULL = all rows
     const int* ray_list;         // second pass: the remaining rows of the listed (deferred) rays
     const int* ray_list_count;
 };

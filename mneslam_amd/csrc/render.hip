@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64 * WPB) void decode_kernel(RenderArgs a, int pre,
             }
             if (cc + 1 >= ntile) break;
             if (found && !(zr[i0 + n_in] < z_lim)) break;              // the window ends before the next tile
-            if (cc - c >= ResolverExt<CP>::MAX) break;                 // a long unresolved stretch is cheaper tile-parallel (deferred pass)
+            if (cc - c >= (a.ext_feat ? MNE_RESOLVER_MAX_EXT_FEAT : ResolverExt<CP>::MAX)) break;                 // a long unresolved stretch is cheaper tile-parallel (deferred pass)
             s_carry = __shfl(s_me, n_in - 1); have_carry = true;
             ++cc;
             pre_now = a.ext_feat != 0;                                 // tiles beyond the prefix were not pre-gathered
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(64 * RAY_WPB(HID, CP, MODE)) void ray_kernel(Render
         if (HOT && a.adapt && a.adapt[0] && (!a.ray_list || a.list_keeps_prefix)) {
             // mode 1 (every sample was decoded a priori): would the a-priori prefix plus the resolver's extension have
             // resolved this ray?  Feeds the decision to go back to mode 0.
-            int t_ap = apriori_tiles(a, r, ntile) + ResolverExt<CP>::MAX;
+            int t_ap = apriori_tiles(a, r, ntile) + (a.ext_feat ? MNE_RESOLVER_MAX_EXT_FEAT : ResolverExt<CP>::MAX);
             const int D_ap = t_ap * TILE < S ? t_ap * TILE : S;
             const bool resolved = D_ap >= S || (first >= 0 && first + 1 < D_ap && !(zr[D_ap] < zr[first] + a.win_f));
             if (!resolved && lane == 0) atomicAdd(a.adapt + 1, 1);
